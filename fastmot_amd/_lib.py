@@ -1,0 +1,302 @@
+"""ctypes binding of libfastmot_hip.so (include/fastmot_hip.h).
+
+This is the ONLY native boundary of the package.  There is no CPU fallback: if the
+shared library is missing or a call fails, an exception is raised (the reference raises
+RuntimeError when its plugin/engine is missing, fastmot/utils/inference.py:50-63).
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).parent / 'libfastmot_hip.so'
+
+c_int_p = C.POINTER(C.c_int)
+_lib = None
+
+
+class FastMOTHipError(RuntimeError):
+    pass
+
+
+class KFParams(C.Structure):
+    _fields_ = [('dt', C.c_double),
+                ('std_factor_acc', C.c_double), ('std_offset_acc', C.c_double),
+                ('std_factor_det', C.c_double * 2), ('std_factor_klt', C.c_double * 2),
+                ('min_std_det', C.c_double * 2), ('min_std_klt', C.c_double * 2),
+                ('init_pos_weight', C.c_double), ('init_vel_weight', C.c_double),
+                ('vel_coupling', C.c_double), ('vel_half_life', C.c_double)]
+
+
+def load():
+    """Loads the shared library once; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(f'{LIB_PATH} not found: build it with `python -m fastmot_amd.build` '
+                           '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    try:
+        lib = C.CDLL(str(LIB_PATH), mode=os.RTLD_NOW | os.RTLD_LOCAL)
+    except OSError as err:
+        raise RuntimeError(f'Unable to load {LIB_PATH}') from err
+    lib.fm_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(arr, ctype=None):
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def _as(arr, dtype, shape=None):
+    out = np.ascontiguousarray(arr, dtype=dtype)
+    if shape is not None:
+        out = out.reshape(shape)
+    return out
+
+
+def check(rc):
+    if rc != 0:
+        raise FastMOTHipError(f'libfastmot_hip error {rc}: {load().fm_last_error().decode()}')
+
+
+def device_count():
+    n = load().fm_device_count()
+    if n < 0:
+        raise FastMOTHipError(load().fm_last_error().decode())
+    return n
+
+
+class HipContext:
+    """One context = one GPU = one video stream (fm_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self._ctx = C.c_void_p()
+        check(self.lib.fm_ctx_create(C.c_int(device), C.byref(self._ctx)))
+        self.device = device
+        self.feat_dim = 512
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx:
+            self.lib.fm_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    def synchronize(self):
+        check(self.lib.fm_ctx_synchronize(self._ctx))
+
+    def device_info(self):
+        buf = C.create_string_buffer(256)
+        check(self.lib.fm_device_info(self._ctx, buf, 256))
+        # gcnArchName itself contains ':' (gfx950:sramecc+:xnack-) -> parse from the right
+        parts = buf.value.decode().split(':')
+        return {'name': parts[0], 'arch': ':'.join(parts[1:-3]), 'cus': int(parts[-3]),
+                'clock_mhz': int(parts[-2]), 'hbm_bytes': int(parts[-1])}
+
+    # ------------------------------------------------------------------ Kalman
+    def kf_configure(self, dt, std_factor_acc, std_offset_acc, std_factor_det, std_factor_klt,
+                     min_std_det, min_std_klt, init_pos_weight, init_vel_weight, vel_coupling,
+                     vel_half_life):
+        p = KFParams(dt, std_factor_acc, std_offset_acc, (C.c_double * 2)(*std_factor_det),
+                     (C.c_double * 2)(*std_factor_klt), (C.c_double * 2)(*min_std_det),
+                     (C.c_double * 2)(*min_std_klt), init_pos_weight, init_vel_weight, vel_coupling,
+                     vel_half_life)
+        check(self.lib.fm_kf_configure(self._ctx, C.byref(p)))
+
+    def set_frame_rect(self, tlbr):
+        a = _as(tlbr, np.float64, (4,))
+        check(self.lib.fm_set_frame_rect(self._ctx, _ptr(a)))
+
+    def trk_create(self, slots, det_tlbr):
+        s = _as(slots, np.int32)
+        b = _as(det_tlbr, np.float64, (-1, 4))
+        assert len(s) == len(b)
+        check(self.lib.fm_trk_create(self._ctx, C.c_int(len(s)), _ptr(s), _ptr(b)))
+
+    def trk_step(self, slots, H, klt_tlbr, has_klt, mult):
+        s = _as(slots, np.int32)
+        n = len(s)
+        Hm = _as(H, np.float64, (9,))
+        k = _as(klt_tlbr, np.float64, (-1, 4)) if n else np.zeros((0, 4))
+        hk = _as(has_klt, np.uint8)
+        mu = _as(mult, np.float64)
+        assert len(k) == n and len(hk) == n and len(mu) == n
+        tlbr = np.empty((n, 4), np.float64)
+        lost = np.empty(n, np.uint8)
+        check(self.lib.fm_trk_step(self._ctx, C.c_int(n), _ptr(s), _ptr(Hm), _ptr(k), _ptr(hk),
+                                   _ptr(mu), _ptr(tlbr), _ptr(lost)))
+        return tlbr, lost.astype(bool)
+
+    def trk_step_ops(self, ops, slots, H, klt_tlbr, has_klt, mult):
+        s = _as(slots, np.int32)
+        n = len(s)
+        Hm = _as(H, np.float64, (9,))
+        k = _as(klt_tlbr, np.float64, (-1, 4)) if n else np.zeros((0, 4))
+        hk = _as(has_klt, np.uint8)
+        mu = _as(mult, np.float64)
+        tlbr = np.empty((n, 4), np.float64)
+        lost = np.empty(n, np.uint8)
+        check(self.lib.fm_trk_step_ops(self._ctx, C.c_int(ops), C.c_int(n), _ptr(s), _ptr(Hm), _ptr(k),
+                                       _ptr(hk), _ptr(mu), _ptr(tlbr), _ptr(lost)))
+        return tlbr, lost.astype(bool)
+
+    def trk_update_det(self, slots, det_tlbr):
+        s = _as(slots, np.int32)
+        n = len(s)
+        b = _as(det_tlbr, np.float64, (-1, 4)) if n else np.zeros((0, 4))
+        assert len(b) == n
+        tlbr = np.empty((n, 4), np.float64)
+        lost = np.empty(n, np.uint8)
+        check(self.lib.fm_trk_update_det(self._ctx, C.c_int(n), _ptr(s), _ptr(b), _ptr(tlbr), _ptr(lost)))
+        return tlbr, lost.astype(bool)
+
+    def trk_get_state(self, slots):
+        s = _as(slots, np.int32)
+        mean = np.empty((len(s), 8), np.float64)
+        cov = np.empty((len(s), 8, 8), np.float64)
+        check(self.lib.fm_trk_get_state(self._ctx, C.c_int(len(s)), _ptr(s), _ptr(mean), _ptr(cov)))
+        return mean, cov
+
+    def trk_set_state(self, slots, mean, cov):
+        s = _as(slots, np.int32)
+        m = _as(mean, np.float64, (-1, 8))
+        c = _as(cov, np.float64, (-1, 8, 8))
+        assert len(m) == len(s) and len(c) == len(s)
+        check(self.lib.fm_trk_set_state(self._ctx, C.c_int(len(s)), _ptr(s), _ptr(m), _ptr(c)))
+
+    def trk_copy_state(self, dst, src):
+        check(self.lib.fm_trk_copy_state(self._ctx, C.c_int(dst), C.c_int(src)))
+
+    # ------------------------------------------------------------------ features
+    def feat_configure(self, dim):
+        check(self.lib.fm_feat_configure(self._ctx, C.c_int(dim)))
+        self.feat_dim = dim
+
+    def emb_upload(self, emb):
+        if emb is None:
+            raise ValueError('emb is None; use emb_use_device(n)')
+        e = _as(emb, np.float32)
+        if e.ndim != 2 or (len(e) and e.shape[1] != self.feat_dim):
+            raise ValueError('embeddings must be [n][feat_dim]')
+        check(self.lib.fm_emb_upload(self._ctx, C.c_int(len(e)), _ptr(e)))
+
+    def emb_use_device(self, n):
+        check(self.lib.fm_emb_upload(self._ctx, C.c_int(n), None))
+
+    def feat_update(self, slots, emb_rows):
+        s = _as(slots, np.int32)
+        r = _as(emb_rows, np.int32)
+        assert len(s) == len(r)
+        check(self.lib.fm_feat_update(self._ctx, C.c_int(len(s)), _ptr(s), _ptr(r)))
+
+    def feat_merge(self, dst, src):
+        check(self.lib.fm_feat_merge(self._ctx, C.c_int(dst), C.c_int(src)))
+
+    def feat_reset(self, slots):
+        s = _as(slots, np.int32)
+        check(self.lib.fm_feat_reset(self._ctx, C.c_int(len(s)), _ptr(s)))
+
+    def feat_get(self, slot):
+        fsum = np.empty(self.feat_dim, np.float32)
+        avg = np.empty(self.feat_dim, np.float32)
+        cnt = C.c_int32(0)
+        check(self.lib.fm_feat_get(self._ctx, C.c_int(slot), _ptr(fsum), _ptr(avg), C.byref(cnt)))
+        return fsum, avg, cnt.value
+
+    # ------------------------------------------------------------------ association
+    def find_occluded(self, tlbr, thresh):
+        b = _as(tlbr, np.float64, (-1, 4)) if len(tlbr) else np.zeros((0, 4))
+        out = np.zeros(len(b), np.uint8)
+        check(self.lib.fm_find_occluded(self._ctx, C.c_int(len(b)), _ptr(b), C.c_double(thresh), _ptr(out)))
+        return out.astype(bool)
+
+    def iou_dist(self, a, b):
+        a = _as(a, np.float64, (-1, 4))
+        b = _as(b, np.float64, (-1, 4))
+        out = np.empty((len(a), len(b)), np.float64)
+        check(self.lib.fm_iou_dist(self._ctx, C.c_int(len(a)), _ptr(a), C.c_int(len(b)), _ptr(b), _ptr(out)))
+        return out
+
+    def assoc_prepare(self, metric, slots, trk_tlbr, trk_label, det_tlbr, det_label, det_occluded):
+        s = _as(slots, np.int32)
+        nT = len(s)
+        tb = _as(trk_tlbr, np.float64).reshape(nT, 4)
+        tl = _as(trk_label, np.int64)
+        db = _as(det_tlbr, np.float64).reshape(-1, 4)
+        nD = len(db)
+        dl = _as(det_label, np.int64)
+        do = _as(det_occluded, np.uint8)
+        assert len(tl) == nT and len(dl) == nD and len(do) == nD
+        check(self.lib.fm_assoc_prepare(self._ctx, C.c_int(metric), C.c_int(nT), _ptr(s), _ptr(tb),
+                                        _ptr(tl), C.c_int(nD), _ptr(db), _ptr(dl), _ptr(do)))
+
+    def assoc_get_pairwise(self, nT, nD):
+        feat = np.empty((nT, nD), np.float64)
+        maha = np.empty((nT, nD), np.float64)
+        iou = np.empty((nT, nD), np.float64)
+        check(self.lib.fm_assoc_get_pairwise(self._ctx, _ptr(feat), _ptr(maha), _ptr(iou)))
+        return feat, maha, iou
+
+    def assoc_stage(self, stage, solver, rows, cols, motion_weight=0., max_cost=0., fill_val=1.,
+                    row_labels=None, want_cost=False):
+        r = _as(rows, np.int32)
+        c = _as(cols, np.int32)
+        nr, nc = len(r), len(c)
+        mn = min(nr, nc)
+        m_rows = np.empty(mn, np.int32)
+        m_cols = np.empty(mn, np.int32)
+        gated = np.zeros(mn, np.uint8)
+        n_match = C.c_int(0)
+        cost = np.empty((nr, nc), np.float64) if want_cost else None
+        rl = _as(row_labels, np.int64) if row_labels is not None else None
+        check(self.lib.fm_assoc_stage(self._ctx, C.c_int(stage), C.c_int(solver), C.c_int(nr), _ptr(r),
+                                      C.c_int(nc), _ptr(c), C.c_double(motion_weight),
+                                      C.c_double(max_cost), C.c_double(fill_val), _ptr(rl), _ptr(m_rows),
+                                      _ptr(m_cols), _ptr(gated), C.byref(n_match), _ptr(cost)))
+        k = n_match.value
+        return m_rows[:k], m_cols[:k], gated[:k].astype(bool), cost
+
+    def lap(self, cost):
+        cm = _as(cost, np.float64)
+        nr, nc = cm.shape
+        mn = min(nr, nc)
+        m_rows = np.empty(mn, np.int32)
+        m_cols = np.empty(mn, np.int32)
+        n_match = C.c_int(0)
+        check(self.lib.fm_lap(self._ctx, _ptr(cm), C.c_int(nr), C.c_int(nc), _ptr(m_rows), _ptr(m_cols),
+                              C.byref(n_match)))
+        return m_rows[:n_match.value], m_cols[:n_match.value]
+
+    def greedy(self, cost, max_cost):
+        cm = _as(cost, np.float64)
+        nr, nc = cm.shape
+        mn = min(nr, nc)
+        m_rows = np.empty(mn, np.int32)
+        m_cols = np.empty(mn, np.int32)
+        n_match = C.c_int(0)
+        check(self.lib.fm_greedy(self._ctx, _ptr(cm), C.c_int(nr), C.c_int(nc), C.c_double(max_cost),
+                                 _ptr(m_rows), _ptr(m_cols), C.byref(n_match)))
+        return m_rows[:n_match.value], m_cols[:n_match.value]
+
+
+METRIC_EUCLIDEAN = 0
+METRIC_COSINE = 1
+STAGE_MATCHING = 0
+STAGE_IOU = 1
+STAGE_REID = 2
+SOLVER_LAP = 0
+SOLVER_GREEDY = 1

@@ -1,0 +1,653 @@
+// Association kernels: pairwise terms, stage cost matrices, LAP / greedy solvers (all fp64).
+//
+// Replaces MultiTracker._matching_cost/_iou_cost/_reid_cost (fastmot/tracker.py:314-366),
+// utils/distance.py cdist/iou_dist (:17-108), KalmanFilter.motion_distance
+// (kalman_filter.py:206-225,347-353), utils/matching.py fuse_motion/gate_cost (:101-116),
+// scipy.optimize.linear_sum_assignment (called at utils/matching.py:27) and _greedy_match
+// (utils/matching.py:74-97), find_occluded (utils/rect.py:143-157).
+//
+// Design: fm_assoc_prepare computes every (track, detection) term ONCE per detector frame in
+// a single launch (block per track: Cholesky of the 4x4 innovation covariance in LDS, wave
+// reductions over the 512-d features); the association cascade then only gathers/gates
+// sub-matrices and solves them with a single-wavefront shortest-augmenting-path kernel that
+// reproduces SciPy's (Crouse) scan order and tie-breaking exactly, so matched index arrays are
+// identical to the reference's.  Compiled with -ffp-contract=off: cost arithmetic uses
+// separate IEEE mul/add like NumPy, decisions (>, <=) see the same doubles.
+//
+// Roofline: T=D=50, M=512 -> 0.33 MB and 7.7 MFLOP fp64 per frame: launch-latency bound.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr double INF_COST = 1e5;            // utils/matching.py:7
+constexpr double CHI_SQ_INV_95 = 9.4877;    // utils/matching.py:6
+
+__device__ inline double box_area(const double* b) {   // utils/rect.py:28-32
+    const double w = b[2] - b[0] + 1, h = b[3] - b[1] + 1;
+    return (w <= 0 || h <= 0) ? 0. : w * h;
+}
+
+__device__ inline double iou_dist_pair(const double* a, double area_a, const double* b) {
+    // utils/distance.py:98-107
+    const double iw = fmin(a[2], b[2]) - fmax(a[0], b[0]) + 1;
+    const double ih = fmin(a[3], b[3]) - fmax(a[1], b[1]) + 1;
+    if (iw > 0 && ih > 0) {
+        const double inter = iw * ih;
+        const double uni = area_a + box_area(b) - inter;
+        return 1. - inter / uni;
+    }
+    return 1.;
+}
+
+__global__ void occluded_kernel(int n, const double* __restrict__ tlbr, double thresh,
+                                uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* a = tlbr + (size_t)i * 4;
+    const double area_self = box_area(a);
+    uint8_t occ = 0;
+    for (int j = 0; j < n && !occ; ++j) {
+        if (j == i) continue;
+        const double* b = tlbr + (size_t)j * 4;
+        const double iw = fmin(a[2], b[2]) - fmax(a[0], b[0]) + 1;
+        const double ih = fmin(a[3], b[3]) - fmax(a[1], b[1]) + 1;
+        if (iw > 0 && ih > 0 && iw * ih / area_self >= thresh) occ = 1;
+    }
+    out[i] = occ;
+}
+
+__global__ void iou_dist_kernel(int na, const double* __restrict__ a, int nb,
+                                const double* __restrict__ b, double* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= na * nb) return;
+    const int i = idx / nb, j = idx % nb;
+    const double* pa = a + (size_t)i * 4;
+    out[idx] = iou_dist_pair(pa, box_area(pa), b + (size_t)j * 4);
+}
+
+// ---------------------------------------------------------------------------------------
+// pairwise terms: one 256-thread block per track row
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pairwise_kernel(
+    int nT, int nD, int metric, int dim, const int32_t* __restrict__ slots,
+    const double* __restrict__ trk_tlbr, const double* __restrict__ det_tlbr,
+    const double* __restrict__ mean, const double* __restrict__ cov,
+    const float* __restrict__ favg, const int32_t* __restrict__ fcnt,
+    const float* __restrict__ emb, KFConst kf, double* __restrict__ feat,
+    double* __restrict__ maha, double* __restrict__ iou, uint8_t* __restrict__ row_has_feat) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sa = reinterpret_cast<float*>(smem);                         // [dim]
+    double* sd = reinterpret_cast<double*>(smem + (size_t)dim * 4);     // L[16], pm[4], tb[4], area
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int slot = slots[t];
+    const int cnt = fcnt[slot];
+    for (int k = tid; k < dim; k += 256) sa[k] = favg[(size_t)slot * dim + k];
+    if (tid == 0) {
+        // project (kalman_filter.py:321-336, DETECTOR) + Cholesky (kalman_filter.py:350)
+        const double* m = mean + (size_t)slot * 8;
+        const double* P = cov + (size_t)slot * 64;
+        const double w = m[2] - m[0] + 1, h = m[3] - m[1] + 1;
+        const double sw = fmax(kf.fac_det[0] * w, kf.min_det[0]);
+        const double sh = fmax(kf.fac_det[1] * h, kf.min_det[1]);
+        double S[4][4], L[4][4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                S[i][j] = P[i * 8 + j];
+                L[i][j] = 0.;
+            }
+        S[0][0] += sw * sw; S[1][1] += sh * sh; S[2][2] += sw * sw; S[3][3] += sh * sh;
+        for (int j = 0; j < 4; ++j) {
+            double s = S[j][j];
+            for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+            L[j][j] = sqrt(s);
+            for (int i = j + 1; i < 4; ++i) {
+                double v = S[i][j];
+                for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+                L[i][j] = v / L[j][j];
+            }
+        }
+        for (int i = 0; i < 4; ++i) {
+            for (int j = 0; j < 4; ++j) sd[i * 4 + j] = L[i][j];
+            sd[16 + i] = m[i];
+            sd[20 + i] = trk_tlbr[(size_t)t * 4 + i];
+        }
+        sd[24] = box_area(trk_tlbr + (size_t)t * 4);
+        row_has_feat[t] = cnt > 0 ? 1 : 0;
+    }
+    __syncthreads();
+    for (int d = tid; d < nD; d += 256) {
+        const double* z = det_tlbr + (size_t)d * 4;
+        // forward substitution  y = L^-1 (z - Hx)   (kalman_filter.py:349-353)
+        double y[4];
+        for (int i = 0; i < 4; ++i) {
+            double s = z[i] - sd[16 + i];
+            for (int k = 0; k < i; ++k) s -= sd[i * 4 + k] * y[k];
+            y[i] = s / sd[i * 4 + i];
+        }
+        maha[(size_t)t * nD + d] = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+        iou[(size_t)t * nD + d] = iou_dist_pair(sd + 20, sd[24], z);
+    }
+    // feature distance: one wave per detection column, fp64 accumulation (distance.py:47-87)
+    const int wv = tid >> 6, lane = tid & 63;
+    if (cnt > 0) {
+        for (int d = wv; d < nD; d += 4) {
+            const float* b = emb + (size_t)d * dim;
+            double acc0 = 0., acc1 = 0., acc2 = 0.;
+            for (int k4 = lane; k4 < dim / 4; k4 += 64) {
+                const float4 bv = *reinterpret_cast<const float4*>(b + k4 * 4);
+                const float4 av = *reinterpret_cast<const float4*>(sa + k4 * 4);
+                const double a0 = av.x, a1 = av.y, a2 = av.z, a3 = av.w;
+                const double b0 = bv.x, b1 = bv.y, b2 = bv.z, b3 = bv.w;
+                if (metric == FM_METRIC_COSINE) {
+                    acc0 += a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
+                    acc1 += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+                    acc2 += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+                } else {
+                    const double d0 = a0 - b0, d1 = a1 - b1, d2 = a2 - b2, d3 = a3 - b3;
+                    acc0 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                acc0 += __shfl_xor(acc0, off);
+                acc1 += __shfl_xor(acc1, off);
+                acc2 += __shfl_xor(acc2, off);
+            }
+            if (lane == 0) {
+                double v;
+                if (metric == FM_METRIC_COSINE) v = 1. - acc0 / (sqrt(acc1) * sqrt(acc2));
+                else v = sqrt(acc0);
+                feat[(size_t)t * nD + d] = v;
+            }
+        }
+    } else {
+        for (int d = tid; d < nD; d += 256) feat[(size_t)t * nD + d] = 1.;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stage cost matrix (gather + fuse_motion + gate_cost)
+// ---------------------------------------------------------------------------------------
+__global__ void stage_cost_kernel(int stage, int nr, int nc, int nD, const int32_t* __restrict__ rows,
+                                  const int32_t* __restrict__ cols, const int64_t* __restrict__ rlab,
+                                  const int64_t* __restrict__ dlab, const uint8_t* __restrict__ docc,
+                                  const uint8_t* __restrict__ row_has_feat,
+                                  const double* __restrict__ feat, const double* __restrict__ maha,
+                                  const double* __restrict__ iou, double motion_weight,
+                                  double max_cost, double fill_val, double* __restrict__ cost) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nr * nc) return;
+    const int i = idx / nc, j = idx % nc;
+    const int t = rows[i], d = cols[j];
+    const size_t p = (size_t)t * nD + d;
+    const bool lab_bad = rlab[i] != dlab[d];
+    double c;
+    if (stage == FM_STAGE_MATCHING) {
+        // tracker.py:326-340 ; utils/matching.py:101-107
+        const bool empty = (!row_has_feat[t]) || docc[d];
+        const double f = empty ? fill_val : feat[p];
+        const double md = maha[p];
+        const double norm_factor = 1. / CHI_SQ_INV_95;
+        const double f_weight = 1. - motion_weight;
+        c = f_weight * f + (motion_weight * norm_factor) * md;
+        if (md > CHI_SQ_INV_95) c = INF_COST;
+        if (lab_bad || c > max_cost) c = INF_COST;
+    } else if (stage == FM_STAGE_IOU) {
+        c = iou[p];
+        if (lab_bad || c > max_cost) c = INF_COST;   // tracker.py:351-352
+    } else {
+        c = feat[p];
+        if (lab_bad) c = INF_COST;                   // tracker.py:363-365 (no threshold)
+    }
+    cost[idx] = c;
+}
+
+// ---------------------------------------------------------------------------------------
+// Rectangular LAP, one wavefront.  Follows SciPy's rectangular_lsap (Crouse 2016):
+// rows are added one at a time; a Dijkstra-like scan over the `remaining` column list finds
+// the shortest augmenting path; ties on the path cost prefer an unassigned column (the
+// LAST one in scan order), otherwise the FIRST column in scan order.  The `remaining` list
+// starts reversed (nc-1 .. 0) and is compacted by swap-with-last, exactly as in SciPy, so
+// the result (not just its cost) is identical.
+// cost element (i, j) = cost[i * rs + j * cs]; requires nr <= nc (host transposes).
+// ---------------------------------------------------------------------------------------
+constexpr int LAP_CODE_BIG = 1 << 24;
+
+// lds_mode: 2 = cost + work arrays in LDS, 1 = work arrays in LDS, 0 = everything in global.
+__global__ __launch_bounds__(64) void lap_kernel(const double* __restrict__ gcost, int nr, int nc,
+                                                 long rs, long cs, double* __restrict__ gwd,
+                                                 int32_t* __restrict__ gwi,
+                                                 int32_t* __restrict__ col4row_out, int lds_mode) {
+    extern __shared__ __attribute__((aligned(16))) char lap_smem[];
+    const int lane = threadIdx.x;
+    const size_t wd_elems = (size_t)nr + 2 * (size_t)nc;
+    double* wd = lds_mode ? reinterpret_cast<double*>(lap_smem) : gwd;
+    int32_t* wi = lds_mode ? reinterpret_cast<int32_t*>(lap_smem + wd_elems * 8) : gwi;
+    const double* cost = gcost;
+    if (lds_mode == 2) {
+        const size_t wi_bytes = (4 * (size_t)nc + 2 * (size_t)nr) * 4;
+        double* lc = reinterpret_cast<double*>(lap_smem + ((wd_elems * 8 + wi_bytes + 15) & ~size_t(15)));
+        // re-pack as [nr][nc] row-major (handles the transposed view)
+        for (int idx = lane; idx < nr * nc; idx += 64) {
+            const int i = idx / nc, j = idx % nc;
+            lc[idx] = gcost[(long)i * rs + (long)j * cs];
+        }
+        cost = lc;
+        rs = nc;
+        cs = 1;
+    }
+    double* u = wd;            // [nr]
+    double* v = u + nr;        // [nc]
+    double* spc = v + nc;      // [nc]
+    int32_t* path = wi;        // [nc]
+    int32_t* col4row = path + nc;   // [nr]
+    int32_t* row4col = col4row + nr;  // [nc]
+    int32_t* remaining = row4col + nc;  // [nc]
+    int32_t* SR = remaining + nc;   // [nr]
+    int32_t* SC = SR + nr;          // [nc]
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.; col4row[i] = -1; }
+    for (int j = lane; j < nc; j += 64) { v[j] = 0.; row4col[j] = -1; path[j] = -1; }
+    __syncthreads();
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int i = lane; i < nr; i += 64) SR[i] = 0;
+        for (int j = lane; j < nc; j += 64) { SC[j] = 0; spc[j] = INF; remaining[j] = nc - j - 1; }
+        __syncthreads();
+        int num_remaining = nc, sink = -1, i = cur;
+        double minVal = 0.;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            double best = INF;
+            int bcode = -1;
+            const double ui = u[i];
+            for (int it = lane; it < num_remaining; it += 64) {
+                const int j = remaining[it];
+                const double r = ((minVal + cost[(long)i * rs + (long)j * cs]) - ui) - v[j];
+                double s = spc[j];
+                if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                const int code = (row4col[j] == -1) ? (LAP_CODE_BIG + it) : (LAP_CODE_BIG - 1 - it);
+                if (s < best || (s == best && code > bcode)) { best = s; bcode = code; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int oc = __shfl_xor(bcode, off);
+                if (ob < best || (ob == best && oc > bcode)) { best = ob; bcode = oc; }
+            }
+            // best/bcode are now wave-uniform
+            if (bcode < 0 || best == INF) { sink = -2; break; }   // infeasible
+            minVal = best;
+            const int index = bcode >= LAP_CODE_BIG ? bcode - LAP_CODE_BIG : LAP_CODE_BIG - 1 - bcode;
+            const int j = remaining[index];
+            const int r4c = row4col[j];
+            if (r4c == -1) sink = j; else i = r4c;
+            __syncthreads();
+            if (lane == 0) {
+                SC[j] = 1;
+                remaining[index] = remaining[num_remaining - 1];
+            }
+            --num_remaining;
+            __syncthreads();
+        }
+        if (sink < 0) {   // cannot happen for finite costs; flag and stop
+            if (lane == 0) col4row_out[0] = -2;
+            return;
+        }
+        // dual update
+        for (int r = lane; r < nr; r += 64)
+            if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
+        for (int j = lane; j < nc; j += 64)
+            if (SC[j]) v[j] -= minVal - spc[j];
+        __syncthreads();
+        if (lane == 0) {
+            u[cur] += minVal;
+            int j = sink;
+            while (true) {   // augment
+                const int r = path[j];
+                row4col[j] = r;
+                const int tmp = col4row[r];
+                col4row[r] = j;
+                j = tmp;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    for (int r = lane; r < nr; r += 64) col4row_out[r] = col4row[r];
+}
+
+// ---------------------------------------------------------------------------------------
+// greedy matching (utils/matching.py:74-97): repeated first-minimum argmin over the alive
+// sub-matrix; per-row minima are cached and only invalidated rows are rescanned.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void greedy_kernel(const double* __restrict__ cost, int nr, int nc,
+                                                     double max_cost, double* __restrict__ rmin,
+                                                     int32_t* __restrict__ rarg,
+                                                     int32_t* __restrict__ alive,   // [nr] rows | [nc] cols
+                                                     int32_t* __restrict__ m_rows,
+                                                     int32_t* __restrict__ m_cols,
+                                                     int32_t* __restrict__ n_match) {
+    __shared__ double s_val[256];
+    __shared__ int s_row[256];
+    __shared__ int s_state[3];
+    const int tid = threadIdx.x;
+    int32_t* row_alive = alive;
+    int32_t* col_alive = alive + nr;
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    for (int i = tid; i < nr; i += 256) { row_alive[i] = 1; rarg[i] = -2; }
+    for (int j = tid; j < nc; j += 256) col_alive[j] = 1;
+    if (tid == 0) s_state[0] = 0;
+    __syncthreads();
+    const int iters = nr < nc ? nr : nc;
+    for (int it = 0; it < iters; ++it) {
+        // refresh stale row minima
+        for (int i = tid; i < nr; i += 256) {
+            if (!row_alive[i]) continue;
+            const int a = rarg[i];
+            if (a == -2 || !col_alive[a]) {
+                double bv = INF;
+                int bj = -1;
+                for (int j = 0; j < nc; ++j)
+                    if (col_alive[j]) {
+                        const double c = cost[(size_t)i * nc + j];
+                        if (bj < 0 || c < bv) { bv = c; bj = j; }
+                    }
+                rmin[i] = bv;
+                rarg[i] = bj;
+            }
+        }
+        __syncthreads();
+        double bv = INF;
+        int bi = -1;
+        for (int i = tid; i < nr; i += 256)
+            if (row_alive[i] && (bi < 0 || rmin[i] < bv)) { bv = rmin[i]; bi = i; }
+        s_val[tid] = bv;
+        s_row[tid] = bi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                const double ov = s_val[tid + off];
+                const int oi = s_row[tid + off];
+                const int mi = s_row[tid];
+                if (oi >= 0 && (mi < 0 || ov < s_val[tid] || (ov == s_val[tid] && oi < mi))) {
+                    s_val[tid] = ov;
+                    s_row[tid] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const int i = s_row[0];
+            int stop = 1;
+            if (i >= 0 && s_val[0] <= max_cost) {
+                const int j = rarg[i];
+                const int k = s_state[0];
+                m_rows[k] = i;
+                m_cols[k] = j;
+                s_state[0] = k + 1;
+                row_alive[i] = 0;
+                col_alive[j] = 0;
+                stop = 0;
+            }
+            s_state[1] = stop;
+        }
+        __syncthreads();
+        if (s_state[1]) break;
+    }
+    if (tid == 0) *n_match = s_state[0];
+}
+
+int upload(fm_ctx* ctx, DevBuf& buf, const std::vector<std::pair<const void*, size_t>>& parts,
+           std::vector<size_t>& offs) {
+    size_t total = 0;
+    offs.clear();
+    for (auto& p : parts) {
+        offs.push_back(total);
+        total += (p.second + 15) & ~size_t(15);
+    }
+    int rc = buf.reserve(total ? total : 16);
+    if (rc) return rc;
+    FM_HIP(hipStreamSynchronize(ctx->s_main));   // host mirror reuse
+    char* h = buf.host<char>();
+    for (size_t i = 0; i < parts.size(); ++i)
+        if (parts[i].second) memcpy(h + offs[i], parts[i].first, parts[i].second);
+    if (total) FM_HIP(hipMemcpyAsync(buf.d, h, total, hipMemcpyHostToDevice, ctx->s_main));
+    return 0;
+}
+
+// Runs the LAP kernel on a device cost matrix [nr][nc]; outputs SciPy-ordered (rows, cols).
+int run_lap(fm_ctx* ctx, const double* d_cost, int nr, int nc, int32_t* m_rows, int32_t* m_cols,
+            int* n_match) {
+    *n_match = 0;
+    if (nr == 0 || nc == 0) return 0;
+    const bool transpose = nc < nr;   // SciPy works on the transposed problem when nc < nr
+    const int R = transpose ? nc : nr, C = transpose ? nr : nc;
+    const long rs = transpose ? 1 : nc, cs = transpose ? nc : 1;
+    const size_t wd_bytes = sizeof(double) * (R + 2 * (size_t)C);
+    const size_t wi_bytes = sizeof(int32_t) * (4 * (size_t)C + 2 * (size_t)R);
+    int rc = ctx->as_work.reserve(wd_bytes + wi_bytes + 64);
+    if (rc) return rc;
+    if ((rc = ctx->as_out.reserve(sizeof(int32_t) * (size_t)(R + 8)))) return rc;
+    char* w = ctx->as_work.dev<char>();
+    const size_t work_lds = ((wd_bytes + wi_bytes + 15) & ~size_t(15));
+    const size_t cost_lds = sizeof(double) * (size_t)R * C;
+    const size_t lds_limit = 150 * 1024;
+    int lds_mode = 0;
+    size_t shmem = 0;
+    if (work_lds + cost_lds <= lds_limit) { lds_mode = 2; shmem = work_lds + cost_lds; }
+    else if (work_lds <= lds_limit) { lds_mode = 1; shmem = work_lds; }
+    if (shmem > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lap_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(lap_kernel, dim3(1), dim3(64), shmem, ctx->s_main, d_cost, R, C, rs, cs, (double*)w,
+                       (int32_t*)(w + ((wd_bytes + 15) & ~size_t(15))), ctx->as_out.dev<int32_t>(), lds_mode);
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(ctx->as_out.h, ctx->as_out.d, sizeof(int32_t) * R, hipMemcpyDeviceToHost, ctx->s_main));
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    const int32_t* c4r = ctx->as_out.host<int32_t>();
+    if (c4r[0] == -2) {
+        fm_set_error("cost matrix is infeasible");
+        return FM_ERR_STATE;
+    }
+    if (!transpose) {
+        for (int i = 0; i < R; ++i) { m_rows[i] = i; m_cols[i] = c4r[i]; }
+    } else {
+        // rows of the original problem ascending: argsort(col4row)
+        std::vector<int> order(R);
+        for (int i = 0; i < R; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return c4r[a] < c4r[b]; });
+        for (int k = 0; k < R; ++k) { m_rows[k] = c4r[order[k]]; m_cols[k] = order[k]; }
+    }
+    *n_match = R;
+    return 0;
+}
+
+int run_greedy(fm_ctx* ctx, const double* d_cost, int nr, int nc, double max_cost, int32_t* m_rows,
+               int32_t* m_cols, int* n_match) {
+    *n_match = 0;
+    if (nr == 0 || nc == 0) return 0;
+    const int mn = nr < nc ? nr : nc;
+    const size_t o_rarg = sizeof(double) * nr, o_alive = o_rarg + sizeof(int32_t) * nr;
+    int rc = ctx->as_work.reserve(o_alive + sizeof(int32_t) * ((size_t)nr + nc) + 64);
+    if (rc) return rc;
+    const size_t out_bytes = sizeof(int32_t) * (2 * (size_t)mn + 4);
+    if ((rc = ctx->as_out.reserve(out_bytes))) return rc;
+    char* w = ctx->as_work.dev<char>();
+    int32_t* o = ctx->as_out.dev<int32_t>();
+    hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(256), 0, ctx->s_main, d_cost, nr, nc, max_cost,
+                       (double*)w, (int32_t*)(w + o_rarg), (int32_t*)(w + o_alive), o + 4, o + 4 + mn, o);
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(ctx->as_out.h, ctx->as_out.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    const int32_t* ho = ctx->as_out.host<int32_t>();
+    const int n = ho[0];
+    memcpy(m_rows, ho + 4, sizeof(int32_t) * n);
+    memcpy(m_cols, ho + 4 + mn, sizeof(int32_t) * n);
+    *n_match = n;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int fm_find_occluded(fm_ctx* ctx, int n, const double* tlbr, double thresh, uint8_t* out) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return 0;
+    FM_CHECK_ARG(tlbr && out);
+    std::vector<size_t> offs;
+    int rc = upload(ctx, ctx->io0, {{tlbr, sizeof(double) * 4 * n}}, offs);
+    if (rc) return rc;
+    if ((rc = ctx->io1.reserve(n))) return rc;
+    hipLaunchKernelGGL(occluded_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->s_main, n,
+                       ctx->io0.dev<double>(), thresh, ctx->io1.dev<uint8_t>());
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, n, hipMemcpyDeviceToHost, ctx->s_main));
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    memcpy(out, ctx->io1.h, n);
+    return 0;
+}
+
+extern "C" int fm_iou_dist(fm_ctx* ctx, int na, const double* a, int nb, const double* b, double* out) {
+    FM_CHECK_ARG(ctx && na >= 0 && nb >= 0);
+    if (na == 0 || nb == 0) return 0;
+    FM_CHECK_ARG(a && b && out);
+    std::vector<size_t> offs;
+    int rc = upload(ctx, ctx->io0, {{a, sizeof(double) * 4 * na}, {b, sizeof(double) * 4 * nb}}, offs);
+    if (rc) return rc;
+    const size_t ob = sizeof(double) * (size_t)na * nb;
+    if ((rc = ctx->io1.reserve(ob))) return rc;
+    char* d = ctx->io0.dev<char>();
+    hipLaunchKernelGGL(iou_dist_kernel, dim3((na * nb + 255) / 256), dim3(256), 0, ctx->s_main, na,
+                       (const double*)(d + offs[0]), nb, (const double*)(d + offs[1]), ctx->io1.dev<double>());
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, ob, hipMemcpyDeviceToHost, ctx->s_main));
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    memcpy(out, ctx->io1.h, ob);
+    return 0;
+}
+
+
+extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* slots,
+                                const double* trk_tlbr, const int64_t* trk_label, int nD,
+                                const double* det_tlbr, const int64_t* det_label,
+                                const uint8_t* det_occluded) {
+    FM_CHECK_ARG(ctx && nT >= 0 && nD >= 0 && ctx->kf_set);
+    FM_CHECK_ARG(metric == FM_METRIC_EUCLIDEAN || metric == FM_METRIC_COSINE);
+    ctx->as_nT = nT;
+    ctx->as_nD = nD;
+    ctx->as_metric = metric;
+    if (nT == 0 || nD == 0) return 0;
+    FM_CHECK_ARG(slots && trk_tlbr && trk_label && det_tlbr && det_label && det_occluded);
+    FM_CHECK_ARG(nD <= ctx->emb_n);
+    for (int i = 0; i < nT; ++i) FM_CHECK_ARG(slots[i] >= 0 && slots[i] < ctx->slot_cap);
+    std::vector<size_t> offs;
+    int rc = upload(ctx, ctx->as_in,
+                    {{slots, sizeof(int32_t) * nT}, {trk_tlbr, sizeof(double) * 4 * nT},
+                     {trk_label, sizeof(int64_t) * nT}, {det_tlbr, sizeof(double) * 4 * nD},
+                     {det_label, sizeof(int64_t) * nD}, {det_occluded, (size_t)nD}}, offs);
+    if (rc) return rc;
+    for (int i = 0; i < 6; ++i) ctx->as_off[i] = offs[i];
+    const size_t mat = sizeof(double) * (size_t)nT * nD;
+    if ((rc = ctx->as_pair.reserve(3 * mat + nT + 64))) return rc;
+    char* in = ctx->as_in.dev<char>();
+    char* pr = ctx->as_pair.dev<char>();
+    const size_t shmem = (size_t)ctx->feat_dim * 4 + 32 * sizeof(double);
+    hipLaunchKernelGGL(pairwise_kernel, dim3(nT), dim3(256), shmem, ctx->s_main, nT, nD, metric,
+                       ctx->feat_dim, (const int32_t*)(in + offs[0]), (const double*)(in + offs[1]),
+                       (const double*)(in + offs[3]), ctx->mean, ctx->cov, ctx->feat_avg, ctx->feat_cnt,
+                       ctx->emb, ctx->kf, (double*)pr, (double*)(pr + mat), (double*)(pr + 2 * mat),
+                       (uint8_t*)(pr + 3 * mat));
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int fm_assoc_get_pairwise(fm_ctx* ctx, double* feat, double* maha, double* iou) {
+    FM_CHECK_ARG(ctx);
+    const size_t mat = sizeof(double) * (size_t)ctx->as_nT * ctx->as_nD;
+    if (mat == 0) return 0;
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    char* pr = ctx->as_pair.dev<char>();
+    if (feat) FM_HIP(hipMemcpy(feat, pr, mat, hipMemcpyDeviceToHost));
+    if (maha) FM_HIP(hipMemcpy(maha, pr + mat, mat, hipMemcpyDeviceToHost));
+    if (iou) FM_HIP(hipMemcpy(iou, pr + 2 * mat, mat, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int fm_assoc_stage(fm_ctx* ctx, int stage, int solver, int nr, const int32_t* rows, int nc,
+                              const int32_t* cols, double motion_weight, double max_cost,
+                              double fill_val, const int64_t* row_label_override, int32_t* m_rows,
+                              int32_t* m_cols, uint8_t* match_gated, int* n_match, double* cost_out) {
+    FM_CHECK_ARG(ctx && n_match && nr >= 0 && nc >= 0);
+    FM_CHECK_ARG(stage >= FM_STAGE_MATCHING && stage <= FM_STAGE_REID && (solver == 0 || solver == 1));
+    *n_match = 0;
+    if (nr == 0 || nc == 0) return 0;
+    FM_CHECK_ARG(rows && cols && m_rows && m_cols);
+    const int nT = ctx->as_nT, nD = ctx->as_nD;
+    for (int i = 0; i < nr; ++i) FM_CHECK_ARG(rows[i] >= 0 && rows[i] < nT);
+    for (int j = 0; j < nc; ++j) FM_CHECK_ARG(cols[j] >= 0 && cols[j] < nD);
+    // row labels: override or the labels given at prepare time (gathered on the host: tiny)
+    std::vector<int64_t> rlab(nr);
+    if (row_label_override) memcpy(rlab.data(), row_label_override, sizeof(int64_t) * nr);
+    else {
+        const int64_t* tl = reinterpret_cast<const int64_t*>(ctx->as_in.host<char>() + ctx->as_off[2]);
+        for (int i = 0; i < nr; ++i) rlab[i] = tl[rows[i]];
+    }
+    std::vector<size_t> offs;
+    int rc = upload(ctx, ctx->as_stage_in,
+                    {{rows, sizeof(int32_t) * nr}, {cols, sizeof(int32_t) * nc},
+                     {rlab.data(), sizeof(int64_t) * nr}}, offs);
+    if (rc) return rc;
+    const size_t cbytes = sizeof(double) * (size_t)nr * nc;
+    if ((rc = ctx->as_cost.reserve(cbytes))) return rc;
+    const size_t mat = sizeof(double) * (size_t)nT * nD;
+    char* in = ctx->as_in.dev<char>();
+    char* pr = ctx->as_pair.dev<char>();
+    char* si = ctx->as_stage_in.dev<char>();
+    hipLaunchKernelGGL(stage_cost_kernel, dim3((nr * nc + 255) / 256), dim3(256), 0, ctx->s_main, stage,
+                       nr, nc, nD, (const int32_t*)(si + offs[0]), (const int32_t*)(si + offs[1]),
+                       (const int64_t*)(si + offs[2]), (const int64_t*)(in + ctx->as_off[4]),
+                       (const uint8_t*)(in + ctx->as_off[5]), (const uint8_t*)(pr + 3 * mat),
+                       (const double*)pr, (const double*)(pr + mat), (const double*)(pr + 2 * mat),
+                       motion_weight, max_cost, fill_val, ctx->as_cost.dev<double>());
+    FM_HIP(hipGetLastError());
+    const bool need_cost = cost_out != nullptr || (solver == 0 && match_gated != nullptr);
+    if (need_cost)
+        FM_HIP(hipMemcpyAsync(ctx->as_cost.h, ctx->as_cost.d, cbytes, hipMemcpyDeviceToHost, ctx->s_main));
+    if (solver == 0) rc = run_lap(ctx, ctx->as_cost.dev<double>(), nr, nc, m_rows, m_cols, n_match);
+    else rc = run_greedy(ctx, ctx->as_cost.dev<double>(), nr, nc, max_cost, m_rows, m_cols, n_match);
+    if (rc) return rc;
+    const double* hc = ctx->as_cost.host<double>();
+    if (solver == 0 && match_gated)
+        for (int k = 0; k < *n_match; ++k)   // utils/matching.py:65
+            match_gated[k] = hc[(size_t)m_rows[k] * nc + m_cols[k]] < INF_COST ? 0 : 1;
+    if (cost_out) memcpy(cost_out, hc, cbytes);
+    return 0;
+}
+
+extern "C" int fm_lap(fm_ctx* ctx, const double* cost, int nr, int nc, int32_t* m_rows,
+                      int32_t* m_cols, int* n_match) {
+    FM_CHECK_ARG(ctx && n_match && nr >= 0 && nc >= 0);
+    *n_match = 0;
+    if (nr == 0 || nc == 0) return 0;
+    FM_CHECK_ARG(cost && m_rows && m_cols);
+    std::vector<size_t> offs;
+    int rc = upload(ctx, ctx->as_cost, {{cost, sizeof(double) * (size_t)nr * nc}}, offs);
+    if (rc) return rc;
+    return run_lap(ctx, ctx->as_cost.dev<double>(), nr, nc, m_rows, m_cols, n_match);
+}
+
+extern "C" int fm_greedy(fm_ctx* ctx, const double* cost, int nr, int nc, double max_cost,
+                         int32_t* m_rows, int32_t* m_cols, int* n_match) {
+    FM_CHECK_ARG(ctx && n_match && nr >= 0 && nc >= 0);
+    *n_match = 0;
+    if (nr == 0 || nc == 0) return 0;
+    FM_CHECK_ARG(cost && m_rows && m_cols);
+    std::vector<size_t> offs;
+    int rc = upload(ctx, ctx->as_cost, {{cost, sizeof(double) * (size_t)nr * nc}}, offs);
+    if (rc) return rc;
+    return run_greedy(ctx, ctx->as_cost.dev<double>(), nr, nc, max_cost, m_rows, m_cols, n_match);
+}

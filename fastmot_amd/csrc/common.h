@@ -1,0 +1,117 @@
+// Internal definitions shared by the libfastmot_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/fastmot_hip.h"
+
+#define FM_ERR_HIP (-1)
+#define FM_ERR_ARG (-2)
+#define FM_ERR_STATE (-3)
+
+void fm_set_error(const char* fmt, ...);
+
+#define FM_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            fm_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return FM_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+#define FM_CHECK_ARG(cond)                                                     \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            fm_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); \
+            return FM_ERR_ARG;                                                 \
+        }                                                                      \
+    } while (0)
+
+// Growable device buffer with a pinned host mirror (HostDeviceMem of utils/inference.py:7-36).
+struct DevBuf {
+    void* d = nullptr;
+    void* h = nullptr;   // pinned
+    size_t cap = 0;
+    bool pinned_mirror = true;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        size_t ncap = cap ? cap : 4096;
+        while (ncap < bytes) ncap *= 2;
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        d = h = nullptr;
+        cap = 0;
+        FM_HIP(hipMalloc(&d, ncap));
+        if (pinned_mirror) FM_HIP(hipHostMalloc(&h, ncap, hipHostMallocDefault));
+        cap = ncap;
+        return 0;
+    }
+    void release() {
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        d = h = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* dev() { return reinterpret_cast<T*>(d); }
+    template <typename T> T* host() { return reinterpret_cast<T*>(h); }
+};
+
+struct KFConst {           // constants derived from fm_kf_params, passed by value to kernels
+    double F_pos_self;     // vel_coupling * dt
+    double F_pos_other;    // (1 - vel_coupling) * dt
+    double F_vel;          // 0.5^(dt / half_life)
+    double q_pp, q_pv, q_vv;   // dt^4/4, dt^3/2, dt^2
+    double std_factor_acc, std_offset_acc;
+    double fac_det[2], fac_klt[2], min_det[2], min_klt[2];
+    double init_pos_weight, init_vel_weight;
+};
+
+struct NetState;     // conv engine (net.hip)
+struct FlowState;    // KLT (flow.hip)
+
+struct fm_ctx {
+    int device = 0;
+    hipStream_t s_main = nullptr;   // tracker kernels
+    hipStream_t s_det = nullptr;    // detector network
+    hipStream_t s_ext = nullptr;    // ReID network
+    hipStream_t s_flow = nullptr;   // KLT
+
+    // ---- device-resident track table
+    int slot_cap = 0;
+    double* mean = nullptr;      // [cap][8]
+    double* cov = nullptr;       // [cap][64]
+    int feat_dim = 512;
+    float* feat_sum = nullptr;   // [cap][dim]
+    float* feat_avg = nullptr;   // [cap][dim]
+    int32_t* feat_cnt = nullptr; // [cap]
+    KFConst kf{};
+    bool kf_set = false;
+    double frame_rect[4] = {0, 0, 0, 0};
+
+    // ---- per-frame embeddings on the device [n][dim] f32
+    float* emb = nullptr;
+    int emb_cap = 0;
+    int emb_n = 0;
+
+    // ---- association scratch
+    int as_nT = 0, as_nD = 0, as_metric = 0;
+    size_t as_off[6] = {0, 0, 0, 0, 0, 0};   // slots|trk_tlbr|trk_label|det_tlbr|det_label|det_occ
+    DevBuf as_in;       // packed inputs of fm_assoc_prepare
+    DevBuf as_pair;     // feat | maha | iou  [3][nT][nD] f64
+    DevBuf as_stage_in; // rows, cols, labels
+    DevBuf as_cost;     // [nr][nc] f64
+    DevBuf as_work;     // LAP work arrays
+    DevBuf as_out;      // matches
+    DevBuf io0, io1;    // generic staging (kalman etc.)
+
+    NetState* det_net = nullptr;
+    NetState* ext_net = nullptr;
+    FlowState* flow = nullptr;
+};
+
+int fm_ensure_slots(fm_ctx* ctx, int max_slot_plus_1);

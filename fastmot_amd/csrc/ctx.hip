@@ -1,0 +1,366 @@
+// Context / device-resident track table management for libfastmot_hip.so.
+// Replaces the buffer + stream plumbing of fastmot/utils/inference.py:7-125 (HostDeviceMem,
+// TRTInference) with plain HIP: one ctx per video stream, four HIP streams, pinned mirrors.
+#include "common.h"
+#include <cmath>
+
+static thread_local char g_err[1024] = "";
+
+void fm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* fm_last_error(void) { return g_err; }
+
+extern "C" int fm_device_count(void) {
+    int n = 0;
+    FM_HIP(hipGetDeviceCount(&n));
+    return n;
+}
+
+void fm_net_free(NetState* n);
+void fm_flow_free(FlowState* f);
+
+extern "C" int fm_ctx_create(int device, fm_ctx** out) {
+    FM_CHECK_ARG(out != nullptr);
+    int n = 0;
+    FM_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) {
+        fm_set_error("device %d out of range (%d visible)", device, n);
+        return FM_ERR_ARG;
+    }
+    FM_HIP(hipSetDevice(device));
+    fm_ctx* ctx = new fm_ctx();
+    ctx->device = device;
+    FM_HIP(hipStreamCreateWithFlags(&ctx->s_main, hipStreamNonBlocking));
+    FM_HIP(hipStreamCreateWithFlags(&ctx->s_det, hipStreamNonBlocking));
+    FM_HIP(hipStreamCreateWithFlags(&ctx->s_ext, hipStreamNonBlocking));
+    FM_HIP(hipStreamCreateWithFlags(&ctx->s_flow, hipStreamNonBlocking));
+    int rc = fm_ensure_slots(ctx, 1024);
+    if (rc) return rc;
+    *out = ctx;
+    return 0;
+}
+
+extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->det_net) fm_net_free(ctx->det_net);
+    if (ctx->ext_net) fm_net_free(ctx->ext_net);
+    if (ctx->flow) fm_flow_free(ctx->flow);
+    for (void* p : {(void*)ctx->mean, (void*)ctx->cov, (void*)ctx->feat_sum, (void*)ctx->feat_avg,
+                    (void*)ctx->feat_cnt, (void*)ctx->emb})
+        if (p) (void)hipFree(p);
+    for (DevBuf* b : {&ctx->as_in, &ctx->as_pair, &ctx->as_stage_in, &ctx->as_cost, &ctx->as_work,
+                      &ctx->as_out, &ctx->io0, &ctx->io1})
+        b->release();
+    for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_ext, ctx->s_flow})
+        if (s) (void)hipStreamDestroy(s);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int fm_ctx_synchronize(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx);
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    FM_HIP(hipStreamSynchronize(ctx->s_det));
+    FM_HIP(hipStreamSynchronize(ctx->s_ext));
+    FM_HIP(hipStreamSynchronize(ctx->s_flow));
+    return 0;
+}
+
+extern "C" int fm_device_info(fm_ctx* ctx, char* buf, int buflen) {
+    FM_CHECK_ARG(ctx && buf && buflen > 0);
+    hipDeviceProp_t p;
+    FM_HIP(hipGetDeviceProperties(&p, ctx->device));
+    snprintf(buf, buflen, "%s:%s:%d:%d:%zu", p.name, p.gcnArchName, p.multiProcessorCount,
+             p.clockRate / 1000, (size_t)p.totalGlobalMem);
+    return 0;
+}
+
+template <typename T>
+static int grow(T** ptr, size_t old_elems, size_t new_elems, hipStream_t s, bool zero) {
+    T* np_ = nullptr;
+    FM_HIP(hipMalloc(&np_, new_elems * sizeof(T)));
+    if (zero) FM_HIP(hipMemsetAsync(np_, 0, new_elems * sizeof(T), s));
+    if (*ptr && old_elems)
+        FM_HIP(hipMemcpyAsync(np_, *ptr, old_elems * sizeof(T), hipMemcpyDeviceToDevice, s));
+    FM_HIP(hipStreamSynchronize(s));
+    if (*ptr) FM_HIP(hipFree(*ptr));
+    *ptr = np_;
+    return 0;
+}
+
+int fm_ensure_slots(fm_ctx* ctx, int need) {
+    if (need <= ctx->slot_cap) return 0;
+    int ncap = ctx->slot_cap ? ctx->slot_cap : 1024;
+    while (ncap < need) ncap *= 2;
+    size_t o = ctx->slot_cap, n = ncap;
+    int rc;
+    if ((rc = grow(&ctx->mean, o * 8, n * 8, ctx->s_main, true))) return rc;
+    if ((rc = grow(&ctx->cov, o * 64, n * 64, ctx->s_main, true))) return rc;
+    if ((rc = grow(&ctx->feat_sum, o * ctx->feat_dim, n * ctx->feat_dim, ctx->s_main, true))) return rc;
+    if ((rc = grow(&ctx->feat_avg, o * ctx->feat_dim, n * ctx->feat_dim, ctx->s_main, true))) return rc;
+    if ((rc = grow(&ctx->feat_cnt, o, n, ctx->s_main, true))) return rc;
+    ctx->slot_cap = ncap;
+    return 0;
+}
+
+extern "C" int fm_kf_configure(fm_ctx* ctx, const fm_kf_params* p) {
+    FM_CHECK_ARG(ctx && p);
+    FM_CHECK_ARG(p->dt > 0 && p->vel_half_life > 0);
+    KFConst& k = ctx->kf;
+    const double dt = p->dt;
+    // kalman_filter.py:294-306 (_init_mat)
+    k.F_pos_self = p->vel_coupling * dt;
+    k.F_pos_other = (1. - p->vel_coupling) * dt;
+    k.F_vel = std::pow(0.5, dt / p->vel_half_life);
+    k.q_pp = 0.25 * std::pow(dt, 4);
+    k.q_pv = 0.5 * std::pow(dt, 3);
+    k.q_vv = dt * dt;
+    k.std_factor_acc = p->std_factor_acc;
+    k.std_offset_acc = p->std_offset_acc;
+    for (int i = 0; i < 2; ++i) {
+        k.fac_det[i] = p->std_factor_det[i];
+        k.fac_klt[i] = p->std_factor_klt[i];
+        k.min_det[i] = p->min_std_det[i];
+        k.min_klt[i] = p->min_std_klt[i];
+    }
+    k.init_pos_weight = p->init_pos_weight;
+    k.init_vel_weight = p->init_vel_weight;
+    ctx->kf_set = true;
+    return 0;
+}
+
+extern "C" int fm_set_frame_rect(fm_ctx* ctx, const double tlbr[4]) {
+    FM_CHECK_ARG(ctx && tlbr);
+    memcpy(ctx->frame_rect, tlbr, sizeof(double) * 4);
+    return 0;
+}
+
+static int max_slot(int n, const int32_t* slots) {
+    int m = -1;
+    for (int i = 0; i < n; ++i) {
+        if (slots[i] < 0) return -2;
+        if (slots[i] > m) m = slots[i];
+    }
+    return m;
+}
+
+extern "C" int fm_trk_get_state(fm_ctx* ctx, int n, const int32_t* slots, double* mean, double* cov) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return 0;
+    FM_CHECK_ARG(slots && mean && cov);
+    int m = max_slot(n, slots);
+    FM_CHECK_ARG(m >= 0 && m < ctx->slot_cap);
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    for (int i = 0; i < n; ++i) {
+        FM_HIP(hipMemcpy(mean + (size_t)i * 8, ctx->mean + (size_t)slots[i] * 8, 64, hipMemcpyDeviceToHost));
+        FM_HIP(hipMemcpy(cov + (size_t)i * 64, ctx->cov + (size_t)slots[i] * 64, 512, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" int fm_trk_set_state(fm_ctx* ctx, int n, const int32_t* slots, const double* mean, const double* cov) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return 0;
+    FM_CHECK_ARG(slots && mean && cov);
+    int m = max_slot(n, slots);
+    FM_CHECK_ARG(m >= 0);
+    int rc = fm_ensure_slots(ctx, m + 1);
+    if (rc) return rc;
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    for (int i = 0; i < n; ++i) {
+        FM_HIP(hipMemcpy(ctx->mean + (size_t)slots[i] * 8, mean + (size_t)i * 8, 64, hipMemcpyHostToDevice));
+        FM_HIP(hipMemcpy(ctx->cov + (size_t)slots[i] * 64, cov + (size_t)i * 64, 512, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int fm_trk_copy_state(fm_ctx* ctx, int dst, int src) {
+    FM_CHECK_ARG(ctx && dst >= 0 && src >= 0 && src < ctx->slot_cap);
+    int rc = fm_ensure_slots(ctx, dst + 1);
+    if (rc) return rc;
+    FM_HIP(hipMemcpyAsync(ctx->mean + (size_t)dst * 8, ctx->mean + (size_t)src * 8, 64,
+                          hipMemcpyDeviceToDevice, ctx->s_main));
+    FM_HIP(hipMemcpyAsync(ctx->cov + (size_t)dst * 64, ctx->cov + (size_t)src * 64, 512,
+                          hipMemcpyDeviceToDevice, ctx->s_main));
+    return 0;
+}
+
+// ------------------------------------------------------------------ ReID feature table
+extern "C" int fm_feat_configure(fm_ctx* ctx, int dim) {
+    FM_CHECK_ARG(ctx && dim > 0 && dim % 4 == 0);
+    if (dim == ctx->feat_dim) return 0;
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    if (ctx->feat_sum) FM_HIP(hipFree(ctx->feat_sum));
+    if (ctx->feat_avg) FM_HIP(hipFree(ctx->feat_avg));
+    ctx->feat_sum = ctx->feat_avg = nullptr;
+    ctx->feat_dim = dim;
+    size_t n = (size_t)ctx->slot_cap * dim;
+    FM_HIP(hipMalloc(&ctx->feat_sum, n * sizeof(float)));
+    FM_HIP(hipMalloc(&ctx->feat_avg, n * sizeof(float)));
+    FM_HIP(hipMemset(ctx->feat_sum, 0, n * sizeof(float)));
+    FM_HIP(hipMemset(ctx->feat_avg, 0, n * sizeof(float)));
+    FM_HIP(hipMemset(ctx->feat_cnt, 0, (size_t)ctx->slot_cap * sizeof(int32_t)));
+    if (ctx->emb) FM_HIP(hipFree(ctx->emb));
+    ctx->emb = nullptr;
+    ctx->emb_cap = ctx->emb_n = 0;
+    return 0;
+}
+
+int fm_emb_reserve(fm_ctx* ctx, int n) {
+    if (n <= ctx->emb_cap) return 0;
+    int ncap = ctx->emb_cap ? ctx->emb_cap : 64;
+    while (ncap < n) ncap *= 2;
+    if (ctx->emb) FM_HIP(hipFree(ctx->emb));
+    ctx->emb = nullptr;
+    FM_HIP(hipMalloc(&ctx->emb, (size_t)ncap * ctx->feat_dim * sizeof(float)));
+    ctx->emb_cap = ncap;
+    return 0;
+}
+
+extern "C" int fm_emb_upload(fm_ctx* ctx, int n, const float* emb) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (emb == nullptr) {  // embeddings already produced on the device by the extractor
+        FM_CHECK_ARG(n <= ctx->emb_cap || n == 0);
+        ctx->emb_n = n;
+        return 0;
+    }
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    int rc = fm_emb_reserve(ctx, n);
+    if (rc) return rc;
+    if (n)
+        FM_HIP(hipMemcpyAsync(ctx->emb, emb, (size_t)n * ctx->feat_dim * sizeof(float),
+                              hipMemcpyHostToDevice, ctx->s_main));
+    ctx->emb_n = n;
+    return 0;
+}
+
+// track.py:119-126 -- sum += v; avg = sum * (1/count); avg *= 1/||avg||   (fp32, in place)
+// One wave per (slot, embedding) pair; the norm is a wave reduction.
+__global__ void feat_update_kernel(int n, const int32_t* __restrict__ slots,
+                                   const int32_t* __restrict__ rows, const float* __restrict__ emb,
+                                   float* __restrict__ fsum, float* __restrict__ favg,
+                                   int32_t* __restrict__ fcnt, int dim) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const int slot = slots[wave];
+    const float* v = emb + (size_t)rows[wave] * dim;
+    float* s = fsum + (size_t)slot * dim;
+    float* a = favg + (size_t)slot * dim;
+    const int cnt = fcnt[slot] + 1;
+    if (cnt == 1) {   // first feature: sum = avg = embedding.copy()   (track.py:108-110)
+        for (int k = lane; k < dim; k += 64) {
+            const float x = v[k];
+            s[k] = x;
+            a[k] = x;
+        }
+    } else {
+        const float div = (float)(1.0 / (double)cnt);
+        float nrm = 0.f;
+        for (int k = lane; k < dim; k += 64) {
+            const float x = s[k] + v[k];
+            s[k] = x;
+            const float m = x * div;
+            a[k] = m;
+            nrm += m * m;
+        }
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off);
+        const float inv = 1.0f / sqrtf(nrm);
+        for (int k = lane; k < dim; k += 64) a[k] *= inv;
+    }
+    if (lane == 0) fcnt[slot] = cnt;
+}
+
+// AverageFeature.merge (track.py:114-117): count += other.count; average(sum, avg, other.sum)
+__global__ void feat_merge_kernel(int dst, int src, float* __restrict__ fsum,
+                                  float* __restrict__ favg, int32_t* __restrict__ fcnt, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int cd = fcnt[dst], cs = fcnt[src];
+    float* s = fsum + (size_t)dst * dim;
+    float* a = favg + (size_t)dst * dim;
+    const float* os = fsum + (size_t)src * dim;
+    const float* oa = favg + (size_t)src * dim;
+    const int cnt = cd + cs;
+    if (cd == 0) {  // self.sum is None -> adopt other's arrays
+        for (int k = lane; k < dim; k += 64) {
+            s[k] = os[k];
+            a[k] = oa[k];
+        }
+    } else if (cs > 0) {
+        const float div = (float)(1.0 / (double)cnt);
+        float nrm = 0.f;
+        for (int k = lane; k < dim; k += 64) {
+            const float x = s[k] + os[k];
+            s[k] = x;
+            const float m = x * div;
+            a[k] = m;
+            nrm += m * m;
+        }
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off);
+        const float inv = 1.0f / sqrtf(nrm);
+        for (int k = lane; k < dim; k += 64) a[k] *= inv;
+    }
+    if (lane == 0) fcnt[dst] = cnt;
+}
+
+extern "C" int fm_feat_update(fm_ctx* ctx, int n, const int32_t* slots, const int32_t* emb_rows) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return 0;
+    FM_CHECK_ARG(slots && emb_rows);
+    int m = max_slot(n, slots);
+    FM_CHECK_ARG(m >= 0);
+    for (int i = 0; i < n; ++i) FM_CHECK_ARG(emb_rows[i] >= 0 && emb_rows[i] < ctx->emb_n);
+    int rc = fm_ensure_slots(ctx, m + 1);
+    if (rc) return rc;
+    // NB: a slot may appear only once per call (sequential semantics of the reference loop)
+    if ((rc = ctx->io0.reserve(sizeof(int32_t) * 2 * n))) return rc;
+    int32_t* h = ctx->io0.host<int32_t>();
+    memcpy(h, slots, sizeof(int32_t) * n);
+    memcpy(h + n, emb_rows, sizeof(int32_t) * n);
+    FM_HIP(hipMemcpyAsync(ctx->io0.d, h, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, ctx->s_main));
+    const int threads = 256, waves_per_block = threads / 64;
+    hipLaunchKernelGGL(feat_update_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(threads),
+                       0, ctx->s_main, n, ctx->io0.dev<int32_t>(), ctx->io0.dev<int32_t>() + n, ctx->emb,
+                       ctx->feat_sum, ctx->feat_avg, ctx->feat_cnt, ctx->feat_dim);
+    FM_HIP(hipGetLastError());
+    // io0 host mirror is reused by the next call -> wait for the H2D to be consumed
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    return 0;
+}
+
+extern "C" int fm_feat_merge(fm_ctx* ctx, int dst, int src) {
+    FM_CHECK_ARG(ctx && dst >= 0 && src >= 0 && dst < ctx->slot_cap && src < ctx->slot_cap && dst != src);
+    hipLaunchKernelGGL(feat_merge_kernel, dim3(1), dim3(64), 0, ctx->s_main, dst, src, ctx->feat_sum,
+                       ctx->feat_avg, ctx->feat_cnt, ctx->feat_dim);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int fm_feat_reset(fm_ctx* ctx, int n, const int32_t* slots) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return 0;
+    int m = max_slot(n, slots);
+    FM_CHECK_ARG(m >= 0);
+    int rc = fm_ensure_slots(ctx, m + 1);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i)
+        FM_HIP(hipMemsetAsync(ctx->feat_cnt + slots[i], 0, sizeof(int32_t), ctx->s_main));
+    return 0;
+}
+
+extern "C" int fm_feat_get(fm_ctx* ctx, int slot, float* sum, float* avg, int32_t* count) {
+    FM_CHECK_ARG(ctx && slot >= 0 && slot < ctx->slot_cap);
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    size_t bytes = (size_t)ctx->feat_dim * sizeof(float);
+    if (sum) FM_HIP(hipMemcpy(sum, ctx->feat_sum + (size_t)slot * ctx->feat_dim, bytes, hipMemcpyDeviceToHost));
+    if (avg) FM_HIP(hipMemcpy(avg, ctx->feat_avg + (size_t)slot * ctx->feat_dim, bytes, hipMemcpyDeviceToHost));
+    if (count) FM_HIP(hipMemcpy(count, ctx->feat_cnt + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}

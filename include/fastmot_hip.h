@@ -1,0 +1,163 @@
+/*
+ * fastmot_hip.h -- C ABI of libfastmot_hip.so, the MI355X (gfx950) implementation of the
+ * FastMOT per-frame hot path (MOT.step and everything under it).
+ *
+ * The reference (GeekAlexis/FastMOT) is Python; its only native boundary is a TensorRT
+ * plugin loaded with ctypes (fastmot/utils/inference.py:49-53).  TensorRT does not exist
+ * on ROCm, so this header DEFINES the boundary: every entry point below replaces the
+ * numeric body of one reference routine (cited as file:line, relative to /root/reference)
+ * and is bound from Python with ctypes (fastmot_amd/_lib.py; INTEGRATION.md shows the stub
+ * a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; fm_last_error() gives the message.
+ *   - the caller owns every host pointer it passes; the library owns all device memory.
+ *   - a ctx is bound to one GPU and is NOT thread safe (one video stream = one ctx = one
+ *     process, mirroring the reference's single-threaded MOT.step, mot.py:125-168).
+ *   - "slot" = index of a track in the device-resident track table (state mean f64[8],
+ *     covariance f64[8][8], running-mean ReID feature f32[512]); slot bookkeeping (which
+ *     slot belongs to which track id) stays in Python, like the reference's dict of Tracks.
+ *   - boxes are tlbr f64[4] with inclusive corners (utils/rect.py:17-57).
+ */
+#ifndef FASTMOT_HIP_H
+#define FASTMOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fm_ctx fm_ctx;
+
+/* ---------------------------------------------------------------- runtime ------------- */
+/* replaces TRTInference.__init__ stream/buffer setup (utils/inference.py:44-94) */
+int fm_ctx_create(int device, fm_ctx** out);
+int fm_ctx_destroy(fm_ctx* ctx);
+const char* fm_last_error(void);
+/* number of visible HIP devices (<0 on error) */
+int fm_device_count(void);
+/* blocks until every stream of the ctx is idle (TRTInference.synchronize, inference.py:119-121) */
+int fm_ctx_synchronize(fm_ctx* ctx);
+/* writes "name:gcnArch:CUs:clockMHz:hbmBytes" of the ctx device */
+int fm_device_info(fm_ctx* ctx, char* buf, int buflen);
+
+/* ---------------------------------------------------------------- Kalman filter ------- */
+/* KalmanFilter.__init__/reset_dt tunables (kalman_filter.py:13-94, _init_mat :294-306) */
+typedef struct fm_kf_params {
+    double dt;
+    double std_factor_acc, std_offset_acc;
+    double std_factor_det[2], std_factor_klt[2];
+    double min_std_det[2], min_std_klt[2];
+    double init_pos_weight, init_vel_weight;
+    double vel_coupling, vel_half_life;
+} fm_kf_params;
+
+int fm_kf_configure(fm_ctx* ctx, const fm_kf_params* p);
+/* frame rectangle used for the "ios(box, frame) < 0.5 => lost" test (tracker.py:180,263) */
+int fm_set_frame_rect(fm_ctx* ctx, const double tlbr[4]);
+
+/* KalmanFilter.create for n new tracks (kalman_filter.py:96-126): state written to slots */
+int fm_trk_create(fm_ctx* ctx, int n, const int32_t* slots, const double* det_tlbr);
+
+/* MultiTracker.apply_kalman body for n tracks in ONE launch (tracker.py:164-183):
+ *   warp(H) -> predict -> [update(klt box, FLOW, mult)] -> as_tlbr -> ios(frame) test.
+ * H: 3x3 row-major homography.  klt_tlbr[n][4], has_klt[n], mult[n] (std multiplier,
+ * tracker.py:175).  Outputs: tlbr_out[n][4] (rounded half-even), lost_out[n] (ios<0.5). */
+int fm_trk_step(fm_ctx* ctx, int n, const int32_t* slots, const double* H,
+                const double* klt_tlbr, const uint8_t* has_klt, const double* mult,
+                double* tlbr_out, uint8_t* lost_out);
+
+/* Same kernel with an explicit stage mask, so that KalmanFilter.warp / predict / update(FLOW)
+ * (kalman_filter.py:128-204,227-292) remain individually callable through the mirror class. */
+enum { FM_KF_WARP = 1, FM_KF_PREDICT = 2, FM_KF_UPDATE_KLT = 4 };
+int fm_trk_step_ops(fm_ctx* ctx, int ops, int n, const int32_t* slots, const double* H,
+                    const double* klt_tlbr, const uint8_t* has_klt, const double* mult,
+                    double* tlbr_out, uint8_t* lost_out);
+
+/* KalmanFilter.update(..., MeasType.DETECTOR) for n matched (slot, detection box) pairs
+ * (tracker.py:259-262).  Same outputs as fm_trk_step. */
+int fm_trk_update_det(fm_ctx* ctx, int n, const int32_t* slots, const double* det_tlbr,
+                      double* tlbr_out, uint8_t* lost_out);
+
+/* Track.state accessors (track.py:134) -- off the hot path (tests, visualisation). */
+int fm_trk_get_state(fm_ctx* ctx, int n, const int32_t* slots, double* mean, double* cov);
+int fm_trk_set_state(fm_ctx* ctx, int n, const int32_t* slots, const double* mean, const double* cov);
+/* state[dst] = state[src]  (Track.merge_continuation, track.py:204-208) */
+int fm_trk_copy_state(fm_ctx* ctx, int dst_slot, int src_slot);
+
+/* ---------------------------------------------------------------- ReID features ------- */
+/* embedding dimension of the running-mean feature table (default 512) */
+int fm_feat_configure(fm_ctx* ctx, int dim);
+/* upload this frame's L2-normalised embeddings [n][dim] f32 (FeatureExtractor.postprocess
+ * output, feature_extractor.py:62-74) so that association can use them on the device.
+ * If emb == NULL the embeddings already produced on the device by fm_extract_* are used. */
+int fm_emb_upload(fm_ctx* ctx, int n, const float* emb);
+/* AverageFeature.update for n (slot, embedding row) pairs (track.py:106-112,119-126) */
+int fm_feat_update(fm_ctx* ctx, int n, const int32_t* slots, const int32_t* emb_rows);
+/* AverageFeature.merge: dst absorbs src (track.py:114-117) */
+int fm_feat_merge(fm_ctx* ctx, int dst_slot, int src_slot);
+/* clears the feature state of n slots (new Track, track.py:142-143) */
+int fm_feat_reset(fm_ctx* ctx, int n, const int32_t* slots);
+int fm_feat_get(fm_ctx* ctx, int slot, float* sum, float* avg, int32_t* count);
+
+/* ---------------------------------------------------------------- association --------- */
+enum { FM_METRIC_EUCLIDEAN = 0, FM_METRIC_COSINE = 1 }; /* utils/distance.py:12-14 */
+
+/* find_occluded (utils/rect.py:143-157) */
+int fm_find_occluded(fm_ctx* ctx, int n, const double* tlbr, double thresh, uint8_t* out);
+
+/* All pairwise terms of MultiTracker.update in one launch, kept on the device:
+ *   feat[t][d]  cdist(avg_feat[slot t], emb[d])            (utils/distance.py:17-87)
+ *   maha[t][d]  KalmanFilter.motion_distance               (kalman_filter.py:206-225,347-353)
+ *   iou [t][d]  iou_dist(track box, det box)               (utils/distance.py:91-108)
+ * rows = nT tracks (slots[], rounded boxes trk_tlbr[], labels), cols = nD detections
+ * (boxes, labels, occluded mask).  Rows without a valid feature use the fill value at
+ * stage time (tracker.py:328-330). */
+int fm_assoc_prepare(fm_ctx* ctx, int metric,
+                     int nT, const int32_t* slots, const double* trk_tlbr, const int64_t* trk_label,
+                     int nD, const double* det_tlbr, const int64_t* det_label,
+                     const uint8_t* det_occluded);
+
+/* downloads the prepared [nT][nD] f64 matrices (any pointer may be NULL); KalmanFilter.
+ * motion_distance / cdist / iou_dist parity tests read them. */
+int fm_assoc_get_pairwise(fm_ctx* ctx, double* feat, double* maha, double* iou);
+
+enum {
+    FM_STAGE_MATCHING = 0, /* _matching_cost: 0.8 feat + 0.2 maha/chi2, gates (tracker.py:314-341) */
+    FM_STAGE_IOU      = 1, /* _iou_cost: gate 1-iou_thresh                     (tracker.py:343-353) */
+    FM_STAGE_REID     = 2  /* _reid_cost: feat, label gate only                (tracker.py:355-366) */
+};
+
+/* Builds the gated cost matrix of one association stage from the prepared pairwise terms
+ * for the given row / column subsets (indices into the fm_assoc_prepare arrays), then
+ * solves it on the device:
+ *   solver 0 = rectangular LAP (scipy.optimize.linear_sum_assignment semantics incl.
+ *              tie-breaking; utils/matching.py:10-30) followed by the INF_COST un-matching
+ *              of utils/matching.py:58-70: match_gated[k]=1 when cost>=1e5.
+ *   solver 1 = greedy argmin matching while cost <= max_cost (utils/matching.py:74-97).
+ * row_label_override: _reid_cost quirk (tracker.py:364) -- labels used for the rows; NULL
+ * = labels given to fm_assoc_prepare.
+ * Outputs: m_rows/m_cols (local indices into rows[]/cols[], in the solver's output order),
+ * n_match.  cost_out (optional, may be NULL): the [nr][nc] f64 cost matrix. */
+int fm_assoc_stage(fm_ctx* ctx, int stage, int solver,
+                   int nr, const int32_t* rows, int nc, const int32_t* cols,
+                   double motion_weight, double max_cost, double fill_val,
+                   const int64_t* row_label_override,
+                   int32_t* m_rows, int32_t* m_cols, uint8_t* match_gated, int* n_match,
+                   double* cost_out);
+
+/* Stand-alone solvers on a host cost matrix [nr][nc] f64 (device kernels; used by
+ * _rectify_matches' greedy_match, tracker.py:384, and by the parity tests). */
+int fm_lap(fm_ctx* ctx, const double* cost, int nr, int nc,
+           int32_t* m_rows, int32_t* m_cols, int* n_match);
+int fm_greedy(fm_ctx* ctx, const double* cost, int nr, int nc, double max_cost,
+              int32_t* m_rows, int32_t* m_cols, int* n_match);
+/* iou_dist on host boxes (utils/distance.py:91-108) -- used by _rectify_matches */
+int fm_iou_dist(fm_ctx* ctx, int na, const double* a, int nb, const double* b, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTMOT_HIP_H */

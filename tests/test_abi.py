@@ -1,0 +1,42 @@
+"""CPU: the C-ABI library loads and exports every symbol include/fastmot_hip.h declares."""
+import ctypes
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_symbols():
+    text = (ROOT / 'include' / 'fastmot_hip.h').read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(fm_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_symbols():
+    syms = declared_symbols()
+    assert 'fm_ctx_create' in syms and 'fm_assoc_stage' in syms and len(syms) >= 25
+
+
+def test_library_exports_every_declared_symbol():
+    from fastmot_amd import _lib
+    lib = _lib.load()
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f'missing exports: {missing}'
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    from fastmot_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', tmp_path / 'nope.so')
+    try:
+        _lib.load()
+    except RuntimeError as err:
+        assert 'no CPU fallback' in str(err)
+    else:
+        raise AssertionError('load() must fail loudly')
+
+
+def test_error_string_is_a_c_string():
+    from fastmot_amd import _lib
+    lib = _lib.load()
+    assert isinstance(lib.fm_last_error(), bytes)
