@@ -231,7 +231,8 @@ class HipContext:
         check(self.lib.fm_iou_dist(self._ctx, C.c_int(len(a)), _ptr(a), C.c_int(len(b)), _ptr(b), _ptr(out)))
         return out
 
-    def assoc_prepare(self, metric, slots, trk_tlbr, trk_label, det_tlbr, det_label, det_occluded):
+    def assoc_prepare(self, metric, slots, trk_tlbr, trk_label, det_tlbr, det_label, det_occluded,
+                      trk_feat_f32=None):
         s = _as(slots, np.int32)
         nT = len(s)
         tb = _as(trk_tlbr, np.float64).reshape(nT, 4)
@@ -240,9 +241,10 @@ class HipContext:
         nD = len(db)
         dl = _as(det_label, np.int64)
         do = _as(det_occluded, np.uint8)
-        assert len(tl) == nT and len(dl) == nD and len(do) == nD
+        f32 = np.zeros(nT, np.uint8) if trk_feat_f32 is None else _as(trk_feat_f32, np.uint8)
+        assert len(tl) == nT and len(dl) == nD and len(do) == nD and len(f32) == nT
         check(self.lib.fm_assoc_prepare(self._ctx, C.c_int(metric), C.c_int(nT), _ptr(s), _ptr(tb),
-                                        _ptr(tl), C.c_int(nD), _ptr(db), _ptr(dl), _ptr(do)))
+                                        _ptr(tl), C.c_int(nD), _ptr(db), _ptr(dl), _ptr(do), _ptr(f32)))
 
     def assoc_get_pairwise(self, nT, nD):
         feat = np.empty((nT, nD), np.float64)

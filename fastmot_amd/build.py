@@ -1,0 +1,65 @@
+"""Builds libfastmot_hip.so in-tree with hipcc for gfx950 (MI355X).
+
+    python -m fastmot_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots.
+"""
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / 'csrc'
+OUT = PKG / 'libfastmot_hip.so'
+HIPCC = '/opt/rocm/bin/hipcc'
+# -ffp-contract=off: association/Kalman decisions compare doubles produced with separate IEEE
+# mul/add like NumPy (see assoc.hip header); conv kernels use explicit MFMA/fma intrinsics.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+         '-Wno-unused-result']
+
+
+def sources():
+    return sorted(CSRC.glob('*.hip'))
+
+
+def needs_build():
+    if not OUT.exists():
+        return True
+    t = OUT.stat().st_mtime
+    deps = list(CSRC.glob('*')) + [PKG.parent / 'include' / 'fastmot_hip.h']
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    objs = []
+    procs = []
+    bdir = PKG / 'build'
+    bdir.mkdir(exist_ok=True)
+    for src in sources():
+        obj = bdir / (src.stem + '.o')
+        objs.append(obj)
+        if not force and obj.exists() and obj.stat().st_mtime > max(
+                src.stat().st_mtime, *(h.stat().st_mtime for h in CSRC.glob('*.h')),
+                (PKG.parent / 'include' / 'fastmot_hip.h').stat().st_mtime):
+            continue
+        cmd = [HIPCC] + [f for f in FLAGS if f != '-shared'] + ['-c', str(src), '-o', str(obj)]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
+        if verbose and out.strip():
+            print(out.decode())
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(OUT)] + [str(o) for o in objs]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError(f'link failed:\n{res.stdout.decode()}')
+    if verbose:
+        print(f'built {OUT}')
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     const double* __restrict__ trk_tlbr, const double* __restrict__ det_tlbr,
     const double* __restrict__ mean, const double* __restrict__ cov,
     const float* __restrict__ favg, const int32_t* __restrict__ fcnt,
-    const float* __restrict__ emb, KFConst kf, double* __restrict__ feat,
-    double* __restrict__ maha, double* __restrict__ iou, uint8_t* __restrict__ row_has_feat) {
+    const float* __restrict__ emb, KFConst kf, const uint8_t* __restrict__ row_f32,
+    double* __restrict__ feat, double* __restrict__ maha, double* __restrict__ iou,
+    uint8_t* __restrict__ row_has_feat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sa = reinterpret_cast<float*>(smem);                         // [dim]
     double* sd = reinterpret_cast<double*>(smem + (size_t)dim * 4);     // L[16], pm[4], tb[4], area
@@ -129,8 +130,11 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
         maha[(size_t)t * nD + d] = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
         iou[(size_t)t * nD + d] = iou_dist_pair(sd + 20, sd[24], z);
     }
-    // feature distance: one wave per detection column, fp64 accumulation (distance.py:47-87)
+    // feature distance: one wave per detection column (distance.py:47-87).  Accumulators are
+    // f64; each term has the type the reference's operands give it: track feature f64 x embedding
+    // f32 in _matching_cost (b_norm terms stay f32 products), f32 x f32 in _reid_cost (row_f32).
     const int wv = tid >> 6, lane = tid & 63;
+    const bool f32row = row_f32[t] != 0;
     if (cnt > 0) {
         for (int d = wv; d < nD; d += 4) {
             const float* b = emb + (size_t)d * dim;
@@ -138,15 +142,27 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
             for (int k4 = lane; k4 < dim / 4; k4 += 64) {
                 const float4 bv = *reinterpret_cast<const float4*>(b + k4 * 4);
                 const float4 av = *reinterpret_cast<const float4*>(sa + k4 * 4);
-                const double a0 = av.x, a1 = av.y, a2 = av.z, a3 = av.w;
-                const double b0 = bv.x, b1 = bv.y, b2 = bv.z, b3 = bv.w;
-                if (metric == FM_METRIC_COSINE) {
-                    acc0 += a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
-                    acc1 += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-                    acc2 += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
-                } else {
-                    const double d0 = a0 - b0, d1 = a1 - b1, d2 = a2 - b2, d3 = a3 - b3;
-                    acc0 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                const float af[4] = {av.x, av.y, av.z, av.w};
+                const float bf[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (metric == FM_METRIC_COSINE) {
+                        acc2 += (double)(bf[e] * bf[e]);
+                        if (f32row) {
+                            acc0 += (double)(af[e] * bf[e]);
+                            acc1 += (double)(af[e] * af[e]);
+                        } else {
+                            const double a = af[e];
+                            acc0 += a * (double)bf[e];
+                            acc1 += a * a;
+                        }
+                    } else if (f32row) {
+                        const float df = af[e] - bf[e];
+                        acc0 += (double)(df * df);
+                    } else {
+                        const double dd = (double)af[e] - (double)bf[e];
+                        acc0 += dd * dd;
+                    }
                 }
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -534,21 +550,22 @@ extern "C" int fm_iou_dist(fm_ctx* ctx, int na, const double* a, int nb, const d
 extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* slots,
                                 const double* trk_tlbr, const int64_t* trk_label, int nD,
                                 const double* det_tlbr, const int64_t* det_label,
-                                const uint8_t* det_occluded) {
+                                const uint8_t* det_occluded, const uint8_t* trk_feat_f32) {
     FM_CHECK_ARG(ctx && nT >= 0 && nD >= 0 && ctx->kf_set);
     FM_CHECK_ARG(metric == FM_METRIC_EUCLIDEAN || metric == FM_METRIC_COSINE);
     ctx->as_nT = nT;
     ctx->as_nD = nD;
     ctx->as_metric = metric;
     if (nT == 0 || nD == 0) return 0;
-    FM_CHECK_ARG(slots && trk_tlbr && trk_label && det_tlbr && det_label && det_occluded);
+    FM_CHECK_ARG(slots && trk_tlbr && trk_label && det_tlbr && det_label && det_occluded && trk_feat_f32);
     FM_CHECK_ARG(nD <= ctx->emb_n);
     for (int i = 0; i < nT; ++i) FM_CHECK_ARG(slots[i] >= 0 && slots[i] < ctx->slot_cap);
     std::vector<size_t> offs;
     int rc = upload(ctx, ctx->as_in,
                     {{slots, sizeof(int32_t) * nT}, {trk_tlbr, sizeof(double) * 4 * nT},
                      {trk_label, sizeof(int64_t) * nT}, {det_tlbr, sizeof(double) * 4 * nD},
-                     {det_label, sizeof(int64_t) * nD}, {det_occluded, (size_t)nD}}, offs);
+                     {det_label, sizeof(int64_t) * nD}, {det_occluded, (size_t)nD},
+                     {trk_feat_f32, (size_t)nT}}, offs);
     if (rc) return rc;
     for (int i = 0; i < 6; ++i) ctx->as_off[i] = offs[i];
     const size_t mat = sizeof(double) * (size_t)nT * nD;
@@ -559,7 +576,8 @@ extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* 
     hipLaunchKernelGGL(pairwise_kernel, dim3(nT), dim3(256), shmem, ctx->s_main, nT, nD, metric,
                        ctx->feat_dim, (const int32_t*)(in + offs[0]), (const double*)(in + offs[1]),
                        (const double*)(in + offs[3]), ctx->mean, ctx->cov, ctx->feat_avg, ctx->feat_cnt,
-                       ctx->emb, ctx->kf, (double*)pr, (double*)(pr + mat), (double*)(pr + 2 * mat),
+                       ctx->emb, ctx->kf, (const uint8_t*)(in + offs[6]), (double*)pr, (double*)(pr + mat),
+                       (double*)(pr + 2 * mat),
                        (uint8_t*)(pr + 3 * mat));
     FM_HIP(hipGetLastError());
     return 0;

@@ -229,7 +229,8 @@ class MultiTracker:
                 row_tracks = [self.tracks[t] if t in self.tracks else self.hist_tracks[t] for t in row_ids]
                 ctx.assoc_prepare(self._metric_id, [t.slot for t in row_tracks],
                                   np.array([t.tlbr for t in row_tracks]),
-                                  [t.label for t in row_tracks], det_tlbr, det_label, occluded_det_mask)
+                                  [t.label for t in row_tracks], det_tlbr, det_label, occluded_det_mask,
+                                  trk_feat_f32=[t not in self.tracks for t in row_ids])
 
         # ---- 1st association: motion + embeddings, tracks with small age are prioritized
         fill_val = min(self.max_assoc_cost + 0.1, 1.)

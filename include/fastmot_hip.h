@@ -114,11 +114,13 @@ int fm_find_occluded(fm_ctx* ctx, int n, const double* tlbr, double thresh, uint
  *   iou [t][d]  iou_dist(track box, det box)               (utils/distance.py:91-108)
  * rows = nT tracks (slots[], rounded boxes trk_tlbr[], labels), cols = nD detections
  * (boxes, labels, occluded mask).  Rows without a valid feature use the fill value at
- * stage time (tracker.py:328-330). */
+ * stage time (tracker.py:328-330).  trk_feat_f32[t]=1 marks rows whose feature enters cdist as
+ * float32 (history tracks in _reid_cost, tracker.py:360-362) instead of the float64 copy used by
+ * _matching_cost (tracker.py:321-326): the products are then formed in f32 like the reference. */
 int fm_assoc_prepare(fm_ctx* ctx, int metric,
                      int nT, const int32_t* slots, const double* trk_tlbr, const int64_t* trk_label,
                      int nD, const double* det_tlbr, const int64_t* det_label,
-                     const uint8_t* det_occluded);
+                     const uint8_t* det_occluded, const uint8_t* trk_feat_f32);
 
 /* downloads the prepared [nT][nD] f64 matrices (any pointer may be NULL); KalmanFilter.
  * motion_distance / cdist / iou_dist parity tests read them. */

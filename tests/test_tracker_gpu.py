@@ -1,0 +1,55 @@
+"""GPU parity (end to end, oracle=reference): fastmot_amd.MultiTracker vs the golden runs of the
+reference MultiTracker on the scripted scenes of tests/scenes.py.  Track IDs, dict order,
+rounded boxes, lifecycle flags and history order must be IDENTICAL on every frame; final Kalman
+states agree to fp64 round-off."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', list(scenes.SCENES))
+def test_scene_matches_reference(golden_dir, name):
+    from fastmot_amd import MultiTracker, Track
+    g = np.load(golden_dir / f'tracker_{name}.npz')
+    scene = scenes.Scene(name)
+    Track._count = 0
+    tracker = MultiTracker(scene.size, scene.metric, **scenes.tracker_kwargs())
+    records, final = scenes.run_scene(tracker, scene)
+    out = scenes.pack_records(records, final)
+    exp, got = g['tracks'], out['tracks']
+    for frame_id in range(scene.n_frames):
+        e = exp[exp[:, 0] == frame_id]
+        t = got[got[:, 0] == frame_id]
+        assert e[:, 2].tolist() == t[:, 2].tolist(), f'frame {frame_id}: track ids / order differ'
+        np.testing.assert_array_equal(e, t, err_msg=f'frame {frame_id}')
+    np.testing.assert_array_equal(out['hist'], g['hist'])
+    np.testing.assert_array_equal(out['final_ids'], g['final_ids'])
+    np.testing.assert_allclose(out['final_mean'], g['final_mean'], rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(out['final_cov'], g['final_cov'], rtol=1e-7, atol=1e-6)
+    # every slot handed out is accounted for
+    tracker._clear_tracks()
+    tracker.reset(1 / 30.)
+
+
+def test_kalman_filter_mirror_api(ctx):
+    """KalmanFilter's ndarray methods (create/warp/predict/update/motion_distance) keep working."""
+    import np_oracle as o
+    from fastmot_amd import KalmanFilter, MeasType
+    kf = KalmanFilter()
+    kf.reset_dt(1 / 30.)
+    p = o.KFParams(1 / 30.)
+    box = np.array([100., 200., 180., 420.])
+    m, c = kf.create(box)
+    em, ec = o.kf_create(p, box)
+    np.testing.assert_allclose(m, em[0]); np.testing.assert_allclose(c, ec[0])
+    m2, c2 = kf.predict(m, c)
+    em2, ec2 = o.kf_predict(p, em, ec)
+    np.testing.assert_allclose(m2, em2[0], rtol=1e-12); np.testing.assert_allclose(c2, ec2[0], rtol=1e-10)
+    m3, c3 = kf.update(m2, c2, box + 3, MeasType.FLOW, 2.0)
+    em3, ec3 = o.kf_update(p, em2, ec2, box + 3, 'flow', 2.0)
+    np.testing.assert_allclose(m3, em3[0], rtol=1e-11); np.testing.assert_allclose(c3, ec3[0], rtol=1e-9)
+    d = kf.motion_distance(m3, c3, np.stack([box, box + 10]))
+    np.testing.assert_allclose(d, o.kf_maha(p, em3, ec3, np.stack([box, box + 10]))[0], rtol=1e-10)
