@@ -1,0 +1,44 @@
+// Conv-engine internals (NHWC fp16 activations, fp32 accumulate) shared by conv.hip/ops.hip/net.hip.
+#pragma once
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_LINEAR = 0, ACT_LEAKY = 1, ACT_MISH = 2, ACT_RELU = 3, ACT_LOGISTIC = 4, ACT_SWISH = 5 };
+enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
+
+struct ConvParams {
+    const f16* in;  int in_cs, in_coff;     // pixel stride (elements) / channel offset of the input view
+    const f16* w;                           // [cout_pad32][Kpad] fp16, K = (kh, kw, cin)
+    const float* bias;                      // [cout_pad32] (BN folded)
+    f16* out;       int out_cs, out_coff;   // fp16 output view (may be null when out32 is set)
+    float* out32;                           // optional fp32 output (YOLO heads), same view geometry
+    const f16* res; int res_cs, res_coff;   // residual view (nullable)
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int K, Kpad, P;                         // K = KH*KW*Cin, Kpad = ceil32(K), P = N*Ho*Wo
+    int cout_store;                         // ceil8(Cout): channels written
+    int act, res_mode;
+};
+
+int launch_conv(const ConvParams& p, hipStream_t s);
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_LEAKY: return x > 0.f ? x : 0.1f * x;
+        case ACT_MISH: {   // x * tanh(softplus(x)),  tanh(log(1+e^x)) = (n^2+2n)/(n^2+2n+2), n = e^x
+            if (x > 20.f) return x;
+            const float n = __expf(x);
+            const float t = n * (n + 2.f);
+            return x * (t / (t + 2.f));
+        }
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_LOGISTIC: return 1.f / (1.f + __expf(-x));
+        case ACT_SWISH: return x / (1.f + __expf(-x));
+        default: return x;
+    }
+}

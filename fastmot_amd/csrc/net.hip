@@ -1,0 +1,294 @@
+// Layer-table executor of the conv engine (detector / ReID networks).
+// Replaces TRTInference (fastmot/utils/inference.py:39-125): buffers are allocated once, a run
+// enqueues every layer on the network's own HIP stream; nothing synchronises until the caller
+// asks for results (detect_async/postprocess protocol of fastmot/detector.py:26-42).
+#include "net.h"
+#include <memory>
+
+int launch_dwconv3(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
+                   const float* bias, int N, int H, int W, int C, int act, hipStream_t s);
+int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
+                int W, int C, int Ho, int Wo, int k, int stride, int pad, int avg, hipStream_t s);
+int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
+                     int W, int C, hipStream_t s);
+int launch_copy(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, long npix, int C,
+                hipStream_t s);
+int launch_gate(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int hid, const f16* w1,
+                const float* b1, const f16* w2, const float* b2, float* gate, hipStream_t s);
+int launch_gate_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff,
+                    const float* const* gate, f16* out, int out_cs, int out_coff, int N, int HW, int C,
+                    hipStream_t s);
+int launch_head(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int D, const f16* w,
+                const float* b, float* out, float* raw_out, hipStream_t s);
+int fm_emb_reserve(fm_ctx* ctx, int n);
+
+struct NetState {
+    int which = 0, max_batch = 0;
+    std::vector<fm_tensor> tensors;
+    std::vector<void*> bufs;
+    std::vector<fm_layer> layers;
+    char* weights = nullptr;
+    size_t weight_bytes = 0;
+    float* gates = nullptr;
+    int n_gates = 0, gate_c = 0;
+    hipStream_t stream = nullptr;
+};
+
+void fm_net_free(NetState* n) {
+    if (!n) return;
+    for (void* b : n->bufs)
+        if (b) (void)hipFree(b);
+    if (n->weights) (void)hipFree(n->weights);
+    if (n->gates) (void)hipFree(n->gates);
+    delete n;
+}
+
+static NetState*& net_slot(fm_ctx* ctx, int which) { return which == FM_NET_DETECTOR ? ctx->det_net : ctx->ext_net; }
+
+static size_t elem_size(const fm_tensor& t) { return t.f32 ? 4 : 2; }
+
+extern "C" int fm_net_destroy(fm_ctx* ctx, int which) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1));
+    NetState*& slot = net_slot(ctx, which);
+    if (slot) {
+        FM_HIP(hipStreamSynchronize(slot->stream));
+        fm_net_free(slot);
+        slot = nullptr;
+    }
+    return 0;
+}
+
+extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensors, const fm_tensor* tensors,
+                             int n_layers, const fm_layer* layers, const void* weights, size_t weight_bytes,
+                             int n_gates, int gate_channels) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && max_batch > 0 && n_tensors > 0 && n_layers > 0);
+    FM_CHECK_ARG(tensors && layers && weights && weight_bytes > 0);
+    int rc = fm_net_destroy(ctx, which);
+    if (rc) return rc;
+    std::unique_ptr<NetState, void (*)(NetState*)> net(new NetState(), fm_net_free);
+    net->which = which;
+    net->max_batch = max_batch;
+    net->stream = which == FM_NET_DETECTOR ? ctx->s_det : ctx->s_ext;
+    net->tensors.assign(tensors, tensors + n_tensors);
+    net->layers.assign(layers, layers + n_layers);
+    for (const fm_tensor& t : net->tensors) {
+        FM_CHECK_ARG(t.h > 0 && t.w > 0 && t.c > 0 && t.c % 8 == 0);
+        void* b = nullptr;
+        const size_t bytes = (size_t)max_batch * t.h * t.w * t.c * elem_size(t);
+        FM_HIP(hipMalloc(&b, bytes));
+        FM_HIP(hipMemset(b, 0, bytes));
+        net->bufs.push_back(b);
+    }
+    for (const fm_layer& L : net->layers) {
+        FM_CHECK_ARG(L.out >= 0 && L.out < n_tensors && L.n_in >= 1 && L.n_in <= 4);
+        for (int i = 0; i < L.n_in; ++i) FM_CHECK_ARG(L.in[i] >= 0 && L.in[i] < n_tensors);
+        FM_CHECK_ARG(L.res_mode == FM_RES_NONE || (L.res >= 0 && L.res < n_tensors));
+        FM_CHECK_ARG(L.w_off >= 0 && (size_t)L.w_off <= weight_bytes && L.w_off % 16 == 0 && L.b_off % 16 == 0);
+    }
+    FM_HIP(hipMalloc(&net->weights, weight_bytes));
+    FM_HIP(hipMemcpy(net->weights, weights, weight_bytes, hipMemcpyHostToDevice));
+    net->weight_bytes = weight_bytes;
+    net->n_gates = n_gates;
+    net->gate_c = gate_channels;
+    if (n_gates > 0) {
+        FM_CHECK_ARG(gate_channels > 0);
+        FM_HIP(hipMalloc(&net->gates, sizeof(float) * (size_t)n_gates * max_batch * gate_channels));
+    }
+    if (which == FM_NET_EXTRACTOR) {
+        FM_HIP(hipStreamSynchronize(ctx->s_main));
+        if ((rc = fm_emb_reserve(ctx, max_batch))) return rc;
+    }
+    net_slot(ctx, which) = net.release();
+    return 0;
+}
+
+static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
+    const fm_tensor& ti = net->tensors[L.in[0]];
+    const fm_tensor& to = net->tensors[L.out];
+    hipStream_t s = net->stream;
+    const f16* in0 = (const f16*)net->bufs[L.in[0]];
+    f16* out = (f16*)net->bufs[L.out];
+    switch (L.op) {
+        case FM_OP_CONV: {
+            ConvParams p{};
+            p.in = in0; p.in_cs = ti.c; p.in_coff = L.in_coff[0];
+            p.w = (const f16*)(net->weights + L.w_off);
+            p.bias = (const float*)(net->weights + L.b_off);
+            p.out = to.f32 ? nullptr : out;
+            p.out32 = to.f32 ? (float*)net->bufs[L.out] : nullptr;
+            p.out_cs = to.c; p.out_coff = L.out_coff;
+            if (L.res_mode != FM_RES_NONE) {
+                p.res = (const f16*)net->bufs[L.res];
+                p.res_cs = net->tensors[L.res].c;
+                p.res_coff = L.res_coff;
+            }
+            p.N = B; p.H = ti.h; p.W = ti.w; p.Cin = L.cin; p.Ho = to.h; p.Wo = to.w; p.Cout = L.cout;
+            p.KH = p.KW = L.k; p.stride = L.stride; p.pad = L.pad;
+            p.K = L.k * L.k * L.cin; p.Kpad = (p.K + 31) & ~31; p.P = B * to.h * to.w;
+            p.cout_store = (L.cout + 7) & ~7;
+            p.act = L.act; p.res_mode = L.res_mode;
+            FM_CHECK_ARG((ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h);
+            FM_CHECK_ARG(L.out_coff + p.cout_store <= to.c && L.in_coff[0] + L.cin <= ti.c);
+            return launch_conv(p, s);
+        }
+        case FM_OP_DWCONV3:
+            return launch_dwconv3(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
+                                  (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                                  B, ti.h, ti.w, L.cin, L.act, s);
+        case FM_OP_MAXPOOL:
+        case FM_OP_AVGPOOL:
+            return launch_pool(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, to.h, to.w,
+                               L.k, L.stride, L.pad, L.op == FM_OP_AVGPOOL, s);
+        case FM_OP_UPSAMPLE2:
+            FM_CHECK_ARG(to.h == 2 * ti.h && to.w == 2 * ti.w);
+            return launch_upsample2(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, s);
+        case FM_OP_COPY:
+            return launch_copy(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, (long)B * ti.h * ti.w, L.cin, s);
+        case FM_OP_GATE:
+            FM_CHECK_ARG(L.gate[0] >= 0 && L.gate[0] < net->n_gates && L.cin <= net->gate_c);
+            return launch_gate(in0, ti.c, L.in_coff[0], B, ti.h * ti.w, L.cin, L.hid,
+                               (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                               (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
+                               net->gates + (size_t)L.gate[0] * net->max_batch * net->gate_c, s);
+        case FM_OP_GATE_SUM: {
+            const f16* ins[4];
+            int cs[4], co[4];
+            const float* gs[4];
+            for (int i = 0; i < L.n_in; ++i) {
+                ins[i] = (const f16*)net->bufs[L.in[i]];
+                cs[i] = net->tensors[L.in[i]].c;
+                co[i] = L.in_coff[i];
+                FM_CHECK_ARG(L.gate[i] >= 0 && L.gate[i] < net->n_gates);
+                gs[i] = net->gates + (size_t)L.gate[i] * net->max_batch * net->gate_c;
+            }
+            return launch_gate_sum(L.n_in, ins, cs, co, gs, out, to.c, L.out_coff, B, ti.h * ti.w, L.cin, s);
+        }
+        case FM_OP_HEAD:
+            FM_CHECK_ARG(L.cout == ctx->feat_dim && B <= ctx->emb_cap);
+            return launch_head(in0, ti.c, L.in_coff[0], B, ti.h * ti.w, L.cin, L.cout,
+                               (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                               ctx->emb, nullptr, s);
+        default:
+            fm_set_error("unknown layer op %d", L.op);
+            return FM_ERR_ARG;
+    }
+}
+
+// gate kernels index gate[n*C + c] with C = the gated channel count; buffers are spaced by
+// max_batch*gate_c so any C <= gate_c fits.
+extern "C" int fm_net_run(fm_ctx* ctx, int which, int batch) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1));
+    NetState* net = net_slot(ctx, which);
+    FM_CHECK_ARG(net != nullptr && batch >= 0 && batch <= net->max_batch);
+    if (batch == 0) return 0;
+    for (const fm_layer& L : net->layers) {
+        int rc = run_layer(ctx, net, L, batch);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int fm_net_tensor_write(fm_ctx* ctx, int which, int tensor, const void* host, size_t bytes) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && host);
+    NetState* net = net_slot(ctx, which);
+    FM_CHECK_ARG(net && tensor >= 0 && tensor < (int)net->tensors.size());
+    const fm_tensor& t = net->tensors[tensor];
+    FM_CHECK_ARG(bytes <= (size_t)net->max_batch * t.h * t.w * t.c * elem_size(t));
+    FM_HIP(hipStreamSynchronize(net->stream));
+    FM_HIP(hipMemcpy(net->bufs[tensor], host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int fm_net_tensor_read(fm_ctx* ctx, int which, int tensor, void* host, size_t bytes) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && host);
+    NetState* net = net_slot(ctx, which);
+    FM_CHECK_ARG(net && tensor >= 0 && tensor < (int)net->tensors.size());
+    const fm_tensor& t = net->tensors[tensor];
+    FM_CHECK_ARG(bytes <= (size_t)net->max_batch * t.h * t.w * t.c * elem_size(t));
+    FM_HIP(hipStreamSynchronize(net->stream));
+    FM_HIP(hipMemcpy(host, net->bufs[tensor], bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int fm_net_read_embeddings(fm_ctx* ctx, int n, float* host) {
+    FM_CHECK_ARG(ctx && n >= 0 && n <= ctx->emb_cap);
+    if (n == 0) return 0;
+    FM_CHECK_ARG(host);
+    FM_HIP(hipStreamSynchronize(ctx->s_ext));
+    FM_HIP(hipMemcpy(host, ctx->emb, sizeof(float) * (size_t)n * ctx->feat_dim, hipMemcpyDeviceToHost));
+    ctx->emb_n = n;
+    return 0;
+}
+
+static void layer_cost(const NetState* net, const fm_layer& L, int B, double* flops, double* bytes) {
+    const fm_tensor& ti = net->tensors[L.in[0]];
+    const fm_tensor& to = net->tensors[L.out];
+    const double pin = (double)B * ti.h * ti.w, pout = (double)B * to.h * to.w;
+    *flops = 0;
+    *bytes = 0;
+    switch (L.op) {
+        case FM_OP_CONV:
+            *flops = 2.0 * L.k * L.k * L.cin * L.cout * pout;
+            *bytes = pin * L.cin * 2 + pout * L.cout * (to.f32 ? 4 : 2) + (double)L.k * L.k * L.cin * L.cout * 2 +
+                     (L.res_mode != FM_RES_NONE ? pout * L.cout * 2 : 0);
+            break;
+        case FM_OP_DWCONV3:
+            *flops = 2.0 * 9 * L.cin * pout;
+            *bytes = (pin + pout) * L.cin * 2;
+            break;
+        case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
+        case FM_OP_GATE_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
+        case FM_OP_HEAD:
+            *flops = 2.0 * L.cin * L.cout * B;
+            *bytes = pin * L.cin * 2 + (double)L.cin * L.cout * 2;
+            break;
+        default: *bytes = (pin + pout) * L.cin * 2; break;
+    }
+}
+
+extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, double* bytes) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && flops && bytes);
+    NetState* net = net_slot(ctx, which);
+    FM_CHECK_ARG(net != nullptr);
+    double f = 0, b = 0;
+    for (const fm_layer& L : net->layers)
+        if (L.op == FM_OP_CONV) {
+            double lf, lb;
+            layer_cost(net, L, batch, &lf, &lb);
+            f += lf;
+            b += lb;
+        }
+    *flops = f;
+    *bytes = b;
+    return 0;
+}
+
+extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, double* conv_ms,
+                              double* other_ms, int* n_conv, int* n_other) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && iters > 0);
+    NetState* net = net_slot(ctx, which);
+    FM_CHECK_ARG(net != nullptr && batch > 0 && batch <= net->max_batch);
+    hipEvent_t e0, e1;
+    FM_HIP(hipEventCreate(&e0));
+    FM_HIP(hipEventCreate(&e1));
+    double tc = 0, to = 0;
+    int nc = 0, no = 0;
+    for (int it = 0; it < iters; ++it)
+        for (const fm_layer& L : net->layers) {
+            FM_HIP(hipEventRecord(e0, net->stream));
+            int rc = run_layer(ctx, net, L, batch);
+            if (rc) return rc;
+            FM_HIP(hipEventRecord(e1, net->stream));
+            FM_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            FM_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (L.op == FM_OP_CONV) { tc += ms; ++nc; } else { to += ms; ++no; }
+        }
+    FM_HIP(hipEventDestroy(e0));
+    FM_HIP(hipEventDestroy(e1));
+    if (conv_ms) *conv_ms = tc / iters;
+    if (other_ms) *other_ms = to / iters;
+    if (n_conv) *n_conv = nc / iters;
+    if (n_other) *n_other = no / iters;
+    return 0;
+}

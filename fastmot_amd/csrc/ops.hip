@@ -1,0 +1,336 @@
+// Memory-bound layers of the detector / ReID networks (NHWC fp16, 8 channels = 16 B per lane).
+// Graph semantics: scripts/yolo2onnx.py:733-863 (route/upsample/maxpool) and the torchreid OSNet
+// definition summarised in SURVEY.md appendix A (LightConv3x3, channel gate, pooling, head).
+// All of these are HBM/L2-bandwidth bound: one pass, 16-byte coalesced accesses, no re-reads.
+#include "net.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    const f16x8 h = *reinterpret_cast<const f16x8*>(&v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (f16)f[e];
+    return *reinterpret_cast<const uint4*>(&h);
+}
+
+// depthwise 3x3, stride 1, pad 1, + bias (folded BN) + activation.  w: [9][C] fp16, bias f32[C]
+__global__ void dwconv3_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
+                               f16* __restrict__ out, int out_cs, int out_coff,
+                               const f16* __restrict__ w, const float* __restrict__ bias,
+                               int N, int H, int W, int C, int act) {
+    const int c8n = C / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * H * W * c8n;
+    if (idx >= total) return;
+    const int c = (int)(idx % c8n) * 8;
+    const long pix = idx / c8n;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long n = pix / ((long)W * H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias[c + e];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            float v[8], k[8];
+            unpack8(*reinterpret_cast<const uint4*>(in + ((n * H + yy) * W + xx) * in_cs + in_coff + c), v);
+            unpack8(*reinterpret_cast<const uint4*>(w + ((dy + 1) * 3 + (dx + 1)) * C + c), k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], k[e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = apply_act(acc[e], act);
+    *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = pack8(acc);
+}
+
+// max / average pooling, window k, stride s, pad (window clipped at the border)
+__global__ void pool_kernel(const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out,
+                            int out_cs, int out_coff, int N, int H, int W, int C, int Ho, int Wo,
+                            int k, int s, int pad, int avg) {
+    const int c8n = C / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * Ho * Wo * c8n;
+    if (idx >= total) return;
+    const int c = (int)(idx % c8n) * 8;
+    const long pix = idx / c8n;
+    const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho);
+    const long n = pix / ((long)Wo * Ho);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = avg ? 0.f : -65504.f;
+    const int y0 = yo * s - pad, x0 = xo * s - pad;
+    for (int dy = 0; dy < k; ++dy) {
+        const int yy = y0 + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = x0 + dx;
+            if (xx < 0 || xx >= W) continue;
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(in + ((n * H + yy) * W + xx) * in_cs + in_coff + c), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = avg ? acc[e] + v[e] : fmaxf(acc[e], v[e]);
+        }
+    }
+    if (avg) {
+        const float inv = 1.f / (float)(k * k);   // AvgPool2d(2, 2): full windows only
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    }
+    *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = pack8(acc);
+}
+
+// nearest-neighbour x2 upsample into a channel slice (yolo2onnx.py:806-836)
+__global__ void upsample2_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
+                                 f16* __restrict__ out, int out_cs, int out_coff, int N, int H, int W,
+                                 int C) {
+    const int c8n = C / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * (2 * H) * (2 * W) * c8n;
+    if (idx >= total) return;
+    const int c = (int)(idx % c8n) * 8;
+    const long pix = idx / c8n;
+    const int xo = (int)(pix % (2 * W)), yo = (int)((pix / (2 * W)) % (2 * H));
+    const long n = pix / ((long)4 * W * H);
+    const uint4 v = *reinterpret_cast<const uint4*>(in + ((n * H + (yo >> 1)) * W + (xo >> 1)) * in_cs + in_coff + c);
+    *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = v;
+}
+
+// channel slice copy (route of a tensor that already lives elsewhere)
+__global__ void copy_kernel(const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out,
+                            int out_cs, int out_coff, long npix, int C) {
+    const int c8n = C / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c8n) return;
+    const int c = (int)(idx % c8n) * 8;
+    const long pix = idx / c8n;
+    *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) =
+        *reinterpret_cast<const uint4*>(in + pix * in_cs + in_coff + c);
+}
+
+// OSNet channel gate: gate[n][c] = sigmoid(fc2(relu(fc1(GAP(x[n])))))   (one block per sample)
+// w1: [hid][C] f16, b1: f32[hid], w2: [C][hid] f16, b2: f32[C]; gate out f32 [N][C]
+__global__ __launch_bounds__(256) void gate_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
+                                                   int HW, int C, int hid, const f16* __restrict__ w1,
+                                                   const float* __restrict__ b1,
+                                                   const f16* __restrict__ w2,
+                                                   const float* __restrict__ b2,
+                                                   float* __restrict__ gate) {
+    extern __shared__ float sm[];            // [256 / c8n][C] partial sums | gap[C] | hidden[hid]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int c8n = C / 8;
+    const int groups = 256 / c8n;            // pixel groups (C <= 2048/8)
+    const int cg = tid % c8n, pg = tid / c8n;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pg < groups) {
+        const f16* base = in + (size_t)n * HW * in_cs + in_coff + cg * 8;
+        for (int px = pg; px < HW; px += groups) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(base + (size_t)px * in_cs), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[pg * C + cg * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    float* gap = sm + groups * C;
+    float* hidden = gap + C;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += sm[g * C + c];
+        gap[c] = s / (float)HW;
+    }
+    __syncthreads();
+    for (int h = tid; h < hid; h += 256) {
+        float s = b1[h];
+        for (int c = 0; c < C; ++c) s = fmaf((float)w1[h * C + c], gap[c], s);
+        hidden[h] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = b2[c];
+        for (int h = 0; h < hid; ++h) s = fmaf((float)w2[c * hid + h], hidden[h], s);
+        gate[(size_t)n * C + c] = 1.f / (1.f + __expf(-s));
+    }
+}
+
+// x2 = sum_T s_T * gate_T  (OSNet: four gated streams summed)
+struct GateSumArgs {
+    const f16* in[4];
+    int in_cs[4], in_coff[4];
+    const float* gate[4];
+    int nstreams;
+};
+__global__ void gate_sum_kernel(GateSumArgs a, f16* __restrict__ out, int out_cs, int out_coff, int N,
+                                int HW, int C) {
+    const int c8n = C / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * HW * c8n;
+    if (idx >= total) return;
+    const int c = (int)(idx % c8n) * 8;
+    const long pix = idx / c8n;
+    const long n = pix / HW;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < a.nstreams; ++t) {
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(a.in[t] + pix * a.in_cs[t] + a.in_coff[t] + c), v);
+        const float* g = a.gate[t] + n * C + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], g[e], acc[e]);
+    }
+    *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = pack8(acc);
+}
+
+// OSNet head: global average pool -> Linear(C -> D) + folded BN1d + ReLU -> L2 normalise
+// (models/reid.py OUTPUT_LAYOUT = 512; feature_extractor.py:73).  One block per sample.
+__global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
+                                                   int HW, int C, int D, const f16* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ out,
+                                                   float* __restrict__ raw_out) {
+    extern __shared__ float sm[];   // [groups][C] | gap[C] | feat[D] | red[256]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int c8n = C / 8;
+    const int groups = 256 / c8n > 0 ? 256 / c8n : 1;
+    const int cg = tid % c8n, pg = tid / c8n;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c8n <= 256 && pg < groups) {
+        const f16* base = in + (size_t)n * HW * in_cs + in_coff + cg * 8;
+        for (int px = pg; px < HW; px += groups) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(base + (size_t)px * in_cs), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[pg * C + cg * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    float* gap = sm + groups * C;
+    float* feat = gap + C;
+    float* red = feat + D;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += sm[g * C + c];
+        gap[c] = s / (float)HW;
+    }
+    __syncthreads();
+    float nrm = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        float s = b[d];
+        const f16* wr = w + (size_t)d * C;
+        for (int c = 0; c < C; c += 8) {
+            float k[8];
+            unpack8(*reinterpret_cast<const uint4*>(wr + c), k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(k[e], gap[c + e], s);
+        }
+        s = s > 0.f ? s : 0.f;
+        feat[d] = s;
+        nrm += s * s;
+    }
+    red[tid] = nrm;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    const float inv = 1.f / sqrtf(red[0]);
+    for (int d = tid; d < D; d += 256) {
+        if (raw_out) raw_out[(size_t)n * D + d] = feat[d];
+        out[(size_t)n * D + d] = feat[d] * inv;
+    }
+}
+
+inline dim3 grid1d(long total, int block = 256) { return dim3((unsigned)((total + block - 1) / block)); }
+
+}  // namespace
+
+int launch_dwconv3(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
+                   const float* bias, int N, int H, int W, int C, int act, hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 && out_coff % 8 == 0);
+    const long total = (long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(dwconv3_kernel, grid1d(total), dim3(256), 0, s, in, in_cs, in_coff, out, out_cs,
+                       out_coff, w, bias, N, H, W, C, act);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
+                int W, int C, int Ho, int Wo, int k, int stride, int pad, int avg, hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 && out_coff % 8 == 0);
+    const long total = (long)N * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(pool_kernel, grid1d(total), dim3(256), 0, s, in, in_cs, in_coff, out, out_cs, out_coff,
+                       N, H, W, C, Ho, Wo, k, stride, pad, avg);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
+                     int W, int C, hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 && out_coff % 8 == 0);
+    const long total = (long)N * 4 * H * W * (C / 8);
+    hipLaunchKernelGGL(upsample2_kernel, grid1d(total), dim3(256), 0, s, in, in_cs, in_coff, out, out_cs,
+                       out_coff, N, H, W, C);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_copy(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, long npix, int C,
+                hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 && out_coff % 8 == 0);
+    hipLaunchKernelGGL(copy_kernel, grid1d(npix * (C / 8)), dim3(256), 0, s, in, in_cs, in_coff, out, out_cs,
+                       out_coff, npix, C);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gate(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int hid, const f16* w1,
+                const float* b1, const f16* w2, const float* b2, float* gate, hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && C / 8 <= 256 && in_cs % 8 == 0 && in_coff % 8 == 0);
+    const int groups = 256 / (C / 8);
+    const size_t shmem = sizeof(float) * ((size_t)groups * C + C + hid);
+    hipLaunchKernelGGL(gate_kernel, dim3(N), dim3(256), shmem, s, in, in_cs, in_coff, HW, C, hid, w1, b1, w2,
+                       b2, gate);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gate_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff,
+                    const float* const* gate, f16* out, int out_cs, int out_coff, int N, int HW, int C,
+                    hipStream_t s) {
+    FM_CHECK_ARG(nstreams >= 1 && nstreams <= 4 && C % 8 == 0);
+    GateSumArgs a{};
+    a.nstreams = nstreams;
+    for (int t = 0; t < nstreams; ++t) {
+        a.in[t] = in[t];
+        a.in_cs[t] = in_cs[t];
+        a.in_coff[t] = in_coff[t];
+        a.gate[t] = gate[t];
+    }
+    const long total = (long)N * HW * (C / 8);
+    hipLaunchKernelGGL(gate_sum_kernel, grid1d(total), dim3(256), 0, s, a, out, out_cs, out_coff, N, HW, C);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_head(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int D, const f16* w,
+                const float* b, float* out, float* raw_out, hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && C / 8 <= 256 && in_cs % 8 == 0 && in_coff % 8 == 0);
+    const int groups = 256 / (C / 8);
+    const size_t shmem = sizeof(float) * ((size_t)groups * C + C + D + 256);
+    hipLaunchKernelGGL(head_kernel, dim3(N), dim3(256), shmem, s, in, in_cs, in_coff, HW, C, D, w, b, out,
+                       raw_out);
+    FM_HIP(hipGetLastError());
+    return 0;
+}

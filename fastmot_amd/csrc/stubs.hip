@@ -1,4 +1,3 @@
 // placeholders until net.hip / flow.hip land
 #include "common.h"
-void fm_net_free(NetState*) {}
 void fm_flow_free(FlowState*) {}

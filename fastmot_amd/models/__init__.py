@@ -1,1 +1,3 @@
+from .yolo import YOLO
+from .reid import ReID
 from .label import get_label_name, set_label_map

@@ -1,0 +1,261 @@
+"""Layer-table builder for the HIP conv engine (include/fastmot_hip.h: fm_tensor / fm_layer).
+
+Replaces the ONNX -> TensorRT engine build of the reference (fastmot/models/yolo.py:106-151,
+fastmot/models/reid.py:48-92).  A Graph is a list of NHWC fp16 tensors (channels padded to 8) and
+layers; concat / route is expressed by writing producers into channel slices of a shared tensor,
+BatchNorm is folded into the conv weights (eps 1e-5, scripts/yolo2onnx.py:419-421) and packed in
+the MFMA kernel's [cout_pad32][K_pad32] fp16 layout.
+"""
+import ctypes as C
+
+import numpy as np
+
+OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD = range(9)
+ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
+RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
+
+
+class fm_tensor(C.Structure):
+    _fields_ = [('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32), ('f32', C.c_int32)]
+
+
+class fm_layer(C.Structure):
+    _fields_ = [('op', C.c_int32), ('n_in', C.c_int32),
+                ('in_', C.c_int32 * 4), ('in_coff', C.c_int32 * 4),
+                ('out', C.c_int32), ('out_coff', C.c_int32),
+                ('res', C.c_int32), ('res_coff', C.c_int32), ('res_mode', C.c_int32),
+                ('cin', C.c_int32), ('cout', C.c_int32), ('k', C.c_int32), ('stride', C.c_int32),
+                ('pad', C.c_int32), ('act', C.c_int32), ('hid', C.c_int32),
+                ('gate', C.c_int32 * 4),
+                ('w_off', C.c_int64), ('b_off', C.c_int64), ('w2_off', C.c_int64), ('b2_off', C.c_int64)]
+
+
+def ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class View:
+    """A channel slice [coff, coff + c) of tensor `tid` (c = logical channels)."""
+
+    def __init__(self, tid, coff, c, h, w):
+        self.tid, self.coff, self.c, self.h, self.w = tid, coff, c, h, w
+
+    @property
+    def cpad(self):
+        return ceil_to(self.c, 8)
+
+    def slice(self, coff, c):
+        assert coff % 8 == 0
+        return View(self.tid, self.coff + coff, c, self.h, self.w)
+
+
+class RandomWeights:
+    """Seeded random parameters with variance-preserving scaling (no trained weights are available
+    offline; real Darknet/torchreid checkpoints plug in through the same interface)."""
+
+    def __init__(self, seed=0):
+        self.rng = np.random.default_rng(seed)
+
+    def conv(self, name, cout, cin, k, bn=True, gain=1.0, groups=1):
+        fan_in = cin // groups * k * k
+        w = self.rng.normal(0, gain * np.sqrt(1.0 / fan_in), (cout, cin // groups, k, k)).astype(np.float32)
+        if bn:
+            gamma = self.rng.uniform(0.8, 1.2, cout).astype(np.float32)
+            beta = self.rng.normal(0, 0.1, cout).astype(np.float32)
+            mean = self.rng.normal(0, 0.1, cout).astype(np.float32)
+            var = self.rng.uniform(0.8, 1.2, cout).astype(np.float32)
+            return dict(w=w, gamma=gamma, beta=beta, mean=mean, var=var)
+        return dict(w=w, bias=self.rng.normal(0, 0.1, cout).astype(np.float32))
+
+    def linear(self, name, cout, cin, bn=False):
+        p = self.conv(name, cout, cin, 1, bn=bn)
+        p['w'] = p['w'].reshape(cout, cin)
+        return p
+
+
+def fold_bn(p, eps=1e-5):
+    """-> (weight fp32, bias fp32) with BatchNorm folded (yolo2onnx.py:419-421 eps)."""
+    w = p['w'].astype(np.float32)
+    if 'gamma' in p:
+        scale = p['gamma'] / np.sqrt(p['var'] + eps)
+        w = w * scale.reshape(-1, *([1] * (w.ndim - 1)))
+        b = p['beta'] - p['mean'] * scale
+    else:
+        b = p.get('bias', np.zeros(w.shape[0], np.float32))
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+class Graph:
+    def __init__(self, weights, in_hw, in_c=3):
+        self.wsrc = weights
+        self.tensors = []      # (h, w, cpad, f32)
+        self.layers = []       # dicts
+        self.blob = bytearray()
+        self.n_gates = 0
+        self.gate_c = 8
+        self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
+        h, w = in_hw
+        self.input = self.new(h, w, in_c)
+        self.outputs = []
+
+    # ---------------------------------------------------------------- tensors / blob
+    def new(self, h, w, c, f32=False):
+        self.tensors.append((h, w, ceil_to(c, 8), int(f32)))
+        return View(len(self.tensors) - 1, 0, c, h, w)
+
+    def _push(self, arr):
+        while len(self.blob) % 16:
+            self.blob.append(0)
+        off = len(self.blob)
+        self.blob += np.ascontiguousarray(arr).tobytes()
+        return off
+
+    def _layer(self, **kw):
+        d = dict(op=0, ins=[], out=None, res=None, res_mode=RES_NONE, cin=0, cout=0, k=1, stride=1, pad=0,
+                 act=0, hid=0, gates=[], w_off=0, b_off=0, w2_off=0, b2_off=0)
+        d.update(kw)
+        self.layers.append(d)
+        return d
+
+    # ---------------------------------------------------------------- ops
+    def conv(self, name, x, cout, k=1, stride=1, act='linear', bn=True, dst=None, res=None,
+             res_mode=RES_AFTER_ACT, f32_out=False, pad=None):
+        cin_pad = x.cpad
+        pad = k // 2 if pad is None else pad
+        ho = (x.h + 2 * pad - k) // stride + 1
+        wo = (x.w + 2 * pad - k) // stride + 1
+        if dst is None:
+            dst = self.new(ho, wo, cout, f32=f32_out)
+        assert dst.h == ho and dst.w == wo and dst.c == cout, (name, dst.h, ho, dst.c, cout)
+        p = self.wsrc.conv(name, cout, x.c, k, bn=bn)
+        w, b = fold_bn(p)
+        w16 = w.astype(np.float16)
+        # pack [cout_pad32][Kpad32], K order (kh, kw, cin_pad)
+        K = k * k * cin_pad
+        kpad = ceil_to(K, 32)
+        cpad = ceil_to(cout, 32)
+        wk = np.zeros((cpad, k, k, cin_pad), np.float16)
+        wk[:cout, :, :, :x.c] = w16.transpose(0, 2, 3, 1)
+        packed = np.zeros((cpad, kpad), np.float16)
+        packed[:, :K] = wk.reshape(cpad, K)
+        bias = np.zeros(cpad, np.float32)
+        bias[:cout] = b
+        lay = self._layer(op=OP_CONV, ins=[x], out=dst, cin=cin_pad, cout=cout, k=k, stride=stride, pad=pad,
+                          act=ACT[act], w_off=self._push(packed), b_off=self._push(bias),
+                          res=res, res_mode=res_mode if res is not None else RES_NONE, name=name)
+        self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
+        return dst
+
+    def dwconv3(self, name, x, act='relu', dst=None):
+        c = x.c
+        if dst is None:
+            dst = self.new(x.h, x.w, c)
+        p = self.wsrc.conv(name, c, c, 3, bn=True, groups=c)
+        w, b = fold_bn(p)                       # [c,1,3,3]
+        w16 = w.astype(np.float16)
+        wk = np.zeros((9, x.cpad), np.float16)
+        wk[:, :c] = w16.reshape(c, 9).T
+        bias = np.zeros(x.cpad, np.float32)
+        bias[:c] = b
+        self._layer(op=OP_DWCONV3, ins=[x], out=dst, cin=x.cpad, cout=c, k=3, stride=1, pad=1, act=ACT[act],
+                    w_off=self._push(wk), b_off=self._push(bias), name=name)
+        self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
+        return dst
+
+    def pool(self, x, k, stride, pad, avg=False, dst=None):
+        ho = (x.h + 2 * pad - k) // stride + 1
+        wo = (x.w + 2 * pad - k) // stride + 1
+        if dst is None:
+            dst = self.new(ho, wo, x.c)
+        assert dst.h == ho and dst.w == wo
+        self._layer(op=OP_AVGPOOL if avg else OP_MAXPOOL, ins=[x], out=dst, cin=x.cpad, cout=x.c, k=k,
+                    stride=stride, pad=pad)
+        return dst
+
+    def upsample2(self, x, dst=None):
+        if dst is None:
+            dst = self.new(2 * x.h, 2 * x.w, x.c)
+        self._layer(op=OP_UPSAMPLE2, ins=[x], out=dst, cin=x.cpad, cout=x.c)
+        return dst
+
+    def copy(self, x, dst):
+        self._layer(op=OP_COPY, ins=[x], out=dst, cin=x.cpad, cout=x.c)
+        return dst
+
+    def gate(self, name, x, hid, gate_params=None):
+        """OSNet ChannelGate weights are shared by the four streams of a block: pass the dict
+        returned by the first call as gate_params to reuse the blob offsets."""
+        c = x.c
+        if gate_params is None:
+            p1 = self.wsrc.conv(name + '.fc1', hid, c, 1, bn=False)
+            p2 = self.wsrc.conv(name + '.fc2', c, hid, 1, bn=False)
+            w1 = np.zeros((hid, x.cpad), np.float16)
+            w1[:, :c] = p1['w'].reshape(hid, c).astype(np.float16)
+            w2 = np.zeros((x.cpad, hid), np.float16)
+            w2[:c] = p2['w'].reshape(c, hid).astype(np.float16)
+            b2 = np.zeros(x.cpad, np.float32)
+            b2[:c] = p2['bias']
+            gate_params = dict(w_off=self._push(w1), b_off=self._push(p1['bias'].astype(np.float32)),
+                               w2_off=self._push(w2), b2_off=self._push(b2),
+                               ref=(w1[:, :c].astype(np.float32), p1['bias'], w2[:c].astype(np.float32), p2['bias']))
+        gid = self.n_gates
+        self.n_gates += 1
+        self.gate_c = max(self.gate_c, x.cpad)
+        self._layer(op=OP_GATE, ins=[x], out=x, cin=x.cpad, cout=c, hid=hid, gates=[gid], name=name,
+                    gate_ref=gate_params['ref'],
+                    **{k: gate_params[k] for k in ('w_off', 'b_off', 'w2_off', 'b2_off')})
+        return gid, gate_params
+
+    def gate_sum(self, xs, gids, dst=None):
+        x = xs[0]
+        if dst is None:
+            dst = self.new(x.h, x.w, x.c)
+        self._layer(op=OP_GATE_SUM, ins=list(xs), out=dst, cin=x.cpad, cout=x.c, gates=list(gids))
+        return dst
+
+    def head(self, name, x, dim):
+        p = self.wsrc.linear(name, dim, x.c, bn=True)
+        w, b = fold_bn(p)
+        w16 = np.zeros((dim, x.cpad), np.float16)
+        w16[:, :x.c] = w.astype(np.float16)
+        dst = View(x.tid, x.coff, x.c, x.h, x.w)   # output goes to the ctx embedding buffer
+        self._layer(op=OP_HEAD, ins=[x], out=dst, cin=x.cpad, cout=dim, w_off=self._push(w16),
+                    b_off=self._push(b.astype(np.float32)), name=name,
+                    head_ref=(w16[:, :x.c].astype(np.float32), b))
+        return dst
+
+    # ---------------------------------------------------------------- C tables
+    def tables(self):
+        ts = (fm_tensor * len(self.tensors))()
+        for i, (h, w, c, f32) in enumerate(self.tensors):
+            ts[i] = fm_tensor(h, w, c, f32)
+        ls = (fm_layer * len(self.layers))()
+        for i, d in enumerate(self.layers):
+            L = fm_layer()
+            L.op = d['op']
+            L.n_in = len(d['ins'])
+            for j, v in enumerate(d['ins']):
+                L.in_[j] = v.tid
+                L.in_coff[j] = v.coff
+            L.out, L.out_coff = d['out'].tid, d['out'].coff
+            if d['res'] is not None:
+                L.res, L.res_coff = d['res'].tid, d['res'].coff
+            else:
+                L.res, L.res_coff = -1, 0
+            L.res_mode = d['res_mode']
+            for key in ('cin', 'cout', 'k', 'stride', 'pad', 'act', 'hid', 'w_off', 'b_off', 'w2_off', 'b2_off'):
+                setattr(L, key, d[key])
+            for j in range(4):
+                L.gate[j] = d['gates'][j] if j < len(d['gates']) else -1
+            ls[i] = L
+        blob = bytes(self.blob) + b'\0' * 64
+        return ts, ls, blob
+
+    def conv_flops(self, batch=1):
+        """2*MAC over conv layers (the 'conv roofline' numerator)."""
+        total = 0
+        for d in self.layers:
+            if d['op'] == OP_CONV:
+                o = d['out']
+                total += 2 * d['k'] * d['k'] * d['ins'][0].c * d['cout'] * o.h * o.w * batch
+        return total

@@ -1,0 +1,99 @@
+"""ReID model descriptors (registry + attributes of fastmot/models/reid.py:10-45,95-109) and the
+OSNet layer table for the HIP conv engine (torchreid osnet_x1_0 / osnet_x0_25 topology,
+SURVEY.md appendix A: 978.9 / 82.3 MMAC per 256x128 crop)."""
+from pathlib import Path
+
+from .graph import Graph, RandomWeights, RES_BEFORE_ACT
+
+
+class ReID:
+    """Base class for ReID models.
+
+    ENGINE_PATH / MODEL_PATH : cache / checkpoint locations; INPUT_SHAPE (c, h, w);
+    OUTPUT_LAYOUT : feature dimension; METRIC : {'euclidean', 'cosine'}.
+    """
+    __registry = {}
+
+    PLUGIN_PATH = None
+    ENGINE_PATH = None
+    MODEL_PATH = None
+    INPUT_SHAPE = None
+    OUTPUT_LAYOUT = None
+    METRIC = None
+    CHANNELS = None
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        cls.__registry[cls.__name__] = cls
+
+    @classmethod
+    def get_model(cls, name):
+        return cls.__registry[name]
+
+    @classmethod
+    def build_graph(cls, weights=None):
+        if weights is None:
+            weights = RandomWeights(seed=1)
+        return osnet_graph(cls, weights)
+
+
+def osnet_graph(model, weights):
+    _, H, W = model.INPUT_SHAPE
+    c0, c1, c2, c3 = model.CHANNELS
+    g = Graph(weights, (H, W), 3)
+
+    def osblock(name, x, cout):
+        mid = cout // 4
+        x1 = g.conv(name + '.conv1', x, mid, 1, 1, 'relu')
+        streams, gids = [], []
+        gp = None
+        for t in range(1, 5):
+            s = x1
+            for i in range(t):
+                y = g.conv(f'{name}.s{t}.{i}.pw', s, mid, 1, 1, 'linear', bn=False)
+                s = g.dwconv3(f'{name}.s{t}.{i}.dw', y, 'relu')
+            gid, gp = g.gate(name + '.gate', s, max(mid // 16, 1), gp)
+            streams.append(s)
+            gids.append(gid)
+        x2 = g.gate_sum(streams, gids)
+        if x.c != cout:
+            ident = g.conv(name + '.down', x, cout, 1, 1, 'linear')
+        else:
+            ident = x
+        return g.conv(name + '.conv3', x2, cout, 1, 1, 'relu', res=ident, res_mode=RES_BEFORE_ACT)
+
+    x = g.conv('conv1', g.input, c0, 7, 2, 'relu', pad=3)
+    x = g.pool(x, 3, 2, 1)
+    x = osblock('conv2.0', x, c1)
+    x = osblock('conv2.1', x, c1)
+    x = g.conv('conv2.t', x, c1, 1, 1, 'relu')
+    x = g.pool(x, 2, 2, 0, avg=True)
+    x = osblock('conv3.0', x, c2)
+    x = osblock('conv3.1', x, c2)
+    x = g.conv('conv3.t', x, c2, 1, 1, 'relu')
+    x = g.pool(x, 2, 2, 0, avg=True)
+    x = osblock('conv4.0', x, c3)
+    x = osblock('conv4.1', x, c3)
+    x = g.conv('conv5', x, c3, 1, 1, 'relu')
+    g.head('fc', x, model.OUTPUT_LAYOUT)
+    g.outputs = [x]
+    return g, x
+
+
+class OSNet025(ReID):
+    ENGINE_PATH = Path(__file__).parent / 'osnet_x0_25_msmt17.hipnet'
+    MODEL_PATH = Path(__file__).parent / 'osnet_x0_25_msmt17.pth'
+    INPUT_SHAPE = (3, 256, 128)
+    OUTPUT_LAYOUT = 512
+    METRIC = 'euclidean'
+    CHANNELS = (16, 64, 96, 128)
+
+
+class OSNet10(ReID):
+    """Multi-source model trained on MSMT17, DukeMTMC, and CUHK03, not provided."""
+    ENGINE_PATH = Path(__file__).parent / 'osnet_x1_0_msdc.hipnet'
+    MODEL_PATH = Path(__file__).parent / 'osnet_x1_0_msdc.pth'
+    INPUT_SHAPE = (3, 256, 128)
+    OUTPUT_LAYOUT = 512
+    METRIC = 'cosine'
+    CHANNELS = (64, 256, 384, 512)

@@ -159,6 +159,67 @@ int fm_greedy(fm_ctx* ctx, const double* cost, int nr, int nc, double max_cost,
 /* iou_dist on host boxes (utils/distance.py:91-108) -- used by _rectify_matches */
 int fm_iou_dist(fm_ctx* ctx, int na, const double* a, int nb, const double* b, double* out);
 
+/* ---------------------------------------------------------------- conv engine --------- */
+/* Replaces the TensorRT engines (fastmot/utils/inference.py:39-125; engine build
+ * fastmot/models/yolo.py:106-151, fastmot/models/reid.py:48-92).  A network is a layer table over
+ * NHWC fp16 tensors (channels padded to 8); Conv+BN+activation(+shortcut) layers run on the MFMA
+ * implicit-GEMM kernel, concat/route is expressed by channel offsets into shared tensors. */
+enum { FM_NET_DETECTOR = 0, FM_NET_EXTRACTOR = 1 };
+enum {
+    FM_OP_CONV = 0,      /* conv k x k, stride, pad + bias + act (+ residual)                    */
+    FM_OP_DWCONV3 = 1,   /* depthwise 3x3 s1 p1 + bias + act (OSNet LightConv3x3)                */
+    FM_OP_MAXPOOL = 2,   /* k, stride, pad (yolo2onnx.py:838-863; OSNet k3 s2 p1)               */
+    FM_OP_AVGPOOL = 3,   /* k = stride (OSNet transition 2x2)                                   */
+    FM_OP_UPSAMPLE2 = 4, /* nearest x2 (yolo2onnx.py:806-836)                                   */
+    FM_OP_COPY = 5,      /* channel-slice copy                                                  */
+    FM_OP_GATE = 6,      /* OSNet channel gate: GAP -> fc1 -> ReLU -> fc2 -> sigmoid -> gate[0] */
+    FM_OP_GATE_SUM = 7,  /* out = sum_i in[i] * gate[i]                                         */
+    FM_OP_HEAD = 8       /* GAP -> Linear(+BN1d) -> ReLU -> L2 normalise -> ctx embeddings      */
+};
+enum { FM_ACT_LINEAR = 0, FM_ACT_LEAKY = 1, FM_ACT_MISH = 2, FM_ACT_RELU = 3, FM_ACT_LOGISTIC = 4,
+       FM_ACT_SWISH = 5 };
+enum { FM_RES_NONE = 0, FM_RES_AFTER_ACT = 1, FM_RES_BEFORE_ACT = 2 };
+
+typedef struct fm_tensor {
+    int32_t h, w, c;     /* per-sample geometry, c = channel stride (multiple of 8) */
+    int32_t f32;         /* 1: fp32 storage (YOLO head outputs), 0: fp16 */
+} fm_tensor;
+
+typedef struct fm_layer {
+    int32_t op;
+    int32_t n_in;
+    int32_t in[4], in_coff[4];
+    int32_t out, out_coff;
+    int32_t res, res_coff, res_mode;
+    int32_t cin, cout, k, stride, pad, act;
+    int32_t hid;
+    int32_t gate[4];
+    int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob (16 B aligned) */
+} fm_layer;
+
+/* weights: CONV  w = fp16 [ceil32(cout)][ceil32(k*k*cin)] (K order kh,kw,cin), b = f32[ceil32(cout)]
+ *          DWCONV3 w = fp16 [9][c], b = f32[c];  GATE w=[hid][c] b=[hid] w2=[c][hid] b2=[c];
+ *          HEAD  w = fp16 [cout][cin], b = f32[cout]  (BN folded everywhere). */
+int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensors, const fm_tensor* tensors,
+                  int n_layers, const fm_layer* layers, const void* weights, size_t weight_bytes,
+                  int n_gates, int gate_channels);
+int fm_net_destroy(fm_ctx* ctx, int which);
+/* enqueues every layer for `batch` samples on the network's stream (no host sync) */
+int fm_net_run(fm_ctx* ctx, int which, int batch);
+/* host <-> tensor copies (synchronous; tests and weight-free smoke runs) */
+int fm_net_tensor_write(fm_ctx* ctx, int which, int tensor, const void* host, size_t bytes);
+int fm_net_tensor_read(fm_ctx* ctx, int which, int tensor, void* host, size_t bytes);
+/* copies the embeddings produced by FM_OP_HEAD ([n][feat_dim] f32, L2-normalised) to the host
+ * after synchronising the extractor stream (FeatureExtractor.postprocess, feature_extractor.py:62-74) */
+int fm_net_read_embeddings(fm_ctx* ctx, int n, float* host);
+/* total FLOPs (2*MAC) and minimal HBM bytes of one run at the given batch: the numbers the
+ * bench's roofline uses (SURVEY.md section 8d formulas) */
+int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, double* bytes);
+/* average duration in ms of the conv (MFMA) launches of the last fm_net_run measured with HIP
+ * events on the network's own stream; enable != 0 switches per-layer timing on (slow path). */
+int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, double* conv_ms, double* other_ms,
+                   int* n_conv, int* n_other);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""TEST INFRASTRUCTURE: plain PyTorch fp32 (CPU, NCHW) interpreter of a models/graph.py layer table
+-- the reference the conv-engine kernels are compared against (the reference's own conv arithmetic
+is TensorRT's, which is neither available nor pinned).
+`emulate_fp16_storage=True` rounds every layer output to fp16, as the engine stores activations."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from fastmot_amd.models import graph as G
+
+
+def act_fn(x, act):
+    if act == G.ACT['leaky']:
+        return F.leaky_relu(x, 0.1)
+    if act == G.ACT['mish']:
+        return x * torch.tanh(F.softplus(x))
+    if act == G.ACT['relu']:
+        return F.relu(x)
+    if act == G.ACT['logistic']:
+        return torch.sigmoid(x)
+    if act == G.ACT['swish']:
+        return x * torch.sigmoid(x)
+    return x
+
+
+def run_graph(graph, x_nchw, emulate_fp16_storage=True):
+    """x_nchw: float tensor [N, C, H, W].  Returns dict tid -> tensor [N, cpad, h, w] and the
+    embedding matrix if the graph has a head."""
+    n = x_nchw.shape[0]
+    bufs = {}
+    for tid, (h, w, c, f32) in enumerate(graph.tensors):
+        bufs[tid] = torch.zeros(n, c, h, w)
+    x = x_nchw.float()
+    if emulate_fp16_storage:
+        x = x.half().float()
+    bufs[graph.input.tid][:, :x.shape[1]] = x
+    params = {idx: (w, b) for idx, w, b in graph.conv_params}
+    gates = {}
+    emb = None
+
+    def rd(v):
+        return bufs[v.tid][:, v.coff:v.coff + v.c]
+
+    def wr(v, val, f32=False):
+        if emulate_fp16_storage and not f32:
+            val = val.half().float()
+        bufs[v.tid][:, v.coff:v.coff + v.c] = val
+
+    for idx, d in enumerate(graph.layers):
+        op = d['op']
+        xin = rd(d['ins'][0])
+        if op == G.OP_CONV:
+            w, b = params[idx]
+            y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), stride=d['stride'], padding=d['pad'])
+            if d['res_mode'] == G.RES_BEFORE_ACT:
+                y = y + rd(d['res'])
+            y = act_fn(y, d['act'])
+            if d['res_mode'] == G.RES_AFTER_ACT:
+                y = y + rd(d['res'])
+            wr(d['out'], y, f32=bool(graph.tensors[d['out'].tid][3]))
+        elif op == G.OP_DWCONV3:
+            w, b = params[idx]
+            y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), padding=1, groups=xin.shape[1])
+            wr(d['out'], act_fn(y, d['act']))
+        elif op == G.OP_MAXPOOL:
+            wr(d['out'], F.max_pool2d(xin, d['k'], d['stride'], d['pad']))
+        elif op == G.OP_AVGPOOL:
+            wr(d['out'], F.avg_pool2d(xin, d['k'], d['stride'], d['pad']))
+        elif op == G.OP_UPSAMPLE2:
+            wr(d['out'], F.interpolate(xin, scale_factor=2, mode='nearest'))
+        elif op == G.OP_COPY:
+            wr(d['out'], xin)
+        elif op == G.OP_GATE:
+            w1, b1, w2, b2 = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['gate_ref'])
+            gap = xin.mean(dim=(2, 3))
+            hid = F.relu(gap @ w1.T + b1)
+            gates[d['gates'][0]] = torch.sigmoid(hid @ w2.T + b2)
+        elif op == G.OP_GATE_SUM:
+            y = 0
+            for v, gid in zip(d['ins'], d['gates']):
+                y = y + rd(v) * gates[gid][:, :, None, None]
+            wr(d['out'], y)
+        elif op == G.OP_HEAD:
+            w, b = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['head_ref'])
+            feat = F.relu(xin.mean(dim=(2, 3)) @ w.T + b)
+            emb = feat / feat.norm(dim=1, keepdim=True)
+        else:
+            raise ValueError(op)
+    return bufs, emb
