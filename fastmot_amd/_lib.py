@@ -302,3 +302,109 @@ STAGE_IOU = 1
 STAGE_REID = 2
 SOLVER_LAP = 0
 SOLVER_GREEDY = 1
+
+
+# ---------------------------------------------------------------------- detector / extractor
+FM_MAX_HEADS, FM_MAX_ANCHORS = 4, 6
+
+
+class YoloCfg(C.Structure):
+    _fields_ = [('in_w', C.c_int32), ('in_h', C.c_int32),
+                ('roi_x', C.c_int32), ('roi_y', C.c_int32), ('roi_w', C.c_int32), ('roi_h', C.c_int32),
+                ('input_tensor', C.c_int32), ('n_heads', C.c_int32),
+                ('head_tensor', C.c_int32 * FM_MAX_HEADS),
+                ('grid_w', C.c_int32 * FM_MAX_HEADS), ('grid_h', C.c_int32 * FM_MAX_HEADS),
+                ('n_anchors', C.c_int32 * FM_MAX_HEADS),
+                ('anchors', (C.c_float * (2 * FM_MAX_ANCHORS)) * FM_MAX_HEADS),
+                ('scale_xy', C.c_float * FM_MAX_HEADS),
+                ('num_classes', C.c_int32), ('new_coords', C.c_int32),
+                ('label_mask', C.c_uint8 * 128),
+                ('conf_thresh', C.c_double), ('nms_thresh', C.c_double), ('max_area', C.c_double),
+                ('min_aspect_ratio', C.c_double),
+                ('size', C.c_double * 2), ('offset', C.c_double * 2),
+                ('max_candidates', C.c_int32)]
+
+
+DET_DTYPE = np.dtype([('tlbr', float, 4), ('label', int), ('conf', float)], align=True)
+assert DET_DTYPE.itemsize == 48
+
+
+def _bind_device_io(cls):
+    def frame_configure(self, width, height, ring_size=0):
+        check(self.lib.fm_frame_configure(self._ctx, C.c_int(width), C.c_int(height), C.c_int(ring_size)))
+        self.frame_size = (width, height)
+        self.ring_size = ring_size
+
+    def frame_upload(self, frame):
+        w, h = self.frame_size
+        if frame.shape != (h, w, 3) or frame.dtype != np.uint8:
+            raise ValueError(f'frame must be uint8 {h}x{w}x3')
+        f = np.ascontiguousarray(frame)
+        check(self.lib.fm_frame_upload(self._ctx, _ptr(f)))
+
+    def frame_ring_store(self, index, frame):
+        f = np.ascontiguousarray(frame, np.uint8)
+        check(self.lib.fm_frame_ring_store(self._ctx, C.c_int(index), _ptr(f)))
+
+    def frame_ring_select(self, index):
+        check(self.lib.fm_frame_ring_select(self._ctx, C.c_int(index)))
+
+    def frame_read(self):
+        w, h = self.frame_size
+        out = np.empty((h, w, 3), np.uint8)
+        check(self.lib.fm_frame_read(self._ctx, _ptr(out)))
+        return out
+
+    def detect_configure(self, cfg):
+        check(self.lib.fm_detect_configure(self._ctx, C.byref(cfg)))
+
+    def detect_async(self):
+        check(self.lib.fm_detect_async(self._ctx))
+
+    def detect_preprocess_only(self):
+        check(self.lib.fm_detect_preprocess_only(self._ctx))
+
+    def detect_sync(self, cap=4096):
+        out = np.zeros(cap, DET_DTYPE)
+        n = C.c_int(0)
+        check(self.lib.fm_detect_sync(self._ctx, _ptr(out), C.c_int(cap), C.byref(n)))
+        return out[:n.value].view(np.recarray)
+
+    def filter_dets(self, rows, cap=8192):
+        r = _as(rows, np.float32).reshape(-1, 7)
+        out = np.zeros(cap, DET_DTYPE)
+        n = C.c_int(0)
+        check(self.lib.fm_filter_dets(self._ctx, _ptr(r), C.c_int(len(r)), _ptr(out), C.c_int(cap), C.byref(n)))
+        return out[:n.value].view(np.recarray)
+
+    def detect_raw_candidates(self, cap=65536):
+        rows = np.empty((cap, 8), np.float32)
+        n = C.c_int(0)
+        check(self.lib.fm_detect_raw_candidates(self._ctx, _ptr(rows), C.c_int(cap), C.byref(n)))
+        return rows[:n.value]
+
+    def extract_configure(self, input_tensor, in_w, in_h):
+        check(self.lib.fm_extract_configure(self._ctx, C.c_int(input_tensor), C.c_int(in_w), C.c_int(in_h)))
+
+    def extract_async(self, tlbrs):
+        b = _as(tlbrs, np.float64).reshape(-1, 4)
+        check(self.lib.fm_extract_async(self._ctx, C.c_int(len(b)), _ptr(b)))
+        return len(b)
+
+    def extract_sync(self, n):
+        out = np.empty((n, self.feat_dim), np.float32)
+        check(self.lib.fm_extract_sync(self._ctx, C.c_int(n), _ptr(out)))
+        return out
+
+    def extract_read_input(self, n, in_w, in_h):
+        out = np.empty((n, in_h, in_w, 3), np.float32)
+        check(self.lib.fm_extract_read_input(self._ctx, C.c_int(n), _ptr(out)))
+        return out
+
+    for fn in (frame_configure, frame_upload, frame_ring_store, frame_ring_select, frame_read,
+               detect_configure, detect_async, detect_preprocess_only, detect_sync, filter_dets,
+               detect_raw_candidates, extract_configure, extract_async, extract_sync, extract_read_input):
+        setattr(cls, fn.__name__, fn)
+
+
+_bind_device_io(HipContext)

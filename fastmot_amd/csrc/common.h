@@ -72,6 +72,8 @@ struct KFConst {           // constants derived from fm_kf_params, passed by val
 };
 
 struct NetState;     // conv engine (net.hip)
+struct DetState;     // detector pre/post (detect.hip)
+struct ExtState;     // extractor pre (extract.hip)
 struct FlowState;    // KLT (flow.hip)
 
 struct fm_ctx {
@@ -109,6 +111,15 @@ struct fm_ctx {
     DevBuf as_out;      // matches
     DevBuf io0, io1;    // generic staging (kalman etc.)
 
+    // ---- frames (BGR u8) resident on the device
+    int frame_w = 0, frame_h = 0, ring_size = 0;
+    uint8_t* frame_cur = nullptr;          // points into frame_own or the ring
+    uint8_t* frame_own = nullptr;
+    uint8_t* frame_ring = nullptr;
+    uint8_t* frame_pinned = nullptr;
+
+    DetState* det = nullptr;
+    ExtState* ext = nullptr;
     NetState* det_net = nullptr;
     NetState* ext_net = nullptr;
     FlowState* flow = nullptr;

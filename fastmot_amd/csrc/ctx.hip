@@ -22,6 +22,8 @@ extern "C" int fm_device_count(void) {
 }
 
 void fm_net_free(NetState* n);
+void fm_det_free(DetState* d);
+void fm_ext_free(ExtState* e);
 void fm_flow_free(FlowState* f);
 
 extern "C" int fm_ctx_create(int device, fm_ctx** out) {
@@ -49,6 +51,11 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    if (ctx->det) fm_det_free(ctx->det);
+    if (ctx->ext) fm_ext_free(ctx->ext);
+    for (void* p : {(void*)ctx->frame_own, (void*)ctx->frame_ring})
+        if (p) (void)hipFree(p);
+    if (ctx->frame_pinned) (void)hipHostFree(ctx->frame_pinned);
     if (ctx->det_net) fm_net_free(ctx->det_net);
     if (ctx->ext_net) fm_net_free(ctx->ext_net);
     if (ctx->flow) fm_flow_free(ctx->flow);

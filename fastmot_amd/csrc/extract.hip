@@ -1,0 +1,166 @@
+// ReID front end on the device: crop -> OpenCV-style fixed-point bilinear resize -> normalise.
+//
+// Replaces FeatureExtractor.extract_async/_preprocess/_normalize (fastmot/feature_extractor.py:
+// 48-60,84-98) and multi_crop (fastmot/utils/rect.py:93-97).  The reference resizes every crop
+// on the CPU (ThreadPool + cv2.resize) and uploads 393 KB per crop; here the crops are read from
+// the frame that is already resident in HBM and written straight into the network input.
+//
+// cv2.resize(INTER_LINEAR) on 8-bit images is restated from OpenCV's published algorithm
+// (imgproc/resize.cpp, 4.1.1 pinned by the reference Dockerfile:5): source coordinate
+// (d + 0.5) * scale - 0.5, 11-bit fixed-point coefficients (INTER_RESIZE_COEF_SCALE = 2048),
+// horizontal pass to int32, vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+// Parity for this stage is pinned only against the restatement in oracle/cv_oracle.py (OpenCV is
+// not available to run; SURVEY.md section 8c "parity unpinned").
+// Roofline: HBM bound; per crop reads <= w*h*3 B of frame, writes 256*128*8*2 B = 512 KB.
+#include "net.h"
+#include <cmath>
+
+struct ExtState {
+    int input_tensor = -1, in_w = 0, in_h = 0;
+    double* boxes = nullptr;       // device [cap][4]
+    double* boxes_host = nullptr;  // pinned
+    int cap = 0;
+};
+
+void fm_ext_free(ExtState* e) {
+    if (!e) return;
+    if (e->boxes) (void)hipFree(e->boxes);
+    if (e->boxes_host) (void)hipHostFree(e->boxes_host);
+    delete e;
+}
+
+namespace {
+
+struct Coef { int s; short a0, a1; };
+
+// OpenCV resize coordinate + coefficient computation for one output index
+__device__ __forceinline__ Coef lin_coef(int d, double scale, int ssize) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    Coef c;
+    c.s = s;
+    // saturate_cast<short>(v * 2048) with cvRound (round half to even)
+    c.a0 = (short)__float2int_rn((1.f - f) * 2048.f);
+    c.a1 = (short)__float2int_rn(f * 2048.f);
+    return c;
+}
+
+__global__ void crop_resize_kernel(const uint8_t* __restrict__ frame, int fw, int fh,
+                                   const double* __restrict__ boxes, int n, f16* __restrict__ out,
+                                   int ow, int oh, int cs) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= ow) return;
+    const double* bx = boxes + (size_t)b * 4;
+    // multi_crop: astype(int) truncation, maximum(., 0), inclusive bottom-right, numpy slice clamp
+    int x1 = max((int)bx[0], 0), y1 = max((int)bx[1], 0);
+    int x2 = max((int)bx[2], 0), y2 = max((int)bx[3], 0);
+    x2 = min(x2 + 1, fw); y2 = min(y2 + 1, fh);
+    const int cw = x2 - x1, ch = y2 - y1;
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)0.f;
+    if (cw > 0 && ch > 0) {
+        const Coef cx = lin_coef(x, (double)cw / ow, cw);
+        const Coef cy = lin_coef(y, (double)ch / oh, ch);
+        const int sx1 = min(cx.s + 1, cw - 1), sy1 = min(cy.s + 1, ch - 1);
+        const uint8_t* r0 = frame + ((size_t)(y1 + cy.s) * fw + x1) * 3;
+        const uint8_t* r1 = frame + ((size_t)(y1 + sy1) * fw + x1) * 3;
+        const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int S0 = r0[cx.s * 3 + c] * cx.a0 + r0[sx1 * 3 + c] * cx.a1;
+            const int S1 = r1[cx.s * 3 + c] * cx.a0 + r1[sx1 * 3 + c] * cx.a1;
+            const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            const int u8 = min(max(v, 0), 255);
+            const int rc = 2 - c;    // BGR -> RGB
+            o[rc] = (f16)(float)(((double)u8 / 255. - mean[rc]) / stdv[rc]);
+        }
+    }
+    *reinterpret_cast<f16x8*>(out + (((size_t)b * oh + y) * ow + x) * cs) = o;
+}
+
+}  // namespace
+
+extern "C" int fm_extract_configure(fm_ctx* ctx, int input_tensor, int in_w, int in_h) {
+    FM_CHECK_ARG(ctx && ctx->ext_net && input_tensor >= 0 && input_tensor < (int)ctx->ext_net->tensors.size());
+    const fm_tensor& t = ctx->ext_net->tensors[input_tensor];
+    FM_CHECK_ARG(t.h == in_h && t.w == in_w && !t.f32);
+    if (!ctx->ext) ctx->ext = new ExtState();
+    ctx->ext->input_tensor = input_tensor;
+    ctx->ext->in_w = in_w;
+    ctx->ext->in_h = in_h;
+    return 0;
+}
+
+int fm_emb_reserve(fm_ctx* ctx, int n);
+
+extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
+    FM_CHECK_ARG(ctx && ctx->ext && ctx->ext_net && n >= 0 && ctx->frame_cur);
+    ctx->emb_n = 0;
+    if (n == 0) return 0;
+    FM_CHECK_ARG(tlbr);
+    ExtState* e = ctx->ext;
+    NetState* net = ctx->ext_net;
+    hipStream_t s = ctx->s_ext;
+    if (n > e->cap) {
+        FM_HIP(hipStreamSynchronize(s));
+        if (e->boxes) FM_HIP(hipFree(e->boxes));
+        if (e->boxes_host) FM_HIP(hipHostFree(e->boxes_host));
+        e->boxes = e->boxes_host = nullptr;
+        int cap = e->cap ? e->cap : 64;
+        while (cap < n) cap *= 2;
+        FM_HIP(hipMalloc(&e->boxes, sizeof(double) * 4 * cap));
+        FM_HIP(hipHostMalloc(&e->boxes_host, sizeof(double) * 4 * cap, hipHostMallocDefault));
+        e->cap = cap;
+    }
+    if (n > ctx->emb_cap) {
+        // association (s_main) may still read the previous embeddings
+        FM_HIP(hipStreamSynchronize(ctx->s_main));
+        FM_HIP(hipStreamSynchronize(s));
+        int rc = fm_emb_reserve(ctx, n);
+        if (rc) return rc;
+    }
+    FM_HIP(hipStreamSynchronize(s));   // boxes_host reuse
+    memcpy(e->boxes_host, tlbr, sizeof(double) * 4 * n);
+    FM_HIP(hipMemcpyAsync(e->boxes, e->boxes_host, sizeof(double) * 4 * n, hipMemcpyHostToDevice, s));
+    const fm_tensor& t = net->tensors[e->input_tensor];
+    for (int off = 0; off < n; off += net->max_batch) {
+        const int b = n - off < net->max_batch ? n - off : net->max_batch;
+        hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, b), dim3(128), 0, s,
+                           ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes + (size_t)off * 4, b,
+                           (f16*)net->bufs[e->input_tensor], e->in_w, e->in_h, t.c);
+        FM_HIP(hipGetLastError());
+        net->emb_offset = off;
+        int rc = fm_net_run_internal(ctx, FM_NET_EXTRACTOR, b);
+        net->emb_offset = 0;
+        if (rc) return rc;
+    }
+    ctx->emb_n = n;
+    return 0;
+}
+
+extern "C" int fm_extract_sync(fm_ctx* ctx, int n, float* emb) {
+    FM_CHECK_ARG(ctx && n >= 0 && n <= ctx->emb_cap);
+    FM_HIP(hipStreamSynchronize(ctx->s_ext));
+    if (n == 0) return 0;
+    FM_CHECK_ARG(emb);
+    FM_HIP(hipMemcpy(emb, ctx->emb, sizeof(float) * (size_t)n * ctx->feat_dim, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int fm_extract_read_input(fm_ctx* ctx, int n, float* out) {
+    FM_CHECK_ARG(ctx && ctx->ext && ctx->ext_net && n > 0 && n <= ctx->ext_net->max_batch && out);
+    ExtState* e = ctx->ext;
+    NetState* net = ctx->ext_net;
+    const fm_tensor& t = net->tensors[e->input_tensor];
+    FM_HIP(hipStreamSynchronize(ctx->s_ext));
+    std::vector<f16> tmp((size_t)n * t.h * t.w * t.c);
+    FM_HIP(hipMemcpy(tmp.data(), net->bufs[e->input_tensor], tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < (size_t)n * t.h * t.w; ++p)
+        for (int c = 0; c < 3; ++c) out[p * 3 + c] = (float)tmp[p * t.c + c];
+    return 0;
+}

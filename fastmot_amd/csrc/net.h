@@ -27,6 +27,23 @@ struct ConvParams {
 
 int launch_conv(const ConvParams& p, hipStream_t s);
 
+struct NetState {
+    int which = 0, max_batch = 0;
+    std::vector<fm_tensor> tensors;
+    std::vector<void*> bufs;
+    std::vector<fm_layer> layers;
+    char* weights = nullptr;
+    size_t weight_bytes = 0;
+    float* gates = nullptr;
+    int n_gates = 0, gate_c = 0;
+    hipStream_t stream = nullptr;
+    int emb_offset = 0;   // row offset of FM_OP_HEAD outputs in ctx->emb (batched extraction)
+    int batch_offset = 0; // sample offset into the input tensor for chunked runs
+};
+
+NetState* fm_net_get(fm_ctx* ctx, int which);
+int fm_net_run_internal(fm_ctx* ctx, int which, int batch);
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case ACT_LEAKY: return x > 0.f ? x : 0.1f * x;

@@ -22,17 +22,6 @@ int launch_head(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int
                 const float* b, float* out, float* raw_out, hipStream_t s);
 int fm_emb_reserve(fm_ctx* ctx, int n);
 
-struct NetState {
-    int which = 0, max_batch = 0;
-    std::vector<fm_tensor> tensors;
-    std::vector<void*> bufs;
-    std::vector<fm_layer> layers;
-    char* weights = nullptr;
-    size_t weight_bytes = 0;
-    float* gates = nullptr;
-    int n_gates = 0, gate_c = 0;
-    hipStream_t stream = nullptr;
-};
 
 void fm_net_free(NetState* n) {
     if (!n) return;
@@ -44,6 +33,8 @@ void fm_net_free(NetState* n) {
 }
 
 static NetState*& net_slot(fm_ctx* ctx, int which) { return which == FM_NET_DETECTOR ? ctx->det_net : ctx->ext_net; }
+NetState* fm_net_get(fm_ctx* ctx, int which) { return net_slot(ctx, which); }
+int fm_net_run_internal(fm_ctx* ctx, int which, int batch) { return fm_net_run(ctx, which, batch); }
 
 static size_t elem_size(const fm_tensor& t) { return t.f32 ? 4 : 2; }
 
@@ -164,10 +155,10 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             return launch_gate_sum(L.n_in, ins, cs, co, gs, out, to.c, L.out_coff, B, ti.h * ti.w, L.cin, s);
         }
         case FM_OP_HEAD:
-            FM_CHECK_ARG(L.cout == ctx->feat_dim && B <= ctx->emb_cap);
+            FM_CHECK_ARG(L.cout == ctx->feat_dim && net->emb_offset + B <= ctx->emb_cap);
             return launch_head(in0, ti.c, L.in_coff[0], B, ti.h * ti.w, L.cin, L.cout,
                                (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
-                               ctx->emb, nullptr, s);
+                               ctx->emb + (size_t)net->emb_offset * ctx->feat_dim, nullptr, s);
         default:
             fm_set_error("unknown layer op %d", L.op);
             return FM_ERR_ARG;

@@ -118,23 +118,25 @@ def yolov4_graph(model, weights):
     n3 = five(u3, 128)
 
     n_out = (5 + model.NUM_CLASSES) * (len(model.ANCHORS[0]) // 2)
+    # new_coords models (Scaled-YOLOv4) apply the logistic activation in the conv before [yolo]
+    head_act = 'logistic' if model.NEW_COORDS else 'linear'
     heads = []
     x = conv(n3, 256, 3, **lk)
-    heads.append(conv(x, n_out, 1, act='linear', bn=False, f32_out=True))
+    heads.append(conv(x, n_out, 1, act=head_act, bn=False, f32_out=True))
 
     d4 = g.new(n4.h, n4.w, 512)
     conv(n3, 256, 3, 2, dst=d4.slice(0, 256), **lk)
     g.copy(n4, d4.slice(256, 256))
     m4 = five(d4, 256)
     x = conv(m4, 512, 3, **lk)
-    heads.append(conv(x, n_out, 1, act='linear', bn=False, f32_out=True))
+    heads.append(conv(x, n_out, 1, act=head_act, bn=False, f32_out=True))
 
     d5 = g.new(p5.h, p5.w, 1024)
     conv(m4, 512, 3, 2, dst=d5.slice(0, 512), **lk)
     g.copy(p5, d5.slice(512, 512))
     m5 = five(d5, 512)
     x = conv(m5, 1024, 3, **lk)
-    heads.append(conv(x, n_out, 1, act='linear', bn=False, f32_out=True))
+    heads.append(conv(x, n_out, 1, act=head_act, bn=False, f32_out=True))
     g.outputs = heads
     return g, heads
 

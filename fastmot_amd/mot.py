@@ -1,0 +1,142 @@
+"""MOT: the per-frame orchestrator (API of fastmot/mot.py:25-196).
+
+Same stage schedule as the reference's MOT.step (mot.py:125-168) -- detector enqueue || KLT,
+extractor enqueue || Kalman, then association -- but every stage is a set of kernels on its own HIP
+stream of one shared device context, and the frame is uploaded once per step (or is already
+resident: pass a detector.DeviceFrame)."""
+from types import SimpleNamespace
+from enum import Enum
+import logging
+
+import numpy as np
+
+from .detector import SSDDetector, YOLODetector, PublicDetector, bind_frame
+from .feature_extractor import FeatureExtractor
+from .tracker import MultiTracker
+from .utils import Profiler
+
+LOGGER = logging.getLogger(__name__)
+
+
+class DetectorType(Enum):
+    SSD = 0
+    YOLO = 1
+    PUBLIC = 2
+
+
+class MOT:
+    def __init__(self, size,
+                 detector_type='YOLO',
+                 detector_frame_skip=5,
+                 class_ids=(1,),
+                 ssd_detector_cfg=None,
+                 yolo_detector_cfg=None,
+                 public_detector_cfg=None,
+                 feature_extractor_cfgs=None,
+                 tracker_cfg=None,
+                 visualizer_cfg=None,
+                 draw=False):
+        """Top level module that integrates detection, feature extraction and tracking
+        (parameters: fastmot/mot.py:37-67).  `draw=True` is not supported on this path
+        (visualisation is out of scope)."""
+        self.size = size
+        self.detector_type = DetectorType[detector_type.upper()]
+        assert detector_frame_skip >= 1
+        self.detector_frame_skip = detector_frame_skip
+        self.class_ids = tuple(np.unique(class_ids))
+        self.draw = draw
+
+        if ssd_detector_cfg is None:
+            ssd_detector_cfg = SimpleNamespace()
+        if yolo_detector_cfg is None:
+            yolo_detector_cfg = SimpleNamespace()
+        if public_detector_cfg is None:
+            public_detector_cfg = SimpleNamespace()
+        if feature_extractor_cfgs is None:
+            feature_extractor_cfgs = (SimpleNamespace(),)
+        if tracker_cfg is None:
+            tracker_cfg = SimpleNamespace()
+        if visualizer_cfg is None:
+            visualizer_cfg = SimpleNamespace()
+        if len(feature_extractor_cfgs) != len(class_ids):
+            raise ValueError('Number of feature extractors must match length of class IDs')
+        if len(feature_extractor_cfgs) != 1:
+            raise NotImplementedError('one ReID network per context (the reference routes every box '
+                                      'to the first extractor anyway: bisect_right quirk, SURVEY Q3)')
+        if draw:
+            raise NotImplementedError('visualisation is out of scope of the MI355X hot path')
+
+        LOGGER.info('Loading detector model...')
+        if self.detector_type == DetectorType.SSD:
+            self.detector = SSDDetector(self.size, self.class_ids, **vars(ssd_detector_cfg))
+        elif self.detector_type == DetectorType.YOLO:
+            self.detector = YOLODetector(self.size, self.class_ids, **vars(yolo_detector_cfg))
+        elif self.detector_type == DetectorType.PUBLIC:
+            self.detector = PublicDetector(self.size, self.class_ids, self.detector_frame_skip,
+                                           **vars(public_detector_cfg))
+
+        LOGGER.info('Loading feature extractor models...')
+        self.extractors = [FeatureExtractor(size=self.size, **vars(cfg)) for cfg in feature_extractor_cfgs]
+        self.tracker = MultiTracker(self.size, self.extractors[0].metric, **vars(tracker_cfg))
+        self.frame_count = 0
+
+    def visible_tracks(self):
+        """Confirmed and active tracks (iterator of Track)."""
+        return (track for track in self.tracker.tracks.values()
+                if track.confirmed and track.active)
+
+    def reset(self, cap_dt):
+        """Resets multiple object tracker. Must be called before `step`."""
+        self.frame_count = 0
+        self.tracker.reset(cap_dt)
+
+    def step(self, frame):
+        """Runs multiple object tracker on the next frame (ndarray HxWx3 uint8 BGR, or a
+        detector.DeviceFrame that is already resident on the GPU)."""
+        ctx = self.tracker.ctx
+        bind_frame(ctx, frame, self.size, begin_step=True)
+        ctx.in_step = True
+        try:
+            self._step(frame)
+        finally:
+            ctx.in_step = False
+        self.frame_count += 1
+
+    def _step(self, frame):
+        if self.frame_count == 0:
+            detections = self.detector(frame)
+            self.tracker.init(frame, detections)
+        elif self.frame_count % self.detector_frame_skip == 0:
+            with Profiler('preproc'):
+                self.detector.detect_async(frame)
+
+            with Profiler('detect'):
+                with Profiler('track'):
+                    self.tracker.compute_flow(frame)
+                detections = self.detector.postprocess()
+
+            with Profiler('extract'):
+                # every box goes to the first extractor, as in the reference (_split_bboxes_by_cls
+                # with its bisect_right quirk, mot.py:180-189)
+                self.extractors[0].extract_async(frame, detections.tlbr)
+
+                with Profiler('track', aggregate=True):
+                    self.tracker.apply_kalman()
+
+                embeddings = self.extractors[0].postprocess()
+
+            with Profiler('assoc'):
+                self.tracker.update(self.frame_count, detections, embeddings)
+        else:
+            with Profiler('track'):
+                self.tracker.track(frame)
+
+    @staticmethod
+    def print_timing_info():
+        LOGGER.debug('=================Timing Stats=================')
+        LOGGER.debug(f"{'track time:':<37}{Profiler.get_avg_millis('track'):>6.3f} ms")
+        LOGGER.debug(f"{'preprocess time:':<37}{Profiler.get_avg_millis('preproc'):>6.3f} ms")
+        LOGGER.debug(f"{'detect/flow time:':<37}{Profiler.get_avg_millis('detect'):>6.3f} ms")
+        LOGGER.debug(f"{'feature extract/kalman filter time:':<37}"
+                     f"{Profiler.get_avg_millis('extract'):>6.3f} ms")
+        LOGGER.debug(f"{'association time:':<37}{Profiler.get_avg_millis('assoc'):>6.3f} ms")

@@ -220,6 +220,71 @@ int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, double* bytes)
 int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, double* conv_ms, double* other_ms,
                    int* n_conv, int* n_other);
 
+/* ---------------------------------------------------------------- frames -------------- */
+/* Frames are BGR u8 HxWx3, C-contiguous (what VideoIO.read() hands to MOT.step, app.py:85).
+ * fm_frame_upload copies a host frame to the ctx's current device frame (pinned staging + async
+ * H2D on the detector stream; replaces cp.asarray(frame), detector.py:292).  A ring of frames can
+ * also be made resident in HBM up front (bench: inputs resident before the timed region). */
+int fm_frame_configure(fm_ctx* ctx, int width, int height, int ring_size);
+int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr);
+int fm_frame_ring_store(fm_ctx* ctx, int index, const uint8_t* bgr);
+int fm_frame_ring_select(fm_ctx* ctx, int index);
+int fm_frame_read(fm_ctx* ctx, uint8_t* bgr);   /* current device frame -> host (tests) */
+
+/* ---------------------------------------------------------------- detector ------------ */
+#define FM_MAX_HEADS 4
+#define FM_MAX_ANCHORS 6   /* yolo_layer.h:11 */
+typedef struct fm_det48 {  /* DET_DTYPE, detector.py:18-23 (aligned, 48 B) */
+    double tlbr[4];
+    int64_t label;
+    double conf;
+} fm_det48;
+
+typedef struct fm_yolo_cfg {
+    int32_t in_w, in_h;                 /* network input (INPUT_SHAPE) */
+    int32_t roi_x, roi_y, roi_w, roi_h; /* letterbox ROI inside the input (whole input if !LETTERBOX) */
+    int32_t input_tensor;               /* tensor id of the network input */
+    int32_t n_heads;
+    int32_t head_tensor[FM_MAX_HEADS];  /* fp32 NHWC head tensors, channel = anchor*(5+C) + attr */
+    int32_t grid_w[FM_MAX_HEADS], grid_h[FM_MAX_HEADS], n_anchors[FM_MAX_HEADS];
+    float anchors[FM_MAX_HEADS][2 * FM_MAX_ANCHORS];
+    float scale_xy[FM_MAX_HEADS];
+    int32_t num_classes, new_coords;
+    uint8_t label_mask[128];            /* class ids to keep (detector.py:262-266) */
+    double conf_thresh, nms_thresh, max_area, min_aspect_ratio;
+    double size[2], offset[2];          /* upscaled_sz / bbox_offset (detector.py:302-320) */
+    int32_t max_candidates;             /* capacity of the candidate list (default 8192) */
+} fm_yolo_cfg;
+
+int fm_detect_configure(fm_ctx* ctx, const fm_yolo_cfg* cfg);
+/* YOLODetector.detect_async (detector.py:270-273): preprocess (bilinear resize in u8, BGR->RGB,
+ * /255, detector.py:289-300) -> network -> head decode (plugins/yolo_layer.cu:127-230) ->
+ * score/class filter -> per-class DIoU-NMS -> box filter (detector.py:322-365), all enqueued on
+ * the detector stream; only the surviving detections are copied to the host. */
+int fm_detect_async(fm_ctx* ctx);
+/* YOLODetector.postprocess (detector.py:275-287): waits for the stream, returns detections sorted
+ * by class id.  Returns FM_ERR_STATE if the candidate list overflowed. */
+int fm_detect_sync(fm_ctx* ctx, fm_det48* out, int cap, int* n);
+/* test hooks: run only the preprocessing / only the filter+NMS stage on host-provided YOLO
+ * candidate rows [n][7] = x, y, w, h, box_conf, class_id, class_prob (yolo_layer.h:34-39) */
+int fm_detect_preprocess_only(fm_ctx* ctx);
+int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* out, int cap, int* n_out);
+int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* n);
+
+/* ---------------------------------------------------------------- feature extractor --- */
+/* FeatureExtractor.extract_async (feature_extractor.py:48-60): for n boxes crop the current
+ * device frame (multi_crop, utils/rect.py:93-97: int truncation, clamp >= 0, inclusive br),
+ * resize to INPUT_SHAPE with OpenCV's fixed-point INTER_LINEAR (cv2.resize, feature_extractor.py:85),
+ * BGR->RGB, /255, ImageNet mean/std (feature_extractor.py:88-98) -> network input, then run the
+ * ReID network in batches of max_batch; FM_OP_HEAD leaves the L2-normalised embeddings
+ * (feature_extractor.py:73) in the ctx embedding table, where association reads them. */
+int fm_extract_configure(fm_ctx* ctx, int input_tensor, int in_w, int in_h);
+int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr);
+/* FeatureExtractor.postprocess (feature_extractor.py:62-74): sync + copy [n][dim] f32 to host */
+int fm_extract_sync(fm_ctx* ctx, int n, float* emb);
+/* test hook: the preprocessed crops [n][in_h][in_w][3] as f32 (RGB, normalised) */
+int fm_extract_read_input(fm_ctx* ctx, int n, float* out);
+
 #ifdef __cplusplus
 }
 #endif

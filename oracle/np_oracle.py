@@ -352,3 +352,136 @@ def average_feature(fsum, vec, count):
     avg = (fsum * np.float32(1. / count)).astype(np.float32)
     norm = np.float32(1. / np.linalg.norm(avg))
     return fsum, (avg * norm).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# detector pre/post-processing -- detector.py:289-365, plugins/yolo_layer.cu:127-230
+# ----------------------------------------------------------------------------
+def yolo_preprocess(frame, in_hw, roi=None):
+    """YOLODetector._preprocess (detector.py:289-300) + _create_letterbox (:302-320).
+    cupyx.scipy.ndimage.zoom(order=1, mode='opencv', grid_mode=True) on uint8 is (CuPy 9.x
+    cupyx/scipy/ndimage/interpolation.py): src = dst*z + (z-1)/2 with z = in/out, linear
+    interpolation in float64, edge clamp ('nearest'), result cast to uint8 by rint.  Then BGR->RGB,
+    HWC->CHW, * 1/255 into float32.  Returns float32 [3, in_h, in_w]; outside `roi`
+    (x, y, w, h) the letterbox value is 0.5."""
+    fh, fw = frame.shape[:2]
+    in_h, in_w = in_hw
+    rx, ry, rw, rh = (0, 0, in_w, in_h) if roi is None else roi
+    out = np.full((3, in_h, in_w), 0.5, np.float32)
+    zy, zx = fh / rh, fw / rw
+    sy = np.arange(rh) * zy + (zy - 1.) / 2.
+    sx = np.arange(rw) * zx + (zx - 1.) / 2.
+    y0 = np.floor(sy); wy = sy - y0
+    x0 = np.floor(sx); wx = sx - x0
+    y0i = np.clip(y0.astype(int), 0, fh - 1); y1i = np.clip(y0.astype(int) + 1, 0, fh - 1)
+    x0i = np.clip(x0.astype(int), 0, fw - 1); x1i = np.clip(x0.astype(int) + 1, 0, fw - 1)
+    f = frame.astype(np.float64)
+    top = (1. - wx)[None, :, None] * f[y0i][:, x0i] + wx[None, :, None] * f[y0i][:, x1i]
+    bot = (1. - wx)[None, :, None] * f[y1i][:, x0i] + wx[None, :, None] * f[y1i][:, x1i]
+    val = np.clip(np.rint((1. - wy)[:, None, None] * top + wy[:, None, None] * bot), 0, 255)
+    rgb = val[..., ::-1].transpose(2, 0, 1)
+    out[:, ry:ry + rh, rx:rx + rw] = (rgb * (1 / 255.)).astype(np.float32)
+    return out
+
+
+def yolo_decode(head, anchors, num_classes, in_wh, scale_xy, new_coords=False):
+    """CalDetection / CalDetection_NewCoords (plugins/yolo_layer.cu:127-230) for one head.
+    head: float32 [(5+C)*A, H, W] (the plugin's NCHW input).  Returns [A*H*W, 7] float32 rows
+    (x, y, w, h, box_conf, class_id, class_prob), (anchor, cell) order, fp32 arithmetic."""
+    f32 = np.float32
+    info = 5 + num_classes
+    A = len(anchors) // 2
+    _, H, W = head.shape
+    h = head.reshape(A, info, H, W).astype(f32)
+    cls_logit = h[:, 5:]
+    cls = np.argmax(cls_logit, axis=1)               # first maximum wins (strict '>')
+    best = np.max(cls_logit, axis=1)
+    col = np.arange(W, dtype=f32)[None, None, :]
+    row = np.arange(H, dtype=f32)[None, :, None]
+    s = f32(scale_xy)
+    sig = lambda v: (f32(1) / (f32(1) + np.exp(-v, dtype=f32))).astype(f32)
+    aw = np.asarray(anchors[0::2], f32)[:, None, None]
+    ah = np.asarray(anchors[1::2], f32)[:, None, None]
+    if not new_coords:
+        cls_prob, box_prob = sig(best), sig(h[:, 4])
+        bx = (col + (s * sig(h[:, 0]) - (s - f32(1)) * f32(0.5))) / f32(W)
+        by = (row + (s * sig(h[:, 1]) - (s - f32(1)) * f32(0.5))) / f32(H)
+        bw = np.exp(h[:, 2], dtype=f32) * aw / f32(in_wh[0])
+        bh = np.exp(h[:, 3], dtype=f32) * ah / f32(in_wh[1])
+    else:
+        cls_prob, box_prob = best, h[:, 4]
+        bx = (col + (s * h[:, 0] - (s - f32(1)) * f32(0.5))) / f32(W)
+        by = (row + (s * h[:, 1] - (s - f32(1)) * f32(0.5))) / f32(H)
+        bw = h[:, 2] * h[:, 2] * f32(4) * aw / f32(in_wh[0])
+        bh = h[:, 3] * h[:, 3] * f32(4) * ah / f32(in_wh[1])
+    bx = bx - bw / f32(2)
+    by = by - bh / f32(2)
+    rows = np.stack([bx, by, bw, bh, box_prob, cls.astype(f32), cls_prob], axis=-1)
+    return rows.reshape(-1, 7).astype(f32)
+
+
+def diou_nms(tlwhs, scores, thresh, beta=0.6):
+    """utils/rect.py:199-244 with the operand types Numba assigns (float32 rows; `- 1` and `/ 2`
+    promote to float64; areas stay float32).  Deterministic order: descending score, ties by
+    ascending index (the reference's argsort is an unstable quicksort: tie order undefined)."""
+    t = np.asarray(tlwhs, np.float32)
+    n = len(t)
+    order = sorted(range(n), key=lambda i: (-float(scores[i]), i))
+    areas = t[:, 2] * t[:, 3]                                    # float32
+    tls = t[:, :2]
+    brs = (t[:, :2] + t[:, 2:]).astype(np.float64) - 1
+    centers = (tls.astype(np.float64) + brs) / 2
+    keep = []
+    alive = list(order)
+    while alive:
+        i = alive[0]
+        keep.append(i)
+        rest = np.array(alive[1:], int)
+        if len(rest) == 0:
+            break
+        ixmin = np.maximum(tls[i, 0], tls[rest, 0]).astype(np.float64)
+        iymin = np.maximum(tls[i, 1], tls[rest, 1]).astype(np.float64)
+        ixmax = np.minimum(brs[i, 0], brs[rest, 0])
+        iymax = np.minimum(brs[i, 1], brs[rest, 1])
+        inter = np.maximum(0, ixmax - ixmin + 1) * np.maximum(0, iymax - iymin + 1)
+        union = (areas[i] + areas[rest]).astype(np.float64) - inter
+        iou = inter / union
+        exmin = np.minimum(tls[i, 0], tls[rest, 0]).astype(np.float64)
+        eymin = np.minimum(tls[i, 1], tls[rest, 1]).astype(np.float64)
+        ew = np.maximum(brs[i, 0], brs[rest, 0]) - exmin + 1
+        eh = np.maximum(brs[i, 1], brs[rest, 1]) - eymin + 1
+        c = ew**2 + eh**2
+        d = np.sum((centers[i] - centers[rest])**2, axis=1)
+        diou = iou - (d / c)**beta
+        alive = rest[diou <= thresh].tolist()
+    return np.array(keep, int)
+
+
+def filter_dets(det_out, size, offset, label_mask, conf_thresh, nms_thresh, max_area, min_ar):
+    """YOLODetector._filter_dets (detector.py:322-365).  det_out float32 [n,7].
+    Returns (tlbr [m,4] f64, label [m] i64, conf [m] f64) sorted by class, then NMS keep order."""
+    d = np.asarray(det_out, np.float32)
+    cls = d[:, 5].astype(int)
+    ok = (cls >= 0) & (cls < len(label_mask))
+    keep = np.zeros(len(d), bool)
+    keep[ok] = np.asarray(label_mask, bool)[cls[ok]]
+    keep &= (d[:, 4] * d[:, 6]) >= conf_thresh                    # float32 product
+    idx = np.flatnonzero(keep)
+    d = d[idx].copy()
+    sz = np.append(np.asarray(size, np.float64), np.asarray(size, np.float64))
+    d[:, :4] = (d[:, :4].astype(np.float64) * sz).astype(np.float32)
+    d[:, :2] = (d[:, :2].astype(np.float64) - np.asarray(offset, np.float64)).astype(np.float32)
+    tl, lb, cf = [], [], []
+    for c in np.unique(d[:, 5]):
+        rows = np.flatnonzero(d[:, 5] == c)
+        # deterministic tie-break: original candidate index
+        k = diou_nms(d[rows, :4], d[rows, 4], nms_thresh)
+        for r in rows[k]:
+            x, y, w, h = (float(v) for v in d[r, :4])
+            box = np.array([np.rint(x), np.rint(y), np.rint(x + w - 1.), np.rint(y + h - 1.)])
+            bw, bh = box[2] - box[0] + 1, box[3] - box[1] + 1
+            area = 0. if bw <= 0 or bh <= 0 else bw * bh
+            ar = bh / bw if bw > 0 else 0.
+            if 0 < area <= max_area and ar >= min_ar:
+                tl.append(box); lb.append(int(d[r, 5])); cf.append(float(d[r, 4] * d[r, 6]))
+    return (np.array(tl, np.float64).reshape(-1, 4), np.array(lb, np.int64), np.array(cf, np.float64))

@@ -1,0 +1,121 @@
+"""GPU parity of the detector / extractor pre- and post-processing (detect.hip, extract.hip).
+  * filter + DIoU-NMS: oracle=reference (tests/golden/nms_kat.npz from detector.py:322-365) --
+    boxes, labels identical, conf equal
+  * head decode: oracle=restated (np_oracle.yolo_decode, plugins/yolo_layer.cu:127-230), fp32
+    tolerance 2e-6 relative (fast-exp intrinsics differ between vendors)
+  * preprocessing: oracle=restated (np_oracle.yolo_preprocess / cv_oracle.reid_preprocess),
+    identical uint8 pixels -> fp16 input within 1e-3"""
+import numpy as np
+import pytest
+
+import cv_oracle
+import np_oracle as o
+from fastmot_amd import _lib
+from fastmot_amd.detector import YOLODetector
+from fastmot_amd.feature_extractor import FeatureExtractor
+from fastmot_amd.models import YOLO, ReID
+from fastmot_amd.models.graph import RandomWeights
+
+pytestmark = pytest.mark.gpu
+
+
+def synthetic_frame(w, h, seed=0):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h // 8 + 1, w // 8 + 1, 3)).astype(np.uint8)
+    frame = np.kron(base, np.ones((8, 8, 1), np.uint8))[:h, :w]
+    noise = rng.integers(-20, 20, frame.shape)
+    return np.clip(frame.astype(int) + noise, 0, 255).astype(np.uint8)
+
+
+class TinyYOLO(YOLO):
+    NUM_CLASSES = 3
+    INPUT_SHAPE = (3, 96, 128)
+    LAYER_FACTORS = [8, 16, 32]
+    SCALES = [1.2, 1.1, 1.05]
+    ANCHORS = [[4, 7, 8, 15, 12, 30], [18, 40, 25, 60, 30, 80], [40, 90, 60, 70, 80, 95]]
+
+
+class TinyLetterbox(TinyYOLO):
+    LETTERBOX = True
+    NEW_COORDS = True
+    SCALES = [2.0, 2.0, 2.0]
+
+
+@pytest.mark.parametrize('tag,n_cls', [('p', 1), ('q', 3)])
+def test_filter_dets_matches_reference(ctx, golden_dir, tag, n_cls):
+    g = np.load(golden_dir / 'nms_kat.npz')
+    det = YOLODetector((1920, 1080), tuple(range(n_cls)), model='TinyYOLO' if n_cls <= 3 else None,
+                       conf_thresh=0.25, nms_thresh=0.5, max_area=800000, min_aspect_ratio=1.2)
+    out = ctx.filter_dets(g[f'{tag}_det_out'])
+    np.testing.assert_array_equal(out.tlbr, g[f'{tag}_tlbr'])
+    np.testing.assert_array_equal(out.label, g[f'{tag}_label'])
+    np.testing.assert_allclose(out.conf, g[f'{tag}_conf'], rtol=1e-7)
+
+
+def test_filter_dets_random_vs_oracle(ctx):
+    rng = np.random.default_rng(5)
+    det = YOLODetector((1920, 1080), (0, 2), model='TinyYOLO', conf_thresh=0.3, nms_thresh=0.45,
+                       max_area=200000, min_aspect_ratio=0.5)
+    for n in (0, 1, 7, 600, 3000):
+        rows = np.stack([rng.uniform(0, 0.9, n), rng.uniform(0, 0.8, n), rng.uniform(0.01, 0.15, n),
+                         rng.uniform(0.02, 0.3, n), rng.uniform(0, 1, n), rng.integers(0, 3, n),
+                         rng.uniform(0.3, 1, n)], 1).astype(np.float32)
+        out = ctx.filter_dets(rows)
+        lm = np.array([True, False, True])
+        tl, lb, cf = o.filter_dets(rows, [1920, 1080], [0, 0], lm, 0.3, 0.45, 200000, 0.5)
+        np.testing.assert_array_equal(out.tlbr, tl)
+        np.testing.assert_array_equal(out.label, lb)
+        np.testing.assert_allclose(out.conf, cf, rtol=1e-7)
+
+
+@pytest.mark.parametrize('model', ['TinyYOLO', 'TinyLetterbox'])
+def test_preprocess_decode_end_to_end(ctx, model):
+    size = (320, 180)
+    det = YOLODetector(size, (0, 1, 2), model=model, conf_thresh=0.1, nms_thresh=0.5,
+                       weights=RandomWeights(seed=4), max_candidates=16384)
+    frame = synthetic_frame(*size, seed=1)
+    ctx.frame_configure(*size)
+    ctx.frame_upload(frame)
+    ctx.detect_preprocess_only()
+    m = det.model
+    inp = det.backend.read(det.graph.input, 1)[0]            # [h, w, 3] RGB
+    exp = o.yolo_preprocess(frame, m.INPUT_SHAPE[1:], det.roi if m.LETTERBOX else None)
+    np.testing.assert_allclose(inp.transpose(2, 0, 1), exp, rtol=0, atol=6e-4)   # fp16 storage of u8/255
+    # the u8 pixels themselves must be identical
+    np.testing.assert_array_equal(np.rint(inp.transpose(2, 0, 1) * 255), np.rint(exp * 255))
+    dets = det(frame)
+    # oracle: decode the engine's own head tensors, then the reference filter
+    rows = []
+    for i, head in enumerate(det.heads):
+        t = det.backend.read(head, 1)[0]                       # [gh, gw, (5+C)*A] fp32
+        rows.append(o.yolo_decode(t.transpose(2, 0, 1), m.ANCHORS[i], m.NUM_CLASSES,
+                                  (m.INPUT_SHAPE[2], m.INPUT_SHAPE[1]), m.SCALES[i], m.NEW_COORDS))
+    rows = np.concatenate(rows)
+    tl, lb, cf = o.filter_dets(rows, det.upscaled_sz, det.bbox_offset, det.label_mask, 0.1, 0.5, 800000, 1.2)
+    assert len(dets) == len(tl) and len(tl) > 0
+    np.testing.assert_array_equal(dets.label, lb)
+    # boxes come from fp32 fast-exp decode: allow +-1 px on <=1% of coordinates, confidences 2e-6
+    diff = np.abs(dets.tlbr - tl)
+    assert diff.max() <= 1 and (diff > 0).mean() <= 0.01
+    np.testing.assert_allclose(dets.conf, cf, rtol=5e-6)
+
+
+def test_reid_crop_resize_normalise(ctx):
+    size = (640, 360)
+    frame = synthetic_frame(*size, seed=2)
+    ext = FeatureExtractor('OSNet025', batch_size=8, weights=RandomWeights(seed=3), size=size)
+    boxes = np.array([[10.7, 20.2, 70.9, 200.1], [-5., -8., 40., 90.], [600., 300., 700., 400.],
+                      [100., 50., 131., 113.], [300., 10., 555., 355.]])
+    ext.extract_async(frame, boxes)
+    emb = ext.postprocess()
+    assert emb.shape == (5, 512)
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1, atol=1e-5)
+    inp = ctx.extract_read_input(5, 128, 256)
+    exp = cv_oracle.reid_preprocess(frame, boxes).transpose(0, 2, 3, 1)
+    np.testing.assert_allclose(inp, exp, rtol=0, atol=2.5e-3)     # fp16 storage of values in [-2.2, 2.7]
+    # chunked extraction (n > batch_size) gives the same embeddings row by row
+    many = np.concatenate([boxes] * 4)
+    ext.extract_async(frame, many)
+    emb2 = ext.postprocess()
+    np.testing.assert_allclose(emb2[:5], emb, atol=1e-6)
+    np.testing.assert_allclose(emb2[15:20], emb, atol=1e-6)
