@@ -408,3 +408,97 @@ def _bind_device_io(cls):
 
 
 _bind_device_io(HipContext)
+
+
+# ---------------------------------------------------------------------- optical flow
+class FlowCfg(C.Structure):
+    _fields_ = [('small_w', C.c_int32), ('small_h', C.c_int32), ('bg_w', C.c_int32), ('bg_h', C.c_int32),
+                ('win_size', C.c_int32), ('max_level', C.c_int32), ('max_count', C.c_int32),
+                ('epsilon', C.c_double), ('fast_thresh', C.c_int32), ('max_corners', C.c_int32),
+                ('block_size', C.c_int32), ('quality_level', C.c_double)]
+
+
+def _bind_flow(cls):
+    def flow_configure(self, cfg):
+        check(self.lib.fm_flow_configure(self._ctx, C.byref(cfg)))
+
+    def flow_init(self):
+        check(self.lib.fm_flow_init(self._ctx))
+
+    def flow_begin(self):
+        check(self.lib.fm_flow_begin(self._ctx))
+
+    def flow_swap(self):
+        check(self.lib.fm_flow_swap(self._ctx))
+
+    def flow_targets(self, inside_tlbr, kps, kp_off):
+        r = _as(inside_tlbr, np.float64).reshape(-1, 4)
+        nT = len(r)
+        off = _as(kp_off, np.int32)
+        k = _as(kps, np.float32).reshape(-1, 2)
+        assert len(off) == nT + 1 and off[-1] == len(k)
+        area = np.zeros(nT, np.int32)
+        keep = np.zeros(len(k), np.uint8)
+        check(self.lib.fm_flow_targets(self._ctx, C.c_int(nT), _ptr(r), _ptr(k), _ptr(off), _ptr(area), _ptr(keep)))
+        return area, keep.astype(bool)
+
+    def flow_detect(self, track_idx, track_tlbr, min_dist, cap=1000):
+        idx = _as(track_idx, np.int32)
+        n = len(idx)
+        tb = _as(track_tlbr, np.float64).reshape(n, 4)
+        md = _as(min_dist, np.int32)
+        pts = np.empty((n, cap, 2), np.float32)
+        cnt = np.zeros(n, np.int32)
+        check(self.lib.fm_flow_detect(self._ctx, C.c_int(n), _ptr(idx), _ptr(tb), _ptr(md), C.c_int(cap),
+                                      _ptr(pts), _ptr(cnt)))
+        return pts, cnt
+
+    def flow_background(self, cap=8192):
+        pts = np.empty((cap, 2), np.float32)
+        n = C.c_int(0)
+        check(self.lib.fm_flow_background(self._ctx, C.c_int(cap), _ptr(pts), C.byref(n)))
+        return pts[:n.value]
+
+    def flow_lk(self, prev_pts):
+        p = _as(prev_pts, np.float32).reshape(-1, 2)
+        n = len(p)
+        nxt = np.empty((n, 2), np.float32)
+        status = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        check(self.lib.fm_flow_lk(self._ctx, C.c_int(n), _ptr(p), _ptr(nxt), _ptr(status), _ptr(err)))
+        return nxt, status, err
+
+    def flow_estimate(self, prev_pts, cur_pts, status, begins, ends, bg_begin, bg_end, track_tlbr, size,
+                      ransac_max_iter, ransac_conf, inlier_thresh):
+        p = _as(prev_pts, np.float32).reshape(-1, 2)
+        c = _as(cur_pts, np.float32).reshape(-1, 2)
+        st = _as(status, np.uint8)
+        n = len(p)
+        b, e = _as(begins, np.int32), _as(ends, np.int32)
+        nT = len(b)
+        tb = _as(track_tlbr, np.float64).reshape(nT, 4)
+        H = np.zeros((3, 3))
+        ok = C.c_int(0)
+        result = np.zeros(nT, np.int32)
+        est = np.zeros((nT, 4))
+        n_matched = np.zeros(nT, np.int32)
+        inl = np.zeros(n, np.uint8)
+        check(self.lib.fm_flow_estimate(self._ctx, C.c_int(n), _ptr(p), _ptr(c), _ptr(st), C.c_int(nT), _ptr(b),
+                                        _ptr(e), C.c_int(bg_begin), C.c_int(bg_end), _ptr(tb), C.c_int(size[0]),
+                                        C.c_int(size[1]), C.c_int(ransac_max_iter), C.c_double(ransac_conf),
+                                        C.c_int(inlier_thresh), _ptr(H), C.byref(ok), _ptr(result), _ptr(est),
+                                        _ptr(n_matched), _ptr(inl)))
+        return (H if ok.value else None), result, est, n_matched, inl.astype(bool)
+
+    def flow_read_image(self, which):
+        w, h = C.c_int(0), C.c_int(0)
+        buf = np.empty(self.frame_size[0] * self.frame_size[1], np.uint8)
+        check(self.lib.fm_flow_read_image(self._ctx, C.c_int(which), _ptr(buf), C.byref(w), C.byref(h)))
+        return buf[:w.value * h.value].reshape(h.value, w.value).copy()
+
+    for fn in (flow_configure, flow_init, flow_begin, flow_swap, flow_targets, flow_detect, flow_background,
+               flow_lk, flow_estimate, flow_read_image):
+        setattr(cls, fn.__name__, fn)
+
+
+_bind_flow(HipContext)

@@ -1,0 +1,533 @@
+// Host-side half of Flow.predict: robust camera-motion and per-track motion estimation.
+//
+// Replaces (fastmot/flow.py:215-263): cv2.findHomography(RANSAC, maxIters, confidence),
+// cv2.estimateAffinePartial2D(RANSAC, maxIters, confidence) and the Numba helpers _get_good_match
+// (:347-352), _fg_filter (:308-323), _estimate_bbox (:273-280), _get_inliers (:354-357).
+//
+// Why host C++ and not a kernel: each RANSAC loop is a short, strictly serial chain (OpenCV's RNG
+// stream, data-dependent sample rejection, adaptive iteration count: typically 3-10 hypotheses over
+// ~100 points, i.e. a few microseconds) and the per-track loop is ordered through the foreground
+// mask; a device round trip (>= 20 us) per dependent step would dominate.  The pixel work that
+// feeds it (pyramids, LK, corners) is on the GPU (flow.hip).  Times are reported, not rooflined
+// ("latency-bound serial algorithms -- report us").
+//
+// Restated from OpenCV's published algorithms (calib3d/ptsetreg.cpp RANSACPointSetRegistrator,
+// fundam.cpp HomographyEstimatorCallback / HomographyRefineCallback, ptsetreg.cpp
+// AffinePartial2DEstimatorCallback / RefineCallback, levmarq.cpp LMSolverImpl, core rand.cpp RNG).
+// OpenCV is not available: parity of this stage is UNPINNED; the numpy
+// restatement in oracle/cv_oracle.py is the checker.
+#include "common.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+struct Pt { float x, y; };
+
+struct CvRNG {   // cv::RNG (multiply-with-carry), seeded with (uint64)-1 like RANSACPointSetRegistrator
+    uint64_t state = 0xffffffffffffffffULL;
+    unsigned next() {
+        state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// symmetric eigen-decomposition (cyclic Jacobi), eigenvalues descending, rows of V = eigenvectors
+void jacobi_eigen(int n, std::vector<double>& A, std::vector<double>& W, std::vector<double>& V) {
+    V.assign((size_t)n * n, 0.);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[(size_t)p * n + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2. * apq);
+                const double t = (theta >= 0 ? 1. : -1.) / (std::fabs(theta) + std::sqrt(theta * theta + 1.));
+                const double c = 1. / std::sqrt(t * t + 1.), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - s * akq;
+                    A[(size_t)k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - s * aqk;
+                    A[(size_t)q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vpk = V[(size_t)p * n + k], vqk = V[(size_t)q * n + k];
+                    V[(size_t)p * n + k] = c * vpk - s * vqk;
+                    V[(size_t)q * n + k] = s * vpk + c * vqk;
+                }
+            }
+    }
+    W.resize(n);
+    for (int i = 0; i < n; ++i) W[i] = A[(size_t)i * n + i];
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return W[a] > W[b]; });
+    std::vector<double> W2(n), V2((size_t)n * n);
+    for (int i = 0; i < n; ++i) {
+        W2[i] = W[idx[i]];
+        for (int k = 0; k < n; ++k) V2[(size_t)i * n + k] = V[(size_t)idx[i] * n + k];
+    }
+    W.swap(W2);
+    V.swap(V2);
+}
+
+// x = pinv(A) b for symmetric A (cv::solve / cv::invert with DECOMP_EIGEN)
+void sym_solve(int n, const std::vector<double>& A, const double* b, double* x, std::vector<double>* inv_diag) {
+    std::vector<double> M(A), W, V;
+    jacobi_eigen(n, M, W, V);
+    double wmax = 0;
+    for (double w : W) wmax = std::max(wmax, std::fabs(w));
+    const double thr = DBL_EPSILON * 2 * wmax * n;
+    std::vector<double> coef(n);
+    for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int k = 0; k < n; ++k) s += V[(size_t)i * n + k] * b[k];
+        coef[i] = std::fabs(W[i]) > thr ? s / W[i] : 0.;
+    }
+    for (int k = 0; k < n; ++k) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += V[(size_t)i * n + k] * coef[i];
+        x[k] = s;
+    }
+    if (inv_diag) {
+        inv_diag->assign(n, 0.);
+        for (int k = 0; k < n; ++k) {
+            double s = 0;
+            for (int i = 0; i < n; ++i)
+                if (std::fabs(W[i]) > thr) s += V[(size_t)i * n + k] * V[(size_t)i * n + k] / W[i];
+            (*inv_diag)[k] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- model callbacks
+struct Model {
+    virtual ~Model() {}
+    virtual int model_points() const = 0;
+    virtual int n_params() const = 0;
+    virtual bool check_subset(const Pt* a, const Pt* b, int count) const = 0;
+    virtual bool run_kernel(const Pt* a, const Pt* b, int count, double* M) const = 0;   // M: 9 doubles
+    virtual void compute_error(const Pt* a, const Pt* b, int count, const double* M, float* err) const = 0;
+    // LM refinement residuals / Jacobian on the parameter vector
+    virtual void to_params(const double* M, double* h) const = 0;
+    virtual void from_params(const double* h, double* M) const = 0;
+    virtual void residuals(const Pt* a, const Pt* b, int count, const double* h, double* r, double* J) const = 0;
+};
+
+bool have_collinear(const Pt* p, int count) {
+    const int i = count - 1;
+    for (int j = 0; j < i; ++j) {
+        const double dx1 = p[j].x - p[i].x, dy1 = p[j].y - p[i].y;
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = p[k].x - p[i].x, dy2 = p[k].y - p[i].y;
+            if (std::fabs(dx2 * dy1 - dy2 * dx1) <=
+                FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+
+double det3(const double m[3][3]) {
+    return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+struct Homography : Model {
+    int model_points() const override { return 4; }
+    int n_params() const override { return 8; }
+    bool check_subset(const Pt* a, const Pt* b, int count) const override {
+        if (have_collinear(a, count) || have_collinear(b, count)) return false;
+        if (count == 4) {   // orientation consistency of the 4 triangles
+            static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+            int negative = 0;
+            for (int i = 0; i < 4; ++i) {
+                const int* t = tt[i];
+                const double A[3][3] = {{a[t[0]].x, a[t[0]].y, 1.}, {a[t[1]].x, a[t[1]].y, 1.}, {a[t[2]].x, a[t[2]].y, 1.}};
+                const double B[3][3] = {{b[t[0]].x, b[t[0]].y, 1.}, {b[t[1]].x, b[t[1]].y, 1.}, {b[t[2]].x, b[t[2]].y, 1.}};
+                negative += det3(A) * det3(B) < 0;
+            }
+            if (negative != 0 && negative != 4) return false;
+        }
+        return true;
+    }
+    // normalised DLT, smallest eigenvector of L^T L (fundam.cpp HomographyEstimatorCallback::runKernel)
+    bool run_kernel(const Pt* M, const Pt* m, int count, double* H) const override {
+        double cMx = 0, cMy = 0, cmx = 0, cmy = 0;
+        for (int i = 0; i < count; ++i) { cmx += m[i].x; cmy += m[i].y; cMx += M[i].x; cMy += M[i].y; }
+        cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+        double smx = 0, smy = 0, sMx = 0, sMy = 0;
+        for (int i = 0; i < count; ++i) {
+            smx += std::fabs(m[i].x - cmx); smy += std::fabs(m[i].y - cmy);
+            sMx += std::fabs(M[i].x - cMx); sMy += std::fabs(M[i].y - cMy);
+        }
+        if (std::fabs(smx) < DBL_EPSILON || std::fabs(smy) < DBL_EPSILON || std::fabs(sMx) < DBL_EPSILON ||
+            std::fabs(sMy) < DBL_EPSILON)
+            return false;
+        smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+        std::vector<double> LtL(81, 0.);
+        for (int i = 0; i < count; ++i) {
+            const double x = (m[i].x - cmx) * smx, y = (m[i].y - cmy) * smy;
+            const double X = (M[i].x - cMx) * sMx, Y = (M[i].y - cMy) * sMy;
+            const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+            const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+            for (int j = 0; j < 9; ++j)
+                for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+        }
+        for (int j = 0; j < 9; ++j)
+            for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];
+        std::vector<double> W, V;
+        jacobi_eigen(9, LtL, W, V);
+        const double* h0 = &V[8 * 9];
+        const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+        const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+        double T[9], R[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += invHnorm[i * 3 + k] * h0[k * 3 + j];
+                T[i * 3 + j] = s;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * Hnorm2[k * 3 + j];
+                R[i * 3 + j] = s;
+            }
+        if (std::fabs(R[8]) < DBL_MIN) return false;
+        for (int i = 0; i < 9; ++i) H[i] = R[i] / R[8];
+        for (int i = 0; i < 9; ++i)
+            if (!std::isfinite(H[i])) return false;
+        return true;
+    }
+    void compute_error(const Pt* M, const Pt* m, int count, const double* H, float* err) const override {
+        const float Hf[8] = {(float)H[0], (float)H[1], (float)H[2], (float)H[3], (float)H[4], (float)H[5], (float)H[6], (float)H[7]};
+        for (int i = 0; i < count; ++i) {
+            const float ww = 1.f / (Hf[6] * M[i].x + Hf[7] * M[i].y + 1.f);
+            const float dx = (Hf[0] * M[i].x + Hf[1] * M[i].y + Hf[2]) * ww - m[i].x;
+            const float dy = (Hf[3] * M[i].x + Hf[4] * M[i].y + Hf[5]) * ww - m[i].y;
+            err[i] = dx * dx + dy * dy;
+        }
+    }
+    void to_params(const double* M, double* h) const override { for (int i = 0; i < 8; ++i) h[i] = M[i]; }
+    void from_params(const double* h, double* M) const override { for (int i = 0; i < 8; ++i) M[i] = h[i]; M[8] = 1.; }
+    void residuals(const Pt* M, const Pt* m, int count, const double* h, double* r, double* J) const override {
+        for (int i = 0; i < count; ++i) {
+            const double Mx = M[i].x, My = M[i].y;
+            double ww = h[6] * Mx + h[7] * My + 1.;
+            ww = std::fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+            const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+            r[2 * i] = xi - m[i].x;
+            r[2 * i + 1] = yi - m[i].y;
+            if (J) {
+                double* j0 = J + (size_t)(2 * i) * 8;
+                double* j1 = j0 + 8;
+                j0[0] = Mx * ww; j0[1] = My * ww; j0[2] = ww; j0[3] = j0[4] = j0[5] = 0.;
+                j0[6] = -Mx * ww * xi; j0[7] = -My * ww * xi;
+                j1[0] = j1[1] = j1[2] = 0.; j1[3] = Mx * ww; j1[4] = My * ww; j1[5] = ww;
+                j1[6] = -Mx * ww * yi; j1[7] = -My * ww * yi;
+            }
+        }
+    }
+};
+
+struct AffinePartial : Model {
+    int model_points() const override { return 2; }
+    int n_params() const override { return 4; }
+    bool check_subset(const Pt* a, const Pt*, int count) const override { return !have_collinear(a, count); }
+    bool run_kernel(const Pt* f, const Pt* t, int, double* M) const override {
+        const double x1 = f[0].x, y1 = f[0].y, x2 = f[1].x, y2 = f[1].y;
+        const double X1 = t[0].x, Y1 = t[0].y, X2 = t[1].x, Y2 = t[1].y;
+        const double d = 1. / ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+        const double S0 = d * ((X1 - X2) * (x1 - x2) + (Y1 - Y2) * (y1 - y2));
+        const double S1 = d * ((Y1 - Y2) * (x1 - x2) - (X1 - X2) * (y1 - y2));
+        const double S2 = d * ((Y1 - Y2) * (x1 * y2 - x2 * y1) - (X1 * y2 - X2 * y1) * (y1 - y2) - (X1 * x2 - X2 * x1) * (x1 - x2));
+        const double S3 = d * (-(X1 - X2) * (x1 * y2 - x2 * y1) - (Y1 * x2 - Y2 * x1) * (x1 - x2) - (Y1 * y2 - Y2 * y1) * (y1 - y2));
+        M[0] = S0; M[1] = -S1; M[2] = S2; M[3] = S1; M[4] = S0; M[5] = S3; M[6] = 0; M[7] = 0; M[8] = 1;
+        return true;
+    }
+    void compute_error(const Pt* f, const Pt* t, int count, const double* M, float* err) const override {
+        const float F0 = (float)M[0], F1 = (float)M[1], F2 = (float)M[2], F3 = (float)M[3], F4 = (float)M[4], F5 = (float)M[5];
+        for (int i = 0; i < count; ++i) {
+            const float a = F0 * f[i].x + F1 * f[i].y + F2 - t[i].x;
+            const float b = F3 * f[i].x + F4 * f[i].y + F5 - t[i].y;
+            err[i] = a * a + b * b;
+        }
+    }
+    void to_params(const double* M, double* h) const override { h[0] = M[0]; h[1] = M[3]; h[2] = M[2]; h[3] = M[5]; }
+    void from_params(const double* h, double* M) const override {
+        M[0] = h[0]; M[1] = -h[1]; M[2] = h[2]; M[3] = h[1]; M[4] = h[0]; M[5] = h[3]; M[6] = 0; M[7] = 0; M[8] = 1;
+    }
+    void residuals(const Pt* f, const Pt* t, int count, const double* h, double* r, double* J) const override {
+        for (int i = 0; i < count; ++i) {
+            const double Mx = f[i].x, My = f[i].y;
+            r[2 * i] = h[0] * Mx - h[1] * My + h[2] - t[i].x;
+            r[2 * i + 1] = h[1] * Mx + h[0] * My + h[3] - t[i].y;
+            if (J) {
+                double* j0 = J + (size_t)(2 * i) * 4;
+                j0[0] = Mx; j0[1] = -My; j0[2] = 1.; j0[3] = 0.;
+                j0[4] = My; j0[5] = Mx; j0[6] = 0.; j0[7] = 1.;
+            }
+        }
+    }
+};
+
+int ransac_update_iters(double p, double ep, int model_points, int max_iters) {
+    p = std::min(std::max(p, 0.), 1.);
+    ep = std::min(std::max(ep, 0.), 1.);
+    const double num0 = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    const double num = std::log(num0);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::nearbyint(num / denom);
+}
+
+// RANSACPointSetRegistrator::run.  Returns true and fills M (9) + mask when a model was found.
+bool ransac_run(const Model& cb, const Pt* m1, const Pt* m2, int count, double threshold, double confidence,
+                int max_iters, double* M, std::vector<uint8_t>& best_mask) {
+    const int mp = cb.model_points();
+    best_mask.assign(count, 0);
+    if (count < mp) return false;
+    if (count == mp) {
+        if (!cb.run_kernel(m1, m2, count, M)) return false;
+        std::fill(best_mask.begin(), best_mask.end(), 1);
+        return true;
+    }
+    CvRNG rng;
+    int niters = std::max(max_iters, 1);
+    std::vector<float> err(count);
+    std::vector<uint8_t> mask(count);
+    std::vector<Pt> s1(mp), s2(mp);
+    std::vector<int> idx(mp);
+    int max_good = 0;
+    const float thr2 = (float)(threshold * threshold);
+    for (int iter = 0; iter < niters; ++iter) {
+        // getSubset
+        bool found = false;
+        int attempts = 0;
+        const int max_attempts = 1000;
+        for (; attempts < max_attempts; ++attempts) {
+            int i = 0;
+            for (; i < mp; ++i) {
+                int v;
+                for (;;) {
+                    v = rng.uniform(0, count);
+                    bool dup = false;
+                    for (int j = 0; j < i; ++j) dup |= idx[j] == v;
+                    if (!dup) break;
+                }
+                idx[i] = v;
+                s1[i] = m1[v];
+                s2[i] = m2[v];
+            }
+            if (!cb.check_subset(s1.data(), s2.data(), mp)) continue;
+            found = true;
+            break;
+        }
+        if (!found) {
+            if (iter == 0) return false;
+            break;
+        }
+        double model[9];
+        if (!cb.run_kernel(s1.data(), s2.data(), mp, model)) continue;
+        cb.compute_error(m1, m2, count, model, err.data());
+        int good = 0;
+        for (int i = 0; i < count; ++i) {
+            mask[i] = err[i] <= thr2 ? 1 : 0;
+            good += mask[i];
+        }
+        if (good > std::max(max_good, mp - 1)) {
+            best_mask = mask;
+            memcpy(M, model, sizeof(double) * 9);
+            max_good = good;
+            niters = ransac_update_iters(confidence, (double)(count - good) / count, mp, niters);
+        }
+    }
+    return max_good > 0;
+}
+
+// LMSolverImpl::run (levmarq.cpp), maxIters iterations, eps = FLT_EPSILON
+void lm_refine(const Model& cb, const Pt* a, const Pt* b, int count, double* M, int max_iters) {
+    const int lx = cb.n_params();
+    std::vector<double> x(lx), xd(lx), r(2 * count), rd(2 * count), J((size_t)2 * count * lx);
+    cb.to_params(M, x.data());
+    cb.residuals(a, b, count, x.data(), r.data(), J.data());
+    auto normsq = [&](const std::vector<double>& v) { double s = 0; for (double e : v) s += e * e; return s; };
+    auto build = [&](std::vector<double>& A, std::vector<double>& v) {
+        A.assign((size_t)lx * lx, 0.);
+        v.assign(lx, 0.);
+        for (int i = 0; i < 2 * count; ++i) {
+            const double* ji = &J[(size_t)i * lx];
+            for (int p = 0; p < lx; ++p) {
+                v[p] += ji[p] * r[i];
+                for (int q = p; q < lx; ++q) A[(size_t)p * lx + q] += ji[p] * ji[q];
+            }
+        }
+        for (int p = 0; p < lx; ++p)
+            for (int q = 0; q < p; ++q) A[(size_t)p * lx + q] = A[(size_t)q * lx + p];
+    };
+    double S = normsq(r);
+    std::vector<double> A, v, Ap, d(lx), temp_d(lx), D(lx);
+    build(A, v);
+    for (int i = 0; i < lx; ++i) D[i] = A[(size_t)i * lx + i];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    const double eps = FLT_EPSILON;
+    for (int iter = 0;;) {
+        Ap = A;
+        for (int i = 0; i < lx; ++i) Ap[(size_t)i * lx + i] += lambda * D[i];
+        sym_solve(lx, Ap, v.data(), d.data(), nullptr);
+        for (int i = 0; i < lx; ++i) xd[i] = x[i] - d[i];
+        cb.residuals(a, b, count, xd.data(), rd.data(), nullptr);
+        const double Sd = normsq(rd);
+        for (int i = 0; i < lx; ++i) {   // temp_d = 2 v - A d
+            double s = 0;
+            for (int k = 0; k < lx; ++k) s += A[(size_t)i * lx + k] * d[k];
+            temp_d[i] = 2 * v[i] - s;
+        }
+        double dS = 0;
+        for (int i = 0; i < lx; ++i) dS += d[i] * temp_d[i];
+        const double R = (S - Sd) / (std::fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (R > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (R < Rlo) {
+            double t = 0;
+            for (int i = 0; i < lx; ++i) t += d[i] * v[i];
+            double nu = (Sd - S) / (std::fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = std::min(std::max(nu, 2.), 10.);
+            if (lambda == 0) {
+                std::vector<double> inv_diag, dummy(lx, 0.), xx(lx);
+                sym_solve(lx, A, dummy.data(), xx.data(), &inv_diag);
+                double maxval = DBL_EPSILON;
+                for (int i = 0; i < lx; ++i) maxval = std::max(maxval, std::fabs(inv_diag[i]));
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            x.swap(xd);
+            cb.residuals(a, b, count, x.data(), r.data(), J.data());
+            build(A, v);
+        }
+        ++iter;
+        double dinf = 0, rinf = 0;
+        for (double e : d) dinf = std::max(dinf, std::fabs(e));
+        for (double e : r) rinf = std::max(rinf, std::fabs(e));
+        if (!(iter < max_iters && dinf >= eps && rinf >= eps)) break;
+    }
+    cb.from_params(x.data(), M);
+}
+
+double round_half_even(double v) { return std::nearbyint(v); }
+
+}  // namespace
+
+extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, const float* cur_pts,
+                                const uint8_t* status, int nT, const int32_t* begins, const int32_t* ends,
+                                int bg_begin, int bg_end, const double* track_tlbr, int frame_w, int frame_h,
+                                int ransac_max_iter, double ransac_conf, int inlier_thresh, double* H_out,
+                                int* ok_out, int32_t* result_out, double* est_tlbr_out, int32_t* n_matched_out,
+                                uint8_t* inlier_out) {
+    FM_CHECK_ARG(ctx && n_pts >= 0 && nT >= 0 && H_out && ok_out && inlier_out);
+    FM_CHECK_ARG(bg_begin >= 0 && bg_begin <= bg_end && bg_end <= n_pts);
+    memset(inlier_out, 0, n_pts);
+    *ok_out = 0;
+    for (int k = 0; k < nT; ++k) {
+        result_out[k] = 0;
+        n_matched_out[k] = 0;
+    }
+    const Pt* P = reinterpret_cast<const Pt*>(prev_pts);
+    const Pt* C = reinterpret_cast<const Pt*>(cur_pts);
+    // ---- camera motion: background matches [bg_begin, bg_end) with status (flow.py:216-232)
+    std::vector<Pt> a, b;
+    std::vector<int> gidx;
+    for (int i = bg_begin; i < bg_end; ++i)
+        if (status[i]) { a.push_back(P[i]); b.push_back(C[i]); gidx.push_back(i); }
+    if ((int)a.size() < 4) return 0;
+    Homography hcb;
+    std::vector<uint8_t> mask;
+    double H[9];
+    bool ok = ransac_run(hcb, a.data(), b.data(), (int)a.size(), 3.0, ransac_conf, ransac_max_iter, H, mask);
+    int n_in = 0;
+    if (ok) {
+        std::vector<Pt> ia, ib;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (mask[i]) { ia.push_back(a[i]); ib.push_back(b[i]); }
+        n_in = (int)ia.size();
+        if (a.size() > 4 && n_in > 0) {
+            if (hcb.run_kernel(ia.data(), ib.data(), n_in, H)) lm_refine(hcb, ia.data(), ib.data(), n_in, H, 10);
+        }
+    }
+    if (!ok || n_in < inlier_thresh) return 0;
+    for (size_t i = 0; i < a.size(); ++i)
+        if (mask[i]) inlier_out[gidx[i]] = 1;
+    memcpy(H_out, H, sizeof(double) * 9);
+    *ok_out = 1;
+
+    // ---- per-track motion (flow.py:235-263), closest-first order; the foreground mask is the set
+    // of predicted boxes of the tracks accepted so far
+    AffinePartial acb;
+    std::vector<double> boxes;   // accepted est_tlbr, crop() semantics
+    for (int k = 0; k < nT; ++k) {
+        a.clear(); b.clear(); gidx.clear();
+        for (int i = begins[k]; i < ends[k]; ++i) {
+            if (!status[i]) continue;
+            // _fg_filter: inside the frame and not under an already predicted box
+            const int x = (int)std::nearbyint(C[i].x), y = (int)std::nearbyint(C[i].y);
+            if (x < 0 || y < 0 || x >= frame_w || y >= frame_h) continue;
+            bool covered = false;
+            for (size_t q = 0; q < boxes.size(); q += 4)
+                if (x >= boxes[q] && x <= boxes[q + 2] && y >= boxes[q + 1] && y <= boxes[q + 3]) { covered = true; break; }
+            if (covered) continue;
+            a.push_back(P[i]); b.push_back(C[i]); gidx.push_back(i);
+        }
+        const int n = (int)a.size();
+        n_matched_out[k] = n;
+        if (n < 3) continue;
+        double M[9];
+        if (!ransac_run(acb, a.data(), b.data(), n, 3.0, ransac_conf, ransac_max_iter, M, mask)) continue;
+        std::vector<Pt> ia, ib;
+        std::vector<int> ii;
+        for (int i = 0; i < n; ++i)
+            if (mask[i]) { ia.push_back(a[i]); ib.push_back(b[i]); ii.push_back(gidx[i]); }
+        if (n > 2 && !ia.empty()) lm_refine(acb, ia.data(), ib.data(), (int)ia.size(), M, 10);
+        // _estimate_bbox (flow.py:273-280)
+        const double* tb = track_tlbr + 4 * k;
+        const double tlx = tb[0] * M[0] + tb[1] * M[1] + M[2], tly = tb[0] * M[3] + tb[1] * M[4] + M[5];
+        double scale = std::sqrt(M[0] * M[0] + M[3] * M[3]);
+        if (scale < 0.9 || scale > 1.1) scale = 1.;
+        const double w = tb[2] - tb[0] + 1, h = tb[3] - tb[1] + 1;
+        double est[4] = {round_half_even(tlx), round_half_even(tly), round_half_even(tlx + w * scale - 1.),
+                         round_half_even(tly + h * scale - 1.)};
+        for (int i : ii) inlier_out[i] = 1;
+        memcpy(est_tlbr_out + 4 * k, est, sizeof(est));
+        const double ix1 = std::max(est[0], 0.), iy1 = std::max(est[1], 0.);
+        const double ix2 = std::min(est[2], (double)frame_w - 1), iy2 = std::min(est[3], (double)frame_h - 1);
+        const bool outside = ix2 < ix1 || iy2 < iy1;
+        if (outside || (int)ii.size() < inlier_thresh) {
+            result_out[k] = 2;   // estimated but rejected: prev_keypoints updated, keypoints cleared
+            continue;
+        }
+        result_out[k] = 1;
+        // crop(fg_mask, est_tlbr)[:] = 0 : int truncation, clamp at 0 (utils/rect.py:83-89)
+        boxes.push_back(std::max((double)(int)est[0], 0.));
+        boxes.push_back(std::max((double)(int)est[1], 0.));
+        boxes.push_back(std::max((double)(int)est[2], 0.));
+        boxes.push_back(std::max((double)(int)est[3], 0.));
+    }
+    return 0;
+}

@@ -4,6 +4,8 @@ import logging
 
 import numpy as np
 
+from . import _lib
+from .detector import bind_frame
 from .runtime import get_context
 
 LOGGER = logging.getLogger(__name__)
@@ -59,9 +61,131 @@ class Flow:
         self.bg_keypoints = None
         self.prev_bg_keypoints = None
         self.frame_rect = np.array([0., 0., round(float(size[0]) - 1.), round(float(size[1]) - 1.)])
+        self._opt_scale = np.array(self.opt_flow_scale_factor, np.float32)
+        self._bg_scale = np.array(self.bg_feat_scale_factor, np.float32)
+        self._configured = False
+
+    def _configure(self):
+        """Allocates the device images / pyramids (flow.py:100-118 preallocates pinned buffers)."""
+        ctx = self.ctx
+        if getattr(ctx, 'frame_size', None) != tuple(self.size):
+            ctx.frame_configure(self.size[0], self.size[1], getattr(ctx, 'ring_size', 0))
+        cfg = _lib.FlowCfg()
+        cfg.small_w = round(self.opt_flow_scale_factor[0] * self.size[0])
+        cfg.small_h = round(self.opt_flow_scale_factor[1] * self.size[1])
+        cfg.bg_w = round(self.bg_feat_scale_factor[0] * self.size[0])
+        cfg.bg_h = round(self.bg_feat_scale_factor[1] * self.size[1])
+        win = self.opt_flow_params['winSize']
+        assert win[0] == win[1], 'square LK windows only'
+        cfg.win_size = win[0]
+        cfg.max_level = self.opt_flow_params['maxLevel']
+        crit = self.opt_flow_params['criteria']
+        cfg.max_count = crit[1] if crit[0] & 1 else 30        # TermCriteria.COUNT
+        cfg.epsilon = crit[2] if crit[0] & 2 else 0.01        # TermCriteria.EPS
+        cfg.fast_thresh = self.bg_feat_thresh
+        cfg.max_corners = self.obj_feat_params['maxCorners']
+        cfg.block_size = self.obj_feat_params['blockSize']
+        cfg.quality_level = self.obj_feat_params['qualityLevel']
+        ctx.flow_configure(cfg)
+        self._configured = True
 
     def init(self, frame):
-        raise NotImplementedError('flow.hip lands in a later milestone of this round')
+        """Preprocesses the first frame to prepare for subsequent `predict` (flow.py:121-133)."""
+        if not self._configured:
+            self._configure()
+        bind_frame(self.ctx, frame, self.size)
+        self.ctx.flow_init()
+        self.bg_keypoints = np.empty((0, 2), np.float32)
+        self.prev_bg_keypoints = np.empty((0, 2), np.float32)
 
     def predict(self, frame, tracks):
-        raise NotImplementedError('flow.hip lands in a later milestone of this round')
+        """Predicts tracklet positions in the next frame and estimates camera motion
+        (flow.py:135-264).  Returns ({trk_id: tlbr}, 3x3 homography) or ({}, None) on failure;
+        keypoints / inlier ratios of `tracks` are updated in place."""
+        ctx = self.ctx
+        bind_frame(ctx, frame, self.size)
+        ctx.flow_begin()                       # gray + small + pyramid of the new frame (async)
+
+        # order tracks from closest to farthest
+        tracks.sort(reverse=True)
+        n_trk = len(tracks)
+        fr = self.frame_rect
+        empty = np.empty((0, 2), np.float32)
+
+        # detect target feature points
+        all_prev_pts = []
+        if n_trk:
+            tlbrs = np.array([t.tlbr for t in tracks], np.float64).reshape(n_trk, 4)
+            inside = np.concatenate([np.maximum(tlbrs[:, :2], fr[:2]), np.minimum(tlbrs[:, 2:], fr[2:])], axis=1)
+            assert (inside[:, 2] >= inside[:, 0]).all() and (inside[:, 3] >= inside[:, 1]).all()
+            kp_off = np.zeros(n_trk + 1, np.int32)
+            np.cumsum([len(t.keypoints) for t in tracks], out=kp_off[1:])
+            kps = np.concatenate([t.keypoints for t in tracks]).astype(np.float32) if kp_off[-1] else empty
+            areas, keep = ctx.flow_targets(inside, kps, kp_off)
+            needy, dists = [], []
+            for k in range(n_trk):
+                pts = kps[kp_off[k]:kp_off[k + 1]][keep[kp_off[k]:kp_off[k + 1]]]
+                # only detect new keypoints when too few are propagated
+                if len(pts) < self.feat_density * areas[k]:
+                    needy.append(k)
+                    dists.append(max(round(np.sqrt(areas[k]) * self.feat_dist_factor), 1))
+                    pts = None
+                all_prev_pts.append(pts)
+            if needy:
+                new_pts, counts = ctx.flow_detect(needy, tlbrs[needy], dists,
+                                                  cap=min(self.obj_feat_params['maxCorners'], 1024))
+                for i, k in enumerate(needy):
+                    all_prev_pts[k] = new_pts[i, :counts[i]].copy()
+        else:
+            tlbrs = np.zeros((0, 4))
+            ctx.flow_targets(np.zeros((0, 4)), empty, np.zeros(1, np.int32))
+        target_ends = np.cumsum([len(p) for p in all_prev_pts]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
+        target_begins = np.concatenate([[0], target_ends[:-1]]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
+
+        # detect background feature points
+        keypoints = ctx.flow_background()
+        if len(keypoints) == 0:
+            self.bg_keypoints = empty
+            ctx.flow_swap()
+            LOGGER.warning('Camera motion estimation failed')
+            return {}, None
+        keypoints = keypoints * (1 / self._bg_scale)
+        bg_begin = int(target_ends[-1]) if n_trk else 0
+        all_prev_pts.append(keypoints)
+
+        # match features using optical flow (frame buffers are swapped inside)
+        all_prev_pts = np.concatenate(all_prev_pts).astype(np.float32)
+        scaled_prev_pts = all_prev_pts * self._opt_scale
+        all_cur_pts, status, err = ctx.flow_lk(scaled_prev_pts)
+        status = status.astype(np.bool_) & (err < self.max_error)
+        all_cur_pts[status] = all_cur_pts[status] * (1 / self._opt_scale)
+
+        # camera motion + per-track boxes (RANSAC; host side of the library)
+        n_pts = len(all_prev_pts)
+        homography, result, est, n_matched, inl = ctx.flow_estimate(
+            all_prev_pts, all_cur_pts, status, target_begins, target_ends, bg_begin, max(n_pts - 1, bg_begin),
+            tlbrs, self.size, self.ransac_max_iter, self.ransac_conf, self.inlier_thresh)
+        if homography is None:
+            self.bg_keypoints = empty
+            LOGGER.warning('Camera motion estimation failed')
+            return {}, None
+        bg = slice(bg_begin, n_pts)
+        self.prev_bg_keypoints = all_prev_pts[bg][inl[bg]]
+        self.bg_keypoints = all_cur_pts[bg][inl[bg]]
+
+        # estimate target bounding boxes
+        next_bboxes = {}
+        for k, track in enumerate(tracks):
+            code = result[k]
+            if code == 0:
+                track.keypoints = empty
+                continue
+            sl = slice(target_begins[k], target_ends[k])
+            track.prev_keypoints = all_prev_pts[sl][inl[sl]]
+            track.keypoints = all_cur_pts[sl][inl[sl]]
+            if code == 2:
+                track.keypoints = empty
+                continue
+            next_bboxes[track.trk_id] = est[k].copy()
+            track.inlier_ratio = len(track.keypoints) / n_matched[k]
+        return next_bboxes, homography

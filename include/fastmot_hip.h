@@ -285,6 +285,62 @@ int fm_extract_sync(fm_ctx* ctx, int n, float* emb);
 /* test hook: the preprocessed crops [n][in_h][in_w][3] as f32 (RGB, normalised) */
 int fm_extract_read_input(fm_ctx* ctx, int n, float* out);
 
+/* ---------------------------------------------------------------- optical flow (KLT) --- */
+/* Flow.__init__ buffers / parameters (flow.py:17-119).  Image sizes: full frame, optical-flow
+ * frame (opt_flow_scale_factor) and background-feature frame (bg_feat_scale_factor). */
+typedef struct fm_flow_cfg {
+    int32_t small_w, small_h;     /* round(opt_flow_scale_factor * size) */
+    int32_t bg_w, bg_h;           /* round(bg_feat_scale_factor * size)  */
+    int32_t win_size, max_level, max_count;   /* cv2.calcOpticalFlowPyrLK winSize / maxLevel / criteria */
+    double epsilon;
+    int32_t fast_thresh;          /* bg_feat_thresh */
+    int32_t max_corners, block_size;
+    double quality_level;         /* obj_feat_params */
+} fm_flow_cfg;
+int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg);
+/* Flow.init (flow.py:121-133): BGR->gray + optical-flow resize (+pyramid) of the current device frame
+ * become the "previous" images */
+int fm_flow_init(fm_ctx* ctx);
+/* first part of Flow.predict (flow.py:153-154): gray / small / pyramid of the current device
+ * frame, enqueued on the flow stream (overlaps the detector) */
+int fm_flow_begin(fm_ctx* ctx);
+/* mask bookkeeping of flow.py:159-181 for nT tracks in closest-first order:
+ * area_out[k]  = mask_area(crop(fg_mask, rect_k)) with every earlier rect already zeroed,
+ * keep_out[i]  = _rect_filter verdict of propagated keypoint i (kp_off[k]..kp_off[k+1]) */
+int fm_flow_targets(fm_ctx* ctx, int nT, const double* inside_tlbr, const float* kps, const int32_t* kp_off,
+                    int32_t* area_out, uint8_t* keep_out);
+/* cv2.goodFeaturesToTrack on the previous gray crop of each listed track (flow.py:169-178) with
+ * the foreground mask of fm_flow_targets, followed by _ellipse_filter (flow.py:297-306).
+ * track_idx: indices into the fm_flow_targets arrays; track_tlbr: full (unclipped) boxes;
+ * min_dist: minDistance per track.  pts_out: [n][cap][2] f32 frame coordinates, counts_out[n]. */
+int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, const double* track_tlbr,
+                   const int32_t* min_dist, int cap, float* pts_out, int32_t* counts_out);
+/* background keypoints (flow.py:187-200): INTER_LINEAR resize of the previous gray frame,
+ * INTER_NEAREST resize of the final foreground mask, FAST-9/16 + NMS, mask filter.
+ * pts_out: [cap][2] f32 in background-frame coordinates (not yet unscaled). */
+int fm_flow_background(fm_ctx* ctx, int cap, float* pts_out, int* n_out);
+/* cv2.calcOpticalFlowPyrLK(prev_small, cur_small, pts) (flow.py:205-207): Scharr derivatives +
+ * pyramidal LK for n points; then the frame buffers are swapped (flow.py:212-213). */
+int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next_pts, uint8_t* status, float* err);
+/* swap without LK (failure paths of flow.py:191-196) */
+int fm_flow_swap(fm_ctx* ctx);
+/* second half of Flow.predict on the host side of the library (flow.py:215-263): camera motion by
+ * cv2.findHomography(RANSAC) over the background matches, then per track _fg_filter ->
+ * cv2.estimateAffinePartial2D(RANSAC) -> _estimate_bbox -> inlier bookkeeping.  Latency-bound
+ * serial work (a few microseconds per hypothesis loop): kept in C++ on the host, see DESIGN.md.
+ * Inputs: prev/cur points (frame coordinates), status, target ranges [begin,end) per track
+ * (closest-first), bg range, boxes.  Outputs: H (3x3), ok flag, per track result code
+ * (0 = skipped, 1 = box estimated), est_tlbr, n_matched, inlier flags over all points. */
+int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, const float* cur_pts,
+                     const uint8_t* status, int nT, const int32_t* begins, const int32_t* ends,
+                     int bg_begin, int bg_end, const double* track_tlbr, int frame_w, int frame_h,
+                     int ransac_max_iter, double ransac_conf, int inlier_thresh,
+                     double* H_out, int* ok_out, int32_t* result_out, double* est_tlbr_out,
+                     int32_t* n_matched_out, uint8_t* inlier_out);
+/* test hooks: read the device images (which: 0 prev gray, 1 cur gray, 2.. pyramid levels of prev
+ * (2+l) and cur (10+l), 20 bg image) */
+int fm_flow_read_image(fm_ctx* ctx, int which, uint8_t* out, int* w, int* h);
+
 #ifdef __cplusplus
 }
 #endif

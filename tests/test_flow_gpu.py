@@ -1,0 +1,183 @@
+"""GPU parity of the KLT stage (flow.hip + flow_estimate.hip) against oracle=restated
+(oracle/cv_oracle.py: OpenCV algorithms restated in numpy -- the reference delegates this stage
+to OpenCV, which is not available, so parity here is pinned only between restatement and kernels;
+SURVEY.md section 8c).  Integer image results must be IDENTICAL; LK points agree to 1e-3 px
+(float32 accumulation order inside the 5x5 window is the same sequential order)."""
+import numpy as np
+import pytest
+
+import cv_oracle as cv
+import scenes
+from fastmot_amd import _lib
+from fastmot_amd.flow import Flow
+
+pytestmark = pytest.mark.gpu
+
+
+def textured_frame(w, h, seed, shift=(0, 0)):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h // 6 + 8, w // 6 + 8, 3)).astype(np.uint8)
+    big = np.kron(base, np.ones((6, 6, 1), np.uint8))
+    big = np.clip(big.astype(int) + rng.integers(-12, 12, big.shape), 0, 255).astype(np.uint8)
+    oy, ox = 12 + shift[1], 12 + shift[0]
+    return np.ascontiguousarray(big[oy:oy + h, ox:ox + w])
+
+
+class FakeTrack:
+    def __init__(self, trk_id, tlbr, age=0):
+        self.trk_id, self.age = trk_id, age
+        self._tlbr = np.asarray(tlbr, float)
+        self.keypoints = np.empty((0, 2), np.float32)
+        self.prev_keypoints = np.empty((0, 2), np.float32)
+        self.inlier_ratio = 1.
+
+    @property
+    def tlbr(self):
+        return self._tlbr
+
+    def __lt__(self, other):
+        return (self.tlbr[-1], -self.age) < (other.tlbr[-1], -other.age)
+
+
+def make_flow(size):
+    kw = scenes.tracker_kwargs()['flow_cfg']
+    return Flow(size, **vars(kw))
+
+
+def test_images_pyramid_lk(ctx):
+    size = (640, 360)
+    f0, f1 = textured_frame(*size, 1), textured_frame(*size, 1, shift=(4, 2))
+    flow = make_flow(size)
+    flow.init(f0)
+    g0 = cv.bgr2gray(f0)
+    np.testing.assert_array_equal(ctx.flow_read_image(0), g0)
+    small0 = cv.resize_linear_u8(g0, (320, 180))
+    np.testing.assert_array_equal(ctx.flow_read_image(2), small0)
+    pyr = cv.build_pyramid(small0, 5, 5)
+    for l, img in enumerate(pyr):
+        np.testing.assert_array_equal(ctx.flow_read_image(2 + l), img)
+    # LK on arbitrary points
+    ctx.frame_upload(f1)
+    ctx.flow_begin()
+    ctx.flow_targets(np.zeros((0, 4)), np.zeros((0, 2), np.float32), np.zeros(1, np.int32))
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(-3, 323, 400), rng.uniform(-3, 183, 400)], 1).astype(np.float32)
+    nxt, st, err = ctx.flow_lk(pts)
+    small1 = cv.resize_linear_u8(cv.bgr2gray(f1), (320, 180))
+    en, es, ee = cv.calc_optical_flow_pyr_lk(small0, small1, pts)
+    np.testing.assert_array_equal(st, es)
+    ok = es > 0
+    np.testing.assert_allclose(nxt[ok], en[ok], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(err[ok], ee[ok], rtol=1e-4, atol=1e-3)
+    assert ok.mean() > 0.7
+    # the dominant motion is the shift (-4, -2)/2 in the half-resolution frame
+    med = np.median((nxt - pts)[ok], axis=0)
+    np.testing.assert_allclose(med, [-2, -1], atol=0.1)
+
+
+def test_targets_gftt_fast(ctx):
+    size = (640, 360)
+    f0 = textured_frame(*size, 5)
+    flow = make_flow(size)
+    flow.init(f0)
+    g0 = cv.bgr2gray(f0)
+    rects = np.array([[100, 200, 180, 359], [150, 120, 230, 300], [400, 50, 460, 200], [0, 0, 50, 90]], float)
+    kps = np.array([[120.4, 250.2], [160., 210.], [200., 150.], [155., 250.], [420.6, 60.5], [700., 10.]], np.float32)
+    off = np.array([0, 2, 4, 6, 6], np.int32)
+    area, keep = ctx.flow_targets(rects, kps, off)
+    mask = np.full((360, 640), 255, np.uint8)
+    exp_area, exp_keep = [], []
+    for k, r in enumerate(rects.astype(int)):
+        crop = mask[r[1]:r[3] + 1, r[0]:r[2] + 1]
+        exp_area.append(int((crop != 0).sum()))
+        for p in kps[off[k]:off[k + 1]]:
+            x, y = int(np.rint(p[0])), int(np.rint(p[1]))
+            inside = r[0] <= x <= r[2] and r[1] <= y <= r[3]
+            exp_keep.append(bool(inside and mask[y, x] == 255))
+        masks_k = crop.copy() if k == 1 else None
+        if k == 1:
+            mask1 = masks_k
+        crop[:] = 0
+    np.testing.assert_array_equal(area, exp_area)
+    np.testing.assert_array_equal(keep, exp_keep)
+    # GFTT on track 1 (partly occluded by track 0) and track 2
+    pts, cnt = ctx.flow_detect([1, 2], rects[[1, 2]], [6, 5], cap=1000)
+    for i, (k, md) in enumerate(((1, 6), (2, 5))):
+        r = rects[k].astype(int)
+        m = np.full((r[3] - r[1] + 1, r[2] - r[0] + 1), 255, np.uint8) if k == 2 else mask1
+        exp = cv.good_features_to_track(g0[r[1]:r[3] + 1, r[0]:r[2] + 1], m, 1000, 0.06, md)
+        exp = exp + np.array(r[:2], np.float32)
+        c = (rects[k][:2] + rects[k][2:]) / 2
+        ax = (rects[k][2:] - rects[k][:2] + 1) * 0.5
+        exp = exp[(((exp - c) / ax) ** 2).sum(1) <= 1.]
+        got = pts[i, :cnt[i]]
+        assert len(got) == len(exp) and len(exp) > 3
+        np.testing.assert_array_equal(got, exp)
+    # background FAST keypoints under the final mask
+    bg = ctx.flow_background()
+    bg_img = cv.resize_linear_u8(g0, (64, 36))
+    np.testing.assert_array_equal(ctx.flow_read_image(20), bg_img)
+    kp = cv.fast_detect(bg_img, 10)
+    mask_small = cv.resize_nearest(mask, (64, 36))
+    kp = kp[[mask_small[int(p[1] + 0.5), int(p[0] + 0.5)] != 0 for p in kp]]
+    np.testing.assert_array_equal(bg, kp)
+    assert len(kp) > 10
+
+
+def test_estimate_vs_oracle(ctx):
+    rng = np.random.default_rng(9)
+    size = (640, 360)
+    Htrue = np.array([[1.002, 0.001, 3.0], [-0.0015, 0.999, -2.0], [1e-6, -2e-6, 1.]])
+    n_bg = 150
+    bgp = np.stack([rng.uniform(0, 640, n_bg), rng.uniform(0, 360, n_bg)], 1)
+    q = np.c_[bgp, np.ones(n_bg)] @ Htrue.T
+    bgc = q[:, :2] / q[:, 2:] + rng.normal(0, 0.3, (n_bg, 2))
+    bgc[::7] += rng.normal(0, 25, bgc[::7].shape)           # outliers
+    tracks = np.array([[100, 100, 160, 280], [140, 120, 200, 300], [400, 60, 450, 200], [300, 300, 340, 359]], float)
+    prev, cur, begins, ends = [], [], [], []
+    for k, t in enumerate(tracks):
+        n = [40, 30, 25, 2][k]
+        p = np.stack([rng.uniform(t[0], t[2], n), rng.uniform(t[1], t[3], n)], 1)
+        c = p * 1.01 + np.array([5., -3.]) + rng.normal(0, 0.4, (n, 2))
+        c[::6] += rng.normal(0, 15, c[::6].shape)
+        begins.append(len(np.concatenate(prev)) if prev else 0)
+        prev.append(p); cur.append(c)
+        ends.append(begins[-1] + n)
+    prev.append(bgp); cur.append(bgc)
+    P = np.concatenate(prev).astype(np.float32); Cc = np.concatenate(cur).astype(np.float32)
+    status = rng.random(len(P)) > 0.05
+    args = (P, Cc, status, np.array(begins, np.int32), np.array(ends, np.int32), ends[-1], len(P) - 1, tracks,
+            size, 500, 0.99, 4)
+    H, res, est, nm, inl = ctx.flow_estimate(*args)
+    eH, eres, eest, enm, einl = cv.flow_estimate(*args)
+    assert H is not None and eH is not None
+    np.testing.assert_array_equal(res, eres)
+    np.testing.assert_array_equal(nm, enm)
+    np.testing.assert_array_equal(inl, einl)
+    np.testing.assert_array_equal(est, eest)
+    np.testing.assert_allclose(H, eH, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(H, Htrue, atol=5e-2, rtol=5e-2)
+    assert list(res) == [1, 1, 1, 0]
+
+
+def test_flow_predict_moving_scene(ctx):
+    """End to end: Flow.predict on a synthetic camera pan -> boxes follow the motion."""
+    size = (640, 360)
+    flow = make_flow(size)
+    f0 = textured_frame(*size, 11)
+    f1 = textured_frame(*size, 11, shift=(6, -4))      # content moves by (-6, +4) px
+    flow.init(f0)
+    tracks = [FakeTrack(1, [100, 100, 170, 300]), FakeTrack(2, [300, 50, 380, 330], age=1), FakeTrack(3, [500, 20, 560, 180])]
+    boxes, H = flow.predict(f1, tracks)
+    assert H is not None and len(boxes) == 3
+    np.testing.assert_allclose(H, [[1, 0, -6], [0, 1, 4], [0, 0, 1]], atol=0.05)
+    for t in tracks:
+        np.testing.assert_allclose(boxes[t.trk_id], t.tlbr + np.array([-6, 4, -6, 4]), atol=1.01)
+        assert len(t.keypoints) >= 4 and 0 < t.inlier_ratio <= 1
+    # second call reuses propagated keypoints (no GFTT) and still tracks
+    f2 = textured_frame(*size, 11, shift=(12, -8))
+    for t in tracks:
+        t._tlbr = boxes[t.trk_id]
+    boxes2, H2 = flow.predict(f2, tracks)
+    assert H2 is not None and len(boxes2) == 3
+    np.testing.assert_allclose(H2, [[1, 0, -6], [0, 1, 4], [0, 0, 1]], atol=0.05)
