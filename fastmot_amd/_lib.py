@@ -361,6 +361,11 @@ def _bind_device_io(cls):
     def detect_async(self):
         check(self.lib.fm_detect_async(self._ctx))
 
+    def detect_net_ms(self):
+        ms = C.c_float(0)
+        check(self.lib.fm_detect_net_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
     def detect_preprocess_only(self):
         check(self.lib.fm_detect_preprocess_only(self._ctx))
 
@@ -402,7 +407,7 @@ def _bind_device_io(cls):
         return out
 
     for fn in (frame_configure, frame_upload, frame_ring_store, frame_ring_select, frame_read,
-               detect_configure, detect_async, detect_preprocess_only, detect_sync, filter_dets,
+               detect_configure, detect_async, detect_net_ms, detect_preprocess_only, detect_sync, filter_dets,
                detect_raw_candidates, extract_configure, extract_async, extract_sync, extract_read_input):
         setattr(cls, fn.__name__, fn)
 

@@ -35,6 +35,8 @@ struct DetState {
     uint8_t* label_mask = nullptr;
     float* rows_in = nullptr;     // test hook upload
     int rows_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the network launches of detect_async
+    bool ev_valid = false;
 };
 
 void fm_det_free(DetState* d) {
@@ -44,6 +46,8 @@ void fm_det_free(DetState* d) {
         if (p) (void)hipFree(p);
     if (d->dets_host) (void)hipHostFree(d->dets_host);
     if (d->counters_host) (void)hipHostFree(d->counters_host);
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
     delete d;
 }
 
@@ -480,7 +484,14 @@ extern "C" int fm_detect_async(fm_ctx* ctx) {
     hipStream_t s = ctx->s_det;
     int rc = enqueue_preprocess(ctx, d, net);
     if (rc) return rc;
+    if (!d->ev0) {
+        FM_HIP(hipEventCreate(&d->ev0));
+        FM_HIP(hipEventCreate(&d->ev1));
+    }
+    FM_HIP(hipEventRecord(d->ev0, s));
     if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
+    FM_HIP(hipEventRecord(d->ev1, s));
+    d->ev_valid = true;
     FM_HIP(hipMemsetAsync(d->counters, 0, sizeof(int32_t) * 4, s));
     FilterArgs fa = filter_args(d);
     int base = 0;
@@ -536,5 +547,14 @@ extern "C" int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* 
     FM_CHECK_ARG(k <= cap);
     FM_HIP(hipMemcpy(rows, d->sorted, sizeof(float) * 8 * k, hipMemcpyDeviceToHost));
     *n = k;
+    return 0;
+}
+
+// HIP-event time (ms) of the network launches of the last fm_detect_async, measured on the
+// detector stream itself (bench.py roofline: conv FLOPs / this time).
+extern "C" int fm_detect_net_ms(fm_ctx* ctx, float* ms) {
+    FM_CHECK_ARG(ctx && ctx->det && ms && ctx->det->ev_valid);
+    FM_HIP(hipEventSynchronize(ctx->det->ev1));
+    FM_HIP(hipEventElapsedTime(ms, ctx->det->ev0, ctx->det->ev1));
     return 0;
 }

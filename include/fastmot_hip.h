@@ -270,6 +270,9 @@ int fm_detect_sync(fm_ctx* ctx, fm_det48* out, int cap, int* n);
 int fm_detect_preprocess_only(fm_ctx* ctx);
 int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* out, int cap, int* n_out);
 int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* n);
+/* HIP-event duration (ms) of the network launches of the last fm_detect_async, recorded on the
+ * detector stream (the bench's live roofline measurement) */
+int fm_detect_net_ms(fm_ctx* ctx, float* ms);
 
 /* ---------------------------------------------------------------- feature extractor --- */
 /* FeatureExtractor.extract_async (feature_extractor.py:48-60): for n boxes crop the current

@@ -1,0 +1,73 @@
+"""GPU end to end: MOT.step on a synthetic video (frames -> detector net -> injected detections ->
+KLT -> OSNet -> Kalman -> association).  Checks the API contract of mot.py:103-168 and that the
+identities of the synthetic objects are held (one track id per object over the clip)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+class TinyDet:
+    pass
+
+
+def build_mot(size, video, skip):
+    import fastmot_amd.mot as mot_mod
+    from fastmot_amd.models import YOLO
+    from fastmot_amd.utils.synthetic import InjectedYOLODetector
+
+    class BenchTiny(YOLO):
+        NUM_CLASSES = 2
+        INPUT_SHAPE = (3, 160, 288)
+        LAYER_FACTORS = [8, 16, 32]
+        SCALES = [1.2, 1.1, 1.05]
+        ANCHORS = [[4, 7, 8, 15, 12, 30], [18, 40, 25, 60, 30, 80], [40, 90, 60, 70, 80, 95]]
+    kw = scenes.tracker_kwargs()
+    mot_mod.YOLODetector = InjectedYOLODetector
+    try:
+        mot = mot_mod.MOT(size, detector_type='YOLO', detector_frame_skip=skip, class_ids=(1,),
+                          yolo_detector_cfg=SimpleNamespace(model='BenchTiny', conf_thresh=0.25, nms_thresh=0.5,
+                                                            max_area=800000, min_aspect_ratio=1.2),
+                          feature_extractor_cfgs=(SimpleNamespace(model='OSNet025', batch_size=16),),
+                          tracker_cfg=SimpleNamespace(**kw))
+    finally:
+        from fastmot_amd.detector import YOLODetector
+        mot_mod.YOLODetector = YOLODetector
+    mot.detector.bind_video(video)
+    return mot
+
+
+@pytest.mark.parametrize('skip', [1, 3])
+def test_mot_step_holds_identities(ctx, skip):
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from fastmot_amd import Track
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=12, n_frames=24, seed=3)
+    mot = build_mot(size, video, 1)
+    mot.detector_frame_skip = skip
+    # injected detections are consumed once per detector frame -> index by frame
+    mot.detector._video = video
+    Track._count = 0
+    mot.reset(1 / 30.)
+    ids_per_obj = [set() for _ in range(video.n_ids)]
+    for f in range(video.n_frames):
+        mot.detector._frame_idx = f
+        mot.step(video.frames[f])
+        assert mot.frame_count == f + 1
+        vis = list(mot.visible_tracks())
+        for t in vis:
+            c = (t.tlbr[:2] + t.tlbr[2:]) / 2
+            gt = video.gt[f]
+            inside = (gt[:, 0] <= c[0]) & (c[0] <= gt[:, 2]) & (gt[:, 1] <= c[1]) & (c[1] <= gt[:, 3])
+            if inside.sum() == 1:
+                ids_per_obj[int(np.flatnonzero(inside)[0])].add(t.trk_id)
+        if f >= skip:
+            assert len(vis) >= video.n_ids - 3
+    # every object is followed, and almost all by a single identity
+    assert all(len(s) >= 1 for s in ids_per_obj)
+    assert sum(len(s) == 1 for s in ids_per_obj) >= video.n_ids - 2
+    assert mot.tracker.homography is not None

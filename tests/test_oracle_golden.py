@@ -59,3 +59,19 @@ def test_assoc(golden_dir, tag):
     assert [(100 + a, b) for a, b in m] == [tuple(x) for x in g[f'{tag}_gr_m'].tolist()]
     assert [100 + a for a in ur] == g[f'{tag}_gr_ut'].tolist()
     assert uc == g[f'{tag}_gr_ud'].tolist()
+
+
+@pytest.mark.parametrize('name', ['s20_skip5_euclid', 's50_skip1_cosine', 's50_skip2_euclid', 's8_flowfail'])
+def test_tracker_scenes(golden_dir, name):
+    """The restated CPU tracker (oracle/cpu_tracker.py) reproduces the reference MultiTracker's
+    golden runs: identical track ids / order / rounded boxes / lifecycle on every frame."""
+    import scenes
+    import cpu_tracker
+    g = np.load(golden_dir / f'tracker_{name}.npz')
+    scene = scenes.Scene(name)
+    tracker = cpu_tracker.OracleTracker(scene.size, scene.metric, **scenes.tracker_kwargs())
+    records, final = scenes.run_scene(tracker, scene)
+    out = scenes.pack_records(records, final)
+    np.testing.assert_array_equal(out['tracks'], g['tracks'])
+    np.testing.assert_array_equal(out['hist'], g['hist'])
+    np.testing.assert_allclose(out['final_mean'], g['final_mean'], rtol=1e-9, atol=1e-7)
