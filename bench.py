@@ -187,6 +187,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(video)
+        from fastmot_amd.utils import Profiler
+        stages = {k: round(Profiler.get_avg_millis(k), 3) for k in ('preproc', 'detect', 'track', 'extract', 'assoc')}
+        print('stage ms (Profiler, incl. warmup):', stages, file=sys.stderr)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
