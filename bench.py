@@ -55,7 +55,7 @@ def build_mot(video):
         mot = mot_mod.MOT(SIZE, detector_type='YOLO', detector_frame_skip=1, class_ids=(1,),
                           yolo_detector_cfg=SimpleNamespace(model='YOLOv4_608', conf_thresh=0.25, nms_thresh=0.5,
                                                             max_area=800000, min_aspect_ratio=1.2,
-                                                            max_candidates=32768),
+                                                            max_candidates=8192),
                           feature_extractor_cfgs=(SimpleNamespace(model='OSNet025', batch_size=64),),
                           tracker_cfg=tracker_cfg())
     finally:

@@ -447,6 +447,29 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_targets(self._ctx, C.c_int(nT), _ptr(r), _ptr(k), _ptr(off), _ptr(area), _ptr(keep)))
         return area, keep.astype(bool)
 
+    def flow_prepare(self, inside_tlbr, full_tlbr, kps, kp_off, feat_density, feat_dist_factor,
+                     pts_cap=65536, bg_cap=8192):
+        r = _as(inside_tlbr, np.float64).reshape(-1, 4)
+        nT = len(r)
+        fb = _as(full_tlbr, np.float64).reshape(nT, 4)
+        off = _as(kp_off, np.int32)
+        k = _as(kps, np.float32).reshape(-1, 2)
+        assert len(off) == nT + 1 and off[-1] == len(k)
+        area = np.zeros(nT, np.int32)
+        keep = np.zeros(len(k), np.uint8)
+        needy = np.zeros(nT, np.uint8)
+        if not hasattr(self, '_flow_bufs') or self._flow_bufs[0].shape[0] < pts_cap or self._flow_bufs[1].shape[0] < bg_cap:
+            self._flow_bufs = (np.empty((pts_cap, 2), np.float32), np.empty((bg_cap, 2), np.float32))
+        new_pts, bg = self._flow_bufs
+        new_off = np.zeros(nT, np.int32)
+        new_cnt = np.zeros(nT, np.int32)
+        n_new, n_bg = C.c_int(0), C.c_int(0)
+        check(self.lib.fm_flow_prepare(self._ctx, C.c_int(nT), _ptr(r), _ptr(fb), _ptr(k), _ptr(off),
+                                       C.c_double(feat_density), C.c_double(feat_dist_factor), _ptr(area), _ptr(keep),
+                                       _ptr(needy), C.c_int(pts_cap), _ptr(new_pts), _ptr(new_off), _ptr(new_cnt),
+                                       C.byref(n_new), C.c_int(bg_cap), _ptr(bg), C.byref(n_bg)))
+        return area, keep.astype(bool), needy.astype(bool), new_pts, new_off, new_cnt, bg[:n_bg.value].copy()
+
     def flow_detect(self, track_idx, track_tlbr, min_dist, cap=1000):
         idx = _as(track_idx, np.int32)
         n = len(idx)
@@ -501,7 +524,7 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_read_image(self._ctx, C.c_int(which), _ptr(buf), C.byref(w), C.byref(h)))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 
-    for fn in (flow_configure, flow_init, flow_begin, flow_swap, flow_targets, flow_detect, flow_background,
+    for fn in (flow_configure, flow_init, flow_begin, flow_swap, flow_targets, flow_prepare, flow_detect, flow_background,
                flow_lk, flow_estimate, flow_read_image):
         setattr(cls, fn.__name__, fn)
 

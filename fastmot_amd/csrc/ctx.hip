@@ -37,10 +37,14 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     FM_HIP(hipSetDevice(device));
     fm_ctx* ctx = new fm_ctx();
     ctx->device = device;
-    FM_HIP(hipStreamCreateWithFlags(&ctx->s_main, hipStreamNonBlocking));
-    FM_HIP(hipStreamCreateWithFlags(&ctx->s_det, hipStreamNonBlocking));
-    FM_HIP(hipStreamCreateWithFlags(&ctx->s_ext, hipStreamNonBlocking));
-    FM_HIP(hipStreamCreateWithFlags(&ctx->s_flow, hipStreamNonBlocking));
+    // the detector network is the long, throughput-oriented stream; tracker / KLT / ReID launches are
+    // short and latency critical (the host waits on them), so they get the higher priority
+    int prio_lo = 0, prio_hi = 0;
+    FM_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least, hi = greatest priority
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, prio_hi));
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_lo));
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext, hipStreamNonBlocking, prio_hi));
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_flow, hipStreamNonBlocking, prio_hi));
     int rc = fm_ensure_slots(ctx, 1024);
     if (rc) return rc;
     *out = ctx;

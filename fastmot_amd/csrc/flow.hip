@@ -30,7 +30,7 @@ struct FlowState {
     int lw[MAX_LEVELS], lh[MAX_LEVELS];
     uint8_t* gray[2] = {nullptr, nullptr};          // full resolution
     uint8_t* pyr[2][MAX_LEVELS] = {};               // level 0 = optical-flow frame
-    int16_t* deriv[MAX_LEVELS] = {};                // Scharr of the previous pyramid (dx,dy interleaved)
+    int16_t* deriv[2][MAX_LEVELS] = {};             // Scharr of each pyramid (dx,dy interleaved)
     uint8_t* bg_img = nullptr;
     int prev = 0;                                   // index of the "previous" set
     // targets of the current predict
@@ -39,8 +39,9 @@ struct FlowState {
     DevBuf tgt_in, tgt_out, det_in, det_out, lk_in, lk_out, bg_out;
     float* eig = nullptr;                           // scratch for GFTT
     size_t eig_cap = 0;
-    float* cand = nullptr;                          // [tracks][cand_cap][2] (value, raster index as float bits)
-    int cand_tracks = 0;
+    int32_t* ov_idx = nullptr;                      // overlap lists (earlier rects intersecting rect k)
+    int32_t* ov_off = nullptr;
+    int ov_cap = 0;
     int32_t* bg_flags = nullptr;                    // FAST score / flags
 };
 
@@ -51,9 +52,10 @@ void fm_flow_free(FlowState* f) {
         for (int l = 0; l < MAX_LEVELS; ++l)
             if (f->pyr[s][l]) (void)hipFree(f->pyr[s][l]);
     }
-    for (int l = 0; l < MAX_LEVELS; ++l)
-        if (f->deriv[l]) (void)hipFree(f->deriv[l]);
-    for (void* p : {(void*)f->bg_img, (void*)f->rects, (void*)f->eig, (void*)f->cand, (void*)f->bg_flags})
+    for (int st = 0; st < 2; ++st)
+        for (int l = 0; l < MAX_LEVELS; ++l)
+            if (f->deriv[st][l]) (void)hipFree(f->deriv[st][l]);
+    for (void* p : {(void*)f->bg_img, (void*)f->rects, (void*)f->eig, (void*)f->ov_idx, (void*)f->ov_off, (void*)f->bg_flags})
         if (p) (void)hipFree(p);
     for (DevBuf* b : {&f->tgt_in, &f->tgt_out, &f->det_in, &f->det_out, &f->lk_in, &f->lk_out, &f->bg_out})
         b->release();
@@ -157,20 +159,37 @@ struct LKArgs {
 };
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
-constexpr int LK_MAX_WIN = 7;
 
-__global__ void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts, float* __restrict__ next_pts,
-                          uint8_t* __restrict__ status, float* __restrict__ err) {
-    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pt >= n) return;
+__device__ __forceinline__ float group_sum32(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    return v;
+}
+
+// 32 lanes per point: lane g < win*win owns window pixel (g / win, g % win); sums over the window
+// are 32-lane butterfly reductions (float32; the summation order differs from OpenCV's scalar loop,
+// results agree to ~1e-4 px).  All lanes of a group follow the same control flow.
+__global__ __launch_bounds__(256) void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+                                                 float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                 float* __restrict__ err) {
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pt = gidx >> 5, g = gidx & 31;
+    if (pt >= n) return;                       // whole 32-lane group exits together
     const int win = a.win;
+    const bool lane_on = g < win * win;
+    const int wy = lane_on ? g / win : 0, wx = lane_on ? g % win : 0;
     const float half = (win - 1) * 0.5f;
     const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
     float nx = 0.f, ny = 0.f;
     bool st = true;
     float er = 0.f;
-    short Ipatch[LK_MAX_WIN * LK_MAX_WIN], dIx[LK_MAX_WIN * LK_MAX_WIN], dIy[LK_MAX_WIN * LK_MAX_WIN];
     const float FLT_SCALE = 1.f / (1 << 20);
+    auto weights = [](float fa, float fb, int& iw00, int& iw01, int& iw10, int& iw11) {
+        iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
+        iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
+        iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
+        iw11 = (1 << 14) - iw00 - iw01 - iw10;
+    };
     for (int level = a.levels - 1; level >= 0; --level) {
         const int w = a.w[level], h = a.h[level];
         const uint8_t* I = a.I[level];
@@ -186,37 +205,28 @@ __global__ void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts, f
             if (level == 0) { st = false; er = 0.f; }
             continue;
         }
-        float fa = ppx - ipx, fb = ppy - ipy;
-        int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
-        int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
-        int iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
-        int iw11 = (1 << 14) - iw00 - iw01 - iw10;
-        float A11 = 0.f, A12 = 0.f, A22 = 0.f;
-        for (int y = 0; y < win; ++y) {
-            const int yy0 = ipy + y, yy1 = yy0 + 1;
+        int iw00, iw01, iw10, iw11;
+        weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
+        int ival = 0, ixval = 0, iyval = 0;
+        if (lane_on) {
+            const int xx0 = ipx + wx, xx1 = xx0 + 1, yy0 = ipy + wy, yy1 = yy0 + 1;
             const uint8_t* r0 = I + (size_t)reflect101(yy0, h) * w;
             const uint8_t* r1 = I + (size_t)reflect101(yy1, h) * w;
-            for (int x = 0; x < win; ++x) {
-                const int xx0 = ipx + x, xx1 = xx0 + 1;
-                const int c0 = reflect101(xx0, w), c1 = reflect101(xx1, w);
-                const int ival = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5);
-                // derivative image is zero outside (BORDER_CONSTANT), lkpyramid.cpp
-                auto dv = [&](int xx, int yy, int ch) -> int {
-                    return (xx < 0 || xx >= w || yy < 0 || yy >= h) ? 0 : (int)D[((size_t)yy * w + xx) * 2 + ch];
-                };
-                const int ixval = LK_DESCALE(dv(xx0, yy0, 0) * iw00 + dv(xx1, yy0, 0) * iw01 +
-                                             dv(xx0, yy1, 0) * iw10 + dv(xx1, yy1, 0) * iw11, 14);
-                const int iyval = LK_DESCALE(dv(xx0, yy0, 1) * iw00 + dv(xx1, yy0, 1) * iw01 +
-                                             dv(xx0, yy1, 1) * iw10 + dv(xx1, yy1, 1) * iw11, 14);
-                Ipatch[y * win + x] = (short)ival;
-                dIx[y * win + x] = (short)ixval;
-                dIy[y * win + x] = (short)iyval;
-                A11 += (float)(ixval * ixval);
-                A12 += (float)(ixval * iyval);
-                A22 += (float)(iyval * iyval);
-            }
+            const int c0 = reflect101(xx0, w), c1 = reflect101(xx1, w);
+            ival = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5);
+            // derivative image is zero outside (BORDER_CONSTANT), lkpyramid.cpp
+            auto dv = [&](int xx, int yy) -> int2 {
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return make_int2(0, 0);
+                const int v = *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
+                return make_int2((int)(short)(v & 0xffff), (int)(short)(v >> 16));
+            };
+            const int2 d00 = dv(xx0, yy0), d01 = dv(xx1, yy0), d10 = dv(xx0, yy1), d11 = dv(xx1, yy1);
+            ixval = LK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
+            iyval = LK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
         }
-        A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+        const float A11 = group_sum32((float)(ixval * ixval)) * FLT_SCALE;
+        const float A12 = group_sum32((float)(ixval * iyval)) * FLT_SCALE;
+        const float A22 = group_sum32((float)(iyval * iyval)) * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
         if (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f) {
@@ -227,30 +237,24 @@ __global__ void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts, f
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
         float outx = nx + half, outy = ny + half;
+        bool running = true;
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-            if (inx < -win || inx >= w || iny < -win || iny >= h) {
+            if (running && (inx < -win || inx >= w || iny < -win || iny >= h)) {
                 if (level == 0) st = false;
-                break;
+                running = false;
             }
-            fa = nx - inx; fb = ny - iny;
-            iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
-            iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
-            iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
-            iw11 = (1 << 14) - iw00 - iw01 - iw10;
-            float b1 = 0.f, b2 = 0.f;
-            for (int y = 0; y < win; ++y) {
-                const uint8_t* r0 = J + (size_t)reflect101(iny + y, h) * w;
-                const uint8_t* r1 = J + (size_t)reflect101(iny + y + 1, h) * w;
-                for (int x = 0; x < win; ++x) {
-                    const int c0 = reflect101(inx + x, w), c1 = reflect101(inx + x + 1, w);
-                    const int diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) -
-                                     Ipatch[y * win + x];
-                    b1 += (float)(diff * dIx[y * win + x]);
-                    b2 += (float)(diff * dIy[y * win + x]);
-                }
+            if (!running) break;                 // uniform within the 32-lane group
+            weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
+            int diff = 0;
+            if (lane_on) {
+                const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
+                const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
+                const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
+                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
             }
-            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            const float b1 = group_sum32((float)(diff * ixval)) * FLT_SCALE;
+            const float b2 = group_sum32((float)(diff * iyval)) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
             nx += dx; ny += dy;
             outx = nx + half; outy = ny + half;
@@ -266,52 +270,61 @@ __global__ void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts, f
             const float ex = nx - half, ey = ny - half;
             const int inx = (int)floorf(ex), iny = (int)floorf(ey);
             if (inx < -win || inx >= w || iny < -win || iny >= h) { st = false; continue; }
-            fa = ex - inx; fb = ey - iny;
-            iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
-            iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
-            iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
-            iw11 = (1 << 14) - iw00 - iw01 - iw10;
-            float errval = 0.f;
-            for (int y = 0; y < win; ++y) {
-                const uint8_t* r0 = J + (size_t)reflect101(iny + y, h) * w;
-                const uint8_t* r1 = J + (size_t)reflect101(iny + y + 1, h) * w;
-                for (int x = 0; x < win; ++x) {
-                    const int c0 = reflect101(inx + x, w), c1 = reflect101(inx + x + 1, w);
-                    const int diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) -
-                                     Ipatch[y * win + x];
-                    errval += fabsf((float)diff);
-                }
+            weights(ex - inx, ey - iny, iw00, iw01, iw10, iw11);
+            int diff = 0;
+            if (lane_on) {
+                const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
+                const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
+                const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
+                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
             }
-            er = errval * 1.f / (32 * win * win);
+            er = group_sum32(fabsf((float)diff)) * 1.f / (32 * win * win);
         }
     }
-    next_pts[2 * pt] = nx;
-    next_pts[2 * pt + 1] = ny;
-    status[pt] = st ? 1 : 0;
-    err[pt] = er;
+    if (g == 0) {
+        next_pts[2 * pt] = nx;
+        next_pts[2 * pt + 1] = ny;
+        status[pt] = st ? 1 : 0;
+        err[pt] = er;
+    }
 }
 
-// ---- foreground-mask bookkeeping: rect k sees pixel p as foreground iff no rect j<k covers p
-__device__ __forceinline__ bool covered_before(const int32_t* rects, int k, int x, int y) {
-    for (int j = 0; j < k; ++j) {
+// ---- foreground-mask bookkeeping: rect k sees pixel p as foreground iff no rect j<k covers p.
+// Only earlier rects that intersect rect k can cover its pixels: the host passes that (short) list.
+struct Overlaps { const int32_t* idx; const int32_t* off; };   // idx[off[k] .. off[k+1]) = j < k intersecting k
+
+__device__ __forceinline__ bool covered_by(const int32_t* rects, const int32_t* list, int cnt, int x, int y) {
+    for (int q = 0; q < cnt; ++q) {
+        const int32_t* r = rects + 4 * list[q];
+        if (x >= r[0] && x <= r[2] && y >= r[1] && y <= r[3]) return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ bool covered_any(const int32_t* rects, int n, int x, int y) {
+    for (int j = 0; j < n; ++j) {
         const int32_t* r = rects + 4 * j;
         if (x >= r[0] && x <= r[2] && y >= r[1] && y <= r[3]) return true;
     }
     return false;
 }
 
-__global__ __launch_bounds__(256) void target_area_kernel(const int32_t* __restrict__ rects, int nT,
+__global__ __launch_bounds__(256) void target_area_kernel(const int32_t* __restrict__ rects, Overlaps ov,
                                                           int32_t* __restrict__ area) {
     const int k = blockIdx.x;
     const int32_t* r = rects + 4 * k;
     const int w = r[2] - r[0] + 1, h = r[3] - r[1] + 1;
-    int cnt = 0;
-    for (int i = threadIdx.x; i < w * h; i += 256) {
-        const int x = r[0] + i % w, y = r[1] + i / w;
-        cnt += covered_before(rects, k, x, y) ? 0 : 1;
+    const int32_t* list = ov.idx + ov.off[k];
+    const int cnt = ov.off[k + 1] - ov.off[k];
+    int c = 0;
+    if (cnt == 0) {
+        c = threadIdx.x == 0 ? w * h : 0;
+    } else {
+        for (int i = threadIdx.x; i < w * h; i += 256)
+            c += covered_by(rects, list, cnt, r[0] + i % w, r[1] + i / w) ? 0 : 1;
     }
     __shared__ int red[256];
-    red[threadIdx.x] = cnt;
+    red[threadIdx.x] = c;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(256) void target_area_kernel(const int32_t* __restr
 }
 
 // _rect_filter (flow.py:282-295): rounded point inside rect k and still foreground
-__global__ void kp_filter_kernel(const int32_t* __restrict__ rects, const float* __restrict__ kps,
+__global__ void kp_filter_kernel(const int32_t* __restrict__ rects, Overlaps ov, const float* __restrict__ kps,
                                  const int32_t* __restrict__ kp_track, int n, uint8_t* __restrict__ keep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -329,7 +342,46 @@ __global__ void kp_filter_kernel(const int32_t* __restrict__ rects, const float*
     const int32_t* r = rects + 4 * k;
     const int x = (int)rintf(kps[2 * i]), y = (int)rintf(kps[2 * i + 1]);
     const bool inside = x >= r[0] && x <= r[2] && y >= r[1] && y <= r[3];
-    keep[i] = (inside && !covered_before(rects, k, x, y)) ? 1 : 0;
+    keep[i] = (inside && !covered_by(rects, ov.idx + ov.off[k], ov.off[k + 1] - ov.off[k], x, y)) ? 1 : 0;
+}
+
+// fused bookkeeping of flow.py:163-169 for one track per block: mask area, _rect_filter of the
+// propagated keypoints, the "too few keypoints" decision and the GFTT minDistance (flow.py:267-271)
+__global__ __launch_bounds__(256) void prepare_kernel(const int32_t* __restrict__ rects, Overlaps ov,
+                                                      const float* __restrict__ kps,
+                                                      const int32_t* __restrict__ kp_off, double feat_density,
+                                                      double feat_dist_factor, int32_t* __restrict__ area,
+                                                      uint8_t* __restrict__ keep, uint8_t* __restrict__ needy,
+                                                      int32_t* __restrict__ min_dist) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int32_t* r = rects + 4 * k;
+    const int w = r[2] - r[0] + 1, h = r[3] - r[1] + 1;
+    const int32_t* list = ov.idx + ov.off[k];
+    const int cnt = ov.off[k + 1] - ov.off[k];
+    int c = 0, kept = 0;
+    if (cnt == 0) c = tid == 0 ? w * h : 0;
+    else
+        for (int i = tid; i < w * h; i += 256) c += covered_by(rects, list, cnt, r[0] + i % w, r[1] + i / w) ? 0 : 1;
+    for (int i = kp_off[k] + tid; i < kp_off[k + 1]; i += 256) {
+        const int x = (int)rintf(kps[2 * i]), y = (int)rintf(kps[2 * i + 1]);
+        const bool ok = x >= r[0] && x <= r[2] && y >= r[1] && y <= r[3] && !covered_by(rects, list, cnt, x, y);
+        keep[i] = ok ? 1 : 0;
+        kept += ok ? 1 : 0;
+    }
+    __shared__ int red[256], red2[256];
+    red[tid] = c;
+    red2[tid] = kept;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) { red[tid] += red[tid + off]; red2[tid] += red2[tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        area[k] = red[0];
+        needy[k] = (double)red2[0] < feat_density * (double)red[0] ? 1 : 0;
+        const int md = (int)rint(sqrt((double)red[0]) * feat_dist_factor);
+        min_dist[k] = md > 1 ? md : 1;
+    }
 }
 
 // ---- goodFeaturesToTrack pieces (imgproc/featureselect.cpp, corner.cpp)
@@ -353,8 +405,9 @@ __device__ __forceinline__ void sobel_at(const uint8_t* img, int stride, const C
 }
 
 __global__ void eig_kernel(const uint8_t* __restrict__ img, int stride, const CropArgs* __restrict__ crops,
-                           float* __restrict__ eig, int block_size) {
+                           float* __restrict__ eig, int block_size, const uint8_t* __restrict__ needy) {
     const CropArgs c = crops[blockIdx.y];
+    if (needy && !needy[c.k]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.w * c.h) return;
     const int x = i % c.w, y = i / c.w;
@@ -374,26 +427,43 @@ __global__ void eig_kernel(const uint8_t* __restrict__ img, int stride, const Cr
     eig[c.eig_off + i] = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
 }
 
-// one block per needy track: masked max -> threshold -> 3x3 local maxima -> sort -> min-distance
-// selection -> ellipse filter
+// one block per needy track: masked max -> threshold -> 3x3 local maxima -> bitonic sort in LDS ->
+// min-distance selection on a cell grid (cell = minDistance, <= 4 accepted corners per cell, the
+// same 3x3-cell neighbourhood test as featureselect.cpp) -> ellipse filter
+constexpr int GFTT_MAX_CAND = 4096;      // sorted in LDS (32 KB)
+constexpr int GFTT_MAX_CELLS = 1536;     // x 4 slots x 4 B = 24 KB
+
 __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __restrict__ crops,
-                                                          const int32_t* __restrict__ rects,
+                                                          const int32_t* __restrict__ rects, Overlaps ov,
                                                           const float* __restrict__ eig, float quality,
                                                           int max_corners, const int32_t* __restrict__ min_dist,
                                                           const double* __restrict__ full_tlbr,
-                                                          float* __restrict__ cand, int cand_cap,
                                                           float* __restrict__ pts_out, int cap,
-                                                          int32_t* __restrict__ counts) {
+                                                          int32_t* __restrict__ counts,
+                                                          const uint8_t* __restrict__ needy,
+                                                          int32_t* __restrict__ compact_total,
+                                                          int32_t* __restrict__ compact_off) {
     const int t = blockIdx.x, tid = threadIdx.x;
     const CropArgs c = crops[t];
+    if (needy && !needy[c.k]) {            // enough propagated keypoints: nothing to detect
+        if (tid == 0) {
+            counts[t] = 0;
+            if (compact_off) compact_off[t] = 0;
+        }
+        return;
+    }
     const float* e = eig + c.eig_off;
+    const int32_t* list = ov.idx + ov.off[c.k];
+    const int lcnt = ov.off[c.k + 1] - ov.off[c.k];
     __shared__ float red[256];
     __shared__ int s_n;
+    __shared__ unsigned long long keys[GFTT_MAX_CAND];
+    __shared__ int cells[GFTT_MAX_CELLS * 4];
     // masked maximum (minMaxLoc with mask)
     float mx = 0.f;
     for (int i = tid; i < c.w * c.h; i += 256) {
         const int x = i % c.w, y = i / c.w;
-        if (!covered_before(rects, c.k, c.x0 + x, c.y0 + y)) mx = fmaxf(mx, e[i]);
+        if (lcnt == 0 || !covered_by(rects, list, lcnt, c.x0 + x, c.y0 + y)) mx = fmaxf(mx, e[i]);
     }
     red[tid] = mx;
     if (tid == 0) s_n = 0;
@@ -404,10 +474,9 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
     }
     const float thr = red[0] * quality;
     __syncthreads();
-    // candidates: val > thr, val >= 8 neighbours (dilate inside the crop), mask set, 1-px border skipped
-    float* cval = cand + (size_t)t * cand_cap * 4;                       // [cand_cap] values
-    int* cidx = reinterpret_cast<int*>(cval + cand_cap);                  // [cand_cap] raster indices
-    int* order = reinterpret_cast<int*>(cval + 2 * (size_t)cand_cap);     // [cand_cap] sorted raster indices
+    // candidates: val > thr, val >= 8 neighbours (dilate inside the crop), mask set, 1-px border skipped.
+    // key = (float bits of val << 32) | raster index : descending 64-bit order == (val desc, index desc),
+    // the order of std::sort(..., greaterThanPtr) in featureselect.cpp
     for (int i = tid; i < c.w * c.h; i += 256) {
         const int x = i % c.w, y = i / c.w;
         if (x < 1 || y < 1 || x >= c.w - 1 || y >= c.h - 1) continue;
@@ -417,62 +486,111 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
         for (int j = -1; j <= 1 && is_max; ++j)
             for (int ii = -1; ii <= 1; ++ii)
                 if (e[(y + j) * c.w + x + ii] > v) { is_max = false; break; }
-        if (!is_max || covered_before(rects, c.k, c.x0 + x, c.y0 + y)) continue;
+        if (!is_max || (lcnt && covered_by(rects, list, lcnt, c.x0 + x, c.y0 + y))) continue;
         const int slot = atomicAdd(&s_n, 1);
-        if (slot < cand_cap) {
-            cval[slot] = v;
-            cidx[slot] = i;
-        }
+        if (slot < GFTT_MAX_CAND) keys[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
     }
     __syncthreads();
-    const int n = min(s_n, cand_cap);
-    // rank sort: value descending, ties by larger raster index first (greaterThanPtr)
-    for (int i = tid; i < n; i += 256) {
-        const float vi = cval[i];
-        const int ri = cidx[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const float vj = cval[j];
-            const int rj = cidx[j];
-            rank += (vj > vi || (vj == vi && rj > ri)) ? 1 : 0;
-        }
-        order[rank] = ri;
-    }
+    const int n = min(s_n, GFTT_MAX_CAND);
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += 256) keys[i] = 0ull;     // padding sorts last
     __syncthreads();
-    // greedy min-distance selection by the first wavefront (accepted points in LDS)
+    for (int k2 = 2; k2 <= np2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a0 = keys[i], a1 = keys[l];
+                    const bool desc = (i & k2) == 0;
+                    if (desc ? a0 < a1 : a0 > a1) { keys[i] = a1; keys[l] = a0; }
+                }
+            }
+            __syncthreads();
+        }
+    // greedy min-distance selection by the first wavefront
+    const int md = min_dist[needy ? c.k : t];
+    const int gw = (c.w + md - 1) / md, gh = (c.h + md - 1) / md;
+    const bool use_grid = gw * gh <= GFTT_MAX_CELLS;
     __shared__ short acc_x[1024], acc_y[1024];
     __shared__ int s_acc;
+    if (use_grid)
+        for (int i = tid; i < gw * gh * 4; i += 256) cells[i] = -1;
     if (tid == 0) s_acc = 0;
     __syncthreads();
     if (tid < 64) {
-        const int md = min_dist[t];
         const int md2 = md * md;
         const int limit = min(max_corners, 1024);
         int nacc = 0;
         for (int q = 0; q < n && nacc < limit; ++q) {
-            const int ri = order[q];
+            const int ri = (int)(keys[q] & 0xffffffffu);
             const int x = ri % c.w, y = ri / c.w;
             bool bad = false;
-            for (int j = tid; j < nacc; j += 64) {
-                const int dx = x - acc_x[j], dy = y - acc_y[j];
-                if (dx * dx + dy * dy < md2) bad = true;
+            if (use_grid) {
+                // 9 neighbouring cells x 4 slots = 36 lanes
+                if (tid < 36) {
+                    const int cxn = x / md + (tid / 4) % 3 - 1, cyn = y / md + (tid / 12) - 1;
+                    if (cxn >= 0 && cyn >= 0 && cxn < gw && cyn < gh) {
+                        const int p = cells[(cyn * gw + cxn) * 4 + (tid & 3)];
+                        if (p >= 0) {
+                            const int dx = x - (p & 0xffff), dy = y - (p >> 16);
+                            bad = dx * dx + dy * dy < md2;
+                        }
+                    }
+                }
+            } else {
+                for (int j = tid; j < nacc; j += 64) {
+                    const int dx = x - acc_x[j], dy = y - acc_y[j];
+                    if (dx * dx + dy * dy < md2) bad = true;
+                }
             }
             bad = __any(bad);
             if (!bad) {
-                if (tid == 0) { acc_x[nacc] = (short)x; acc_y[nacc] = (short)y; }
+                if (tid == 0) {
+                    acc_x[nacc] = (short)x;
+                    acc_y[nacc] = (short)y;
+                    if (use_grid) {
+                        int* cell = cells + ((y / md) * gw + x / md) * 4;
+                        for (int sidx = 0; sidx < 4; ++sidx)
+                            if (cell[sidx] < 0) { cell[sidx] = (y << 16) | x; break; }
+                    }
+                }
                 ++nacc;
             }
             __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
         }
         if (tid == 0) s_acc = nacc;
     }
     __syncthreads();
-    // _ellipse_filter (flow.py:297-306) in float32/float64 mixed like numpy: pts f32 + offset f32
+    // _ellipse_filter (flow.py:297-306): pts (f32) + offset (f32), then float64 ellipse test
     if (tid == 0) {
         const double* b = full_tlbr + 4 * t;
         const double cx = (b[0] + b[2]) / 2, cy = (b[1] + b[3]) / 2;
         const double ax = (b[2] - b[0] + 1) * 0.5, ay = (b[3] - b[1] + 1) * 0.5;
         int m = 0;
+        if (compact_total) {               // compacted output: count first, reserve, then write
+            for (int q = 0; q < s_acc; ++q) {
+                const float px = (float)acc_x[q] + (float)c.x0, py = (float)acc_y[q] + (float)c.y0;
+                const double ux = ((double)px - cx) / ax, uy = ((double)py - cy) / ay;
+                m += ux * ux + uy * uy <= 1. ? 1 : 0;
+            }
+            int base = atomicAdd(compact_total, m);
+            if (base + m > cap) { m = max(0, cap - base); }
+            compact_off[t] = base;
+            int w_ = 0;
+            for (int q = 0; q < s_acc && w_ < m; ++q) {
+                const float px = (float)acc_x[q] + (float)c.x0, py = (float)acc_y[q] + (float)c.y0;
+                const double ux = ((double)px - cx) / ax, uy = ((double)py - cy) / ay;
+                if (ux * ux + uy * uy <= 1.) {
+                    pts_out[((size_t)base + w_) * 2] = px;
+                    pts_out[((size_t)base + w_) * 2 + 1] = py;
+                    ++w_;
+                }
+            }
+            counts[t] = m;
+            return;
+        }
         for (int q = 0; q < s_acc && m < cap; ++q) {
             const float px = (float)acc_x[q] + (float)c.x0, py = (float)acc_y[q] + (float)c.y0;
             const double ux = ((double)px - cx) / ax, uy = ((double)py - cy) / ay;
@@ -515,54 +633,56 @@ __global__ void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h,
     score[(size_t)y * w + x] = sc;
 }
 
-// NMS + mask + raster-order compaction in ONE block (the background image is ~20 k pixels)
-__global__ __launch_bounds__(1024) void fast_collect_kernel(const int32_t* __restrict__ score, int w, int h,
-                                                            const int32_t* __restrict__ rects, int nT,
-                                                            int full_w, int full_h, float* __restrict__ pts,
-                                                            int cap, int32_t* __restrict__ n_out) {
+// NMS + mask (INTER_NEAREST sample of the final foreground mask at the keypoint) -> flag per pixel
+__global__ void fast_flag_kernel(const int32_t* __restrict__ score, int w, int h,
+                                 const int32_t* __restrict__ rects, int nT, int full_w, int full_h,
+                                 uint8_t* __restrict__ flag) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int i = y * w + x;
+    bool kp = false;
+    const int s = score[i];
+    if (s > 0 && x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
+        kp = s > score[i - 1] && s > score[i + 1] && s > score[i - w - 1] && s > score[i - w] &&
+             s > score[i - w + 1] && s > score[i + w - 1] && s > score[i + w] && s > score[i + w + 1];
+        if (kp) {
+            const int fx = min((int)floor((double)x * ((double)full_w / w)), full_w - 1);
+            const int fy = min((int)floor((double)y * ((double)full_h / h)), full_h - 1);
+            if (covered_any(rects, nT, fx, fy)) kp = false;
+        }
+    }
+    flag[i] = kp ? 1 : 0;
+}
+
+// raster-order compaction with ONE block-wide scan: thread t owns a contiguous pixel segment
+__global__ __launch_bounds__(1024) void fast_compact_kernel(const uint8_t* __restrict__ flag, int w, int h,
+                                                            float* __restrict__ pts, int cap,
+                                                            int32_t* __restrict__ n_out) {
     __shared__ int s_cnt[1024];
-    __shared__ int s_base;
     const int tid = threadIdx.x;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
     const int total = w * h;
-    for (int start = 0; start < total; start += 1024) {
-        const int i = start + tid;
-        bool kp = false;
-        int x = 0, y = 0;
-        if (i < total) {
-            x = i % w; y = i / w;
-            const int s = score[i];
-            if (s > 0 && x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
-                kp = s > score[i - 1] && s > score[i + 1] && s > score[i - w - 1] && s > score[i - w] &&
-                     s > score[i - w + 1] && s > score[i + w - 1] && s > score[i + w] && s > score[i + w + 1];
-                if (kp) {
-                    // INTER_NEAREST sample of the full-resolution foreground mask at the keypoint
-                    const int fx = min((int)floor((double)x * ((double)full_w / w)), full_w - 1);
-                    const int fy = min((int)floor((double)y * ((double)full_h / h)), full_h - 1);
-                    if (covered_before(rects, nT, fx, fy)) kp = false;
-                }
-            }
-        }
-        s_cnt[tid] = kp ? 1 : 0;
+    const int seg = (total + 1023) / 1024;
+    const int b = tid * seg, e = min(b + seg, total);
+    int cnt = 0;
+    for (int i = b; i < e; ++i) cnt += flag[i];
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? s_cnt[tid - off] : 0;
         __syncthreads();
-        // inclusive scan (Hillis-Steele)
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int v = tid >= off ? s_cnt[tid - off] : 0;
-            __syncthreads();
-            s_cnt[tid] += v;
-            __syncthreads();
-        }
-        const int pos = s_base + s_cnt[tid] - 1;
-        if (kp && pos < cap) {
-            pts[2 * pos] = (float)x;
-            pts[2 * pos + 1] = (float)y;
-        }
-        __syncthreads();
-        if (tid == 1023) s_base += s_cnt[1023];
+        s_cnt[tid] += v;
         __syncthreads();
     }
-    if (tid == 0) *n_out = s_base;
+    int pos = s_cnt[tid] - cnt;
+    for (int i = b; i < e; ++i)
+        if (flag[i]) {
+            if (pos < cap) {
+                pts[2 * pos] = (float)(i % w);
+                pts[2 * pos + 1] = (float)(i / w);
+            }
+            ++pos;
+        }
+    if (tid == 1023) *n_out = s_cnt[1023];
 }
 
 int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
@@ -574,6 +694,10 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
     for (int l = 1; l < f->levels; ++l)
         hipLaunchKernelGGL(pyrdown_kernel, dim3((f->lw[l] + 255) / 256, f->lh[l]), dim3(256), 0, s,
                            f->pyr[set][l - 1], f->lw[l - 1], f->lh[l - 1], f->pyr[set][l], f->lw[l], f->lh[l]);
+    // Scharr derivatives of this pyramid: consumed when it has become the "previous" one
+    for (int l = 0; l < f->levels; ++l)
+        hipLaunchKernelGGL(scharr_kernel, dim3((f->lw[l] + 255) / 256, f->lh[l]), dim3(256), 0, s, f->pyr[set][l],
+                           f->lw[l], f->lh[l], f->deriv[set][l]);
     FM_HIP(hipGetLastError());
     return 0;
 }
@@ -582,7 +706,7 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
 
 extern "C" int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg) {
     FM_CHECK_ARG(ctx && cfg && ctx->frame_w > 0);
-    FM_CHECK_ARG(cfg->win_size >= 3 && cfg->win_size <= LK_MAX_WIN && cfg->max_level >= 0 && cfg->max_level < MAX_LEVELS);
+    FM_CHECK_ARG(cfg->win_size >= 3 && cfg->win_size * cfg->win_size <= 32 && cfg->max_level >= 0 && cfg->max_level < MAX_LEVELS);
     FM_CHECK_ARG(cfg->block_size == 3 || cfg->block_size == 5);
     FM_HIP(hipDeviceSynchronize());
     if (ctx->flow) fm_flow_free(ctx->flow);
@@ -606,9 +730,10 @@ extern "C" int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg) {
         FM_HIP(hipMalloc(&f->gray[s], (size_t)f->W * f->H));
         for (int l = 0; l < f->levels; ++l) FM_HIP(hipMalloc(&f->pyr[s][l], (size_t)f->lw[l] * f->lh[l]));
     }
-    for (int l = 0; l < f->levels; ++l) FM_HIP(hipMalloc(&f->deriv[l], (size_t)f->lw[l] * f->lh[l] * 4));
+    for (int st = 0; st < 2; ++st)
+        for (int l = 0; l < f->levels; ++l) FM_HIP(hipMalloc(&f->deriv[st][l], (size_t)f->lw[l] * f->lh[l] * 4));
     FM_HIP(hipMalloc(&f->bg_img, (size_t)cfg->bg_w * cfg->bg_h));
-    FM_HIP(hipMalloc(&f->bg_flags, sizeof(int32_t) * ((size_t)cfg->bg_w * cfg->bg_h + 4)));
+    FM_HIP(hipMalloc(&f->bg_flags, sizeof(int32_t) * ((size_t)cfg->bg_w * cfg->bg_h + 8) + (size_t)cfg->bg_w * cfg->bg_h));
     f->eig_cap = (size_t)4 * f->W * f->H;
     FM_HIP(hipMalloc(&f->eig, sizeof(float) * f->eig_cap));
     return 0;
@@ -654,28 +779,56 @@ extern "C" int fm_flow_targets(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         FM_HIP(hipMalloc(&f->rects, sizeof(int32_t) * 4 * cap));
         f->rect_cap = cap;
     }
-    // packed upload: rects i32[nT][4] | kp_track i32[nk] | kps f32[nk][2]
+    // overlap lists: earlier rects (closer tracks) that intersect rect k
+    std::vector<int32_t> irect(4 * (size_t)nT), ov_off(nT + 1, 0), ov_idx;
+    for (int k = 0; k < nT; ++k)
+        for (int e = 0; e < 4; ++e) irect[4 * k + e] = (int32_t)inside_tlbr[4 * k + e];   // crop(): int() truncation
+    for (int k = 0; k < nT; ++k) {
+        const int32_t* a = &irect[4 * k];
+        for (int j = 0; j < k; ++j) {
+            const int32_t* b = &irect[4 * j];
+            if (b[0] <= a[2] && b[2] >= a[0] && b[1] <= a[3] && b[3] >= a[1]) ov_idx.push_back(j);
+        }
+        ov_off[k + 1] = (int32_t)ov_idx.size();
+    }
+    const int n_ov = (int)ov_idx.size();
+    if (nT + 1 > f->ov_cap || n_ov > f->ov_cap * 8) {
+        FM_HIP(hipStreamSynchronize(s));
+        if (f->ov_idx) FM_HIP(hipFree(f->ov_idx));
+        if (f->ov_off) FM_HIP(hipFree(f->ov_off));
+        f->ov_idx = f->ov_off = nullptr;
+        int cap = f->ov_cap ? f->ov_cap : 64;
+        while (cap < nT + 1 || cap * 8 < n_ov) cap *= 2;
+        FM_HIP(hipMalloc(&f->ov_off, sizeof(int32_t) * cap));
+        FM_HIP(hipMalloc(&f->ov_idx, sizeof(int32_t) * cap * 8));
+        f->ov_cap = cap;
+    }
+    // packed upload: rects i32[nT][4] | kp_track i32[nk] | kps f32[nk][2] | ov_off i32[nT+1] | ov_idx i32[n_ov]
     const size_t o_rect = 0, o_trk = sizeof(int32_t) * 4 * nT, o_kps = o_trk + sizeof(int32_t) * nk;
-    const size_t in_bytes = o_kps + sizeof(float) * 2 * nk;
+    const size_t o_ovoff = o_kps + sizeof(float) * 2 * nk, o_ovidx = o_ovoff + sizeof(int32_t) * (nT + 1);
+    const size_t in_bytes = o_ovidx + sizeof(int32_t) * n_ov;
     int rc = f->tgt_in.reserve(in_bytes + 16);
     if (rc) return rc;
     if ((rc = f->tgt_out.reserve(sizeof(int32_t) * nT + nk + 16))) return rc;
     FM_HIP(hipStreamSynchronize(s));
     char* hbuf = f->tgt_in.host<char>();
-    int32_t* hr = reinterpret_cast<int32_t*>(hbuf + o_rect);
-    for (int k = 0; k < nT; ++k)
-        for (int e = 0; e < 4; ++e) hr[4 * k + e] = (int32_t)inside_tlbr[4 * k + e];   // crop(): int() truncation
+    memcpy(hbuf + o_rect, irect.data(), sizeof(int32_t) * 4 * nT);
+    memcpy(hbuf + o_ovoff, ov_off.data(), sizeof(int32_t) * (nT + 1));
+    if (n_ov) memcpy(hbuf + o_ovidx, ov_idx.data(), sizeof(int32_t) * n_ov);
     int32_t* ht = reinterpret_cast<int32_t*>(hbuf + o_trk);
     for (int k = 0; k < nT; ++k)
         for (int i = kp_off[k]; i < kp_off[k + 1]; ++i) ht[i] = k;
     if (nk) memcpy(hbuf + o_kps, kps, sizeof(float) * 2 * nk);
     FM_HIP(hipMemcpyAsync(f->tgt_in.d, hbuf, in_bytes, hipMemcpyHostToDevice, s));
     FM_HIP(hipMemcpyAsync(f->rects, f->tgt_in.dev<char>() + o_rect, sizeof(int32_t) * 4 * nT, hipMemcpyDeviceToDevice, s));
+    FM_HIP(hipMemcpyAsync(f->ov_off, f->tgt_in.dev<char>() + o_ovoff, sizeof(int32_t) * (nT + 1), hipMemcpyDeviceToDevice, s));
+    if (n_ov) FM_HIP(hipMemcpyAsync(f->ov_idx, f->tgt_in.dev<char>() + o_ovidx, sizeof(int32_t) * n_ov, hipMemcpyDeviceToDevice, s));
+    const Overlaps ov{f->ov_idx, f->ov_off};
     int32_t* d_area = f->tgt_out.dev<int32_t>();
     uint8_t* d_keep = reinterpret_cast<uint8_t*>(d_area + nT);
-    hipLaunchKernelGGL(target_area_kernel, dim3(nT), dim3(256), 0, s, f->rects, nT, d_area);
+    hipLaunchKernelGGL(target_area_kernel, dim3(nT), dim3(256), 0, s, f->rects, ov, d_area);
     if (nk)
-        hipLaunchKernelGGL(kp_filter_kernel, dim3((nk + 255) / 256), dim3(256), 0, s, f->rects,
+        hipLaunchKernelGGL(kp_filter_kernel, dim3((nk + 255) / 256), dim3(256), 0, s, f->rects, ov,
                            reinterpret_cast<const float*>(f->tgt_in.dev<char>() + o_kps),
                            reinterpret_cast<const int32_t*>(f->tgt_in.dev<char>() + o_trk), nk, d_keep);
     FM_HIP(hipGetLastError());
@@ -712,13 +865,6 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
         fm_set_error("GFTT scratch too small (%zu > %zu px)", off, f->eig_cap);
         return FM_ERR_STATE;
     }
-    const int cand_cap = 8192;   // per track: [cand_cap][2] values + order area
-    if (n > f->cand_tracks) {
-        if (f->cand) FM_HIP(hipFree(f->cand));
-        f->cand = nullptr;
-        FM_HIP(hipMalloc(&f->cand, sizeof(float) * (size_t)n * cand_cap * 4));   // vals | idx | order | spare
-        f->cand_tracks = n;
-    }
     const size_t o_crop = 0, o_md = sizeof(CropArgs) * n, o_box = (o_md + sizeof(int32_t) * n + 15) & ~size_t(15);
     const size_t in_bytes = o_box + sizeof(double) * 4 * n;
     int rc = f->det_in.reserve(in_bytes);
@@ -732,13 +878,13 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
     FM_HIP(hipMemcpyAsync(f->det_in.d, hb, in_bytes, hipMemcpyHostToDevice, s));
     char* db = f->det_in.dev<char>();
     hipLaunchKernelGGL(eig_kernel, dim3((max_area + 255) / 256, n), dim3(256), 0, s, f->gray[f->prev], f->W,
-                       reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size);
+                       reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, nullptr);
     float* d_pts = f->det_out.dev<float>();
     int32_t* d_cnt = reinterpret_cast<int32_t*>(d_pts + 2 * (size_t)n * cap);
     hipLaunchKernelGGL(gftt_select_kernel, dim3(n), dim3(256), 0, s, reinterpret_cast<const CropArgs*>(db + o_crop),
-                       f->rects, f->eig, (float)f->cfg.quality_level, f->cfg.max_corners,
-                       reinterpret_cast<const int32_t*>(db + o_md), reinterpret_cast<const double*>(db + o_box),
-                       f->cand, cand_cap, d_pts, cap, d_cnt);
+                       f->rects, Overlaps{f->ov_idx, f->ov_off}, f->eig, (float)f->cfg.quality_level,
+                       f->cfg.max_corners, reinterpret_cast<const int32_t*>(db + o_md),
+                       reinterpret_cast<const double*>(db + o_box), d_pts, cap, d_cnt, nullptr, nullptr, nullptr);
     FM_HIP(hipGetLastError());
     FM_HIP(hipMemcpyAsync(f->det_out.h, f->det_out.d, out_bytes, hipMemcpyDeviceToHost, s));
     FM_HIP(hipStreamSynchronize(s));
@@ -759,8 +905,10 @@ extern "C" int fm_flow_background(fm_ctx* ctx, int cap, float* pts_out, int* n_o
     hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_img, bw, bh,
                        f->cfg.fast_thresh, f->bg_flags);
     int32_t* d_n = f->bg_flags + (size_t)bw * bh;
-    hipLaunchKernelGGL(fast_collect_kernel, dim3(1), dim3(1024), 0, s, f->bg_flags, bw, bh, f->rects, f->nT, f->W,
-                       f->H, f->bg_out.dev<float>(), cap, d_n);
+    uint8_t* d_flag = reinterpret_cast<uint8_t*>(d_n + 8);
+    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->rects,
+                       f->nT, f->W, f->H, d_flag);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh, f->bg_out.dev<float>(), cap, d_n);
     FM_HIP(hipGetLastError());
     FM_HIP(hipMemcpyAsync(f->bg_out.host<char>() + sizeof(float) * 2 * cap, d_n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     FM_HIP(hipMemcpyAsync(f->bg_out.h, f->bg_out.d, sizeof(float) * 2 * cap, hipMemcpyDeviceToHost, s));
@@ -793,11 +941,9 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const int p = f->prev, c = p ^ 1;
         LKArgs a{};
         for (int l = 0; l < f->levels; ++l) {
-            hipLaunchKernelGGL(scharr_kernel, dim3((f->lw[l] + 255) / 256, f->lh[l]), dim3(256), 0, s, f->pyr[p][l],
-                               f->lw[l], f->lh[l], f->deriv[l]);
             a.I[l] = f->pyr[p][l];
             a.J[l] = f->pyr[c][l];
-            a.D[l] = f->deriv[l];
+            a.D[l] = f->deriv[p][l];
             a.w[l] = f->lw[l];
             a.h[l] = f->lh[l];
         }
@@ -808,7 +954,7 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         a.eps2 = (float)(eps * eps);
         a.min_eig_thresh = 1e-4f;
         char* o = f->lk_out.dev<char>();
-        hipLaunchKernelGGL(lk_kernel, dim3((n + 63) / 64), dim3(64), 0, s, a, n, f->lk_in.dev<float>(),
+        hipLaunchKernelGGL(lk_kernel, dim3((n * 32 + 255) / 256), dim3(256), 0, s, a, n, f->lk_in.dev<float>(),
                            reinterpret_cast<float*>(o), reinterpret_cast<uint8_t*>(o + o_st),
                            reinterpret_cast<float*>(o + o_err));
         FM_HIP(hipGetLastError());
@@ -847,5 +993,146 @@ extern "C" int fm_flow_read_image(fm_ctx* ctx, int which, uint8_t* out, int* w, 
         return FM_ERR_ARG;
     }
     FM_HIP(hipMemcpy(out, src, (size_t)(*w) * (*h), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// One-sync version of flow.py:159-200 for all tracks: mask bookkeeping, neediness, GFTT for the
+// needy tracks, background FAST keypoints.  Variable-length outputs are written by the kernels
+// straight into pinned host memory (only the produced bytes cross PCIe).
+extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr,
+                               const float* kps, const int32_t* kp_off, double feat_density,
+                               double feat_dist_factor, int32_t* area_out, uint8_t* keep_out,
+                               uint8_t* needy_out, int pts_cap, float* new_pts_out, int32_t* new_off_out,
+                               int32_t* new_cnt_out, int* n_new_out, int bg_cap, float* bg_pts_out,
+                               int* n_bg_out) {
+    FM_CHECK_ARG(ctx && ctx->flow && nT >= 0 && pts_cap > 0 && bg_cap > 0 && n_new_out && n_bg_out && bg_pts_out);
+    FlowState* f = ctx->flow;
+    hipStream_t s = ctx->s_flow;
+    f->nT = nT;
+    const int nk = nT ? kp_off[nT] : 0;
+    // ---- host side: integer rects, overlap lists, crop table
+    std::vector<int32_t> irect(4 * (size_t)nT), ov_off(nT + 1, 0), ov_idx;
+    std::vector<CropArgs> crops(nT);
+    size_t eig_total = 0;
+    int max_area = 0;
+    for (int k = 0; k < nT; ++k) {
+        for (int e = 0; e < 4; ++e) irect[4 * k + e] = (int32_t)inside_tlbr[4 * k + e];
+        const int32_t* a = &irect[4 * k];
+        for (int j = 0; j < k; ++j) {
+            const int32_t* b = &irect[4 * j];
+            if (b[0] <= a[2] && b[2] >= a[0] && b[1] <= a[3] && b[3] >= a[1]) ov_idx.push_back(j);
+        }
+        ov_off[k + 1] = (int32_t)ov_idx.size();
+        CropArgs c;
+        c.x0 = a[0]; c.y0 = a[1]; c.w = a[2] - a[0] + 1; c.h = a[3] - a[1] + 1; c.k = k; c.eig_off = eig_total;
+        eig_total += (size_t)c.w * c.h;
+        max_area = std::max(max_area, c.w * c.h);
+        crops[k] = c;
+    }
+    const int n_ov = (int)ov_idx.size();
+    FM_HIP(hipStreamSynchronize(s));
+    if (eig_total > f->eig_cap) {
+        FM_HIP(hipFree(f->eig));
+        f->eig = nullptr;
+        FM_HIP(hipMalloc(&f->eig, sizeof(float) * eig_total * 2));
+        f->eig_cap = eig_total * 2;
+    }
+    if (nT > f->rect_cap) {
+        if (f->rects) FM_HIP(hipFree(f->rects));
+        f->rects = nullptr;
+        int cap = f->rect_cap ? f->rect_cap : 64;
+        while (cap < nT) cap *= 2;
+        FM_HIP(hipMalloc(&f->rects, sizeof(int32_t) * 4 * cap));
+        f->rect_cap = cap;
+    }
+    if (nT + 1 > f->ov_cap || n_ov > f->ov_cap * 8) {
+        if (f->ov_idx) FM_HIP(hipFree(f->ov_idx));
+        if (f->ov_off) FM_HIP(hipFree(f->ov_off));
+        f->ov_idx = f->ov_off = nullptr;
+        int cap = f->ov_cap ? f->ov_cap : 64;
+        while (cap < nT + 1 || cap * 8 < n_ov) cap *= 2;
+        FM_HIP(hipMalloc(&f->ov_off, sizeof(int32_t) * cap));
+        FM_HIP(hipMalloc(&f->ov_idx, sizeof(int32_t) * cap * 8));
+        f->ov_cap = cap;
+    }
+    // ---- packed upload
+    auto al = [](size_t v) { return (v + 15) & ~size_t(15); };
+    const size_t o_rect = 0, o_kpoff = al(o_rect + sizeof(int32_t) * 4 * nT), o_kps = al(o_kpoff + sizeof(int32_t) * (nT + 1));
+    const size_t o_ovoff = al(o_kps + sizeof(float) * 2 * nk), o_ovidx = al(o_ovoff + sizeof(int32_t) * (nT + 1));
+    const size_t o_crop = al(o_ovidx + sizeof(int32_t) * n_ov), o_box = al(o_crop + sizeof(CropArgs) * nT);
+    const size_t in_bytes = al(o_box + sizeof(double) * 4 * nT) + 16;
+    int rc = f->tgt_in.reserve(in_bytes);
+    if (rc) return rc;
+    // outputs (device-visible pinned host memory): area | md | counts | off | total,n_bg | needy | keep | pts | bg
+    const size_t q_area = 0, q_md = al(q_area + 4 * (size_t)nT), q_cnt = al(q_md + 4 * (size_t)nT);
+    const size_t q_off = al(q_cnt + 4 * (size_t)nT), q_tot = al(q_off + 4 * (size_t)nT), q_needy = al(q_tot + 16);
+    const size_t q_keep = al(q_needy + nT), q_pts = al(q_keep + nk), q_bg = al(q_pts + sizeof(float) * 2 * pts_cap);
+    const size_t out_bytes = al(q_bg + sizeof(float) * 2 * bg_cap);
+    if ((rc = f->tgt_out.reserve(out_bytes))) return rc;
+    char* hb = f->tgt_in.host<char>();
+    if (nT) {
+        memcpy(hb + o_rect, irect.data(), sizeof(int32_t) * 4 * nT);
+        memcpy(hb + o_kpoff, kp_off, sizeof(int32_t) * (nT + 1));
+        if (nk) memcpy(hb + o_kps, kps, sizeof(float) * 2 * nk);
+        memcpy(hb + o_ovoff, ov_off.data(), sizeof(int32_t) * (nT + 1));
+        if (n_ov) memcpy(hb + o_ovidx, ov_idx.data(), sizeof(int32_t) * n_ov);
+        memcpy(hb + o_crop, crops.data(), sizeof(CropArgs) * nT);
+        memcpy(hb + o_box, full_tlbr, sizeof(double) * 4 * nT);
+        FM_HIP(hipMemcpyAsync(f->tgt_in.d, hb, in_bytes, hipMemcpyHostToDevice, s));
+        char* db = f->tgt_in.dev<char>();
+        FM_HIP(hipMemcpyAsync(f->rects, db + o_rect, sizeof(int32_t) * 4 * nT, hipMemcpyDeviceToDevice, s));
+        FM_HIP(hipMemcpyAsync(f->ov_off, db + o_ovoff, sizeof(int32_t) * (nT + 1), hipMemcpyDeviceToDevice, s));
+        if (n_ov) FM_HIP(hipMemcpyAsync(f->ov_idx, db + o_ovidx, sizeof(int32_t) * n_ov, hipMemcpyDeviceToDevice, s));
+    }
+    char* ho = f->tgt_out.host<char>();      // pinned, device accessible
+    int32_t* tot_host = reinterpret_cast<int32_t*>(ho + q_tot);
+    int32_t* tot = f->bg_flags + (size_t)f->cfg.bg_w * f->cfg.bg_h;    // device counters: [0] new pts, [1] bg pts
+    FM_HIP(hipMemsetAsync(tot, 0, sizeof(int32_t) * 2, s));
+    if (nT) {
+        char* db = f->tgt_in.dev<char>();
+        const Overlaps ov{f->ov_idx, f->ov_off};
+        uint8_t* d_needy = reinterpret_cast<uint8_t*>(ho + q_needy);
+        int32_t* d_md = reinterpret_cast<int32_t*>(ho + q_md);
+        hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(256), 0, s, f->rects, ov,
+                           reinterpret_cast<const float*>(db + o_kps), reinterpret_cast<const int32_t*>(db + o_kpoff),
+                           feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(ho + q_area),
+                           reinterpret_cast<uint8_t*>(ho + q_keep), d_needy, d_md);
+        hipLaunchKernelGGL(eig_kernel, dim3((max_area + 255) / 256, nT), dim3(256), 0, s, f->gray[f->prev], f->W,
+                           reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, d_needy);
+        hipLaunchKernelGGL(gftt_select_kernel, dim3(nT), dim3(256), 0, s, reinterpret_cast<const CropArgs*>(db + o_crop),
+                           f->rects, ov, f->eig, (float)f->cfg.quality_level, f->cfg.max_corners, d_md,
+                           reinterpret_cast<const double*>(db + o_box), reinterpret_cast<float*>(ho + q_pts), pts_cap,
+                           reinterpret_cast<int32_t*>(ho + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(ho + q_off));
+    }
+    // background keypoints under the final mask
+    const int bw = f->cfg.bg_w, bh = f->cfg.bg_h;
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((bw + 255) / 256, bh), dim3(256), 0, s, f->gray[f->prev], f->W,
+                       f->H, f->bg_img, bw, bh);
+    hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_img, bw, bh,
+                       f->cfg.fast_thresh, f->bg_flags);
+    uint8_t* d_flag = reinterpret_cast<uint8_t*>(f->bg_flags + (size_t)bw * bh + 8);
+    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->rects,
+                       nT, f->W, f->H, d_flag);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh,
+                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1);
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(tot_host, tot, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, s));
+    FM_HIP(hipStreamSynchronize(s));
+    if (nT) {
+        memcpy(area_out, ho + q_area, 4 * (size_t)nT);
+        memcpy(needy_out, ho + q_needy, nT);
+        if (nk) memcpy(keep_out, ho + q_keep, nk);
+        memcpy(new_cnt_out, ho + q_cnt, 4 * (size_t)nT);
+        memcpy(new_off_out, ho + q_off, 4 * (size_t)nT);
+    }
+    const int n_new = tot_host[0], n_bg = tot_host[1];
+    if (n_new > pts_cap || n_bg > bg_cap) {
+        fm_set_error("keypoint capacity exceeded (%d/%d new, %d/%d background)", n_new, pts_cap, n_bg, bg_cap);
+        return FM_ERR_ARG;
+    }
+    if (n_new) memcpy(new_pts_out, ho + q_pts, sizeof(float) * 2 * n_new);
+    if (n_bg) memcpy(bg_pts_out, ho + q_bg, sizeof(float) * 2 * n_bg);
+    *n_new_out = n_new;
+    *n_bg_out = n_bg;
     return 0;
 }

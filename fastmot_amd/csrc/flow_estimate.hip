@@ -39,10 +39,12 @@ void jacobi_eigen(int n, std::vector<double>& A, std::vector<double>& W, std::ve
     V.assign((size_t)n * n, 0.);
     for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.;
     for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.;
-        for (int i = 0; i < n; ++i)
+        double off = 0., diag = 0.;
+        for (int i = 0; i < n; ++i) {
+            diag += A[(size_t)i * n + i] * A[(size_t)i * n + i];
             for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
-        if (off < 1e-300) break;
+        }
+        if (off <= 1e-30 * diag || off < 1e-300) break;   // converged to round-off
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[(size_t)p * n + q];

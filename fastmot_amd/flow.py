@@ -112,7 +112,7 @@ class Flow:
         fr = self.frame_rect
         empty = np.empty((0, 2), np.float32)
 
-        # detect target feature points
+        # detect target feature points + background feature points (one device round trip)
         all_prev_pts = []
         if n_trk:
             tlbrs = np.array([t.tlbr for t in tracks], np.float64).reshape(n_trk, 4)
@@ -121,29 +121,19 @@ class Flow:
             kp_off = np.zeros(n_trk + 1, np.int32)
             np.cumsum([len(t.keypoints) for t in tracks], out=kp_off[1:])
             kps = np.concatenate([t.keypoints for t in tracks]).astype(np.float32) if kp_off[-1] else empty
-            areas, keep = ctx.flow_targets(inside, kps, kp_off)
-            needy, dists = [], []
-            for k in range(n_trk):
-                pts = kps[kp_off[k]:kp_off[k + 1]][keep[kp_off[k]:kp_off[k + 1]]]
-                # only detect new keypoints when too few are propagated
-                if len(pts) < self.feat_density * areas[k]:
-                    needy.append(k)
-                    dists.append(max(round(np.sqrt(areas[k]) * self.feat_dist_factor), 1))
-                    pts = None
-                all_prev_pts.append(pts)
-            if needy:
-                new_pts, counts = ctx.flow_detect(needy, tlbrs[needy], dists,
-                                                  cap=min(self.obj_feat_params['maxCorners'], 1024))
-                for i, k in enumerate(needy):
-                    all_prev_pts[k] = new_pts[i, :counts[i]].copy()
         else:
-            tlbrs = np.zeros((0, 4))
-            ctx.flow_targets(np.zeros((0, 4)), empty, np.zeros(1, np.int32))
+            tlbrs, inside = np.zeros((0, 4)), np.zeros((0, 4))
+            kp_off, kps = np.zeros(1, np.int32), empty
+        areas, keep, needy, new_pts, new_off, new_cnt, keypoints = ctx.flow_prepare(
+            inside, tlbrs, kps, kp_off, self.feat_density, self.feat_dist_factor)
+        for k in range(n_trk):
+            if needy[k]:     # only detect new keypoints when too few are propagated
+                all_prev_pts.append(new_pts[new_off[k]:new_off[k] + new_cnt[k]].copy())
+            else:
+                all_prev_pts.append(kps[kp_off[k]:kp_off[k + 1]][keep[kp_off[k]:kp_off[k + 1]]])
         target_ends = np.cumsum([len(p) for p in all_prev_pts]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
         target_begins = np.concatenate([[0], target_ends[:-1]]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
 
-        # detect background feature points
-        keypoints = ctx.flow_background()
         if len(keypoints) == 0:
             self.bg_keypoints = empty
             ctx.flow_swap()

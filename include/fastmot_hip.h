@@ -322,6 +322,15 @@ int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, const double* t
  * INTER_NEAREST resize of the final foreground mask, FAST-9/16 + NMS, mask filter.
  * pts_out: [cap][2] f32 in background-frame coordinates (not yet unscaled). */
 int fm_flow_background(fm_ctx* ctx, int cap, float* pts_out, int* n_out);
+/* fm_flow_targets + fm_flow_detect (for the tracks that turn out to need new keypoints,
+ * flow.py:167-178: len(kept) < feat_density * area, minDistance = max(round(sqrt(area) *
+ * feat_dist_factor), 1)) + fm_flow_background in ONE stream round trip.  New keypoints are returned
+ * compacted: track k owns new_pts[new_off[k] .. new_off[k] + new_cnt[k]). */
+int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr,
+                    const float* kps, const int32_t* kp_off, double feat_density, double feat_dist_factor,
+                    int32_t* area_out, uint8_t* keep_out, uint8_t* needy_out, int pts_cap,
+                    float* new_pts_out, int32_t* new_off_out, int32_t* new_cnt_out, int* n_new_out,
+                    int bg_cap, float* bg_pts_out, int* n_bg_out);
 /* cv2.calcOpticalFlowPyrLK(prev_small, cur_small, pts) (flow.py:205-207): Scharr derivatives +
  * pyramidal LK for n points; then the frame buffers are swapped (flow.py:212-213). */
 int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next_pts, uint8_t* status, float* err);

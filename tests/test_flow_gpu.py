@@ -181,3 +181,35 @@ def test_flow_predict_moving_scene(ctx):
     boxes2, H2 = flow.predict(f2, tracks)
     assert H2 is not None and len(boxes2) == 3
     np.testing.assert_allclose(H2, [[1, 0, -6], [0, 1, 4], [0, 0, 1]], atol=0.05)
+
+
+def test_prepare_matches_staged_calls(ctx):
+    """fm_flow_prepare (one round trip) == fm_flow_targets + fm_flow_detect + fm_flow_background."""
+    size = (640, 360)
+    f0 = textured_frame(*size, 21)
+    flow = make_flow(size)
+    flow.init(f0)
+    rects = np.array([[100, 200, 180, 359], [150, 120, 230, 300], [400, 50, 460, 200], [0, 0, 50, 90]], float)
+    rng = np.random.default_rng(4)
+    kps, off = [], [0]
+    for k, r in enumerate(rects):
+        n = [0, 3, 120, 5][k]
+        kps.append(np.stack([rng.uniform(r[0] - 5, r[2] + 5, n), rng.uniform(r[1] - 5, r[3] + 5, n)], 1))
+        off.append(off[-1] + n)
+    kps = np.concatenate(kps).astype(np.float32)
+    off = np.array(off, np.int32)
+    area0, keep0 = ctx.flow_targets(rects, kps, off)
+    kept = [int(keep0[off[k]:off[k + 1]].sum()) for k in range(4)]
+    needy0 = [kept[k] < 0.005 * area0[k] for k in range(4)]
+    idx = [k for k in range(4) if needy0[k]]
+    md = [max(round(np.sqrt(area0[k]) * 0.06), 1) for k in idx]
+    pts0, cnt0 = ctx.flow_detect(idx, rects[idx], md, cap=1000)
+    bg0 = ctx.flow_background()
+    area, keep, needy, new_pts, new_off, new_cnt, bg = ctx.flow_prepare(rects, rects, kps, off, 0.005, 0.06)
+    np.testing.assert_array_equal(area, area0)
+    np.testing.assert_array_equal(keep, keep0)
+    np.testing.assert_array_equal(needy, needy0)
+    np.testing.assert_array_equal(bg, bg0)
+    assert needy.tolist() == [True, True, False, True]
+    for i, k in enumerate(idx):
+        np.testing.assert_array_equal(new_pts[new_off[k]:new_off[k] + new_cnt[k]], pts0[i, :cnt0[i]])
