@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int row = lrow + 64 * i;
         const int pix = p0 + row;
         pvalid[i] = (row < BNP) && (pix < p.P);
-        const int pp = pvalid[i] ? pix : 0;
+        const int pp = min(pix, p.P - 1);                        // clamped pixels are never stored
         const int hw = p.Ho * p.Wo;
         const int n = pp / hw, rem = pp - n * hw;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -65,43 +65,67 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     int kc = kk - tap * p.Cin;
     int kh = tap / p.KW, kw = tap - kh * p.KW;
 
-    uint4 ra[A_IT], rb[B_IT];
-    auto load_tiles = [&](int ks) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int row = c0 + lrow + 64 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (lrow + 64 * i < BMC && row < cout_pad)
-                v = *reinterpret_cast<const uint4*>(p.w + (size_t)row * p.Kpad + ks * BK + lchunk * 8);
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int hi = phi0[i] + kh, wi = pwi0[i] + kw;
-            if (pvalid[i] && kk < p.K && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
-                v = *reinterpret_cast<const uint4*>(pbase[i] + ((size_t)hi * p.W + wi) * p.in_cs + kc);
-            rb[i] = v;
-        }
-    };
-    auto advance = [&]() {
-        kk += BK;
-        kc += BK;
-        while (kc >= p.Cin) {
-            kc -= p.Cin;
-            if (++kw == p.KW) { kw = 0; ++kh; }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            if (lrow + 64 * i < BMC)
-                *reinterpret_cast<uint4*>(&sA[buf][(lrow + 64 * i) * LDK + lchunk * 8]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            if (lrow + 64 * i < BNP)
-                *reinterpret_cast<uint4*>(&sB[buf][(lrow + 64 * i) * LDK + lchunk * 8]) = rb[i];
-    };
+    // ---- software pipeline: DEPTH K-steps of global loads in flight (registers), LDS double buffered.
+    // Batch-1 layers launch few workgroups (often < 1 per CU), so nothing else hides the ~1-2k cycle
+    // L2/HBM latency of a K-step: with one step of prefetch the loop ran at ~1.2k cycles per step.
+    constexpr int DEPTH = 4;   // even: the LDS buffer of a step is then a compile-time constant
+    // Stage registers.  Everything below is written with macros and literal stage indices: passing
+    // the stage arrays to lambdas by pointer/reference kept them in scratch memory (no SROA).
+    uint4 ra0[A_IT], ra1[A_IT], ra2[A_IT], ra3[A_IT], rb0[B_IT], rb1[B_IT], rb2[B_IT], rb3[B_IT];
+    unsigned okm0 = 0, okm1 = 0, okm2 = 0, okm3 = 0;    // bit i: tap of rb[.][i] is inside the image.  The zeroing select is
+                            // deferred to the LDS store; right after the load it would force vmcnt(0).
+    const int arow_max = cout_pad - 1;
+    // Loads are UNCONDITIONAL (addresses clamped into the tensor): a load inside an exec-masked
+    // branch makes hipcc fall back to s_waitcnt vmcnt(0) around it, which serialises the pipeline.
+#define CONV_LOAD_STAGE(S, KS)                                                                              \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                  \
+            const int row = min(c0 + lrow + 64 * i, arow_max);                                              \
+            ra##S[i] = *reinterpret_cast<const uint4*>(p.w + (size_t)row * p.Kpad + (KS) * BK + lchunk * 8); \
+        }                                                                                                   \
+        unsigned m_ = 0;                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                                  \
+            const int hi = phi0[i] + kh, wi = pwi0[i] + kw;                                                 \
+            const bool ok = kk < p.K && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;                         \
+            m_ |= ok ? (1u << i) : 0u;                                                                      \
+            const int hc = min(max(hi, 0), p.H - 1), wcl = min(max(wi, 0), p.W - 1);                        \
+            const int kcc = kk < p.K ? kc : 0;                                                              \
+            rb##S[i] = *reinterpret_cast<const uint4*>(pbase[i] + ((size_t)hc * p.W + wcl) * p.in_cs + kcc); \
+        }                                                                                                   \
+        okm##S = m_;                                                                                        \
+        kk += BK;                                                                                           \
+        kc += BK;                                                                                           \
+        while (kc >= p.Cin) {                                                                               \
+            kc -= p.Cin;                                                                                    \
+            if (++kw == p.KW) { kw = 0; ++kh; }                                                             \
+        }                                                                                                   \
+    }
+#define CONV_STORE_STAGE(S, BUF)                                                                            \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i)                                                    \
+            if (lrow + 64 * i < BMC)                                                                        \
+                *reinterpret_cast<uint4*>(&sA[BUF][(lrow + 64 * i) * LDK + lchunk * 8]) = ra##S[i];         \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                                    \
+            if (lrow + 64 * i < BNP) {                                                                      \
+                uint4 v = rb##S[i];                                                                         \
+                const bool ok = (okm##S >> i) & 1u;                                                         \
+                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;         \
+                *reinterpret_cast<uint4*>(&sB[BUF][(lrow + 64 * i) * LDK + lchunk * 8]) = v;                \
+            }                                                                                               \
+    }
+#define CONV_COMPUTE(BUF)                                                                                   \
+    {                                                                                                       \
+        _Pragma("unroll") for (int k16 = 0; k16 < 2; ++k16) {                                               \
+            f16x8 af[MC], bf[MP];                                                                           \
+            _Pragma("unroll") for (int mi = 0; mi < MC; ++mi)                                               \
+                af[mi] = *reinterpret_cast<const f16x8*>(&sA[BUF][((wc * MC + mi) * 32 + frow) * LDK + k16 * 16 + fk]); \
+            _Pragma("unroll") for (int pi = 0; pi < MP; ++pi)                                               \
+                bf[pi] = *reinterpret_cast<const f16x8*>(&sB[BUF][((wp * MP + pi) * 32 + frow) * LDK + k16 * 16 + fk]); \
+            _Pragma("unroll") for (int mi = 0; mi < MC; ++mi)                                               \
+                _Pragma("unroll") for (int pi = 0; pi < MP; ++pi)                                           \
+                    acc[mi][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[pi], acc[mi][pi], 0, 0, 0); \
+        }                                                                                                   \
+    }
 
     f32x16 acc[MC][MP];
 #pragma unroll
@@ -112,36 +136,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[mi][pi][r] = 0.f;
 
     const int nk = p.Kpad / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
     const int frow = lane & 31, fk = (lane >> 5) * 8;
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) {
-            advance();
-            load_tiles(ks + 1);
-        }
-#pragma unroll
-        for (int k16 = 0; k16 < 2; ++k16) {
-            f16x8 af[MC], bf[MP];
-#pragma unroll
-            for (int mi = 0; mi < MC; ++mi)
-                af[mi] = *reinterpret_cast<const f16x8*>(
-                    &sA[cur][((wc * MC + mi) * 32 + frow) * LDK + k16 * 16 + fk]);
-#pragma unroll
-            for (int pi = 0; pi < MP; ++pi)
-                bf[pi] = *reinterpret_cast<const f16x8*>(
-                    &sB[cur][((wp * MP + pi) * 32 + frow) * LDK + k16 * 16 + fk]);
-#pragma unroll
-            for (int mi = 0; mi < MC; ++mi)
-#pragma unroll
-                for (int pi = 0; pi < MP; ++pi)
-                    acc[mi][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[pi], acc[mi][pi], 0, 0, 0);
-        }
-        if (ks + 1 < nk) store_tiles(cur ^ 1);
+    CONV_LOAD_STAGE(0, 0)
+    if (1 < nk) CONV_LOAD_STAGE(1, 1)
+    if (2 < nk) CONV_LOAD_STAGE(2, 2)
+    if (3 < nk) CONV_LOAD_STAGE(3, 3)
+    CONV_STORE_STAGE(0, 0)
+    __syncthreads();
+    int ks0 = 0;
+    // steady state: each step refills the stage it has just retired, DEPTH steps ahead; no guards
+    for (; ks0 + 2 * DEPTH <= nk; ks0 += DEPTH) {
+        CONV_LOAD_STAGE(0, ks0 + 4) CONV_COMPUTE(0) CONV_STORE_STAGE(1, 1) __syncthreads();
+        CONV_LOAD_STAGE(1, ks0 + 5) CONV_COMPUTE(1) CONV_STORE_STAGE(2, 0) __syncthreads();
+        CONV_LOAD_STAGE(2, ks0 + 6) CONV_COMPUTE(0) CONV_STORE_STAGE(3, 1) __syncthreads();
+        CONV_LOAD_STAGE(3, ks0 + 7) CONV_COMPUTE(1) CONV_STORE_STAGE(0, 0) __syncthreads();
+    }
+    // drain: the last (up to 2*DEPTH - 1) steps, guarded
+    for (; ks0 < nk; ks0 += DEPTH) {
+        if (ks0 + 4 < nk) CONV_LOAD_STAGE(0, ks0 + 4)
+        CONV_COMPUTE(0)
+        if (ks0 + 1 < nk) CONV_STORE_STAGE(1, 1)
+        __syncthreads();
+        if (ks0 + 1 >= nk) break;
+        if (ks0 + 5 < nk) CONV_LOAD_STAGE(1, ks0 + 5)
+        CONV_COMPUTE(1)
+        if (ks0 + 2 < nk) CONV_STORE_STAGE(2, 0)
+        __syncthreads();
+        if (ks0 + 2 >= nk) break;
+        if (ks0 + 6 < nk) CONV_LOAD_STAGE(2, ks0 + 6)
+        CONV_COMPUTE(0)
+        if (ks0 + 3 < nk) CONV_STORE_STAGE(3, 1)
+        __syncthreads();
+        if (ks0 + 3 >= nk) break;
+        if (ks0 + 7 < nk) CONV_LOAD_STAGE(3, ks0 + 7)
+        CONV_COMPUTE(1)
+        if (ks0 + 4 < nk) CONV_STORE_STAGE(0, 0)
         __syncthreads();
     }
+#undef CONV_LOAD_STAGE
+#undef CONV_STORE_STAGE
+#undef CONV_COMPUTE
 
     // ---- epilogue: bias + activation (+ residual), 4 consecutive channels per 8-byte store
 #pragma unroll
