@@ -3,19 +3,28 @@
 // Replaces the TensorRT engines of the reference (YOLOv4: fastmot/models/yolo.py:106-151,
 // OSNet: fastmot/models/reid.py:48-92; graph semantics scripts/yolo2onnx.py:558-705): every
 // Conv + folded BatchNorm + activation (+ shortcut add, + concat by output-channel offset) is ONE
-// launch of this kernel.
+// launch of this kernel (plus a tiny reduce launch when the layer is split along K).
 //
 // GEMM view   D[cout][pixel] = sum_k W[cout][k] * X[pixel][k],  k = (kh, kw, cin)
-//   A operand = weights  (M = output channels), pre-packed [cout_pad32][Kpad32] fp16
+//   A operand = weights  (M = output channels), pre-packed [cout_pad32][Kpad64] fp16
 //   B operand = im2col of the NHWC fp16 input, gathered on the fly (16 B = 8 channels per load,
 //               zero fill outside the image), never materialised in HBM
 //   both are K-contiguous per lane, which is exactly the 32x32x16 f16 fragment layout
 //   D fragment: lane owns pixel (lane&31) and 4 consecutive output channels per register quad
 //               -> 8-byte NHWC stores, epilogue (bias, activation, residual) fused in registers.
-// Tiling: 256 threads = 4 waves; block tile (WC*MC*32 channels) x (WP*MP*32 pixels) x 32 (K);
-// LDS rows padded to 80 B (conflict-free ds_read_b128 for the fragment reads, see
-// cdna_hip_programming.md section 2), double buffered, global loads for step k+1 in flight
-// during the MFMAs of step k, one barrier per K step.
+//
+// What shapes the kernel is that the detector runs at batch 1: a layer has 0.2-1.5 M outputs, i.e.
+// only 48-700 tiles of 64x64 for 256 CUs, and K is long (up to 4608).  Measured with one K step
+// of prefetch and K=32 steps the loop ran at ~1.2 k cycles per step (latency bound: global load ->
+// LDS store -> barrier -> LDS read -> 2 MFMAs per wave).  Hence:
+//   * K step 64 (4 MFMAs per wave between barriers), LDS rows padded to 144 B (conflict-free
+//     ds_read_b128 fragment reads), LDS double buffered, one barrier per step;
+//   * 4-stage software pipeline in registers with UNCONDITIONAL, clamped loads (a load inside an
+//     exec-masked branch makes hipcc emit s_waitcnt vmcnt(0)); out-of-image taps are zeroed when
+//     the stage is written to LDS, so the waits are counted (vmcnt(N > 0)) and 3 steps stay in flight;
+//   * split-K over gridDim.z when a layer has fewer than ~2 workgroups per CU: fp32 partial tiles
+//     go to a workspace, a second small kernel sums them in a fixed order (deterministic) and
+//     applies the epilogue.
 //
 // Roofline: per layer max(2*K*Cout*P / 2.5 PFLOP/s, (in + out + weights) * 2 B / 8 TB/s);
 // YOLOv4 @608 = 128.4 GFLOP, 618 MB -> 0.089 ms/frame lower bound.
@@ -23,75 +32,83 @@
 
 namespace {
 
-constexpr int BK = 32;    // K elements per step
-constexpr int LDK = 40;   // padded LDS row (halves): 80 B
+constexpr int BK = 64;    // K elements per step
+constexpr int LDK = 72;   // padded LDS row (halves): 144 B
 
 template <int WC, int WP, int MC, int MP>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p, float* __restrict__ ws) {
     static_assert(WC * WP == 4, "4 waves per block");
+    static_assert(WC * MC <= 4 && WP * MP <= 4, "at most 4 chunks per thread and operand");
     constexpr int BMC = WC * MC * 32;
     constexpr int BNP = WP * MP * 32;
-    constexpr int A_IT = (BMC + 63) / 64;
-    constexpr int B_IT = (BNP + 63) / 64;
+    constexpr int A_IT = (BMC + 31) / 32;
+    constexpr int B_IT = (BNP + 31) / 32;
     __shared__ __attribute__((aligned(16))) f16 sA[2][BMC * LDK];
     __shared__ __attribute__((aligned(16))) f16 sB[2][BNP * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wc = wv / WP, wp = wv % WP;
     const int c0 = blockIdx.y * BMC, p0 = blockIdx.x * BNP;
-    const int lrow = tid >> 2, lchunk = tid & 3;
+    const int lrow = tid >> 3, lchunk = tid & 7;
     const int cout_pad = (p.Cout + 31) & ~31;
+
+    // K range of this split
+    const int nk_total = p.Kpad / BK;
+    const int per = (nk_total + gridDim.z - 1) / gridDim.z;
+    const int k_begin = blockIdx.z * per;
+    const int nk = min(per, nk_total - k_begin);     // >= 1 by construction of the launch
 
     // ---- per-thread im2col state of the pixels this thread stages
     const f16* pbase[B_IT];
     int phi0[B_IT], pwi0[B_IT];
-    bool pvalid[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int row = lrow + 64 * i;
-        const int pix = p0 + row;
-        pvalid[i] = (row < BNP) && (pix < p.P);
-        const int pp = min(pix, p.P - 1);                        // clamped pixels are never stored
+        const int pix = min(p0 + lrow + 32 * i, p.P - 1);    // clamped pixels are never stored
         const int hw = p.Ho * p.Wo;
-        const int n = pp / hw, rem = pp - n * hw;
+        const int n = pix / hw, rem = pix - n * hw;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         phi0[i] = ho * p.stride - p.pad;
         pwi0[i] = wo * p.stride - p.pad;
         pbase[i] = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_coff;
     }
-    // K walk of this thread's 8-channel chunk: k = kbase + lchunk*8 -> (kh, kw, c)
-    int kk = lchunk * 8;
+    // K walk of this thread's 8-channel chunk: k = (k_begin + step) * 64 + lchunk*8 -> (kh, kw, c)
+    int kk = k_begin * BK + lchunk * 8;
     int tap = kk / p.Cin;
     int kc = kk - tap * p.Cin;
     int kh = tap / p.KW, kw = tap - kh * p.KW;
 
-    // ---- software pipeline: DEPTH K-steps of global loads in flight (registers), LDS double buffered.
-    // Batch-1 layers launch few workgroups (often < 1 per CU), so nothing else hides the ~1-2k cycle
-    // L2/HBM latency of a K-step: with one step of prefetch the loop ran at ~1.2k cycles per step.
-    constexpr int DEPTH = 4;   // even: the LDS buffer of a step is then a compile-time constant
-    // Stage registers.  Everything below is written with macros and literal stage indices: passing
-    // the stage arrays to lambdas by pointer/reference kept them in scratch memory (no SROA).
-    uint4 ra0[A_IT], ra1[A_IT], ra2[A_IT], ra3[A_IT], rb0[B_IT], rb1[B_IT], rb2[B_IT], rb3[B_IT];
-    unsigned okm0 = 0, okm1 = 0, okm2 = 0, okm3 = 0;    // bit i: tap of rb[.][i] is inside the image.  The zeroing select is
-                            // deferred to the LDS store; right after the load it would force vmcnt(0).
+    // Stage registers.  Everything below uses macros with literal stage names: passing stage
+    // arrays to lambdas by pointer/reference kept them in scratch memory (no SROA).
+    // (plain scalars, no arrays: hipcc left two-element register arrays in scratch memory)
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    uint4 ra0_0 = z4, ra0_1 = z4, ra0_2 = z4, ra0_3 = z4, ra1_0 = z4, ra1_1 = z4, ra1_2 = z4, ra1_3 = z4;
+    uint4 ra2_0 = z4, ra2_1 = z4, ra2_2 = z4, ra2_3 = z4, ra3_0 = z4, ra3_1 = z4, ra3_2 = z4, ra3_3 = z4;
+    uint4 rb0_0 = z4, rb0_1 = z4, rb0_2 = z4, rb0_3 = z4, rb1_0 = z4, rb1_1 = z4, rb1_2 = z4, rb1_3 = z4;
+    uint4 rb2_0 = z4, rb2_1 = z4, rb2_2 = z4, rb2_3 = z4, rb3_0 = z4, rb3_1 = z4, rb3_2 = z4, rb3_3 = z4;
+    unsigned okm0 = 0, okm1 = 0, okm2 = 0, okm3 = 0;   // bit i: tap of rb?[i] lies inside the image
     const int arow_max = cout_pad - 1;
-    // Loads are UNCONDITIONAL (addresses clamped into the tensor): a load inside an exec-masked
-    // branch makes hipcc fall back to s_waitcnt vmcnt(0) around it, which serialises the pipeline.
+    const f16* wbase = p.w + (size_t)k_begin * BK + lchunk * 8;
+    // (loops over the per-thread chunk index are unrolled by hand with `if constexpr`: a
+    // `_Pragma("unroll") for` inside these macros was not unrolled and sent the arrays to scratch)
+#define CONV_LOAD_A(S, I, KS)                                                                               \
+    if constexpr ((I) < A_IT) {                                                                             \
+        const int row = min(c0 + lrow + 32 * (I), arow_max);                                                \
+        ra##S##_##I = *reinterpret_cast<const uint4*>(wbase + (size_t)row * p.Kpad + (KS) * BK);               \
+    }
+#define CONV_LOAD_B(S, I)                                                                                   \
+    if constexpr ((I) < B_IT) {                                                                             \
+        const int hi = phi0[I] + kh, wi = pwi0[I] + kw;                                                     \
+        const bool ok = kk < p.K && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;                             \
+        m_ |= ok ? (1u << (I)) : 0u;                                                                        \
+        const int hc = min(max(hi, 0), p.H - 1), wcl = min(max(wi, 0), p.W - 1);                            \
+        const int kcc = kk < p.K ? kc : 0;                                                                  \
+        rb##S##_##I = *reinterpret_cast<const uint4*>(pbase[I] + ((size_t)hc * p.W + wcl) * p.in_cs + kcc);    \
+    }
 #define CONV_LOAD_STAGE(S, KS)                                                                              \
     {                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                  \
-            const int row = min(c0 + lrow + 64 * i, arow_max);                                              \
-            ra##S[i] = *reinterpret_cast<const uint4*>(p.w + (size_t)row * p.Kpad + (KS) * BK + lchunk * 8); \
-        }                                                                                                   \
+        CONV_LOAD_A(S, 0, KS) CONV_LOAD_A(S, 1, KS) CONV_LOAD_A(S, 2, KS) CONV_LOAD_A(S, 3, KS)             \
         unsigned m_ = 0;                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                                  \
-            const int hi = phi0[i] + kh, wi = pwi0[i] + kw;                                                 \
-            const bool ok = kk < p.K && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;                         \
-            m_ |= ok ? (1u << i) : 0u;                                                                      \
-            const int hc = min(max(hi, 0), p.H - 1), wcl = min(max(wi, 0), p.W - 1);                        \
-            const int kcc = kk < p.K ? kc : 0;                                                              \
-            rb##S[i] = *reinterpret_cast<const uint4*>(pbase[i] + ((size_t)hc * p.W + wcl) * p.in_cs + kcc); \
-        }                                                                                                   \
+        CONV_LOAD_B(S, 0) CONV_LOAD_B(S, 1) CONV_LOAD_B(S, 2) CONV_LOAD_B(S, 3)                             \
         okm##S = m_;                                                                                        \
         kk += BK;                                                                                           \
         kc += BK;                                                                                           \
@@ -100,22 +117,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             if (++kw == p.KW) { kw = 0; ++kh; }                                                             \
         }                                                                                                   \
     }
+#define CONV_STORE_A(S, I, BUF)                                                                             \
+    if constexpr ((I) < A_IT) {                                                                             \
+        if (lrow + 32 * (I) < BMC)                                                                          \
+            *reinterpret_cast<uint4*>(&sA[BUF][(lrow + 32 * (I)) * LDK + lchunk * 8]) = ra##S##_##I;           \
+    }
+#define CONV_STORE_B(S, I, BUF)                                                                             \
+    if constexpr ((I) < B_IT) {                                                                             \
+        if (lrow + 32 * (I) < BNP) {                                                                        \
+            uint4 v = rb##S##_##I;                                                                             \
+            const bool ok = (okm##S >> (I)) & 1u;                                                           \
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;             \
+            *reinterpret_cast<uint4*>(&sB[BUF][(lrow + 32 * (I)) * LDK + lchunk * 8]) = v;                  \
+        }                                                                                                   \
+    }
 #define CONV_STORE_STAGE(S, BUF)                                                                            \
     {                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < A_IT; ++i)                                                    \
-            if (lrow + 64 * i < BMC)                                                                        \
-                *reinterpret_cast<uint4*>(&sA[BUF][(lrow + 64 * i) * LDK + lchunk * 8]) = ra##S[i];         \
-        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                                    \
-            if (lrow + 64 * i < BNP) {                                                                      \
-                uint4 v = rb##S[i];                                                                         \
-                const bool ok = (okm##S >> i) & 1u;                                                         \
-                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;         \
-                *reinterpret_cast<uint4*>(&sB[BUF][(lrow + 64 * i) * LDK + lchunk * 8]) = v;                \
-            }                                                                                               \
+        CONV_STORE_A(S, 0, BUF) CONV_STORE_A(S, 1, BUF) CONV_STORE_A(S, 2, BUF) CONV_STORE_A(S, 3, BUF)     \
+        CONV_STORE_B(S, 0, BUF) CONV_STORE_B(S, 1, BUF) CONV_STORE_B(S, 2, BUF) CONV_STORE_B(S, 3, BUF)     \
     }
 #define CONV_COMPUTE(BUF)                                                                                   \
     {                                                                                                       \
-        _Pragma("unroll") for (int k16 = 0; k16 < 2; ++k16) {                                               \
+        _Pragma("unroll") for (int k16 = 0; k16 < BK / 16; ++k16) {                                         \
             f16x8 af[MC], bf[MP];                                                                           \
             _Pragma("unroll") for (int mi = 0; mi < MC; ++mi)                                               \
                 af[mi] = *reinterpret_cast<const f16x8*>(&sA[BUF][((wc * MC + mi) * 32 + frow) * LDK + k16 * 16 + fk]); \
@@ -135,7 +158,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][pi][r] = 0.f;
 
-    const int nk = p.Kpad / BK;
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     CONV_LOAD_STAGE(0, 0)
     if (1 < nk) CONV_LOAD_STAGE(1, 1)
@@ -144,15 +166,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     CONV_STORE_STAGE(0, 0)
     __syncthreads();
     int ks0 = 0;
-    // steady state: each step refills the stage it has just retired, DEPTH steps ahead; no guards
-    for (; ks0 + 2 * DEPTH <= nk; ks0 += DEPTH) {
+    // steady state: each step refills the stage it has just retired, 4 steps ahead; no guards
+    for (; ks0 + 8 <= nk; ks0 += 4) {
         CONV_LOAD_STAGE(0, ks0 + 4) CONV_COMPUTE(0) CONV_STORE_STAGE(1, 1) __syncthreads();
         CONV_LOAD_STAGE(1, ks0 + 5) CONV_COMPUTE(1) CONV_STORE_STAGE(2, 0) __syncthreads();
         CONV_LOAD_STAGE(2, ks0 + 6) CONV_COMPUTE(0) CONV_STORE_STAGE(3, 1) __syncthreads();
         CONV_LOAD_STAGE(3, ks0 + 7) CONV_COMPUTE(1) CONV_STORE_STAGE(0, 0) __syncthreads();
     }
-    // drain: the last (up to 2*DEPTH - 1) steps, guarded
-    for (; ks0 < nk; ks0 += DEPTH) {
+    // drain: the last (up to 7) steps, guarded
+    for (; ks0 < nk; ks0 += 4) {
         if (ks0 + 4 < nk) CONV_LOAD_STAGE(0, ks0 + 4)
         CONV_COMPUTE(0)
         if (ks0 + 1 < nk) CONV_STORE_STAGE(1, 1)
@@ -174,10 +196,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 #undef CONV_LOAD_STAGE
+#undef CONV_LOAD_A
+#undef CONV_LOAD_B
+#undef CONV_STORE_A
+#undef CONV_STORE_B
 #undef CONV_STORE_STAGE
 #undef CONV_COMPUTE
 
-    // ---- epilogue: bias + activation (+ residual), 4 consecutive channels per 8-byte store
+    // ---- epilogue
 #pragma unroll
     for (int pi = 0; pi < MP; ++pi) {
         const int pix = p0 + (wp * MP + pi) * 32 + (lane & 31);
@@ -188,6 +214,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int g = 0; g < 4; ++g) {
                 const int co = c0 + (wc * MC + mi) * 32 + 8 * g + 4 * (lane >> 5);
                 if (co >= p.cout_store) continue;
+                if (gridDim.z > 1) {   // split-K: raw fp32 partial sums, reduced by splitk_reduce_kernel
+                    *reinterpret_cast<float4*>(ws + ((size_t)blockIdx.z * p.P + pix) * cout_pad + co) =
+                        make_float4(acc[mi][pi][4 * g + 0], acc[mi][pi][4 * g + 1], acc[mi][pi][4 * g + 2],
+                                    acc[mi][pi][4 * g + 3]);
+                    continue;
+                }
                 const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
                 float v[4] = {acc[mi][pi][4 * g + 0] + b.x, acc[mi][pi][4 * g + 1] + b.y,
                               acc[mi][pi][4 * g + 2] + b.z, acc[mi][pi][4 * g + 3] + b.w};
@@ -217,33 +249,83 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
+// sum of the split-K partials (fixed order z = 0..S-1) + bias + activation (+ residual)
+__global__ void splitk_reduce_kernel(const ConvParams p, const float* __restrict__ ws, int S) {
+    const int cout_pad = (p.Cout + 31) & ~31;
+    const int c4n = p.cout_store / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)p.P * c4n) return;
+    const int co = (int)(idx % c4n) * 4;
+    const long pix = idx / c4n;
+    float4 a = *reinterpret_cast<const float4*>(ws + (size_t)pix * cout_pad + co);
+    for (int z = 1; z < S; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(ws + ((size_t)z * p.P + pix) * cout_pad + co);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+    float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.res_mode != RES_NONE) {
+        const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)pix * p.res_cs + p.res_coff + co);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (float)rv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.res_mode == RES_BEFORE_ACT) v[e] += r[e];
+        v[e] = apply_act(v[e], p.act);
+        if (p.res_mode == RES_AFTER_ACT) v[e] += r[e];
+    }
+    if (p.out32) {
+        *reinterpret_cast<float4*>(p.out32 + (size_t)pix * p.out_cs + p.out_coff + co) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+        *reinterpret_cast<f16x4*>(p.out + (size_t)pix * p.out_cs + p.out_coff + co) = o;
+    }
+}
+
 template <int WC, int WP, int MC, int MP>
-int launch_cfg(const ConvParams& p, hipStream_t s) {
+int launch_cfg(const ConvParams& p, int S, float* ws, hipStream_t s) {
     constexpr int BMC = WC * MC * 32, BNP = WP * MP * 32;
     const int cout_pad = (p.Cout + 31) & ~31;
-    dim3 grid((p.P + BNP - 1) / BNP, (cout_pad + BMC - 1) / BMC);
-    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, MC, MP>), grid, dim3(256), 0, s, p);
+    dim3 grid((p.P + BNP - 1) / BNP, (cout_pad + BMC - 1) / BMC, S);
+    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, MC, MP>), grid, dim3(256), 0, s, p, ws);
+    if (S > 1) {
+        const long total = (long)p.P * (p.cout_store / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, ws, S);
+    }
     FM_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-// Tile selection: the largest tile that still fills the 256 CUs; small-channel layers use the
-// 32- or 64-channel tiles (OSNet x0.25 mid = 16..32, YOLO stem 32/64).
-int launch_conv(const ConvParams& p, hipStream_t s) {
+// Tile + split selection.  Tiles: 32c x 128p for narrow layers (OSNet x0.25, stems), 64c x 128p when
+// that still gives >= 2 workgroups per CU, otherwise 64c x 64p.  Split-K brings the launch to ~2
+// workgroups per CU as long as every split keeps >= 4 K-steps.
+int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s) {
     FM_CHECK_ARG(p.Cin % 8 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0);
     FM_CHECK_ARG(p.out_cs % 4 == 0 && p.out_coff % 4 == 0 && p.Kpad % BK == 0);
     const int cout_pad = (p.Cout + 31) & ~31;
-    auto nwg = [&](int bmc, int bnp) {
-        return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc);
+    auto tiles = [&](int bmc, int bnp) { return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc); };
+    const int nk = p.Kpad / BK;
+    auto split_for = [&](long t) {
+        int S = 1;
+        if (t < 256) {
+            S = (int)((512 + t - 1) / t);
+            S = S < nk / 4 ? S : nk / 4;
+            S = S > 16 ? 16 : S;
+            if (S < 1) S = 1;
+            // every split must own at least one step
+            while (S > 1 && (long)((nk + S - 1) / S) * (S - 1) >= nk) --S;
+            while (S > 1 && (size_t)S * p.P * cout_pad > ws_floats) --S;
+        }
+        return S;
     };
-    if (cout_pad <= 32) return launch_cfg<1, 4, 1, 1>(p, s);                  //  32c x 128p
-    if (cout_pad <= 64) {
-        if (nwg(64, 128) >= 256) return launch_cfg<2, 2, 1, 2>(p, s);         //  64c x 128p
-        return launch_cfg<2, 2, 1, 1>(p, s);                                  //  64c x  64p
-    }
-    if (nwg(128, 128) >= 384) return launch_cfg<2, 2, 2, 2>(p, s);            // 128c x 128p
-    if (nwg(128, 64) >= 256) return launch_cfg<2, 2, 2, 1>(p, s);             // 128c x  64p
-    return launch_cfg<2, 2, 1, 1>(p, s);                                      //  64c x  64p
+    if (cout_pad <= 32) return launch_cfg<1, 4, 1, 1>(p, 1, ws, s);                      //  32c x 128p
+    if (tiles(64, 128) >= 512) return launch_cfg<2, 2, 1, 2>(p, 1, ws, s);               //  64c x 128p
+    const long t = tiles(64, 64);
+    return launch_cfg<2, 2, 1, 1>(p, split_for(t), ws, s);                               //  64c x  64p
 }

@@ -20,12 +20,12 @@ struct ConvParams {
     float* out32;                           // optional fp32 output (YOLO heads), same view geometry
     const f16* res; int res_cs, res_coff;   // residual view (nullable)
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
-    int K, Kpad, P;                         // K = KH*KW*Cin, Kpad = ceil32(K), P = N*Ho*Wo
+    int K, Kpad, P;                         // K = KH*KW*Cin, Kpad = ceil64(K), P = N*Ho*Wo
     int cout_store;                         // ceil8(Cout): channels written
     int act, res_mode;
 };
 
-int launch_conv(const ConvParams& p, hipStream_t s);
+int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s);
 
 struct NetState {
     int which = 0, max_batch = 0;
@@ -37,6 +37,8 @@ struct NetState {
     float* gates = nullptr;
     int n_gates = 0, gate_c = 0;
     hipStream_t stream = nullptr;
+    float* ws = nullptr;      // split-K partial sums (fp32)
+    size_t ws_floats = 0;
     int emb_offset = 0;   // row offset of FM_OP_HEAD outputs in ctx->emb (batched extraction)
     int batch_offset = 0; // sample offset into the input tensor for chunked runs
 };

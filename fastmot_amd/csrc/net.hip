@@ -29,6 +29,7 @@ void fm_net_free(NetState* n) {
         if (b) (void)hipFree(b);
     if (n->weights) (void)hipFree(n->weights);
     if (n->gates) (void)hipFree(n->gates);
+    if (n->ws) (void)hipFree(n->ws);
     delete n;
 }
 
@@ -81,6 +82,8 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
     net->weight_bytes = weight_bytes;
     net->n_gates = n_gates;
     net->gate_c = gate_channels;
+    net->ws_floats = (size_t)16 << 20;   // 64 MB of fp32 split-K partials
+    FM_HIP(hipMalloc(&net->ws, net->ws_floats * sizeof(float)));
     if (n_gates > 0) {
         FM_CHECK_ARG(gate_channels > 0);
         FM_HIP(hipMalloc(&net->gates, sizeof(float) * (size_t)n_gates * max_batch * gate_channels));
@@ -115,12 +118,12 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             }
             p.N = B; p.H = ti.h; p.W = ti.w; p.Cin = L.cin; p.Ho = to.h; p.Wo = to.w; p.Cout = L.cout;
             p.KH = p.KW = L.k; p.stride = L.stride; p.pad = L.pad;
-            p.K = L.k * L.k * L.cin; p.Kpad = (p.K + 31) & ~31; p.P = B * to.h * to.w;
+            p.K = L.k * L.k * L.cin; p.Kpad = (p.K + 63) & ~63; p.P = B * to.h * to.w;
             p.cout_store = (L.cout + 7) & ~7;
             p.act = L.act; p.res_mode = L.res_mode;
             FM_CHECK_ARG((ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h);
             FM_CHECK_ARG(L.out_coff + p.cout_store <= to.c && L.in_coff[0] + L.cin <= ti.c);
-            return launch_conv(p, s);
+            return launch_conv(p, net->ws, net->ws_floats, s);
         }
         case FM_OP_DWCONV3:
             return launch_dwconv3(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
@@ -281,5 +284,31 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
     if (other_ms) *other_ms = to / iters;
     if (n_conv) *n_conv = nc / iters;
     if (n_other) *n_other = no / iters;
+    return 0;
+}
+
+// per-layer HIP-event times (ms), averaged over iters; out[n_layers]
+extern "C" int fm_net_profile_layers(fm_ctx* ctx, int which, int batch, int iters, double* out) {
+    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && iters > 0 && out);
+    NetState* net = net_slot(ctx, which);
+    FM_CHECK_ARG(net != nullptr && batch > 0 && batch <= net->max_batch);
+    hipEvent_t e0, e1;
+    FM_HIP(hipEventCreate(&e0));
+    FM_HIP(hipEventCreate(&e1));
+    const size_t n = net->layers.size();
+    for (size_t i = 0; i < n; ++i) out[i] = 0;
+    for (int it = 0; it < iters; ++it)
+        for (size_t i = 0; i < n; ++i) {
+            FM_HIP(hipEventRecord(e0, net->stream));
+            int rc = run_layer(ctx, net, net->layers[i], batch);
+            if (rc) return rc;
+            FM_HIP(hipEventRecord(e1, net->stream));
+            FM_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            FM_HIP(hipEventElapsedTime(&ms, e0, e1));
+            out[i] += ms / iters;
+        }
+    FM_HIP(hipEventDestroy(e0));
+    FM_HIP(hipEventDestroy(e1));
     return 0;
 }

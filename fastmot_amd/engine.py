@@ -56,5 +56,11 @@ class HipNet:
                                                C.byref(conv_ms), C.byref(other_ms), C.byref(n_conv), C.byref(n_other)))
         return dict(conv_ms=conv_ms.value, other_ms=other_ms.value, n_conv=n_conv.value, n_other=n_other.value)
 
+    def profile_layers(self, batch, iters=5):
+        out = np.zeros(len(self.graph.layers))
+        _lib.check(self.ctx.lib.fm_net_profile_layers(self.ctx.handle, C.c_int(self.which), C.c_int(batch), C.c_int(iters),
+                                                      out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def close(self):
         _lib.check(self.ctx.lib.fm_net_destroy(self.ctx.handle, C.c_int(self.which)))

@@ -4,7 +4,7 @@ Replaces the ONNX -> TensorRT engine build of the reference (fastmot/models/yolo
 fastmot/models/reid.py:48-92).  A Graph is a list of NHWC fp16 tensors (channels padded to 8) and
 layers; concat / route is expressed by writing producers into channel slices of a shared tensor,
 BatchNorm is folded into the conv weights (eps 1e-5, scripts/yolo2onnx.py:419-421) and packed in
-the MFMA kernel's [cout_pad32][K_pad32] fp16 layout.
+the MFMA kernel's [cout_pad32][K_pad64] fp16 layout.
 """
 import ctypes as C
 
@@ -130,9 +130,9 @@ class Graph:
         p = self.wsrc.conv(name, cout, x.c, k, bn=bn)
         w, b = fold_bn(p)
         w16 = w.astype(np.float16)
-        # pack [cout_pad32][Kpad32], K order (kh, kw, cin_pad)
+        # pack [cout_pad32][Kpad64], K order (kh, kw, cin_pad)
         K = k * k * cin_pad
-        kpad = ceil_to(K, 32)
+        kpad = ceil_to(K, 64)
         cpad = ceil_to(cout, 32)
         wk = np.zeros((cpad, k, k, cin_pad), np.float16)
         wk[:cout, :, :, :x.c] = w16.transpose(0, 2, 3, 1)

@@ -197,7 +197,7 @@ typedef struct fm_layer {
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob (16 B aligned) */
 } fm_layer;
 
-/* weights: CONV  w = fp16 [ceil32(cout)][ceil32(k*k*cin)] (K order kh,kw,cin), b = f32[ceil32(cout)]
+/* weights: CONV  w = fp16 [ceil32(cout)][ceil64(k*k*cin)] (K order kh,kw,cin), b = f32[ceil32(cout)]
  *          DWCONV3 w = fp16 [9][c], b = f32[c];  GATE w=[hid][c] b=[hid] w2=[c][hid] b2=[c];
  *          HEAD  w = fp16 [cout][cin], b = f32[cout]  (BN folded everywhere). */
 int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensors, const fm_tensor* tensors,
@@ -219,6 +219,9 @@ int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, double* bytes)
  * events on the network's own stream; enable != 0 switches per-layer timing on (slow path). */
 int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, double* conv_ms, double* other_ms,
                    int* n_conv, int* n_other);
+
+/* per-layer HIP-event times in ms (out[n_layers]); tuning aid */
+int fm_net_profile_layers(fm_ctx* ctx, int which, int batch, int iters, double* out);
 
 /* ---------------------------------------------------------------- frames -------------- */
 /* Frames are BGR u8 HxWx3, C-contiguous (what VideoIO.read() hands to MOT.step, app.py:85).
