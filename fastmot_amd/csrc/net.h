@@ -39,6 +39,8 @@ struct NetState {
     hipStream_t stream = nullptr;
     float* ws = nullptr;      // split-K partial sums (fp32)
     size_t ws_floats = 0;
+    std::vector<std::pair<long, hipGraphExec_t>> graphs;   // (batch, emb_offset) -> captured layer sequence
+    bool use_graphs = true;
     int emb_offset = 0;   // row offset of FM_OP_HEAD outputs in ctx->emb (batched extraction)
     int batch_offset = 0; // sample offset into the input tensor for chunked runs
 };
