@@ -124,6 +124,10 @@ struct Model {
     virtual void to_params(const double* M, double* h) const = 0;
     virtual void from_params(const double* h, double* M) const = 0;
     virtual void residuals(const Pt* a, const Pt* b, int count, const double* h, double* r, double* J) const = 0;
+    // one pass over the points: A = J^T J (row-major lx*lx), v = J^T r, returns |r|^2 and max |r|
+    // (exploits the sparsity of the two Jacobian rows of a point; J is never stored)
+    virtual double normal_eq(const Pt* a, const Pt* b, int count, const double* h, double* A, double* v,
+                             double* rinf) const = 0;
 };
 
 bool have_collinear(const Pt* p, int count) {
@@ -146,6 +150,52 @@ double det3(const double m[3][3]) {
 }
 
 struct Homography : Model {
+    double normal_eq(const Pt* M, const Pt* m, int count, const double* h, double* A, double* v,
+                     double* rinf) const override {
+        double G[6] = {0, 0, 0, 0, 0, 0};        // sum g g^T (upper: 00 01 02 11 12 22)
+        double X[6] = {0, 0, 0, 0, 0, 0};        // sum -xi g * (g0, g1): [g0*g0, g0*g1, g1*g0.., ] stored as 3x2
+        double Y[6] = {0, 0, 0, 0, 0, 0};
+        double Q[3] = {0, 0, 0};                 // sum (xi^2 + yi^2) [g0 g0, g0 g1, g1 g1]
+        double vv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double S = 0, ri = 0;
+        for (int i = 0; i < count; ++i) {
+            const double Mx = M[i].x, My = M[i].y;
+            double ww = h[6] * Mx + h[7] * My + 1.;
+            ww = std::fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+            const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+            const double rx = xi - m[i].x, ry = yi - m[i].y;
+            const double g0 = Mx * ww, g1 = My * ww, g2 = ww;
+            G[0] += g0 * g0; G[1] += g0 * g1; G[2] += g0 * g2; G[3] += g1 * g1; G[4] += g1 * g2; G[5] += g2 * g2;
+            X[0] -= xi * g0 * g0; X[1] -= xi * g0 * g1; X[2] -= xi * g1 * g0; X[3] -= xi * g1 * g1;
+            X[4] -= xi * g2 * g0; X[5] -= xi * g2 * g1;
+            Y[0] -= yi * g0 * g0; Y[1] -= yi * g0 * g1; Y[2] -= yi * g1 * g0; Y[3] -= yi * g1 * g1;
+            Y[4] -= yi * g2 * g0; Y[5] -= yi * g2 * g1;
+            const double q = xi * xi + yi * yi;
+            Q[0] += q * g0 * g0; Q[1] += q * g0 * g1; Q[2] += q * g1 * g1;
+            vv[0] += g0 * rx; vv[1] += g1 * rx; vv[2] += g2 * rx;
+            vv[3] += g0 * ry; vv[4] += g1 * ry; vv[5] += g2 * ry;
+            const double w = -(xi * rx + yi * ry);
+            vv[6] += w * g0; vv[7] += w * g1;
+            S += rx * rx + ry * ry;
+            ri = std::max(ri, std::max(std::fabs(rx), std::fabs(ry)));
+        }
+        for (int i = 0; i < 64; ++i) A[i] = 0.;
+        const double Gm[3][3] = {{G[0], G[1], G[2]}, {G[1], G[3], G[4]}, {G[2], G[4], G[5]}};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                A[i * 8 + j] = Gm[i][j];
+                A[(i + 3) * 8 + j + 3] = Gm[i][j];
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 2; ++j) {
+                A[i * 8 + 6 + j] = A[(6 + j) * 8 + i] = X[i * 2 + j];
+                A[(i + 3) * 8 + 6 + j] = A[(6 + j) * 8 + i + 3] = Y[i * 2 + j];
+            }
+        A[6 * 8 + 6] = Q[0]; A[6 * 8 + 7] = A[7 * 8 + 6] = Q[1]; A[7 * 8 + 7] = Q[2];
+        for (int i = 0; i < 8; ++i) v[i] = vv[i];
+        *rinf = ri;
+        return S;
+    }
     int model_points() const override { return 4; }
     int n_params() const override { return 8; }
     bool check_subset(const Pt* a, const Pt* b, int count) const override {
@@ -244,6 +294,25 @@ struct Homography : Model {
 };
 
 struct AffinePartial : Model {
+    double normal_eq(const Pt* f, const Pt* t, int count, const double* h, double* A, double* v,
+                     double* rinf) const override {
+        double m2 = 0, sx = 0, sy = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, S = 0, ri = 0;
+        for (int i = 0; i < count; ++i) {
+            const double Mx = f[i].x, My = f[i].y;
+            const double rx = h[0] * Mx - h[1] * My + h[2] - t[i].x;
+            const double ry = h[1] * Mx + h[0] * My + h[3] - t[i].y;
+            m2 += Mx * Mx + My * My; sx += Mx; sy += My;
+            v0 += Mx * rx + My * ry; v1 += -My * rx + Mx * ry; v2 += rx; v3 += ry;
+            S += rx * rx + ry * ry;
+            ri = std::max(ri, std::max(std::fabs(rx), std::fabs(ry)));
+        }
+        const double n = count;
+        const double Am[16] = {m2, 0, sx, sy, 0, m2, -sy, sx, sx, -sy, n, 0, sy, sx, 0, n};
+        for (int i = 0; i < 16; ++i) A[i] = Am[i];
+        v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
+        *rinf = ri;
+        return S;
+    }
     int model_points() const override { return 2; }
     int n_params() const override { return 4; }
     bool check_subset(const Pt* a, const Pt*, int count) const override { return !have_collinear(a, count); }
@@ -362,26 +431,11 @@ bool ransac_run(const Model& cb, const Pt* m1, const Pt* m2, int count, double t
 // LMSolverImpl::run (levmarq.cpp), maxIters iterations, eps = FLT_EPSILON
 void lm_refine(const Model& cb, const Pt* a, const Pt* b, int count, double* M, int max_iters) {
     const int lx = cb.n_params();
-    std::vector<double> x(lx), xd(lx), r(2 * count), rd(2 * count), J((size_t)2 * count * lx);
-    cb.to_params(M, x.data());
-    cb.residuals(a, b, count, x.data(), r.data(), J.data());
-    auto normsq = [&](const std::vector<double>& v) { double s = 0; for (double e : v) s += e * e; return s; };
-    auto build = [&](std::vector<double>& A, std::vector<double>& v) {
-        A.assign((size_t)lx * lx, 0.);
-        v.assign(lx, 0.);
-        for (int i = 0; i < 2 * count; ++i) {
-            const double* ji = &J[(size_t)i * lx];
-            for (int p = 0; p < lx; ++p) {
-                v[p] += ji[p] * r[i];
-                for (int q = p; q < lx; ++q) A[(size_t)p * lx + q] += ji[p] * ji[q];
-            }
-        }
-        for (int p = 0; p < lx; ++p)
-            for (int q = 0; q < p; ++q) A[(size_t)p * lx + q] = A[(size_t)q * lx + p];
-    };
-    double S = normsq(r);
-    std::vector<double> A, v, Ap, d(lx), temp_d(lx), D(lx);
-    build(A, v);
+    double x[8], xd[8], d[8], temp_d[8], D[8], v[8], vn[8];
+    std::vector<double> A((size_t)lx * lx), An((size_t)lx * lx), Ap, rd(2 * (size_t)count);
+    cb.to_params(M, x);
+    double rinf = 0;
+    double S = cb.normal_eq(a, b, count, x, A.data(), v, &rinf);
     for (int i = 0; i < lx; ++i) D[i] = A[(size_t)i * lx + i];
     const double Rlo = 0.25, Rhi = 0.75;
     double lambda = 1, lc = 0.75;
@@ -389,10 +443,11 @@ void lm_refine(const Model& cb, const Pt* a, const Pt* b, int count, double* M, 
     for (int iter = 0;;) {
         Ap = A;
         for (int i = 0; i < lx; ++i) Ap[(size_t)i * lx + i] += lambda * D[i];
-        sym_solve(lx, Ap, v.data(), d.data(), nullptr);
+        sym_solve(lx, Ap, v, d, nullptr);
         for (int i = 0; i < lx; ++i) xd[i] = x[i] - d[i];
-        cb.residuals(a, b, count, xd.data(), rd.data(), nullptr);
-        const double Sd = normsq(rd);
+        // trial point: the normal equations at xd also give |r(xd)|^2; reused if the step is accepted
+        double rinf_d = 0;
+        const double Sd = cb.normal_eq(a, b, count, xd, An.data(), vn, &rinf_d);
         for (int i = 0; i < lx; ++i) {   // temp_d = 2 v - A d
             double s = 0;
             for (int k = 0; k < lx; ++k) s += A[(size_t)i * lx + k] * d[k];
@@ -410,8 +465,9 @@ void lm_refine(const Model& cb, const Pt* a, const Pt* b, int count, double* M, 
             double nu = (Sd - S) / (std::fabs(t) > DBL_EPSILON ? t : 1) + 2;
             nu = std::min(std::max(nu, 2.), 10.);
             if (lambda == 0) {
-                std::vector<double> inv_diag, dummy(lx, 0.), xx(lx);
-                sym_solve(lx, A, dummy.data(), xx.data(), &inv_diag);
+                std::vector<double> inv_diag;
+                double dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xx[8];
+                sym_solve(lx, A, dummy, xx, &inv_diag);
                 double maxval = DBL_EPSILON;
                 for (int i = 0; i < lx; ++i) maxval = std::max(maxval, std::fabs(inv_diag[i]));
                 lambda = lc = 1. / maxval;
@@ -421,17 +477,16 @@ void lm_refine(const Model& cb, const Pt* a, const Pt* b, int count, double* M, 
         }
         if (Sd < S) {
             S = Sd;
-            x.swap(xd);
-            cb.residuals(a, b, count, x.data(), r.data(), J.data());
-            build(A, v);
+            rinf = rinf_d;
+            for (int i = 0; i < lx; ++i) { x[i] = xd[i]; v[i] = vn[i]; }
+            A.swap(An);
         }
         ++iter;
-        double dinf = 0, rinf = 0;
-        for (double e : d) dinf = std::max(dinf, std::fabs(e));
-        for (double e : r) rinf = std::max(rinf, std::fabs(e));
+        double dinf = 0;
+        for (int i = 0; i < lx; ++i) dinf = std::max(dinf, std::fabs(d[i]));
         if (!(iter < max_iters && dinf >= eps && rinf >= eps)) break;
     }
-    cb.from_params(x.data(), M);
+    cb.from_params(x, M);
 }
 
 double round_half_even(double v) { return std::nearbyint(v); }

@@ -102,6 +102,13 @@ class Flow:
         """Predicts tracklet positions in the next frame and estimates camera motion
         (flow.py:135-264).  Returns ({trk_id: tlbr}, 3x3 homography) or ({}, None) on failure;
         keypoints / inlier ratios of `tracks` are updated in place."""
+        self.predict_begin(frame, tracks)
+        return self.predict_finish()
+
+    def predict_begin(self, frame, tracks):
+        """First half of `predict` (flow.py:153-200): images, keypoint bookkeeping / detection and
+        background keypoints -- one device round trip.  MOT.step calls the two halves separately so
+        that the ReID network can be enqueued in between."""
         ctx = self.ctx
         bind_frame(ctx, frame, self.size)
         ctx.flow_begin()                       # gray + small + pyramid of the new frame (async)
@@ -134,6 +141,15 @@ class Flow:
         target_ends = np.cumsum([len(p) for p in all_prev_pts]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
         target_begins = np.concatenate([[0], target_ends[:-1]]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
 
+        self._pending = (tracks, tlbrs, all_prev_pts, target_begins, target_ends, keypoints)
+
+    def predict_finish(self):
+        """Second half of `predict` (flow.py:201-264): LK matching, camera motion, target boxes."""
+        ctx = self.ctx
+        tracks, tlbrs, all_prev_pts, target_begins, target_ends, keypoints = self._pending
+        self._pending = None
+        n_trk = len(tracks)
+        empty = np.empty((0, 2), np.float32)
         if len(keypoints) == 0:
             self.bg_keypoints = empty
             ctx.flow_swap()

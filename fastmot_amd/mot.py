@@ -110,9 +110,13 @@ class MOT:
             with Profiler('preproc'):
                 self.detector.detect_async(frame)
 
+            # Same stages as mot.py:138-161, interleaved so that the GPU always has work: KLT keypoint
+            # bookkeeping while the detector runs, then the ReID network while the host finishes KLT
+            # (LK read-back + RANSAC) and the Kalman step.  Results are identical (the stages are
+            # independent exactly as in the reference's CPU || GPU overlap).
             with Profiler('detect'):
                 with Profiler('track'):
-                    self.tracker.compute_flow(frame)
+                    self.tracker.compute_flow_begin(frame)
                 detections = self.detector.postprocess()
 
             with Profiler('extract'):
@@ -121,6 +125,7 @@ class MOT:
                 self.extractors[0].extract_async(frame, detections.tlbr)
 
                 with Profiler('track', aggregate=True):
+                    self.tracker.compute_flow_finish()
                     self.tracker.apply_kalman()
 
                 embeddings = self.extractors[0].postprocess()
