@@ -217,6 +217,19 @@ class HipContext:
         check(self.lib.fm_feat_get(self._ctx, C.c_int(slot), _ptr(fsum), _ptr(avg), C.byref(cnt)))
         return fsum, avg, cnt.value
 
+    def feat_read(self, slots):
+        s = _as(slots, np.int32)
+        avg = np.empty((len(s), self.feat_dim), np.float32)
+        cnt = np.zeros(len(s), np.int32)
+        check(self.lib.fm_feat_read(self._ctx, C.c_int(len(s)), _ptr(s), _ptr(avg), _ptr(cnt)))
+        return avg, cnt
+
+    def feat_write(self, slots, avg, count):
+        s = _as(slots, np.int32)
+        a = _as(avg, np.float32).reshape(len(s), self.feat_dim)
+        c = _as(count, np.int32)
+        check(self.lib.fm_feat_write(self._ctx, C.c_int(len(s)), _ptr(s), _ptr(a), _ptr(c)))
+
     # ------------------------------------------------------------------ association
     def find_occluded(self, tlbr, thresh):
         b = _as(tlbr, np.float64, (-1, 4)) if len(tlbr) else np.zeros((0, 4))

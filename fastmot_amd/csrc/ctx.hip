@@ -375,3 +375,41 @@ extern "C" int fm_feat_get(fm_ctx* ctx, int slot, float* sum, float* avg, int32_
     if (count) FM_HIP(hipMemcpy(count, ctx->feat_cnt + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
 }
+
+// batched feature access for the cross-stream gallery exchange (fastmot_amd/gallery.py)
+extern "C" int fm_feat_read(fm_ctx* ctx, int n, const int32_t* slots, float* avg_out, int32_t* count_out) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return 0;
+    FM_CHECK_ARG(slots && avg_out && count_out);
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    const size_t bytes = (size_t)ctx->feat_dim * sizeof(float);
+    for (int i = 0; i < n; ++i) {
+        FM_CHECK_ARG(slots[i] >= 0 && slots[i] < ctx->slot_cap);
+        FM_HIP(hipMemcpyAsync(avg_out + (size_t)i * ctx->feat_dim, ctx->feat_avg + (size_t)slots[i] * ctx->feat_dim,
+                              bytes, hipMemcpyDeviceToHost, ctx->s_main));
+        FM_HIP(hipMemcpyAsync(count_out + i, ctx->feat_cnt + slots[i], sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_main));
+    }
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    return 0;
+}
+
+// sets avg (and sum = avg * count) of n slots: seeds the feature state of foreign gallery entries
+extern "C" int fm_feat_write(fm_ctx* ctx, int n, const int32_t* slots, const float* avg, const int32_t* count) {
+    FM_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return 0;
+    FM_CHECK_ARG(slots && avg && count);
+    int m = max_slot(n, slots);
+    FM_CHECK_ARG(m >= 0);
+    int rc = fm_ensure_slots(ctx, m + 1);
+    if (rc) return rc;
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    std::vector<float> sum(ctx->feat_dim);
+    const size_t bytes = (size_t)ctx->feat_dim * sizeof(float);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < ctx->feat_dim; ++k) sum[k] = avg[(size_t)i * ctx->feat_dim + k] * (float)count[i];
+        FM_HIP(hipMemcpy(ctx->feat_avg + (size_t)slots[i] * ctx->feat_dim, avg + (size_t)i * ctx->feat_dim, bytes, hipMemcpyHostToDevice));
+        FM_HIP(hipMemcpy(ctx->feat_sum + (size_t)slots[i] * ctx->feat_dim, sum.data(), bytes, hipMemcpyHostToDevice));
+        FM_HIP(hipMemcpy(ctx->feat_cnt + slots[i], count + i, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return 0;
+}

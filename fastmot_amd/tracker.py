@@ -47,10 +47,13 @@ class MultiTracker:
                  confirm_hits=1,
                  history_size=50,
                  kalman_filter_cfg=None,
-                 flow_cfg=None):
+                 flow_cfg=None,
+                 gallery_sync=None):
         """Tracks multiple objects with KLT + Kalman filtering and associates detections to
         tracklets by motion and appearance.  Parameters, defaults and range checks follow
-        fastmot/tracker.py:19-107."""
+        fastmot/tracker.py:19-107.  `gallery_sync` (optional, NOT in the reference): a
+        gallery.GallerySync that all-gathers the lost-track galleries of all streams (RCCL); None
+        keeps every stream bit-identical to a single-GPU run."""
         self.size = size
         if metric.upper() not in _METRICS:
             raise KeyError(metric.upper())
@@ -94,6 +97,8 @@ class MultiTracker:
 
         self.klt_bboxes = {}
         self.homography = None
+        self.gallery_sync = gallery_sync
+        self._foreign_slots = []
 
     # ------------------------------------------------------------------ lifecycle
     def reset(self, dt):
@@ -230,18 +235,21 @@ class MultiTracker:
                     if track.avg_feat.count >= 2]
         row_ids = list(self.tracks.keys()) + hist_ids
         row_of = {trk_id: i for i, trk_id in enumerate(row_ids)}
+        foreign = self._exchange_gallery(hist_ids) if self.gallery_sync is not None else []
         if n_det > 0:
             if embeddings is ctx.device_emb_host and embeddings is not None:
                 ctx.emb_use_device(n_det)
             else:
                 ctx.emb_upload(embeddings)
                 ctx.device_emb_host = None
-            if row_ids:
+            if row_ids or foreign:
                 row_tracks = [self.tracks[t] if t in self.tracks else self.hist_tracks[t] for t in row_ids]
-                ctx.assoc_prepare(self._metric_id, [t.slot for t in row_tracks],
-                                  np.array([t.tlbr for t in row_tracks]),
-                                  [t.label for t in row_tracks], det_tlbr, det_label, occluded_det_mask,
-                                  trk_feat_f32=[t not in self.tracks for t in row_ids])
+                # foreign gallery entries (other streams) come after all local rows
+                ctx.assoc_prepare(self._metric_id, [t.slot for t in row_tracks] + self._foreign_slots[:len(foreign)],
+                                  np.array([t.tlbr for t in row_tracks] + [np.zeros(4)] * len(foreign)),
+                                  [t.label for t in row_tracks] + [e['label'] for e in foreign],
+                                  det_tlbr, det_label, occluded_det_mask,
+                                  trk_feat_f32=[t not in self.tracks for t in row_ids] + [True] * len(foreign))
 
         # ---- 1st association: motion + embeddings, tracks with small age are prioritized
         fill_val = min(self.max_assoc_cost + 0.1, 1.)
@@ -278,10 +286,13 @@ class MultiTracker:
         n_hist = len(hist_ids)
         # quirk Q4 (tracker.py:364): labels come from the first n_hist of ALL history tracks
         hist_labels = list(itertools.islice((t.label for t in self.hist_tracks.values()), n_hist))
+        n_rows = len(row_ids)
         m_rows, m_cols, _ = self._solve(_lib.STAGE_REID, _lib.SOLVER_GREEDY, hist_ids,
-                                        [row_of[t] for t in hist_ids], valid_u_det_ids, valid_u_det_ids,
-                                        max_cost=self.max_reid_cost, row_labels=hist_labels)
-        reid_matches = [(hist_ids[r], valid_u_det_ids[c]) for r, c in zip(m_rows, m_cols)]
+                                        [row_of[t] for t in hist_ids] + list(range(n_rows, n_rows + len(foreign))),
+                                        valid_u_det_ids, valid_u_det_ids, max_cost=self.max_reid_cost,
+                                        row_labels=hist_labels + [e['label'] for e in foreign])
+        reid_matches = [(hist_ids[r], valid_u_det_ids[c]) for r, c in zip(m_rows, m_cols) if r < n_hist]
+        foreign_matches = [(foreign[r - n_hist], valid_u_det_ids[c]) for r, c in zip(m_rows, m_cols) if r >= n_hist]
         taken = set(m_cols)
         reid_u_det_ids = [det_id for c, det_id in enumerate(valid_u_det_ids) if c not in taken]
 
@@ -350,6 +361,33 @@ class MultiTracker:
         new_det_ids = list(itertools.chain(invalid_u_det_ids, reid_u_det_ids))
         self._new_tracks(frame_id, [det_tlbr[d] for d in new_det_ids],
                          [int(det_label[d]) for d in new_det_ids])
+
+        # ---- identities re-identified from ANOTHER stream's gallery (opt-in extension): a new local
+        # track seeded with the foreign appearance, tagged with its global identity
+        for entry, det_id in foreign_matches if self.gallery_sync is not None else ():
+            self._new_tracks(frame_id, [det_tlbr[det_id]], [int(det_label[det_id])])
+            trk = next(reversed(self.tracks.values()))
+            trk.global_id = (entry['rank'], entry['trk_id'])
+            ctx.feat_write([trk.slot], entry['feat'][None], [entry['count']])
+            trk.avg_feat.count = entry['count']
+            ctx.feat_update([trk.slot], [det_id])
+            trk.avg_feat.count += 1
+            trk.hits = self.confirm_hits
+
+    def _exchange_gallery(self, hist_ids):
+        """All-gathers {id, label, count, avg feature} of the local history (RCCL via torch.distributed)
+        and parks the foreign features in device slots."""
+        ctx = self.ctx
+        tracks = [self.hist_tracks[t] for t in hist_ids]
+        avg, cnt = ctx.feat_read([t.slot for t in tracks]) if tracks else (np.zeros((0, ctx.feat_dim), np.float32), [])
+        foreign = self.gallery_sync.exchange([(tid, t.label, int(c), a) for tid, t, a, c in
+                                              zip(hist_ids, tracks, avg, cnt)])
+        while len(self._foreign_slots) < len(foreign):
+            self._foreign_slots.append(ctx.slots.alloc())
+        if foreign:
+            ctx.feat_write(self._foreign_slots[:len(foreign)], np.array([e['feat'] for e in foreign]),
+                           [e['count'] for e in foreign])
+        return foreign
 
     def _mark_lost(self, trk_id):
         track = self.tracks.pop(trk_id)

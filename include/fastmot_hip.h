@@ -101,6 +101,10 @@ int fm_feat_merge(fm_ctx* ctx, int dst_slot, int src_slot);
 /* clears the feature state of n slots (new Track, track.py:142-143) */
 int fm_feat_reset(fm_ctx* ctx, int n, const int32_t* slots);
 int fm_feat_get(fm_ctx* ctx, int slot, float* sum, float* avg, int32_t* count);
+/* batched read / seed of the running-mean features (cross-stream gallery exchange; not in the
+ * reference, opt-in, see fastmot_amd/gallery.py) */
+int fm_feat_read(fm_ctx* ctx, int n, const int32_t* slots, float* avg_out, int32_t* count_out);
+int fm_feat_write(fm_ctx* ctx, int n, const int32_t* slots, const float* avg, const int32_t* count);
 
 /* ---------------------------------------------------------------- association --------- */
 enum { FM_METRIC_EUCLIDEAN = 0, FM_METRIC_COSINE = 1 }; /* utils/distance.py:12-14 */

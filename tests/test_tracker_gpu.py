@@ -53,3 +53,42 @@ def test_kalman_filter_mirror_api(ctx):
     np.testing.assert_allclose(m3, em3[0], rtol=1e-11); np.testing.assert_allclose(c3, ec3[0], rtol=1e-9)
     d = kf.motion_distance(m3, c3, np.stack([box, box + 10]))
     np.testing.assert_allclose(d, o.kf_maha(p, em3, ec3, np.stack([box, box + 10]))[0], rtol=1e-10)
+
+
+def test_foreign_gallery_reid(ctx):
+    """Opt-in cross-stream ReID: a detection whose embedding matches a FOREIGN gallery entry starts
+    a local track tagged with the foreign identity; with no sync object nothing changes."""
+    from fastmot_amd import MultiTracker, Track
+
+    class FakeSync:                      # stands in for gallery.GallerySync (no process group here)
+        def __init__(self, entries):
+            self.entries, self.calls = entries, 0
+
+        def exchange(self, local):
+            self.calls += 1
+            self.local = list(local)
+            return self.entries
+
+    rng = np.random.default_rng(0)
+    feat = rng.normal(0, 1, 512).astype(np.float32)
+    feat /= np.linalg.norm(feat)
+    other = rng.normal(0, 1, 512).astype(np.float32)
+    other /= np.linalg.norm(other)
+    sync = FakeSync([dict(rank=3, trk_id=17, label=1, count=4, feat=feat)])
+    Track._count = 0
+    trk = MultiTracker((1920, 1080), 'cosine', gallery_sync=sync, **scenes.tracker_kwargs())
+    trk.flow = scenes.Scene('s8_flowfail').make_flow()
+    trk.reset(1 / 30.)
+    dets = np.zeros(2, scenes.DET_DTYPE).view(np.recarray)
+    dets.tlbr = [[100, 100, 160, 280], [900, 300, 960, 480]]
+    dets.label = 1
+    dets.conf = 0.9
+    emb = np.stack([feat + 0.01 * other, other]).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    trk.update(1, dets, emb)
+    assert sync.calls == 1
+    tagged = [t for t in trk.tracks.values() if getattr(t, 'global_id', None) == (3, 17)]
+    assert len(tagged) == 1 and tagged[0].avg_feat.count == 5 and tagged[0].confirmed
+    np.testing.assert_array_equal(tagged[0].tlbr, dets.tlbr[0])
+    assert len(trk.tracks) == 2
+    trk._clear_tracks()
