@@ -1,0 +1,140 @@
+// Fused OSNet "LightConv3x3" (torchreid osnet.py LightConv3x3: 1x1 pointwise, linear, no bias ->
+// depthwise 3x3 -> BN -> ReLU), one launch instead of two and no HBM round trip of the pointwise map.
+//
+// One workgroup (4 waves) produces a th x tw output tile of one sample:
+//   phase A  pointwise GEMM on the matrix cores for the (th+2) x (tw+2) halo positions:
+//            D[cout][pos] = W[cout][cin] * X[pos][cin] with v_mfma_f32_32x32x16_f16; every lane loads
+//            its 8-channel operand straight from HBM/L2 (NHWC rows are the K-contiguous operand the
+//            instruction wants, so the input never touches LDS); positions outside the image give 0,
+//            which is exactly the zero padding of the depthwise stage because the pointwise has no bias.
+//            The fp16-rounded result (the engine stores every activation as fp16) goes to LDS with a row
+//            stride of an odd number of 16 B chunks, conflict-free for the 16 B reads of phase B.
+//   phase B  depthwise 3x3 + folded-BN bias + activation from LDS, 16 B coalesced stores.
+#include "net.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float lc_act(float v, int act) { return apply_act(v, act); }
+
+template <int NT, int KS, int MAXPOS, int SMAX>
+__global__ __launch_bounds__(256) void liteconv_kernel(
+    const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out, int out_cs, int out_coff,
+    const f16* __restrict__ wpw, int kpad, const f16* __restrict__ wdw, const float* __restrict__ bias,
+    int H, int W, int C, int th, int tw, int tiles_x, int tiles_y, int act) {
+    __shared__ __attribute__((aligned(16))) f16 ys[MAXPOS * SMAX];
+    __shared__ __attribute__((aligned(16))) f16 wd[9 * 32 * NT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = C + (((C >> 3) & 1) ? 0 : 8);
+    const int tile = blockIdx.x % (tiles_x * tiles_y);
+    const long n = blockIdx.x / (tiles_x * tiles_y);
+    const int ty0 = (tile / tiles_x) * th, tx0 = (tile % tiles_x) * tw;
+    const int hw = tw + 2, npos = (th + 2) * hw;
+    const f16* img = in + n * (long)H * W * in_cs + in_coff;
+
+    for (int i = tid; i < 9 * C / 8; i += 256)
+        *reinterpret_cast<uint4*>(&wd[i * 8]) = *reinterpret_cast<const uint4*>(wdw + i * 8);
+
+    // ---- phase A
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    f16x8 afr[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            afr[nt][ks] = *reinterpret_cast<const f16x8*>(wpw + (long)(nt * 32 + frow) * kpad + ks * 16 + fk);
+    const int mtiles = (npos + 31) / 32;
+    for (int mt = wave; mt < mtiles; mt += 4) {
+        const int pos = mt * 32 + frow;
+        const int py = ty0 - 1 + pos / hw, px = tx0 - 1 + pos % hw;
+        const bool inside = pos < npos && py >= 0 && py < H && px >= 0 && px < W;
+        const f16* src = img + ((long)min(max(py, 0), H - 1) * W + min(max(px, 0), W - 1)) * in_cs;
+        f16x8 bfr[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kc = ks * 16 + fk;
+            uint4 v = *reinterpret_cast<const uint4*>(src + (kc < C ? kc : 0));
+            const bool ok = inside && kc < C;
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            bfr[ks] = *reinterpret_cast<f16x8*>(&v);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[nt][ks], bfr[ks], acc, 0, 0, 0);
+            if (pos < npos) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = nt * 32 + g * 8 + (lane >> 5) * 4;
+                    if (c0 < C) {
+                        union { f16 h[4]; uint2 u; } pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk.h[e] = (f16)acc[g * 4 + e];
+                        *reinterpret_cast<uint2*>(&ys[pos * S + c0]) = pk.u;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B
+    const int c8n = C / 8, total = th * tw * c8n;
+    f16* dst = out + n * (long)H * W * out_cs + out_coff;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int cg = idx % c8n, pix = idx / c8n;
+        const int oy = pix / tw, ox = pix % tw;
+        const int gy = ty0 + oy, gx = tx0 + ox;
+        if (gy >= H || gx >= W) continue;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias[cg * 8 + e];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float v[8], k[8];
+                unpack8(*reinterpret_cast<const uint4*>(&ys[((oy + dy) * hw + ox + dx) * S + cg * 8]), v);
+                unpack8(*reinterpret_cast<const uint4*>(&wd[(dy * 3 + dx) * C + cg * 8]), k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], k[e], acc[e]);
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = lc_act(acc[e], act);
+        *reinterpret_cast<uint4*>(dst + ((long)gy * W + gx) * out_cs + cg * 8) = pack8(acc);
+    }
+}
+
+}  // namespace
+
+// in/out: NHWC fp16 with channel strides in_cs/out_cs and channel offsets; wpw: packed pointwise weights
+// [ceil32(C)][kpad] (same packing as launch_conv); wdw: [9][C]; bias: f32[C] (folded BN of the depthwise).
+int launch_liteconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* wpw,
+                    int kpad, const f16* wdw, const float* bias, int N, int H, int W, int C, int act,
+                    hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && C >= 8 && C <= 128 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 &&
+                 out_coff % 8 == 0);
+    const int nt = (C + 31) / 32, ks = (C + 15) / 16;
+    int th, tw;
+    if (nt == 1) { th = 16; tw = W > 8 ? 16 : 8; }
+    else if (W > 8) { th = 8; tw = 16; }
+    else { th = 16; tw = 8; }
+    const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    const dim3 grid((unsigned)((long)N * tiles_x * tiles_y)), block(256);
+#define LC_LAUNCH(NT_, KS_, MAXPOS_, SMAX_)                                                                  \
+    hipLaunchKernelGGL((liteconv_kernel<NT_, KS_, MAXPOS_, SMAX_>), grid, block, 0, s, in, in_cs, in_coff, out, \
+                       out_cs, out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act)
+    if (ks == 1) LC_LAUNCH(1, 1, 324, 40);
+    else if (nt == 1) LC_LAUNCH(1, 2, 324, 40);
+    else if (nt == 2) { if (ks <= 3) LC_LAUNCH(2, 3, 180, 72); else LC_LAUNCH(2, 4, 180, 72); }
+    else if (nt == 3) { if (ks <= 5) LC_LAUNCH(3, 5, 180, 104); else LC_LAUNCH(3, 6, 180, 104); }
+    else { if (ks <= 7) LC_LAUNCH(4, 7, 180, 136); else LC_LAUNCH(4, 8, 180, 136); }
+#undef LC_LAUNCH
+    FM_HIP(hipGetLastError());
+    return 0;
+}

@@ -37,6 +37,7 @@ struct NetState {
     float* gates = nullptr;
     int n_gates = 0, gate_c = 0;
     hipStream_t stream = nullptr;
+    char* arena = nullptr;    // shared activation arena (tensors with offset >= 0)
     float* ws = nullptr;      // split-K partial sums (fp32)
     size_t ws_floats = 0;
     std::vector<std::pair<long, hipGraphExec_t>> graphs;   // (batch, emb_offset) -> captured layer sequence
@@ -47,6 +48,18 @@ struct NetState {
 
 NetState* fm_net_get(fm_ctx* ctx, int which);
 int fm_net_run_internal(fm_ctx* ctx, int which, int batch);
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    const f16x8 h = *reinterpret_cast<const f16x8*>(&v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (f16)f[e];
+    return *reinterpret_cast<const uint4*>(&h);
+}
 
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {

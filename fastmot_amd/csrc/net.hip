@@ -7,6 +7,9 @@
 
 int launch_dwconv3(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
                    const float* bias, int N, int H, int W, int C, int act, hipStream_t s);
+int launch_liteconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* wpw,
+                    int kpad, const f16* wdw, const float* bias, int N, int H, int W, int C, int act,
+                    hipStream_t s);
 int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
                 int W, int C, int Ho, int Wo, int k, int stride, int pad, int avg, hipStream_t s);
 int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
@@ -25,8 +28,9 @@ int fm_emb_reserve(fm_ctx* ctx, int n);
 
 void fm_net_free(NetState* n) {
     if (!n) return;
-    for (void* b : n->bufs)
-        if (b) (void)hipFree(b);
+    for (size_t i = 0; i < n->bufs.size(); ++i)
+        if (n->bufs[i] && n->tensors[i].offset < 0) (void)hipFree(n->bufs[i]);
+    if (n->arena) (void)hipFree(n->arena);
     if (n->weights) (void)hipFree(n->weights);
     if (n->gates) (void)hipFree(n->gates);
     if (n->ws) (void)hipFree(n->ws);
@@ -53,7 +57,7 @@ extern "C" int fm_net_destroy(fm_ctx* ctx, int which) {
 
 extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensors, const fm_tensor* tensors,
                              int n_layers, const fm_layer* layers, const void* weights, size_t weight_bytes,
-                             int n_gates, int gate_channels) {
+                             int n_gates, int gate_channels, size_t arena_bytes) {
     FM_CHECK_ARG(ctx && (which == 0 || which == 1) && max_batch > 0 && n_tensors > 0 && n_layers > 0);
     FM_CHECK_ARG(tensors && layers && weights && weight_bytes > 0);
     int rc = fm_net_destroy(ctx, which);
@@ -64,12 +68,21 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
     net->stream = which == FM_NET_DETECTOR ? ctx->s_det : ctx->s_ext;
     net->tensors.assign(tensors, tensors + n_tensors);
     net->layers.assign(layers, layers + n_layers);
+    if (arena_bytes) {
+        FM_HIP(hipMalloc(&net->arena, arena_bytes));
+        FM_HIP(hipMemset(net->arena, 0, arena_bytes));
+    }
     for (const fm_tensor& t : net->tensors) {
         FM_CHECK_ARG(t.h > 0 && t.w > 0 && t.c > 0 && t.c % 8 == 0);
         void* b = nullptr;
         const size_t bytes = (size_t)max_batch * t.h * t.w * t.c * elem_size(t);
-        FM_HIP(hipMalloc(&b, bytes));
-        FM_HIP(hipMemset(b, 0, bytes));
+        if (t.offset >= 0) {
+            FM_CHECK_ARG(t.offset % 256 == 0 && (size_t)t.offset + bytes <= arena_bytes);
+            b = net->arena + t.offset;
+        } else {
+            FM_HIP(hipMalloc(&b, bytes));
+            FM_HIP(hipMemset(b, 0, bytes));
+        }
         net->bufs.push_back(b);
     }
     for (const fm_layer& L : net->layers) {
@@ -130,6 +143,12 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             return launch_dwconv3(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
                                   (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                   B, ti.h, ti.w, L.cin, L.act, s);
+        case FM_OP_LITECONV:
+            FM_CHECK_ARG(L.cin == ((L.cout + 7) & ~7));
+            return launch_liteconv(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
+                                   (const f16*)(net->weights + L.w_off), (L.cin + 63) & ~63,
+                                   (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b_off),
+                                   B, ti.h, ti.w, L.cin, L.act, s);
         case FM_OP_MAXPOOL:
         case FM_OP_AVGPOOL:
             return launch_pool(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, to.h, to.w,
@@ -266,6 +285,10 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
         case FM_OP_DWCONV3:
             *flops = 2.0 * 9 * L.cin * pout;
             *bytes = (pin + pout) * L.cin * 2;
+            break;
+        case FM_OP_LITECONV:
+            *flops = 2.0 * (L.cin + 9) * L.cout * pout;
+            *bytes = (pin + pout) * L.cin * 2 + (double)L.cin * L.cout * 2;
             break;
         case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
         case FM_OP_GATE_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;

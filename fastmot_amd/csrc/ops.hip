@@ -6,18 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
-    const f16x8 h = *reinterpret_cast<const f16x8*>(&v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
-}
-__device__ __forceinline__ uint4 pack8(const float* f) {
-    f16x8 h;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = (f16)f[e];
-    return *reinterpret_cast<const uint4*>(&h);
-}
-
 // depthwise 3x3, stride 1, pad 1, + bias (folded BN) + activation.  w: [9][C] fp16, bias f32[C]
 __global__ void dwconv3_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
                                f16* __restrict__ out, int out_cs, int out_coff,

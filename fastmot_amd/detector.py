@@ -83,7 +83,8 @@ class YOLODetector(Detector):
                  max_area=800000,
                  min_aspect_ratio=1.2,
                  weights=None,
-                 max_candidates=8192):
+                 max_candidates=8192,
+                 reuse_buffers=True):
         """An object detector for YOLO models; parameters as fastmot/detector.py:221-253
         (`weights`: optional weight source for the layer table, default seeded random;
         `max_candidates`: capacity of the on-device candidate list)."""
@@ -106,7 +107,7 @@ class YOLODetector(Detector):
 
         self.ctx = get_context()
         self.graph, self.heads = self.model.build_graph(weights)
-        self.backend = HipNet(self.ctx, NET_DETECTOR, self.graph, 1)
+        self.backend = HipNet(self.ctx, NET_DETECTOR, self.graph, 1, reuse_buffers=reuse_buffers)
         self.roi, self.upscaled_sz, self.bbox_offset = self._create_letterbox()
         self._configure(max_candidates)
 

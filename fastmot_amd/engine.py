@@ -10,13 +10,16 @@ NET_DETECTOR, NET_EXTRACTOR = 0, 1
 
 
 class HipNet:
-    def __init__(self, ctx, which, graph, max_batch):
+    def __init__(self, ctx, which, graph, max_batch, reuse_buffers=False):
+        """reuse_buffers: share activation memory between tensors with disjoint live ranges (the
+        production setting; intermediate tensors can then not be read back after a run)."""
         self.ctx, self.which, self.graph, self.max_batch = ctx, which, graph, max_batch
-        ts, ls, blob = graph.tables()
+        ts, ls, blob = graph.tables(max_batch, reuse_buffers)
         self._keep = (ts, ls, blob)
         _lib.check(ctx.lib.fm_net_create(ctx.handle, C.c_int(which), C.c_int(max_batch), C.c_int(len(ts)), ts,
                                          C.c_int(len(ls)), ls, blob, C.c_size_t(len(blob)),
-                                         C.c_int(graph.n_gates), C.c_int(graph.gate_c)))
+                                         C.c_int(graph.n_gates), C.c_int(graph.gate_c),
+                                         C.c_size_t(graph.arena_bytes)))
 
     def run(self, batch):
         _lib.check(self.ctx.lib.fm_net_run(self.ctx.handle, C.c_int(self.which), C.c_int(batch)))

@@ -12,7 +12,7 @@ from .runtime import get_context
 
 
 class FeatureExtractor:
-    def __init__(self, model='OSNet025', batch_size=16, weights=None, size=None):
+    def __init__(self, model='OSNet025', batch_size=16, weights=None, size=None, reuse_buffers=True):
         """model : name of a class that inherits `models.ReID`; batch_size : samples per network
         launch (fastmot/feature_extractor.py:12-25).  `size` (frame width, height) is only needed
         when the extractor is used without a detector having bound the frame first."""
@@ -25,7 +25,7 @@ class FeatureExtractor:
         self.ctx = get_context()
         self.ctx.feat_configure(self.feature_dim)
         self.graph, _ = self.model.build_graph(weights)
-        self.backend = HipNet(self.ctx, NET_EXTRACTOR, self.graph, self.batch_size)
+        self.backend = HipNet(self.ctx, NET_EXTRACTOR, self.graph, self.batch_size, reuse_buffers=reuse_buffers)
         self.ctx.extract_configure(self.graph.input.tid, self.model.INPUT_SHAPE[2], self.model.INPUT_SHAPE[1])
         self.last_num_features = 0
 

@@ -10,13 +10,14 @@ import ctypes as C
 
 import numpy as np
 
-OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD = range(9)
+(OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
+ OP_LITECONV) = range(10)
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 
 
 class fm_tensor(C.Structure):
-    _fields_ = [('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32), ('f32', C.c_int32)]
+    _fields_ = [('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32), ('f32', C.c_int32), ('offset', C.c_int64)]
 
 
 class fm_layer(C.Structure):
@@ -119,7 +120,7 @@ class Graph:
 
     # ---------------------------------------------------------------- ops
     def conv(self, name, x, cout, k=1, stride=1, act='linear', bn=True, dst=None, res=None,
-             res_mode=RES_AFTER_ACT, f32_out=False, pad=None):
+             res_mode=RES_AFTER_ACT, f32_out=False, pad=None, bias=True):
         cin_pad = x.cpad
         pad = k // 2 if pad is None else pad
         ho = (x.h + 2 * pad - k) // stride + 1
@@ -129,6 +130,8 @@ class Graph:
         assert dst.h == ho and dst.w == wo and dst.c == cout, (name, dst.h, ho, dst.c, cout)
         p = self.wsrc.conv(name, cout, x.c, k, bn=bn)
         w, b = fold_bn(p)
+        if not bias:
+            b = np.zeros_like(b)
         w16 = w.astype(np.float16)
         # pack [cout_pad32][Kpad64], K order (kh, kw, cin_pad)
         K = k * k * cin_pad
@@ -160,6 +163,29 @@ class Graph:
         self._layer(op=OP_DWCONV3, ins=[x], out=dst, cin=x.cpad, cout=c, k=3, stride=1, pad=1, act=ACT[act],
                     w_off=self._push(wk), b_off=self._push(bias), name=name)
         self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
+        return dst
+
+    def lightconv(self, name, x, cout, act='relu', fuse=True):
+        """torchreid LightConv3x3: 1x1 conv (linear, bias=False) -> depthwise 3x3 (bias=False) -> BN -> act.
+        Fused into one FM_OP_LITECONV launch when cin == cout <= 128, else two layers; both forms
+        draw the same parameters in the same order."""
+        if not (fuse and x.c == cout and cout <= 128 and x.coff % 8 == 0):
+            y = self.conv(name + '.pw', x, cout, 1, 1, 'linear', bn=False, bias=False)
+            return self.dwconv3(name + '.dw', y, act)
+        c, cp = cout, x.cpad
+        pw = self.wsrc.conv(name + '.pw', c, c, 1, bn=False)['w'].astype(np.float16)     # [c, c, 1, 1]
+        packed = np.zeros((ceil_to(c, 32), ceil_to(cp, 64)), np.float16)
+        packed[:c, :c] = pw.reshape(c, c)
+        wd, bd = fold_bn(self.wsrc.conv(name + '.dw', c, c, 3, bn=True, groups=c))
+        wd16 = wd.astype(np.float16)
+        wk = np.zeros((9, cp), np.float16)
+        wk[:, :c] = wd16.reshape(c, 9).T
+        bias = np.zeros(cp, np.float32)
+        bias[:c] = bd
+        dst = self.new(x.h, x.w, c)
+        self._layer(op=OP_LITECONV, ins=[x], out=dst, cin=cp, cout=c, k=3, stride=1, pad=1, act=ACT[act],
+                    w_off=self._push(packed), w2_off=self._push(wk), b_off=self._push(bias), name=name,
+                    lite_ref=(pw.astype(np.float32), wd16.astype(np.float32), bd))
         return dst
 
     def pool(self, x, k, stride, pad, avg=False, dst=None):
@@ -225,10 +251,42 @@ class Graph:
         return dst
 
     # ---------------------------------------------------------------- C tables
-    def tables(self):
+    def plan_arena(self, max_batch, reuse):
+        """Byte offsets of the tensors in one activation arena.  With `reuse`, tensors whose live
+        ranges [first writer/reader layer, last layer touching them] do not overlap share bytes
+        (greedy first-fit by decreasing size).  The network input and the graph outputs are read /
+        written outside the layer sequence and therefore stay live for the whole run."""
+        n = len(self.tensors)
+        size = [ceil_to(max_batch * h * w * c * (4 if f32 else 2), 256) for (h, w, c, f32) in self.tensors]
+        first, last = [10**9] * n, [-1] * n
+        for li, d in enumerate(self.layers):
+            touched = [v.tid for v in d['ins']] + [d['out'].tid] + ([d['res'].tid] if d['res'] is not None else [])
+            for t in touched:
+                first[t], last[t] = min(first[t], li), max(last[t], li)
+        persistent = {self.input.tid} | {v.tid for v in self.outputs}
+        for t in range(n):
+            if t in persistent or not reuse or last[t] < 0:
+                first[t], last[t] = -1, 10**9
+        offsets = [0] * n
+        placed = []                      # (offset, size, first, last)
+        for t in sorted(range(n), key=lambda i: -size[i]):
+            cands = sorted((o, s) for (o, s, f, l) in placed if not (last[t] < f or l < first[t]))
+            off = 0
+            for o, s in cands:
+                if off + size[t] <= o:
+                    break
+                off = max(off, o + s)
+            offsets[t] = off
+            placed.append((off, size[t], first[t], last[t]))
+        total = max((o + s for (o, s, _, _) in placed), default=0)
+        return offsets, total
+
+    def tables(self, max_batch=1, reuse=False):
+        offsets, arena = self.plan_arena(max_batch, reuse)
+        self.arena_bytes = arena
         ts = (fm_tensor * len(self.tensors))()
         for i, (h, w, c, f32) in enumerate(self.tensors):
-            ts[i] = fm_tensor(h, w, c, f32)
+            ts[i] = fm_tensor(h, w, c, f32, offsets[i])
         ls = (fm_layer * len(self.layers))()
         for i, d in enumerate(self.layers):
             L = fm_layer()

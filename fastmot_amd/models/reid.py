@@ -31,13 +31,13 @@ class ReID:
         return cls.__registry[name]
 
     @classmethod
-    def build_graph(cls, weights=None):
+    def build_graph(cls, weights=None, fuse_lightconv=True):
         if weights is None:
             weights = RandomWeights(seed=1)
-        return osnet_graph(cls, weights)
+        return osnet_graph(cls, weights, fuse_lightconv)
 
 
-def osnet_graph(model, weights):
+def osnet_graph(model, weights, fuse_lightconv=True):
     _, H, W = model.INPUT_SHAPE
     c0, c1, c2, c3 = model.CHANNELS
     g = Graph(weights, (H, W), 3)
@@ -50,8 +50,7 @@ def osnet_graph(model, weights):
         for t in range(1, 5):
             s = x1
             for i in range(t):
-                y = g.conv(f'{name}.s{t}.{i}.pw', s, mid, 1, 1, 'linear', bn=False)
-                s = g.dwconv3(f'{name}.s{t}.{i}.dw', y, 'relu')
+                s = g.lightconv(f'{name}.s{t}.{i}', s, mid, 'relu', fuse=fuse_lightconv)
             gid, gp = g.gate(name + '.gate', s, max(mid // 16, 1), gp)
             streams.append(s)
             gids.append(gid)

@@ -178,7 +178,9 @@ enum {
     FM_OP_COPY = 5,      /* channel-slice copy                                                  */
     FM_OP_GATE = 6,      /* OSNet channel gate: GAP -> fc1 -> ReLU -> fc2 -> sigmoid -> gate[0] */
     FM_OP_GATE_SUM = 7,  /* out = sum_i in[i] * gate[i]                                         */
-    FM_OP_HEAD = 8       /* GAP -> Linear(+BN1d) -> ReLU -> L2 normalise -> ctx embeddings      */
+    FM_OP_HEAD = 8,      /* GAP -> Linear(+BN1d) -> ReLU -> L2 normalise -> ctx embeddings      */
+    FM_OP_LITECONV = 9   /* fused OSNet LightConv3x3: 1x1 linear (w_off, no bias) -> depthwise 3x3
+                          * (w2_off) + bias (b_off) + act; cin == cout <= 128                   */
 };
 enum { FM_ACT_LINEAR = 0, FM_ACT_LEAKY = 1, FM_ACT_MISH = 2, FM_ACT_RELU = 3, FM_ACT_LOGISTIC = 4,
        FM_ACT_SWISH = 5 };
@@ -187,6 +189,9 @@ enum { FM_RES_NONE = 0, FM_RES_AFTER_ACT = 1, FM_RES_BEFORE_ACT = 2 };
 typedef struct fm_tensor {
     int32_t h, w, c;     /* per-sample geometry, c = channel stride (multiple of 8) */
     int32_t f32;         /* 1: fp32 storage (YOLO head outputs), 0: fp16 */
+    int64_t offset;      /* byte offset in the network's activation arena (256 B aligned), or -1 for a
+                          * private buffer.  Tensors whose live ranges do not overlap may share bytes:
+                          * keeping the working set small keeps it resident in the 256 MB Infinity Cache */
 } fm_tensor;
 
 typedef struct fm_layer {
@@ -206,7 +211,7 @@ typedef struct fm_layer {
  *          HEAD  w = fp16 [cout][cin], b = f32[cout]  (BN folded everywhere). */
 int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensors, const fm_tensor* tensors,
                   int n_layers, const fm_layer* layers, const void* weights, size_t weight_bytes,
-                  int n_gates, int gate_channels);
+                  int n_gates, int gate_channels, size_t arena_bytes);
 int fm_net_destroy(fm_ctx* ctx, int which);
 /* enqueues every layer for `batch` samples on the network's stream (no host sync) */
 int fm_net_run(fm_ctx* ctx, int which, int batch);

@@ -13,7 +13,7 @@ if which == 0:
 else:
     ctx.feat_configure(512)
     g, _ = ReID.get_model('OSNet025').build_graph(); batch = 50
-net = HipNet(ctx, which, g, batch)
+net = HipNet(ctx, which, g, batch, reuse_buffers=True)
 for _ in range(3):
     net.run(batch)
 ms = net.profile_layers(batch, 10)

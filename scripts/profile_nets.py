@@ -14,7 +14,7 @@ for which, (name, cls, batch) in enumerate((('YOLOv4_608', YOLO.get_model('YOLOv
     g, _ = cls.build_graph()
     if which == 1:
         ctx.feat_configure(512)
-    net = HipNet(ctx, which, g, batch)
+    net = HipNet(ctx, which, g, batch, reuse_buffers=True)
     for _ in range(3):
         net.run(batch)
     ctx.synchronize()

@@ -102,6 +102,69 @@ def test_pool_upsample_dw_gate_ops(ctx):
     net.close()
 
 
+@pytest.mark.parametrize('c,h,w,n', [(16, 64, 32, 3), (24, 32, 16, 5), (32, 16, 8, 7), (16, 21, 19, 2),
+                                     (8, 5, 3, 1), (64, 20, 17, 2), (96, 32, 16, 2), (128, 16, 8, 3),
+                                     (72, 9, 24, 1)])
+def test_lightconv_fused(ctx, c, h, w, n):
+    """Fused LightConv3x3 (liteconv.hip) == pointwise conv + depthwise kernel pair, bit for bit, and
+    both within tolerance of the torch reference; ragged tiles, halo at every border."""
+    rng = np.random.default_rng(c + h)
+    x = rng.normal(0, 1, (n, h, w, c)).astype(np.float16)
+    outs = []
+    for fuse in (True, False):
+        g = Graph(RandomWeights(seed=c), (h, w), c)
+        y = g.lightconv('lc', g.input, c, 'relu', fuse=fuse)
+        assert len(g.layers) == (1 if fuse else 2)
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        net.write(g.input, x)
+        net.run(n)
+        outs.append(net.read(y, n))
+        bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+        close(outs[-1], nhwc(bufs[y.tid][:, :c]), what=f'lightconv c{c} fuse={fuse}')
+        net.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_osnet_fused_and_arena_reuse_identical(ctx):
+    """The production configuration (fused LightConv, activation arena shared between tensors with
+    disjoint live ranges) gives the same embeddings, bit for bit, as the plain layer-per-kernel
+    private-buffer configuration."""
+    class Small(ReID.get_model('OSNet025')):
+        INPUT_SHAPE = (3, 128, 64)
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 1, (6, 128, 64, 3)).astype(np.float16)
+    ctx.feat_configure(512)
+    embs = []
+    for fuse, reuse in ((False, False), (True, True)):
+        g, _ = Small.build_graph(RandomWeights(seed=5), fuse_lightconv=fuse)
+        net = HipNet(ctx, NET_EXTRACTOR, g, 6, reuse_buffers=reuse)
+        for _ in range(2):                      # second run: stale arena contents must not matter
+            net.write(g.input, x)
+            net.run(6)
+        embs.append(net.read_embeddings(6))
+        net.close()
+    np.testing.assert_array_equal(embs[0], embs[1])
+
+
+def test_yolov4_arena_reuse_identical(ctx):
+    class Small(YOLO.get_model('YOLOv4')):
+        INPUT_SHAPE = (3, 128, 160)
+    x = np.random.default_rng(8).uniform(0, 1, (1, 128, 160, 3)).astype(np.float16)
+    outs = []
+    for reuse in (False, True):
+        g, heads = Small.build_graph(RandomWeights(seed=2))
+        net = HipNet(ctx, NET_DETECTOR, g, 1, reuse_buffers=reuse)
+        if reuse:
+            assert g.arena_bytes < 0.5 * sum(h * w * c * (4 if f else 2) for h, w, c, f in g.tensors)
+        for _ in range(2):
+            net.write(g.input, x)
+            net.run(1)
+        outs.append([net.read(h, 1) for h in heads])
+        net.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize('model,size,batch', [('OSNet025', (64, 32), 5), ('OSNet10', (64, 32), 3)])
 def test_osnet_embeddings(ctx, model, size, batch):
     cls = ReID.get_model(model)

@@ -72,7 +72,7 @@ def test_filter_dets_random_vs_oracle(ctx):
 def test_preprocess_decode_end_to_end(ctx, model):
     size = (320, 180)
     det = YOLODetector(size, (0, 1, 2), model=model, conf_thresh=0.1, nms_thresh=0.5,
-                       weights=RandomWeights(seed=4), max_candidates=16384)
+                       weights=RandomWeights(seed=4), max_candidates=16384, reuse_buffers=False)
     frame = synthetic_frame(*size, seed=1)
     ctx.frame_configure(*size)
     ctx.frame_upload(frame)

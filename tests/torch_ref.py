@@ -62,6 +62,13 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             w, b = params[idx]
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), padding=1, groups=xin.shape[1])
             wr(d['out'], act_fn(y, d['act']))
+        elif op == G.OP_LITECONV:
+            pw, wd, bd = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['lite_ref'])
+            y = F.conv2d(xin, pw)
+            if emulate_fp16_storage:
+                y = y.half().float()
+            y = F.conv2d(y, wd, bd, padding=1, groups=y.shape[1])
+            wr(d['out'], act_fn(y, d['act']))
         elif op == G.OP_MAXPOOL:
             wr(d['out'], F.max_pool2d(xin, d['k'], d['stride'], d['pad']))
         elif op == G.OP_AVGPOOL:
