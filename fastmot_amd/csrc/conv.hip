@@ -24,7 +24,11 @@
 //     the stage is written to LDS, so the waits are counted (vmcnt(N > 0)) and 3 steps stay in flight;
 //   * split-K over gridDim.z when a layer has fewer than ~2 workgroups per CU: fp32 partial tiles
 //     go to a workspace, a second small kernel sums them in a fixed order (deterministic) and
-//     applies the epilogue.
+//     applies the epilogue.  (Tried and rejected, round 1: letting the last-arriving workgroup of a
+//     tile do the reduction in the same launch.  The partials cross XCDs, whose L2s are not coherent
+//     with each other: agent-scope fences write back + invalidate a whole L2 per workgroup (network
+//     3.6x slower), and fence-free sc1 write-through stores / sc1 loads made split layers 1.6x slower
+//     than conv + reduce launch, which only pays the ~5 us launch boundary.)
 //
 // Roofline: per layer max(2*K*Cout*P / 2.5 PFLOP/s, (in + out + weights) * 2 B / 8 TB/s);
 // YOLOv4 @608 = 128.4 GFLOP, 618 MB -> 0.089 ms/frame lower bound.
@@ -34,6 +38,23 @@ namespace {
 
 constexpr int BK = 64;    // K elements per step
 constexpr int LDK = 72;   // padded LDS row (halves): 144 B
+
+// fp16 store of 4 output channels of output pixel `pix`; with p.up == 2 the pixel is replicated to its
+// 2x2 block of the (2Ho, 2Wo) destination view: the nearest x2 [upsample] layer (yolo2onnx.py:806-836)
+// folded into its producer, one launch fewer per PAN level.
+__device__ __forceinline__ void store_out(const ConvParams& p, long pix, int co, f16x4 o) {
+    if (p.up == 2) {
+        const int hw = p.Ho * p.Wo, rem = (int)(pix % hw);
+        const size_t o00 = ((size_t)(pix / hw) * 2 * p.Ho + 2 * (rem / p.Wo)) * (2 * p.Wo) + 2 * (rem % p.Wo);
+        f16* dst = p.out + o00 * p.out_cs + p.out_coff + co;
+        *reinterpret_cast<f16x4*>(dst) = o;
+        *reinterpret_cast<f16x4*>(dst + p.out_cs) = o;
+        *reinterpret_cast<f16x4*>(dst + (size_t)2 * p.Wo * p.out_cs) = o;
+        *reinterpret_cast<f16x4*>(dst + (size_t)(2 * p.Wo + 1) * p.out_cs) = o;
+    } else {
+        *reinterpret_cast<f16x4*>(p.out + (size_t)pix * p.out_cs + p.out_coff + co) = o;
+    }
+}
 
 template <int WC, int WP, int MC, int MP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p, float* __restrict__ ws) {
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p, 
                     f16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-                    *reinterpret_cast<f16x4*>(p.out + (size_t)pix * p.out_cs + p.out_coff + co) = o;
+                    store_out(p, pix, co, o);
                 }
             }
         }
@@ -282,7 +303,7 @@ __global__ void splitk_reduce_kernel(const ConvParams p, const float* __restrict
         f16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-        *reinterpret_cast<f16x4*>(p.out + (size_t)pix * p.out_cs + p.out_coff + co) = o;
+        store_out(p, pix, co, o);
     }
 }
 

@@ -18,11 +18,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float lc_act(float v, int act) { return apply_act(v, act); }
 
+// blockIdx.y selects one of up to 4 independent LightConvs of the same geometry (the parallel streams
+// of an OSNet block at the same depth): group g reads view in[g], writes channels
+// [out_coff + g*C, +C) of `out` and uses the g-th slab of the stacked weights.
+struct LiteGroups {
+    const f16* in[4];
+    int in_cs[4], in_coff[4];
+};
+template <typename T>
+__device__ __forceinline__ T pick4(const T (&a)[4], int g) {
+    return g == 0 ? a[0] : g == 1 ? a[1] : g == 2 ? a[2] : a[3];
+}
+
 template <int NT, int KS, int MAXPOS, int SMAX>
 __global__ __launch_bounds__(256) void liteconv_kernel(
-    const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out, int out_cs, int out_coff,
-    const f16* __restrict__ wpw, int kpad, const f16* __restrict__ wdw, const float* __restrict__ bias,
-    int H, int W, int C, int th, int tw, int tiles_x, int tiles_y, int act) {
+    const LiteGroups grp, f16* __restrict__ out, int out_cs, int out_coff_base,
+    const f16* __restrict__ wpw_base, int kpad, const f16* __restrict__ wdw_base,
+    const float* __restrict__ bias_base, int H, int W, int C, int th, int tw, int tiles_x, int tiles_y,
+    int act) {
+    const int grp_id = blockIdx.y;
+    const f16* __restrict__ in = pick4(grp.in, grp_id);
+    const int in_cs = pick4(grp.in_cs, grp_id), in_coff = pick4(grp.in_coff, grp_id);
+    const int out_coff = out_coff_base + grp_id * C;
+    const f16* __restrict__ wpw = wpw_base + (size_t)grp_id * (32 * NT) * kpad;
+    const f16* __restrict__ wdw = wdw_base + (size_t)grp_id * 9 * C;
+    const float* __restrict__ bias = bias_base + (size_t)grp_id * C;
     __shared__ __attribute__((aligned(16))) f16 ys[MAXPOS * SMAX];
     __shared__ __attribute__((aligned(16))) f16 wd[9 * 32 * NT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,23 +132,29 @@ __global__ __launch_bounds__(256) void liteconv_kernel(
 
 }  // namespace
 
-// in/out: NHWC fp16 with channel strides in_cs/out_cs and channel offsets; wpw: packed pointwise weights
-// [ceil32(C)][kpad] (same packing as launch_conv); wdw: [9][C]; bias: f32[C] (folded BN of the depthwise).
-int launch_liteconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* wpw,
-                    int kpad, const f16* wdw, const float* bias, int N, int H, int W, int C, int act,
-                    hipStream_t s) {
-    FM_CHECK_ARG(C % 8 == 0 && C >= 8 && C <= 128 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 &&
-                 out_coff % 8 == 0);
+// in/out: NHWC fp16 with channel strides in_cs/out_cs and channel offsets; per group g < G: wpw packed
+// pointwise weights [ceil32(C)][kpad] (same packing as launch_conv); wdw: [9][C]; bias: f32[C] (folded BN
+// of the depthwise), the G slabs stacked contiguously.
+int launch_liteconv(int G, const f16* const* in, const int* in_cs, const int* in_coff, f16* out, int out_cs,
+                    int out_coff, const f16* wpw, int kpad, const f16* wdw, const float* bias, int N, int H,
+                    int W, int C, int act, hipStream_t s) {
+    FM_CHECK_ARG(G >= 1 && G <= 4 && C % 8 == 0 && C >= 8 && C <= 128 && out_cs % 8 == 0 && out_coff % 8 == 0);
+    LiteGroups grp{};
+    for (int g = 0; g < 4; ++g) {
+        const int q = g < G ? g : 0;
+        FM_CHECK_ARG(in_cs[q] % 8 == 0 && in_coff[q] % 8 == 0);
+        grp.in[g] = in[q]; grp.in_cs[g] = in_cs[q]; grp.in_coff[g] = in_coff[q];
+    }
     const int nt = (C + 31) / 32, ks = (C + 15) / 16;
     int th, tw;
     if (nt == 1) { th = 16; tw = W > 8 ? 16 : 8; }
     else if (W > 8) { th = 8; tw = 16; }
     else { th = 16; tw = 8; }
     const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
-    const dim3 grid((unsigned)((long)N * tiles_x * tiles_y)), block(256);
+    const dim3 grid((unsigned)((long)N * tiles_x * tiles_y), G), block(256);
 #define LC_LAUNCH(NT_, KS_, MAXPOS_, SMAX_)                                                                  \
-    hipLaunchKernelGGL((liteconv_kernel<NT_, KS_, MAXPOS_, SMAX_>), grid, block, 0, s, in, in_cs, in_coff, out, \
-                       out_cs, out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act)
+    hipLaunchKernelGGL((liteconv_kernel<NT_, KS_, MAXPOS_, SMAX_>), grid, block, 0, s, grp, out, out_cs,       \
+                       out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act)
     if (ks == 1) LC_LAUNCH(1, 1, 324, 40);
     else if (nt == 1) LC_LAUNCH(1, 2, 324, 40);
     else if (nt == 2) { if (ks <= 3) LC_LAUNCH(2, 3, 180, 72); else LC_LAUNCH(2, 4, 180, 72); }

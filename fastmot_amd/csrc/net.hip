@@ -7,9 +7,14 @@
 
 int launch_dwconv3(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
                    const float* bias, int N, int H, int W, int C, int act, hipStream_t s);
-int launch_liteconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* wpw,
-                    int kpad, const f16* wdw, const float* bias, int N, int H, int W, int C, int act,
-                    hipStream_t s);
+int launch_liteconv(int G, const f16* const* in, const int* in_cs, const int* in_coff, f16* out, int out_cs,
+                    int out_coff, const f16* wpw, int kpad, const f16* wdw, const float* bias, int N, int H,
+                    int W, int C, int act, hipStream_t s);
+int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
+                     int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
+                     int out_cs, int out_coff, hipStream_t s);
+int launch_spp(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H, int W,
+               int C, hipStream_t s);
 int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
                 int W, int C, int Ho, int Wo, int k, int stride, int pad, int avg, hipStream_t s);
 int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
@@ -130,12 +135,14 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                 p.res_cs = net->tensors[L.res].c;
                 p.res_coff = L.res_coff;
             }
-            p.N = B; p.H = ti.h; p.W = ti.w; p.Cin = L.cin; p.Ho = to.h; p.Wo = to.w; p.Cout = L.cout;
+            p.up = L.up == 2 ? 2 : 1;
+            FM_CHECK_ARG(L.up <= 2 && (p.up == 1 || (!to.f32 && to.h % 2 == 0 && to.w % 2 == 0)));
+            p.N = B; p.H = ti.h; p.W = ti.w; p.Cin = L.cin; p.Ho = to.h / p.up; p.Wo = to.w / p.up; p.Cout = L.cout;
             p.KH = p.KW = L.k; p.stride = L.stride; p.pad = L.pad;
-            p.K = L.k * L.k * L.cin; p.Kpad = (p.K + 63) & ~63; p.P = B * to.h * to.w;
+            p.K = L.k * L.k * L.cin; p.Kpad = (p.K + 63) & ~63; p.P = B * p.Ho * p.Wo;
             p.cout_store = (L.cout + 7) & ~7;
             p.act = L.act; p.res_mode = L.res_mode;
-            FM_CHECK_ARG((ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h);
+            FM_CHECK_ARG((ti.h + 2 * L.pad - L.k) / L.stride + 1 == p.Ho);
             FM_CHECK_ARG(L.out_coff + p.cout_store <= to.c && L.in_coff[0] + L.cin <= ti.c);
             return launch_conv(p, net->ws, net->ws_floats, s);
         }
@@ -143,12 +150,40 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             return launch_dwconv3(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
                                   (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                   B, ti.h, ti.w, L.cin, L.act, s);
-        case FM_OP_LITECONV:
-            FM_CHECK_ARG(L.cin == ((L.cout + 7) & ~7));
-            return launch_liteconv(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
+        case FM_OP_LITECONV: {
+            FM_CHECK_ARG(L.cin == ((L.cout + 7) & ~7) && L.n_in >= 1 && L.n_in <= 4);
+            FM_CHECK_ARG(L.out_coff + L.n_in * L.cin <= to.c);
+            const f16* ins[4];
+            int cs[4], co[4];
+            for (int i = 0; i < L.n_in; ++i) {
+                const fm_tensor& tg = net->tensors[L.in[i]];
+                FM_CHECK_ARG(tg.h == to.h && tg.w == to.w && L.in_coff[i] + L.cin <= tg.c);
+                ins[i] = (const f16*)net->bufs[L.in[i]];
+                cs[i] = tg.c;
+                co[i] = L.in_coff[i];
+            }
+            return launch_liteconv(L.n_in, ins, cs, co, out, to.c, L.out_coff,
                                    (const f16*)(net->weights + L.w_off), (L.cin + 63) & ~63,
                                    (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b_off),
                                    B, ti.h, ti.w, L.cin, L.act, s);
+        }
+        case FM_OP_GATED_SUM: {
+            const f16* ins[4];
+            int cs[4], co[4];
+            FM_CHECK_ARG(L.n_in >= 1 && L.n_in <= 4);
+            for (int i = 0; i < L.n_in; ++i) {
+                ins[i] = (const f16*)net->bufs[L.in[i]];
+                cs[i] = net->tensors[L.in[i]].c;
+                co[i] = L.in_coff[i];
+            }
+            return launch_gated_sum(L.n_in, ins, cs, co, B, ti.h * ti.w, L.cin, L.hid,
+                                    (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                                    (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
+                                    out, to.c, L.out_coff, s);
+        }
+        case FM_OP_SPP:
+            FM_CHECK_ARG(to.h == ti.h && to.w == ti.w && L.out_coff + 3 * L.cin <= to.c);
+            return launch_spp(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, s);
         case FM_OP_MAXPOOL:
         case FM_OP_AVGPOOL:
             return launch_pool(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, to.h, to.w,
@@ -287,9 +322,11 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *bytes = (pin + pout) * L.cin * 2;
             break;
         case FM_OP_LITECONV:
-            *flops = 2.0 * (L.cin + 9) * L.cout * pout;
-            *bytes = (pin + pout) * L.cin * 2 + (double)L.cin * L.cout * 2;
+            *flops = 2.0 * (L.cin + 9) * L.cout * pout * L.n_in;
+            *bytes = ((pin + pout) * L.cin * 2 + (double)L.cin * L.cout * 2) * L.n_in;
             break;
+        case FM_OP_GATED_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
+        case FM_OP_SPP: *bytes = (pin + 3 * pout) * L.cin * 2; break;
         case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
         case FM_OP_GATE_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
         case FM_OP_HEAD:

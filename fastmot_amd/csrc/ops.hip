@@ -42,6 +42,49 @@ __global__ void dwconv3_kernel(const f16* __restrict__ in, int in_cs, int in_cof
     *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = pack8(acc);
 }
 
+// darknet SPP block in one launch: stride-1 max pools k = 5, 9, 13 (window clipped at the border) of
+// one (sample, 8-channel group) per workgroup, entirely in LDS.  pool9 = pool5(pool5), pool13 =
+// pool5(pool9) and each pool5 is a row pass + a column pass: 6 passes of 5 taps instead of
+// 25 + 81 + 169 taps, one read of the input and three launches fewer.
+//   out channel offsets: +0 -> k13, +C -> k9, +2C -> k5  (yolov4.cfg route -1,-3,-5,-6 order)
+constexpr int SPP_MAX_HW = 2048;
+__device__ __forceinline__ f16x8 hmax8(f16x8 a, f16x8 b) { return __builtin_elementwise_max(a, b); }
+__global__ __launch_bounds__(256) void spp_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
+                                                  f16* __restrict__ out, int out_cs, int out_coff, int H,
+                                                  int W, int C) {
+    __shared__ f16x8 a[SPP_MAX_HW], b[SPP_MAX_HW];
+    const int c8n = C / 8, cg = blockIdx.x % c8n;
+    const long n = blockIdx.x / c8n;
+    const int HW = H * W;
+    const f16* src = in + n * HW * in_cs + in_coff + cg * 8;
+    f16* dst = out + n * HW * out_cs + out_coff + cg * 8;
+    for (int i = threadIdx.x; i < HW; i += 256) a[i] = *reinterpret_cast<const f16x8*>(src + (long)i * in_cs);
+    __syncthreads();
+    for (int level = 2; level >= 0; --level) {
+        for (int i = threadIdx.x; i < HW; i += 256) {   // row pass a -> b
+            const int x = i % W, row = i - x;
+            f16x8 m = a[i];
+            for (int d = -2; d <= 2; ++d) {
+                const int xx = min(max(x + d, 0), W - 1);
+                m = hmax8(m, a[row + xx]);
+            }
+            b[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < HW; i += 256) {   // column pass b -> a (+ store)
+            const int y = i / W, x = i - y * W;
+            f16x8 m = b[i];
+            for (int d = -2; d <= 2; ++d) {
+                const int yy = min(max(y + d, 0), H - 1);
+                m = hmax8(m, b[yy * W + x]);
+            }
+            a[i] = m;
+            *reinterpret_cast<f16x8*>(dst + (long)i * out_cs + level * C) = m;
+        }
+        __syncthreads();
+    }
+}
+
 // max / average pooling, window k, stride s, pad (window clipped at the border)
 __global__ void pool_kernel(const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out,
                             int out_cs, int out_coff, int N, int H, int W, int C, int Ho, int Wo,
@@ -180,6 +223,98 @@ __global__ void gate_sum_kernel(GateSumArgs a, f16* __restrict__ out, int out_cs
     *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = pack8(acc);
 }
 
+// OSNet unified aggregation gate, whole block tail in ONE launch (one workgroup of 512 threads per sample):
+//   gap_t = GAP(x_t);  g_t = sigmoid(fc2(relu(fc1(gap_t))));  out = sum_t x_t * g_t     (t < nstreams <= 4)
+// The second pass re-reads x_t from L2 (a sample's four streams are <= 1 MB).  Same arithmetic as
+// gate_kernel + gate_sum_kernel (fp32 sums, fmaf in stream order); only the GAP partial grouping differs.
+constexpr int GS_THREADS = 512;
+__global__ __launch_bounds__(GS_THREADS) void gated_sum_kernel(GateSumArgs a, int HW, int C, int hid,
+                                                               const f16* __restrict__ w1,
+                                                               const float* __restrict__ b1,
+                                                               const f16* __restrict__ w2,
+                                                               const float* __restrict__ b2,
+                                                               f16* __restrict__ out, int out_cs, int out_coff) {
+    extern __shared__ float sm[];            // part[groups][C] | gap[4][C] | hidden[4][hid] | gate[4][C]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int c8n = C / 8;
+    const int groups = GS_THREADS / c8n;
+    const int cg = tid % c8n, pg = tid / c8n;
+    float* gap = sm + groups * C;
+    float* hidden = gap + 4 * C;
+    float* gate = hidden + 4 * hid;
+    const f16* base[4];
+    int cs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = t < a.nstreams ? t : 0;
+        cs[t] = a.in_cs[q];
+        base[t] = a.in[q] + (size_t)n * HW * cs[t] + a.in_coff[q] + cg * 8;
+    }
+    float acc[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    if (pg < groups) {
+        for (int px = pg; px < HW; px += groups) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < a.nstreams) {
+                    float v[8];
+                    unpack8(*reinterpret_cast<const uint4*>(base[t] + (size_t)px * cs[t]), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[t][e] += v[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t >= a.nstreams) break;
+        if (pg < groups) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm[pg * C + cg * 8 + e] = acc[t][e];
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += GS_THREADS) {
+            float s = 0.f;
+            for (int g = 0; g < groups; ++g) s += sm[g * C + c];
+            gap[t * C + c] = s / (float)HW;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < a.nstreams * hid; i += GS_THREADS) {
+        const int t = i / hid, h = i % hid;
+        float s = b1[h];
+        for (int c = 0; c < C; ++c) s = fmaf((float)w1[h * C + c], gap[t * C + c], s);
+        hidden[t * hid + h] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.nstreams * C; i += GS_THREADS) {
+        const int t = i / C, c = i % C;
+        float s = b2[c];
+        for (int h = 0; h < hid; ++h) s = fmaf((float)w2[c * hid + h], hidden[t * hid + h], s);
+        gate[t * C + c] = 1.f / (1.f + __expf(-s));
+    }
+    __syncthreads();
+    if (pg < groups) {
+        f16* dst = out + (size_t)n * HW * out_cs + out_coff + cg * 8;
+        for (int px = pg; px < HW; px += groups) {
+            float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < a.nstreams) {
+                    float v[8];
+                    unpack8(*reinterpret_cast<const uint4*>(base[t] + (size_t)px * cs[t]), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = fmaf(v[e], gate[t * C + cg * 8 + e], o[e]);
+                }
+            }
+            *reinterpret_cast<uint4*>(dst + (size_t)px * out_cs) = pack8(o);
+        }
+    }
+}
+
 // OSNet head: global average pool -> Linear(C -> D) + folded BN1d + ReLU -> L2 normalise
 // (models/reid.py OUTPUT_LAYOUT = 512; feature_extractor.py:73).  One block per sample.
 __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
@@ -254,6 +389,16 @@ int launch_dwconv3(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, 
     return 0;
 }
 
+int launch_spp(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H, int W,
+               int C, hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 && out_coff % 8 == 0);
+    FM_CHECK_ARG(H * W <= SPP_MAX_HW);
+    hipLaunchKernelGGL(spp_kernel, dim3((unsigned)((long)N * (C / 8))), dim3(256), 0, s, in, in_cs, in_coff, out,
+                       out_cs, out_coff, H, W, C);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
                 int W, int C, int Ho, int Wo, int k, int stride, int pad, int avg, hipStream_t s) {
     FM_CHECK_ARG(C % 8 == 0 && in_cs % 8 == 0 && in_coff % 8 == 0 && out_cs % 8 == 0 && out_coff % 8 == 0);
@@ -290,6 +435,26 @@ int launch_gate(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int
     const size_t shmem = sizeof(float) * ((size_t)groups * C + C + hid);
     hipLaunchKernelGGL(gate_kernel, dim3(N), dim3(256), shmem, s, in, in_cs, in_coff, HW, C, hid, w1, b1, w2,
                        b2, gate);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
+                     int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
+                     int out_cs, int out_coff, hipStream_t s) {
+    FM_CHECK_ARG(nstreams >= 1 && nstreams <= 4 && C % 8 == 0 && C / 8 <= GS_THREADS && out_cs % 8 == 0 &&
+                 out_coff % 8 == 0 && hid >= 1);
+    GateSumArgs a{};
+    a.nstreams = nstreams;
+    for (int t = 0; t < nstreams; ++t) {
+        FM_CHECK_ARG(in_cs[t] % 8 == 0 && in_coff[t] % 8 == 0);
+        a.in[t] = in[t]; a.in_cs[t] = in_cs[t]; a.in_coff[t] = in_coff[t];
+    }
+    const int groups = GS_THREADS / (C / 8);
+    const size_t shmem = ((size_t)groups * C + 8 * C + 4 * hid) * sizeof(float);
+    FM_CHECK_ARG(shmem <= 64 * 1024);
+    hipLaunchKernelGGL(gated_sum_kernel, dim3(N), dim3(GS_THREADS), shmem, s, a, HW, C, hid, w1, b1, w2, b2, out,
+                       out_cs, out_coff);
     FM_HIP(hipGetLastError());
     return 0;
 }

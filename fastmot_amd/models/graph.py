@@ -11,7 +11,8 @@ import ctypes as C
 import numpy as np
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV) = range(10)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM) = range(12)
+SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 
@@ -26,7 +27,7 @@ class fm_layer(C.Structure):
                 ('out', C.c_int32), ('out_coff', C.c_int32),
                 ('res', C.c_int32), ('res_coff', C.c_int32), ('res_mode', C.c_int32),
                 ('cin', C.c_int32), ('cout', C.c_int32), ('k', C.c_int32), ('stride', C.c_int32),
-                ('pad', C.c_int32), ('act', C.c_int32), ('hid', C.c_int32),
+                ('pad', C.c_int32), ('act', C.c_int32), ('hid', C.c_int32), ('up', C.c_int32),
                 ('gate', C.c_int32 * 4),
                 ('w_off', C.c_int64), ('b_off', C.c_int64), ('w2_off', C.c_int64), ('b2_off', C.c_int64)]
 
@@ -113,21 +114,22 @@ class Graph:
 
     def _layer(self, **kw):
         d = dict(op=0, ins=[], out=None, res=None, res_mode=RES_NONE, cin=0, cout=0, k=1, stride=1, pad=0,
-                 act=0, hid=0, gates=[], w_off=0, b_off=0, w2_off=0, b2_off=0)
+                 act=0, hid=0, up=1, gates=[], w_off=0, b_off=0, w2_off=0, b2_off=0)
         d.update(kw)
         self.layers.append(d)
         return d
 
     # ---------------------------------------------------------------- ops
     def conv(self, name, x, cout, k=1, stride=1, act='linear', bn=True, dst=None, res=None,
-             res_mode=RES_AFTER_ACT, f32_out=False, pad=None, bias=True):
+             res_mode=RES_AFTER_ACT, f32_out=False, pad=None, bias=True, up=1):
         cin_pad = x.cpad
         pad = k // 2 if pad is None else pad
         ho = (x.h + 2 * pad - k) // stride + 1
         wo = (x.w + 2 * pad - k) // stride + 1
         if dst is None:
-            dst = self.new(ho, wo, cout, f32=f32_out)
-        assert dst.h == ho and dst.w == wo and dst.c == cout, (name, dst.h, ho, dst.c, cout)
+            dst = self.new(ho * up, wo * up, cout, f32=f32_out)
+        assert dst.h == ho * up and dst.w == wo * up and dst.c == cout, (name, dst.h, ho, dst.c, cout)
+        assert up in (1, 2) and not (up == 2 and f32_out)
         p = self.wsrc.conv(name, cout, x.c, k, bn=bn)
         w, b = fold_bn(p)
         if not bias:
@@ -144,7 +146,7 @@ class Graph:
         bias = np.zeros(cpad, np.float32)
         bias[:cout] = b
         lay = self._layer(op=OP_CONV, ins=[x], out=dst, cin=cin_pad, cout=cout, k=k, stride=stride, pad=pad,
-                          act=ACT[act], w_off=self._push(packed), b_off=self._push(bias),
+                          act=ACT[act], up=up, w_off=self._push(packed), b_off=self._push(bias),
                           res=res, res_mode=res_mode if res is not None else RES_NONE, name=name)
         self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
         return dst
@@ -165,14 +167,10 @@ class Graph:
         self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
         return dst
 
-    def lightconv(self, name, x, cout, act='relu', fuse=True):
-        """torchreid LightConv3x3: 1x1 conv (linear, bias=False) -> depthwise 3x3 (bias=False) -> BN -> act.
-        Fused into one FM_OP_LITECONV launch when cin == cout <= 128, else two layers; both forms
-        draw the same parameters in the same order."""
-        if not (fuse and x.c == cout and cout <= 128 and x.coff % 8 == 0):
-            y = self.conv(name + '.pw', x, cout, 1, 1, 'linear', bn=False, bias=False)
-            return self.dwconv3(name + '.dw', y, act)
-        c, cp = cout, x.cpad
+    def lightconv_params(self, name, c):
+        """Draws + packs the parameters of one torchreid LightConv3x3 (1x1 linear bias=False ->
+        depthwise 3x3 bias=False -> BN): pointwise first, then depthwise, as the unfused layers do."""
+        cp = ceil_to(c, 8)
         pw = self.wsrc.conv(name + '.pw', c, c, 1, bn=False)['w'].astype(np.float16)     # [c, c, 1, 1]
         packed = np.zeros((ceil_to(c, 32), ceil_to(cp, 64)), np.float16)
         packed[:c, :c] = pw.reshape(c, c)
@@ -182,11 +180,33 @@ class Graph:
         wk[:, :c] = wd16.reshape(c, 9).T
         bias = np.zeros(cp, np.float32)
         bias[:c] = bd
-        dst = self.new(x.h, x.w, c)
-        self._layer(op=OP_LITECONV, ins=[x], out=dst, cin=cp, cout=c, k=3, stride=1, pad=1, act=ACT[act],
-                    w_off=self._push(packed), w2_off=self._push(wk), b_off=self._push(bias), name=name,
-                    lite_ref=(pw.astype(np.float32), wd16.astype(np.float32), bd))
+        return dict(pw=packed, dw=wk, bias=bias, ref=(pw.astype(np.float32), wd16.astype(np.float32), bd))
+
+    def lightconv_group(self, name, xs, params, act='relu', dst=None):
+        """G = len(xs) <= 4 independent fused LightConv3x3 of equal geometry in ONE launch
+        (FM_OP_LITECONV, blockIdx.y = group): group i reads view xs[i] and writes channels
+        [i*c, (i+1)*c) of the returned view.  c == xs[i].c <= 128 and c % 8 == 0 when G > 1."""
+        G, c = len(xs), xs[0].c
+        assert 1 <= G <= 4 and c <= 128 and all(x.c == c and x.coff % 8 == 0 and (x.h, x.w) == (xs[0].h, xs[0].w) for x in xs)
+        assert G == 1 or c % 8 == 0
+        if dst is None:
+            dst = self.new(xs[0].h, xs[0].w, G * c)
+        assert dst.c == G * c
+        self._layer(op=OP_LITECONV, ins=list(xs), out=dst, cin=xs[0].cpad, cout=c, k=3, stride=1, pad=1, act=ACT[act],
+                    w_off=self._push(np.stack([p['pw'] for p in params])),
+                    w2_off=self._push(np.stack([p['dw'] for p in params])),
+                    b_off=self._push(np.stack([p['bias'] for p in params])), name=name,
+                    lite_ref=[p['ref'] for p in params])
         return dst
+
+    def lightconv(self, name, x, cout, act='relu', fuse=True):
+        """torchreid LightConv3x3: 1x1 conv (linear, bias=False) -> depthwise 3x3 (bias=False) -> BN -> act.
+        Fused into one FM_OP_LITECONV launch when cin == cout <= 128, else two layers; both forms
+        draw the same parameters in the same order."""
+        if not (fuse and x.c == cout and cout <= 128 and x.coff % 8 == 0):
+            y = self.conv(name + '.pw', x, cout, 1, 1, 'linear', bn=False, bias=False)
+            return self.dwconv3(name + '.dw', y, act)
+        return self.lightconv_group(name, [x], [self.lightconv_params(name, cout)], act)
 
     def pool(self, x, k, stride, pad, avg=False, dst=None):
         ho = (x.h + 2 * pad - k) // stride + 1
@@ -196,6 +216,18 @@ class Graph:
         assert dst.h == ho and dst.w == wo
         self._layer(op=OP_AVGPOOL if avg else OP_MAXPOOL, ins=[x], out=dst, cin=x.cpad, cout=x.c, k=k,
                     stride=stride, pad=pad)
+        return dst
+
+    def spp(self, x, dst):
+        """Stride-1 max pools k = 13, 9, 5 of x into dst channels [0,c), [c,2c), [2c,3c) (dst: a view of
+        3*x.c channels).  One fused launch when the map fits LDS, else three pool layers."""
+        c = x.c
+        assert dst.c == 3 * c and dst.h == x.h and dst.w == x.w and c % 8 == 0
+        if x.h * x.w > SPP_MAX_HW:
+            for i, k in enumerate((13, 9, 5)):
+                self.pool(x, k, 1, k // 2, dst=dst.slice(i * c, c))
+            return dst
+        self._layer(op=OP_SPP, ins=[x], out=dst, cin=x.cpad, cout=c, k=5, stride=1, pad=2)
         return dst
 
     def upsample2(self, x, dst=None):
@@ -231,6 +263,28 @@ class Graph:
                     gate_ref=gate_params['ref'],
                     **{k: gate_params[k] for k in ('w_off', 'b_off', 'w2_off', 'b2_off')})
         return gid, gate_params
+
+    def gated_sum(self, name, xs, hid, dst=None):
+        """OSNet unified aggregation gate fused: out = sum_i xs[i] * ChannelGate(xs[i]) with one shared
+        gate (fc1: c -> hid, ReLU, fc2: hid -> c, sigmoid) -- FM_OP_GATED_SUM, one launch."""
+        x = xs[0]
+        c = x.c
+        assert 1 <= len(xs) <= 4 and all(v.c == c and v.coff % 8 == 0 for v in xs)
+        p1 = self.wsrc.conv(name + '.fc1', hid, c, 1, bn=False)
+        p2 = self.wsrc.conv(name + '.fc2', c, hid, 1, bn=False)
+        w1 = np.zeros((hid, x.cpad), np.float16)
+        w1[:, :c] = p1['w'].reshape(hid, c).astype(np.float16)
+        w2 = np.zeros((x.cpad, hid), np.float16)
+        w2[:c] = p2['w'].reshape(c, hid).astype(np.float16)
+        b2 = np.zeros(x.cpad, np.float32)
+        b2[:c] = p2['bias']
+        if dst is None:
+            dst = self.new(x.h, x.w, c)
+        self._layer(op=OP_GATED_SUM, ins=list(xs), out=dst, cin=x.cpad, cout=c, hid=hid, name=name,
+                    w_off=self._push(w1), b_off=self._push(p1['bias'].astype(np.float32)),
+                    w2_off=self._push(w2), b2_off=self._push(b2),
+                    gate_ref=(w1[:, :c].astype(np.float32), p1['bias'], w2[:c].astype(np.float32), p2['bias']))
+        return dst
 
     def gate_sum(self, xs, gids, dst=None):
         x = xs[0]
@@ -301,7 +355,7 @@ class Graph:
             else:
                 L.res, L.res_coff = -1, 0
             L.res_mode = d['res_mode']
-            for key in ('cin', 'cout', 'k', 'stride', 'pad', 'act', 'hid', 'w_off', 'b_off', 'w2_off', 'b2_off'):
+            for key in ('cin', 'cout', 'k', 'stride', 'pad', 'act', 'hid', 'up', 'w_off', 'b_off', 'w2_off', 'b2_off'):
                 setattr(L, key, d[key])
             for j in range(4):
                 L.gate[j] = d['gates'][j] if j < len(d['gates']) else -1

@@ -91,29 +91,29 @@ def yolov4_graph(model, weights):
     x = conv(x, 1024, 3, **lk)
     spp = g.new(x.h, x.w, 2048)
     xs = conv(x, 512, 1, dst=spp.slice(1536, 512), **lk)
-    g.pool(xs, 13, 1, 6, dst=spp.slice(0, 512))
-    g.pool(xs, 9, 1, 4, dst=spp.slice(512, 512))
-    g.pool(xs, 5, 1, 2, dst=spp.slice(1024, 512))
+    g.spp(xs, spp.slice(0, 1536))
     x = conv(spp, 512, 1, **lk)
     x = conv(x, 1024, 3, **lk)
-    p5 = conv(x, 512, 1, **lk)
+    # concat operands are written in place by their producers (no copy layers), and the two
+    # [upsample] layers are folded into the 1x1 convs that feed them (conv ... up=2)
+    d5 = g.new(x.h, x.w, 1024)
+    p5 = conv(x, 512, 1, dst=d5.slice(512, 512), **lk)
 
-    def five(x, c):
+    def five(x, c, dst=None):
         x = conv(x, c, 1, **lk)
         x = conv(x, 2 * c, 3, **lk)
         x = conv(x, c, 1, **lk)
         x = conv(x, 2 * c, 3, **lk)
-        return conv(x, c, 1, **lk)
+        return conv(x, c, 1, dst=dst, **lk)
 
     u4 = g.new(t4.h, t4.w, 512)
-    up = conv(p5, 256, 1, **lk)
-    g.upsample2(up, dst=u4.slice(256, 256))
+    conv(p5, 256, 1, dst=u4.slice(256, 256), up=2, **lk)
     conv(t4, 256, 1, dst=u4.slice(0, 256), **lk)
-    n4 = five(u4, 256)
+    d4 = g.new(t4.h, t4.w, 512)
+    n4 = five(u4, 256, dst=d4.slice(256, 256))
 
     u3 = g.new(t3.h, t3.w, 256)
-    up = conv(n4, 128, 1, **lk)
-    g.upsample2(up, dst=u3.slice(128, 128))
+    conv(n4, 128, 1, dst=u3.slice(128, 128), up=2, **lk)
     conv(t3, 128, 1, dst=u3.slice(0, 128), **lk)
     n3 = five(u3, 128)
 
@@ -124,16 +124,12 @@ def yolov4_graph(model, weights):
     x = conv(n3, 256, 3, **lk)
     heads.append(conv(x, n_out, 1, act=head_act, bn=False, f32_out=True))
 
-    d4 = g.new(n4.h, n4.w, 512)
     conv(n3, 256, 3, 2, dst=d4.slice(0, 256), **lk)
-    g.copy(n4, d4.slice(256, 256))
     m4 = five(d4, 256)
     x = conv(m4, 512, 3, **lk)
     heads.append(conv(x, n_out, 1, act=head_act, bn=False, f32_out=True))
 
-    d5 = g.new(p5.h, p5.w, 1024)
     conv(m4, 512, 3, 2, dst=d5.slice(0, 512), **lk)
-    g.copy(p5, d5.slice(512, 512))
     m5 = five(d5, 512)
     x = conv(m5, 1024, 3, **lk)
     heads.append(conv(x, n_out, 1, act=head_act, bn=False, f32_out=True))

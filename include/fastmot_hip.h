@@ -179,8 +179,17 @@ enum {
     FM_OP_GATE = 6,      /* OSNet channel gate: GAP -> fc1 -> ReLU -> fc2 -> sigmoid -> gate[0] */
     FM_OP_GATE_SUM = 7,  /* out = sum_i in[i] * gate[i]                                         */
     FM_OP_HEAD = 8,      /* GAP -> Linear(+BN1d) -> ReLU -> L2 normalise -> ctx embeddings      */
-    FM_OP_LITECONV = 9   /* fused OSNet LightConv3x3: 1x1 linear (w_off, no bias) -> depthwise 3x3
-                          * (w2_off) + bias (b_off) + act; cin == cout <= 128                   */
+    FM_OP_SPP = 10,      /* darknet SPP block: stride-1 max pools k = 13, 9, 5 of in[0] (cin channels)
+                          * written to out at channel offsets out_coff + {0, cin, 2 cin}; one launch,
+                          * pool9 = pool5 o pool5, pool13 = pool5 o pool9, separable, in LDS      */
+    FM_OP_LITECONV = 9,  /* fused OSNet LightConv3x3: 1x1 linear (w_off, no bias) -> depthwise 3x3
+                          * (w2_off) + bias (b_off) + act; cin == cout <= 128.  n_in = G <= 4
+                          * independent LightConvs of equal geometry in one launch: group g reads
+                          * in[g]/in_coff[g], writes out channels [out_coff + g*cin, +cin) and uses
+                          * the g-th slab of the stacked weights                                */
+    FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
+                          * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
+                          * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */
 };
 enum { FM_ACT_LINEAR = 0, FM_ACT_LEAKY = 1, FM_ACT_MISH = 2, FM_ACT_RELU = 3, FM_ACT_LOGISTIC = 4,
        FM_ACT_SWISH = 5 };
@@ -202,6 +211,8 @@ typedef struct fm_layer {
     int32_t res, res_coff, res_mode;
     int32_t cin, cout, k, stride, pad, act;
     int32_t hid;
+    int32_t up;          /* CONV: nearest-neighbour upsampling factor of the stored output (1 or 2):
+                          * the [upsample] layer of yolo2onnx.py:806-836 folded into its producer */
     int32_t gate[4];
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob (16 B aligned) */
 } fm_layer;

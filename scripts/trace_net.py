@@ -1,0 +1,19 @@
+"""Runs one network a few times (graph replay) so that `rocprofv3 --kernel-trace` records per-dispatch
+durations; scripts/rocpd_dispatches.py then lists the last replay dispatch by dispatch."""
+import sys
+sys.path.insert(0, '.')
+from fastmot_amd.runtime import get_context
+from fastmot_amd.engine import HipNet
+from fastmot_amd.models import YOLO, ReID
+
+which = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ctx = get_context()
+if which == 0:
+    g, _ = YOLO.get_model('YOLOv4_608').build_graph(); batch = 1
+else:
+    ctx.feat_configure(512)
+    g, _ = ReID.get_model('OSNet025').build_graph(); batch = 50
+net = HipNet(ctx, which, g, batch, reuse_buffers=True)
+for _ in range(6):
+    net.run(batch)
+    ctx.synchronize()

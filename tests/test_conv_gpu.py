@@ -58,6 +58,28 @@ def test_single_conv(ctx, cin, cout, k, stride, act, h, w, n):
     net.close()
 
 
+def test_splitk_repeated_runs(ctx):
+    """Split-K layers hand their fp32 partials to the last-arriving workgroup through a workspace that
+    every layer and every run reuses: results must track the inputs run after run (no stale cached
+    partials, counters self-reset) and be deterministic."""
+    g = Graph(RandomWeights(seed=31), (19, 19), 256)
+    a = g.conv('a', g.input, 512, 3, 1, 'leaky')
+    b = g.conv('b', a, 256, 1, 1, 'leaky')
+    c = g.conv('c', b, 512, 3, 1, 'mish', res=a)
+    net = HipNet(ctx, NET_DETECTOR, g, 1)
+    rng = np.random.default_rng(32)
+    for it in range(4):
+        x = rng.normal(0, 1 + it, (1, 19, 19, 256)).astype(np.float16)
+        net.write(g.input, x)
+        net.run(1)
+        first = net.read(c, 1)
+        bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+        close(first, nhwc(bufs[c.tid][:, :512]), what=f'split-K run {it}')
+        net.run(1)
+        np.testing.assert_array_equal(first, net.read(c, 1))
+    net.close()
+
+
 def test_conv_residual_concat_fp32_out(ctx):
     rng = np.random.default_rng(5)
     g = Graph(RandomWeights(seed=9), (24, 24), 32)
@@ -102,6 +124,51 @@ def test_pool_upsample_dw_gate_ops(ctx):
     net.close()
 
 
+@pytest.mark.parametrize('c,h,w,n', [(512, 19, 19, 1), (16, 7, 5, 3), (64, 40, 23, 2)])
+def test_spp_fused(ctx, c, h, w, n):
+    """Fused SPP (k = 13, 9, 5 cascade in LDS) == three independent max-pool launches == torch."""
+    rng = np.random.default_rng(c)
+    x = rng.normal(0, 1, (n, h, w, c)).astype(np.float16)
+    g = Graph(RandomWeights(seed=1), (h, w), c)
+    fused = g.new(h, w, 4 * c)
+    g.spp(g.input, fused.slice(c, 3 * c))
+    assert g.layers[-1]['op'] == 10
+    plain = g.new(h, w, 3 * c)
+    for i, k in enumerate((13, 9, 5)):
+        g.pool(g.input, k, 1, k // 2, dst=plain.slice(i * c, c))
+    net = HipNet(ctx, NET_DETECTOR, g, n)
+    net.write(g.input, x)
+    net.run(n)
+    a, b = net.read(fused, n)[..., c:], net.read(plain, n)
+    np.testing.assert_array_equal(a, b)
+    bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+    np.testing.assert_array_equal(a, nhwc(bufs[plain.tid][:, :3 * c]))
+    net.close()
+
+
+@pytest.mark.parametrize('cin,cout,h,w,n', [(512, 256, 19, 19, 1), (64, 24, 6, 9, 2)])
+def test_conv_fused_upsample(ctx, cin, cout, h, w, n):
+    """conv(up=2) == conv followed by the nearest x2 upsample layer (split-K path for the first case)."""
+    rng = np.random.default_rng(cin)
+    x = rng.normal(0, 1, (n, h, w, cin)).astype(np.float16)
+    g = Graph(RandomWeights(seed=2), (h, w), cin)
+    cat = g.new(2 * h, 2 * w, cout + 8)
+    g.conv('c', g.input, cout, 1, 1, 'leaky', dst=cat.slice(8, cout), up=2)
+    g2 = Graph(RandomWeights(seed=2), (h, w), cin)
+    y = g2.conv('c', g2.input, cout, 1, 1, 'leaky')
+    u = g2.upsample2(y)
+    outs = []
+    for gg, v in ((g, cat), (g2, u)):
+        net = HipNet(ctx, NET_DETECTOR, gg, n)
+        net.write(gg.input, x)
+        net.run(n)
+        outs.append(net.read(v, n))
+        net.close()
+    np.testing.assert_array_equal(outs[0][..., 8:8 + cout], outs[1][..., :cout])
+    bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+    close(outs[0][..., 8:8 + cout], nhwc(bufs[cat.tid][:, 8:8 + cout]), what='conv up2')
+
+
 @pytest.mark.parametrize('c,h,w,n', [(16, 64, 32, 3), (24, 32, 16, 5), (32, 16, 8, 7), (16, 21, 19, 2),
                                      (8, 5, 3, 1), (64, 20, 17, 2), (96, 32, 16, 2), (128, 16, 8, 3),
                                      (72, 9, 24, 1)])
@@ -126,24 +193,77 @@ def test_lightconv_fused(ctx, c, h, w, n):
 
 
 def test_osnet_fused_and_arena_reuse_identical(ctx):
-    """The production configuration (fused LightConv, activation arena shared between tensors with
-    disjoint live ranges) gives the same embeddings, bit for bit, as the plain layer-per-kernel
-    private-buffer configuration."""
+    """The production configuration (grouped fused LightConv + fused gated sum: 53 launches, activation
+    arena shared between tensors with disjoint live ranges) against the layer-per-kernel graph (173
+    launches, private buffers): arena reuse changes nothing bit for bit; the fused graph differs only
+    by the summation grouping of the gate's average pool."""
     class Small(ReID.get_model('OSNet025')):
         INPUT_SHAPE = (3, 128, 64)
     rng = np.random.default_rng(3)
     x = rng.normal(0, 1, (6, 128, 64, 3)).astype(np.float16)
     ctx.feat_configure(512)
-    embs = []
-    for fuse, reuse in ((False, False), (True, True)):
+    embs = {}
+    for fuse, reuse in ((False, False), (True, False), (True, True)):
         g, _ = Small.build_graph(RandomWeights(seed=5), fuse_lightconv=fuse)
+        assert len(g.layers) == (53 if fuse else 173)
         net = HipNet(ctx, NET_EXTRACTOR, g, 6, reuse_buffers=reuse)
         for _ in range(2):                      # second run: stale arena contents must not matter
             net.write(g.input, x)
             net.run(6)
-        embs.append(net.read_embeddings(6))
+        embs[fuse, reuse] = net.read_embeddings(6)
         net.close()
-    np.testing.assert_array_equal(embs[0], embs[1])
+    np.testing.assert_array_equal(embs[True, False], embs[True, True])
+    assert np.abs(embs[True, True] - embs[False, False]).max() < 2e-3
+    assert (np.sum(embs[True, True] * embs[False, False], axis=1) > 0.9999).all()
+
+
+@pytest.mark.parametrize('c,hid,h,w,n,k', [(16, 1, 64, 32, 3, 4), (24, 1, 32, 16, 5, 4), (32, 2, 16, 8, 2, 4),
+                                           (128, 8, 16, 8, 2, 3), (64, 4, 9, 7, 1, 2)])
+def test_gated_sum_fused(ctx, c, hid, h, w, n, k):
+    """FM_OP_GATED_SUM == k gate launches + gate_sum (up to the average-pool grouping) == torch."""
+    rng = np.random.default_rng(c)
+    x = rng.normal(0, 1, (n, h, w, k * c)).astype(np.float16)
+    outs = []
+    for fused in (True, False):
+        g = Graph(RandomWeights(seed=c), (h, w), k * c)
+        xs = [g.input.slice(i * c, c) for i in range(k)]
+        if fused:
+            y = g.gated_sum('gate', xs, hid)
+        else:
+            gp, gids = None, []
+            for v in xs:
+                gid, gp = g.gate('gate', v, hid, gp)
+                gids.append(gid)
+            y = g.gate_sum(xs, gids)
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        net.write(g.input, x)
+        net.run(n)
+        outs.append(net.read(y, n))
+        bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+        close(outs[-1], nhwc(bufs[y.tid][:, :c]), what=f'gated_sum fused={fused}')
+        net.close()
+    assert np.abs(outs[0] - outs[1]).max() <= 4e-3 * np.abs(outs[1]).max()
+
+
+def test_lightconv_grouped(ctx):
+    """Four LightConvs in one launch (blockIdx.y = group) == four single launches, bit for bit."""
+    c, h, w, n = 16, 32, 16, 4
+    rng = np.random.default_rng(1)
+    x = rng.normal(0, 1, (n, h, w, 2 * c)).astype(np.float16)
+    g = Graph(RandomWeights(seed=4), (h, w), 2 * c)
+    ins = [g.input.slice(0, c), g.input.slice(c, c), g.input.slice(0, c)]
+    params = [g.lightconv_params(f'p{i}', c) for i in range(3)]
+    grouped = g.lightconv_group('grp', ins, params)
+    singles = [g.lightconv_group(f's{i}', [ins[i]], [params[i]]) for i in range(3)]
+    net = HipNet(ctx, NET_DETECTOR, g, n)
+    net.write(g.input, x)
+    net.run(n)
+    full = net.read(grouped, n)
+    bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+    for i, s in enumerate(singles):
+        np.testing.assert_array_equal(full[..., i * c:(i + 1) * c], net.read(s, n))
+    close(full, nhwc(bufs[grouped.tid][:, :3 * c]), what='grouped lightconv')
+    net.close()
 
 
 def test_yolov4_arena_reuse_identical(ctx):

@@ -57,18 +57,34 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             y = act_fn(y, d['act'])
             if d['res_mode'] == G.RES_AFTER_ACT:
                 y = y + rd(d['res'])
+            if d['up'] == 2:
+                y = F.interpolate(y, scale_factor=2, mode='nearest')
             wr(d['out'], y, f32=bool(graph.tensors[d['out'].tid][3]))
         elif op == G.OP_DWCONV3:
             w, b = params[idx]
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), padding=1, groups=xin.shape[1])
             wr(d['out'], act_fn(y, d['act']))
         elif op == G.OP_LITECONV:
-            pw, wd, bd = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['lite_ref'])
-            y = F.conv2d(xin, pw)
-            if emulate_fp16_storage:
-                y = y.half().float()
-            y = F.conv2d(y, wd, bd, padding=1, groups=y.shape[1])
-            wr(d['out'], act_fn(y, d['act']))
+            c = d['cout']
+            for gi, (v, ref) in enumerate(zip(d['ins'], d['lite_ref'])):
+                pw, wd, bd = (torch.from_numpy(np.asarray(a, np.float32)) for a in ref)
+                y = F.conv2d(rd(v), pw)
+                if emulate_fp16_storage:
+                    y = y.half().float()
+                y = F.conv2d(y, wd, bd, padding=1, groups=y.shape[1])
+                wr(d['out'].slice(gi * c, c), act_fn(y, d['act']))
+        elif op == G.OP_GATED_SUM:
+            w1, b1, w2, b2 = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['gate_ref'])
+            y = 0
+            for v in d['ins']:
+                xv = rd(v)
+                hid = F.relu(xv.mean(dim=(2, 3)) @ w1.T + b1)
+                y = y + xv * torch.sigmoid(hid @ w2.T + b2)[:, :, None, None]
+            wr(d['out'], y)
+        elif op == G.OP_SPP:
+            c = d['cout']
+            for i, k in enumerate((13, 9, 5)):
+                wr(d['out'].slice(i * c, c), F.max_pool2d(xin, k, 1, k // 2))
         elif op == G.OP_MAXPOOL:
             wr(d['out'], F.max_pool2d(xin, d['k'], d['stride'], d['pad']))
         elif op == G.OP_AVGPOOL:
