@@ -99,6 +99,14 @@ class HipContext:
     def synchronize(self):
         check(self.lib.fm_ctx_synchronize(self._ctx))
 
+    def set_option(self, key, value):
+        """Tunables of the context: 'zero_copy_tracks', 'host_lap_elems' (include/fastmot_hip.h)."""
+        check(self.lib.fm_ctx_set_option(self._ctx, key.encode(), C.c_int(int(value))))
+
+    def bind_thread(self):
+        """Called once by every additional host thread that drives this context."""
+        check(self.lib.fm_ctx_bind_thread(self._ctx))
+
     def device_info(self):
         buf = C.create_string_buffer(256)
         check(self.lib.fm_device_info(self._ctx, buf, 256))

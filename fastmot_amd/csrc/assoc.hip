@@ -234,7 +234,8 @@ constexpr int LAP_CODE_BIG = 1 << 24;
 __global__ __launch_bounds__(64) void lap_kernel(const double* __restrict__ gcost, int nr, int nc,
                                                  long rs, long cs, double* __restrict__ gwd,
                                                  int32_t* __restrict__ gwi,
-                                                 int32_t* __restrict__ col4row_out, int lds_mode) {
+                                                 int32_t* __restrict__ col4row_out,
+                                                 double* __restrict__ mcost_out, int lds_mode) {
     extern __shared__ __attribute__((aligned(16))) char lap_smem[];
     const int lane = threadIdx.x;
     const size_t wd_elems = (size_t)nr + 2 * (size_t)nc;
@@ -329,7 +330,114 @@ __global__ __launch_bounds__(64) void lap_kernel(const double* __restrict__ gcos
         }
         __syncthreads();
     }
-    for (int r = lane; r < nr; r += 64) col4row_out[r] = col4row[r];
+    for (int r = lane; r < nr; r += 64) {
+        col4row_out[r] = col4row[r];
+        mcost_out[r] = cost[(long)r * rs + (long)col4row[r] * cs];
+    }
+}
+
+// Register-resident variant for nr <= nc <= 64 (the common frame: a few dozen tracks / detections):
+// lane j owns column j (v, shortest path cost, path, row4col, visited flag, its position in SciPy's
+// `remaining` list -- the scan position decides ties) and lane r owns row r (u, col4row, visited flag).
+// No work arrays in memory, no barriers; the argmin of every search step is a DPP reduction
+// (row_shr 1/2/4/8, row_bcast 15/31 -> lane 63) and every indexed access a v_readlane with a uniform
+// index -- ds_bpermute shuffles made the step ~2000 cycles.  Same arithmetic, scan order and
+// tie-breaking as lap_kernel, i.e. as scipy.optimize.linear_sum_assignment.
+__device__ __forceinline__ int lane_read(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_read(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// (best, bcode) <- lexicographic min over (value ascending, code descending) with the lane selected by
+// the DPP control; lanes without a source see their own value (idempotent)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void lap_min_step(double& best, int& bcode) {
+    const long long b = __double_as_longlong(best);
+    const int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int oc = __builtin_amdgcn_update_dpp(bcode, bcode, CTRL, ROW_MASK, 0xf, false);
+    const double ob = __longlong_as_double((long long)(((unsigned long long)ohi << 32) | olo));
+    if (ob < best || (ob == best && oc > bcode)) { best = ob; bcode = oc; }
+}
+
+__global__ __launch_bounds__(64) void lap64_kernel(const double* __restrict__ gcost, int nr, int nc, long rs,
+                                                   long cs, int32_t* __restrict__ col4row_out,
+                                                   double* __restrict__ mcost_out) {
+    __shared__ double lc[64 * 64];
+    const int lane = threadIdx.x;
+    for (int idx = lane; idx < nr * nc; idx += 64) {
+        const int i = idx / nc, j = idx % nc;
+        lc[idx] = gcost[(long)i * rs + (long)j * cs];
+    }
+    __syncthreads();
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    const bool is_col = lane < nc;
+    double u = 0., v = 0.;
+    int col4row = -1, row4col = -1, path = -1;
+    for (int cur = 0; cur < nr; ++cur) {
+        double spc = INF;
+        int SC = 0, SR = 0, pos = nc - lane - 1;
+        int num_remaining = nc, sink = -1, i = cur;
+        double minVal = 0.;
+        while (sink == -1) {
+            if (lane == i) SR = 1;
+            const double ui = lane_read(u, i);
+            double best = INF;
+            int bcode = -1;
+            if (is_col && !SC) {
+                const double r = ((minVal + lc[i * nc + lane]) - ui) - v;
+                if (r < spc) { path = i; spc = r; }
+                best = spc;
+                bcode = (row4col == -1) ? (LAP_CODE_BIG + pos) : (LAP_CODE_BIG - 1 - pos);
+            }
+            lap_min_step<0x111, 0xf>(best, bcode);   // row_shr:1
+            lap_min_step<0x112, 0xf>(best, bcode);   // row_shr:2
+            lap_min_step<0x114, 0xf>(best, bcode);   // row_shr:4
+            lap_min_step<0x118, 0xf>(best, bcode);   // row_shr:8  -> lane 15 of every row
+            lap_min_step<0x142, 0xa>(best, bcode);   // row_bcast:15 into rows 1, 3
+            lap_min_step<0x143, 0xc>(best, bcode);   // row_bcast:31 into rows 2, 3 -> lane 63
+            best = lane_read(best, 63);
+            bcode = lane_read(bcode, 63);
+            if (bcode < 0 || best == INF) { sink = -2; break; }   // infeasible
+            minVal = best;
+            const int index = bcode >= LAP_CODE_BIG ? bcode - LAP_CODE_BIG : LAP_CODE_BIG - 1 - bcode;
+            const unsigned long long at_index = __ballot(is_col && !SC && pos == index);
+            const unsigned long long at_last = __ballot(is_col && !SC && pos == num_remaining - 1);
+            const int j = __ffsll((long long)at_index) - 1;
+            const int jl = __ffsll((long long)at_last) - 1;
+            const int r4c = lane_read(row4col, j);
+            if (r4c == -1) sink = j; else i = r4c;
+            // remaining[index] = remaining[num_remaining - 1]
+            if (lane == jl && jl != j) pos = index;
+            if (lane == j) SC = 1;
+            --num_remaining;
+        }
+        if (sink < 0) {   // cannot happen for finite costs; flag and stop
+            if (lane == 0) col4row_out[0] = -2;
+            return;
+        }
+        // dual update (col4row still the assignment before augmentation)
+        const double spc_c = __shfl(spc, col4row < 0 ? 0 : col4row);
+        if (lane < nr && SR && lane != cur) u += minVal - spc_c;
+        if (is_col && SC) v -= minVal - spc;
+        if (lane == cur) u += minVal;
+        int j = sink;
+        while (true) {   // augment
+            const int r = lane_read(path, j);
+            const int tmp = lane_read(col4row, r);
+            if (lane == j) row4col = r;
+            if (lane == r) col4row = j;
+            j = tmp;
+            if (r == cur) break;
+        }
+    }
+    if (lane < nr) {
+        col4row_out[lane] = col4row;
+        mcost_out[lane] = lc[lane * nc + col4row];
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -413,8 +521,11 @@ __global__ __launch_bounds__(256) void greedy_kernel(const double* __restrict__ 
     if (tid == 0) *n_match = s_state[0];
 }
 
+// Stages host inputs for a kernel and returns the pointer the kernel must read (`src`).  Small inputs
+// (zero_copy) stay in the pinned, device-mapped staging buffer and are read by the kernel over PCIe:
+// a blit H2D copy costs more (~10 us of runtime overhead + a copy kernel) than the few uncached reads.
 int upload(fm_ctx* ctx, DevBuf& buf, const std::vector<std::pair<const void*, size_t>>& parts,
-           std::vector<size_t>& offs) {
+           std::vector<size_t>& offs, char** src = nullptr, bool zero_copy = false) {
     size_t total = 0;
     offs.clear();
     for (auto& p : parts) {
@@ -427,23 +538,56 @@ int upload(fm_ctx* ctx, DevBuf& buf, const std::vector<std::pair<const void*, si
     char* h = buf.host<char>();
     for (size_t i = 0; i < parts.size(); ++i)
         if (parts[i].second) memcpy(h + offs[i], parts[i].first, parts[i].second);
-    if (total) FM_HIP(hipMemcpyAsync(buf.d, h, total, hipMemcpyHostToDevice, ctx->s_main));
+    if (src) *src = zero_copy ? h : buf.dev<char>();
+    if (total && !(zero_copy && src)) FM_HIP(hipMemcpyAsync(buf.d, h, total, hipMemcpyHostToDevice, ctx->s_main));
     return 0;
 }
 
 // Runs the LAP kernel on a device cost matrix [nr][nc]; outputs SciPy-ordered (rows, cols).
+// Outputs (col4row, cost of every assignment) are written by the kernel directly into the pinned host
+// buffer: one stream synchronise, no D2H blit.  m_cost (optional): cost[m_rows[k]][m_cols[k]].
+// h_cost (optional): the same matrix in pinned host memory, already complete (stream synchronised) --
+// small problems are then solved by fm_lap_host (see lap_host.hip for why).
 int run_lap(fm_ctx* ctx, const double* d_cost, int nr, int nc, int32_t* m_rows, int32_t* m_cols,
-            int* n_match) {
+            int* n_match, double* m_cost = nullptr, const double* h_cost = nullptr) {
     *n_match = 0;
     if (nr == 0 || nc == 0) return 0;
     const bool transpose = nc < nr;   // SciPy works on the transposed problem when nc < nr
     const int R = transpose ? nc : nr, C = transpose ? nr : nc;
     const long rs = transpose ? 1 : nc, cs = transpose ? nc : 1;
+    if (h_cost) {
+        std::vector<int32_t> c4r(R);
+        if (!fm_lap_host(h_cost, R, C, rs, cs, c4r.data())) {
+            fm_set_error("cost matrix is infeasible");
+            return FM_ERR_STATE;
+        }
+        if (!transpose) {
+            for (int i = 0; i < R; ++i) {
+                m_rows[i] = i; m_cols[i] = c4r[i];
+                if (m_cost) m_cost[i] = h_cost[(size_t)i * nc + c4r[i]];
+            }
+        } else {
+            std::vector<int> order(R);
+            for (int i = 0; i < R; ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return c4r[a] < c4r[b]; });
+            for (int k = 0; k < R; ++k) {
+                m_rows[k] = c4r[order[k]]; m_cols[k] = order[k];
+                if (m_cost) m_cost[k] = h_cost[(size_t)m_rows[k] * nc + m_cols[k]];
+            }
+        }
+        *n_match = R;
+        return 0;
+    }
     const size_t wd_bytes = sizeof(double) * (R + 2 * (size_t)C);
     const size_t wi_bytes = sizeof(int32_t) * (4 * (size_t)C + 2 * (size_t)R);
     int rc = ctx->as_work.reserve(wd_bytes + wi_bytes + 64);
     if (rc) return rc;
-    if ((rc = ctx->as_out.reserve(sizeof(int32_t) * (size_t)(R + 8)))) return rc;
+    const size_t mc_off = (sizeof(int32_t) * (size_t)(R + 8) + 15) & ~size_t(15);
+    if ((rc = ctx->as_out.reserve(mc_off + sizeof(double) * R))) return rc;
+    const bool zc = FM_ZERO_COPY_TRACKS > 0;
+    char* o_base = zc ? ctx->as_out.host<char>() : ctx->as_out.dev<char>();
+    int32_t* o_c4r = reinterpret_cast<int32_t*>(o_base);
+    double* o_mc = reinterpret_cast<double*>(o_base + mc_off);
     char* w = ctx->as_work.dev<char>();
     const size_t work_lds = ((wd_bytes + wi_bytes + 15) & ~size_t(15));
     const size_t cost_lds = sizeof(double) * (size_t)R * C;
@@ -460,24 +604,36 @@ int run_lap(fm_ctx* ctx, const double* d_cost, int nr, int nc, int32_t* m_rows, 
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(lap_kernel, dim3(1), dim3(64), shmem, ctx->s_main, d_cost, R, C, rs, cs, (double*)w,
-                       (int32_t*)(w + ((wd_bytes + 15) & ~size_t(15))), ctx->as_out.dev<int32_t>(), lds_mode);
+    if (C <= 64)
+        hipLaunchKernelGGL(lap64_kernel, dim3(1), dim3(64), 0, ctx->s_main, d_cost, R, C, rs, cs, o_c4r, o_mc);
+    else
+        hipLaunchKernelGGL(lap_kernel, dim3(1), dim3(64), shmem, ctx->s_main, d_cost, R, C, rs, cs, (double*)w,
+                           (int32_t*)(w + ((wd_bytes + 15) & ~size_t(15))), o_c4r, o_mc, lds_mode);
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(ctx->as_out.h, ctx->as_out.d, sizeof(int32_t) * R, hipMemcpyDeviceToHost, ctx->s_main));
+    if (!zc)
+        FM_HIP(hipMemcpyAsync(ctx->as_out.h, ctx->as_out.d, mc_off + sizeof(double) * R, hipMemcpyDeviceToHost,
+                              ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     const int32_t* c4r = ctx->as_out.host<int32_t>();
+    o_mc = reinterpret_cast<double*>(ctx->as_out.host<char>() + mc_off);
     if (c4r[0] == -2) {
         fm_set_error("cost matrix is infeasible");
         return FM_ERR_STATE;
     }
     if (!transpose) {
-        for (int i = 0; i < R; ++i) { m_rows[i] = i; m_cols[i] = c4r[i]; }
+        for (int i = 0; i < R; ++i) {
+            m_rows[i] = i; m_cols[i] = c4r[i];
+            if (m_cost) m_cost[i] = o_mc[i];
+        }
     } else {
         // rows of the original problem ascending: argsort(col4row)
         std::vector<int> order(R);
         for (int i = 0; i < R; ++i) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int a, int b) { return c4r[a] < c4r[b]; });
-        for (int k = 0; k < R; ++k) { m_rows[k] = c4r[order[k]]; m_cols[k] = order[k]; }
+        for (int k = 0; k < R; ++k) {
+            m_rows[k] = c4r[order[k]]; m_cols[k] = order[k];
+            if (m_cost) m_cost[k] = o_mc[order[k]];
+        }
     }
     *n_match = R;
     return 0;
@@ -494,11 +650,12 @@ int run_greedy(fm_ctx* ctx, const double* d_cost, int nr, int nc, double max_cos
     const size_t out_bytes = sizeof(int32_t) * (2 * (size_t)mn + 4);
     if ((rc = ctx->as_out.reserve(out_bytes))) return rc;
     char* w = ctx->as_work.dev<char>();
-    int32_t* o = ctx->as_out.dev<int32_t>();
+    const bool zc = FM_ZERO_COPY_TRACKS > 0;   // pinned, written by the kernel directly
+    int32_t* o = zc ? ctx->as_out.host<int32_t>() : ctx->as_out.dev<int32_t>();
     hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(256), 0, ctx->s_main, d_cost, nr, nc, max_cost,
                        (double*)w, (int32_t*)(w + o_rarg), (int32_t*)(w + o_alive), o + 4, o + 4 + mn, o);
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(ctx->as_out.h, ctx->as_out.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
+    if (!zc) FM_HIP(hipMemcpyAsync(ctx->as_out.h, ctx->as_out.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     const int32_t* ho = ctx->as_out.host<int32_t>();
     const int n = ho[0];
@@ -515,13 +672,15 @@ extern "C" int fm_find_occluded(fm_ctx* ctx, int n, const double* tlbr, double t
     if (n == 0) return 0;
     FM_CHECK_ARG(tlbr && out);
     std::vector<size_t> offs;
-    int rc = upload(ctx, ctx->io0, {{tlbr, sizeof(double) * 4 * n}}, offs);
+    char* src = nullptr;
+    const bool small = n <= FM_ZERO_COPY_TRACKS / 2;
+    int rc = upload(ctx, ctx->io0, {{tlbr, sizeof(double) * 4 * n}}, offs, &src, small);
     if (rc) return rc;
     if ((rc = ctx->io1.reserve(n))) return rc;
     hipLaunchKernelGGL(occluded_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->s_main, n,
-                       ctx->io0.dev<double>(), thresh, ctx->io1.dev<uint8_t>());
+                       (const double*)src, thresh, small ? ctx->io1.host<uint8_t>() : ctx->io1.dev<uint8_t>());
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, n, hipMemcpyDeviceToHost, ctx->s_main));
+    if (!small) FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, n, hipMemcpyDeviceToHost, ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     memcpy(out, ctx->io1.h, n);
     return 0;
@@ -615,34 +774,40 @@ extern "C" int fm_assoc_stage(fm_ctx* ctx, int stage, int solver, int nr, const 
         for (int i = 0; i < nr; ++i) rlab[i] = tl[rows[i]];
     }
     std::vector<size_t> offs;
+    char* si = nullptr;
     int rc = upload(ctx, ctx->as_stage_in,
                     {{rows, sizeof(int32_t) * nr}, {cols, sizeof(int32_t) * nc},
-                     {rlab.data(), sizeof(int64_t) * nr}}, offs);
+                     {rlab.data(), sizeof(int64_t) * nr}}, offs, &si,
+                    FM_ZERO_COPY_TRACKS > 0 && (size_t)nr * nc <= 65536);
     if (rc) return rc;
     const size_t cbytes = sizeof(double) * (size_t)nr * nc;
     if ((rc = ctx->as_cost.reserve(cbytes))) return rc;
+    // small LAP problems: the cost matrix goes straight to pinned host memory and is solved there
+    const bool host_lap = solver == 0 && FM_ZERO_COPY_TRACKS > 0 && (size_t)nr * nc <= (size_t)ctx->opt_host_lap_elems;
+    double* cost_dst = host_lap ? ctx->as_cost.host<double>() : ctx->as_cost.dev<double>();
     const size_t mat = sizeof(double) * (size_t)nT * nD;
     char* in = ctx->as_in.dev<char>();
     char* pr = ctx->as_pair.dev<char>();
-    char* si = ctx->as_stage_in.dev<char>();
     hipLaunchKernelGGL(stage_cost_kernel, dim3((nr * nc + 255) / 256), dim3(256), 0, ctx->s_main, stage,
                        nr, nc, nD, (const int32_t*)(si + offs[0]), (const int32_t*)(si + offs[1]),
                        (const int64_t*)(si + offs[2]), (const int64_t*)(in + ctx->as_off[4]),
                        (const uint8_t*)(in + ctx->as_off[5]), (const uint8_t*)(pr + 3 * mat),
                        (const double*)pr, (const double*)(pr + mat), (const double*)(pr + 2 * mat),
-                       motion_weight, max_cost, fill_val, ctx->as_cost.dev<double>());
+                       motion_weight, max_cost, fill_val, cost_dst);
     FM_HIP(hipGetLastError());
-    const bool need_cost = cost_out != nullptr || (solver == 0 && match_gated != nullptr);
-    if (need_cost)
+    if (host_lap) FM_HIP(hipStreamSynchronize(ctx->s_main));
+    else if (cost_out)   // tests / debugging only
         FM_HIP(hipMemcpyAsync(ctx->as_cost.h, ctx->as_cost.d, cbytes, hipMemcpyDeviceToHost, ctx->s_main));
-    if (solver == 0) rc = run_lap(ctx, ctx->as_cost.dev<double>(), nr, nc, m_rows, m_cols, n_match);
+    std::vector<double> mcost(solver == 0 && match_gated ? (size_t)(nr < nc ? nr : nc) : 0);
+    if (solver == 0)
+        rc = run_lap(ctx, ctx->as_cost.dev<double>(), nr, nc, m_rows, m_cols, n_match,
+                     mcost.empty() ? nullptr : mcost.data(), host_lap ? ctx->as_cost.host<double>() : nullptr);
     else rc = run_greedy(ctx, ctx->as_cost.dev<double>(), nr, nc, max_cost, m_rows, m_cols, n_match);
     if (rc) return rc;
-    const double* hc = ctx->as_cost.host<double>();
     if (solver == 0 && match_gated)
         for (int k = 0; k < *n_match; ++k)   // utils/matching.py:65
-            match_gated[k] = hc[(size_t)m_rows[k] * nc + m_cols[k]] < INF_COST ? 0 : 1;
-    if (cost_out) memcpy(cost_out, hc, cbytes);
+            match_gated[k] = mcost[k] < INF_COST ? 0 : 1;
+    if (cost_out) memcpy(cost_out, ctx->as_cost.host<double>(), cbytes);
     return 0;
 }
 
@@ -652,6 +817,8 @@ extern "C" int fm_lap(fm_ctx* ctx, const double* cost, int nr, int nc, int32_t* 
     *n_match = 0;
     if (nr == 0 || nc == 0) return 0;
     FM_CHECK_ARG(cost && m_rows && m_cols);
+    if ((size_t)nr * nc <= (size_t)ctx->opt_host_lap_elems)
+        return run_lap(ctx, nullptr, nr, nc, m_rows, m_cols, n_match, nullptr, cost);
     std::vector<size_t> offs;
     int rc = upload(ctx, ctx->as_cost, {{cost, sizeof(double) * (size_t)nr * nc}}, offs);
     if (rc) return rc;

@@ -33,6 +33,11 @@ void fm_set_error(const char* fmt, ...);
     } while (0)
 
 // Growable device buffer with a pinned host mirror (HostDeviceMem of utils/inference.py:7-36).
+// batches up to this many tracks exchange their (tiny) kernel inputs / outputs through pinned,
+// device-mapped host memory instead of blit copies
+bool fm_lap_host(const double* cost, int nr, int nc, long rs, long cs, int32_t* col4row_out);
+#define FM_ZERO_COPY_TRACKS (ctx->opt_zero_copy_tracks)
+
 struct DevBuf {
     void* d = nullptr;
     void* h = nullptr;   // pinned
@@ -78,6 +83,9 @@ struct FlowState;    // KLT (flow.hip)
 
 struct fm_ctx {
     int device = 0;
+    // tunables (fm_ctx_set_option; initial values from the environment)
+    int opt_zero_copy_tracks = 2048;   // FASTMOT_ZERO_COPY: 0 = always blit copies
+    int opt_host_lap_elems = 16384;    // FASTMOT_HOST_LAP: cost matrices up to this size use lap_host.hip
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network
     hipStream_t s_ext = nullptr;    // ReID network

@@ -64,8 +64,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p, 
     constexpr int BNP = WP * MP * 32;
     constexpr int A_IT = (BMC + 31) / 32;
     constexpr int B_IT = (BNP + 31) / 32;
-    __shared__ __attribute__((aligned(16))) f16 sA[2][BMC * LDK];
-    __shared__ __attribute__((aligned(16))) f16 sB[2][BNP * LDK];
+    // operand staging (double buffered); the same bytes are reused by the epilogue as an fp32
+    // [pixel][cout + 4] tile so that outputs leave in 16 B pieces of whole NHWC rows
+    constexpr int LDO = BMC + 4;
+    constexpr int SMEM_OPER = 2 * (BMC + BNP) * LDK * 2, SMEM_OUT = BNP * LDO * 4;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_OPER > SMEM_OUT ? SMEM_OPER : SMEM_OUT];
+    f16 (*sA)[BMC * LDK] = reinterpret_cast<f16 (*)[BMC * LDK]>(smem);
+    f16 (*sB)[BNP * LDK] = reinterpret_cast<f16 (*)[BNP * LDK]>(smem + 2 * BMC * LDK * 2);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wc = wv / WP, wp = wv % WP;
@@ -225,45 +230,82 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p, 
 #undef CONV_COMPUTE
 
     // ---- epilogue
+    if (gridDim.z > 1) {   // split-K: raw fp32 partial sums, reduced by splitk_reduce_kernel
 #pragma unroll
-    for (int pi = 0; pi < MP; ++pi) {
-        const int pix = p0 + (wp * MP + pi) * 32 + (lane & 31);
-        if (pix >= p.P) continue;
+        for (int pi = 0; pi < MP; ++pi) {
+            const int pix = p0 + (wp * MP + pi) * 32 + (lane & 31);
+            if (pix >= p.P) continue;
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi) {
+            for (int mi = 0; mi < MC; ++mi)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = c0 + (wc * MC + mi) * 32 + 8 * g + 4 * (lane >> 5);
-                if (co >= p.cout_store) continue;
-                if (gridDim.z > 1) {   // split-K: raw fp32 partial sums, reduced by splitk_reduce_kernel
+                for (int g = 0; g < 4; ++g) {
+                    const int co = c0 + (wc * MC + mi) * 32 + 8 * g + 4 * (lane >> 5);
+                    if (co >= p.cout_store) continue;
                     *reinterpret_cast<float4*>(ws + ((size_t)blockIdx.z * p.P + pix) * cout_pad + co) =
                         make_float4(acc[mi][pi][4 * g + 0], acc[mi][pi][4 * g + 1], acc[mi][pi][4 * g + 2],
                                     acc[mi][pi][4 * g + 3]);
-                    continue;
                 }
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
-                float v[4] = {acc[mi][pi][4 * g + 0] + b.x, acc[mi][pi][4 * g + 1] + b.y,
-                              acc[mi][pi][4 * g + 2] + b.z, acc[mi][pi][4 * g + 3] + b.w};
-                float r[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.res_mode != RES_NONE) {
-                    const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)pix * p.res_cs + p.res_coff + co);
+        }
+        return;
+    }
+    // The MFMA D fragment gives a lane 4 channels of one pixel (8 B, 32 different NHWC rows per
+    // store instruction).  Transposing through LDS makes every lane own 8 consecutive channels and
+    // consecutive lanes consecutive 16 B of the same row: full-line stores and residual loads.
+    float* so = reinterpret_cast<float*>(smem);
+    __syncthreads();                                 // every wave is done with the operand tiles
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) r[e] = (float)rv[e];
-                }
+    for (int pi = 0; pi < MP; ++pi)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (p.res_mode == RES_BEFORE_ACT) v[e] += r[e];
-                    v[e] = apply_act(v[e], p.act);
-                    if (p.res_mode == RES_AFTER_ACT) v[e] += r[e];
-                }
-                if (p.out32) {
-                    *reinterpret_cast<float4*>(p.out32 + (size_t)pix * p.out_cs + p.out_coff + co) =
-                        make_float4(v[0], v[1], v[2], v[3]);
+        for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&so[((wp * MP + pi) * 32 + (lane & 31)) * LDO +
+                                               (wc * MC + mi) * 32 + 8 * g + 4 * (lane >> 5)]) =
+                    make_float4(acc[mi][pi][4 * g + 0], acc[mi][pi][4 * g + 1], acc[mi][pi][4 * g + 2],
+                                acc[mi][pi][4 * g + 3]);
+    __syncthreads();
+    constexpr int CH = BMC / 8;                      // 16 B chunks per pixel row of the tile
+    constexpr int ROWS = 256 / CH;
+    const int och = tid % CH, orow = tid / CH;
+    const int co = c0 + och * 8;
+    if (co < p.cout_store) {
+        float bias8[8];
+        *reinterpret_cast<float4*>(&bias8[0]) = *reinterpret_cast<const float4*>(p.bias + co);
+        *reinterpret_cast<float4*>(&bias8[4]) = *reinterpret_cast<const float4*>(p.bias + co + 4);
+#pragma unroll
+        for (int it = 0; it < BNP / ROWS; ++it) {
+            const int row = it * ROWS + orow;
+            const int pix = p0 + row;
+            if (pix >= p.P) break;
+            float v[8];
+            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&so[row * LDO + och * 8]);
+            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&so[row * LDO + och * 8 + 4]);
+            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.res_mode != RES_NONE)
+                unpack8(*reinterpret_cast<const uint4*>(p.res + (size_t)pix * p.res_cs + p.res_coff + co), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += bias8[e];
+                if (p.res_mode == RES_BEFORE_ACT) v[e] += r[e];
+                v[e] = apply_act(v[e], p.act);
+                if (p.res_mode == RES_AFTER_ACT) v[e] += r[e];
+            }
+            if (p.out32) {
+                float* dst = p.out32 + (size_t)pix * p.out_cs + p.out_coff + co;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                const uint4 o = pack8(v);
+                if (p.up == 2) {   // fused nearest x2 upsample: replicate to the 2x2 block
+                    const int hw = p.Ho * p.Wo, rem = pix % hw;
+                    const size_t o00 = ((size_t)(pix / hw) * 2 * p.Ho + 2 * (rem / p.Wo)) * (2 * p.Wo) + 2 * (rem % p.Wo);
+                    f16* dst = p.out + o00 * p.out_cs + p.out_coff + co;
+                    *reinterpret_cast<uint4*>(dst) = o;
+                    *reinterpret_cast<uint4*>(dst + p.out_cs) = o;
+                    *reinterpret_cast<uint4*>(dst + (size_t)2 * p.Wo * p.out_cs) = o;
+                    *reinterpret_cast<uint4*>(dst + (size_t)(2 * p.Wo + 1) * p.out_cs) = o;
                 } else {
-                    f16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-                    store_out(p, pix, co, o);
+                    *reinterpret_cast<uint4*>(p.out + (size_t)pix * p.out_cs + p.out_coff + co) = o;
                 }
             }
         }
@@ -328,7 +370,8 @@ int launch_cfg(const ConvParams& p, int S, float* ws, hipStream_t s) {
 // workgroups per CU as long as every split keeps >= 4 K-steps.
 int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s) {
     FM_CHECK_ARG(p.Cin % 8 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0);
-    FM_CHECK_ARG(p.out_cs % 4 == 0 && p.out_coff % 4 == 0 && p.Kpad % BK == 0);
+    FM_CHECK_ARG(p.out_cs % 8 == 0 && p.out_coff % 8 == 0 && p.Kpad % BK == 0);
+    FM_CHECK_ARG(p.res_mode == RES_NONE || (p.res_cs % 8 == 0 && p.res_coff % 8 == 0));
     const int cout_pad = (p.Cout + 31) & ~31;
     auto tiles = [&](int bmc, int bnp) { return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc); };
     const int nk = p.Kpad / BK;

@@ -2,6 +2,8 @@
 // Replaces the buffer + stream plumbing of fastmot/utils/inference.py:7-125 (HostDeviceMem,
 // TRTInference) with plain HIP: one ctx per video stream, four HIP streams, pinned mirrors.
 #include "common.h"
+#include <cstring>
+#include <cstdlib>
 #include <cmath>
 
 static thread_local char g_err[1024] = "";
@@ -14,6 +16,23 @@ void fm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fm_last_error(void) { return g_err; }
+
+extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
+    FM_CHECK_ARG(ctx && key && value >= 0);
+    if (!strcmp(key, "zero_copy_tracks")) ctx->opt_zero_copy_tracks = value;
+    else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
+    else {
+        fm_set_error("unknown option '%s'", key);
+        return FM_ERR_ARG;
+    }
+    return 0;
+}
+
+extern "C" int fm_ctx_bind_thread(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx);
+    FM_HIP(hipSetDevice(ctx->device));
+    return 0;
+}
 
 extern "C" int fm_device_count(void) {
     int n = 0;
@@ -37,6 +56,8 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     FM_HIP(hipSetDevice(device));
     fm_ctx* ctx = new fm_ctx();
     ctx->device = device;
+    if (const char* e = getenv("FASTMOT_ZERO_COPY")) ctx->opt_zero_copy_tracks = atoi(e);
+    if (const char* e = getenv("FASTMOT_HOST_LAP")) ctx->opt_host_lap_elems = atoi(e);
     // the detector network is the long, throughput-oriented stream; tracker / KLT / ReID launches are
     // short and latency critical (the host waits on them), so they get the higher priority
     int prio_lo = 0, prio_hi = 0;
@@ -335,10 +356,12 @@ extern "C" int fm_feat_update(fm_ctx* ctx, int n, const int32_t* slots, const in
     int32_t* h = ctx->io0.host<int32_t>();
     memcpy(h, slots, sizeof(int32_t) * n);
     memcpy(h + n, emb_rows, sizeof(int32_t) * n);
-    FM_HIP(hipMemcpyAsync(ctx->io0.d, h, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, ctx->s_main));
+    const bool zc = n <= FM_ZERO_COPY_TRACKS;
+    if (!zc) FM_HIP(hipMemcpyAsync(ctx->io0.d, h, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, ctx->s_main));
+    const int32_t* din = zc ? h : ctx->io0.dev<int32_t>();
     const int threads = 256, waves_per_block = threads / 64;
     hipLaunchKernelGGL(feat_update_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(threads),
-                       0, ctx->s_main, n, ctx->io0.dev<int32_t>(), ctx->io0.dev<int32_t>() + n, ctx->emb,
+                       0, ctx->s_main, n, din, din + n, ctx->emb,
                        ctx->feat_sum, ctx->feat_avg, ctx->feat_cnt, ctx->feat_dim);
     FM_HIP(hipGetLastError());
     // io0 host mirror is reused by the next call -> wait for the H2D to be consumed

@@ -347,19 +347,22 @@ extern "C" int fm_trk_step_ops(fm_ctx* ctx, int ops, int n, const int32_t* slots
     memcpy(h + o_mult, mult, sizeof(double) * n);
     memcpy(h + o_slots, slots, sizeof(int32_t) * n);
     memcpy(h + o_has, has_klt, n);
-    FM_HIP(hipMemcpyAsync(ctx->io0.d, h, in_bytes, hipMemcpyHostToDevice, ctx->s_main));
+    // small batches: the kernel reads the pinned staging buffer and writes the pinned result buffer
+    // directly (one wave per track touches each input once) -- no blit copies, one synchronise
+    const bool zc = n <= FM_ZERO_COPY_TRACKS;
+    if (!zc) FM_HIP(hipMemcpyAsync(ctx->io0.d, h, in_bytes, hipMemcpyHostToDevice, ctx->s_main));
     Hmat Hm;
     memcpy(Hm.h, H, sizeof(double) * 9);
     Rect fr;
     memcpy(fr.r, ctx->frame_rect, sizeof(double) * 4);
-    char* d = ctx->io0.dev<char>();
-    char* o = ctx->io1.dev<char>();
+    char* d = zc ? h : ctx->io0.dev<char>();
+    char* o = zc ? ctx->io1.host<char>() : ctx->io1.dev<char>();
     hipLaunchKernelGGL(kf_step_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, ctx->s_main, n,
                        (const int32_t*)(d + o_slots), Hm, (const double*)(d + o_klt),
                        (const uint8_t*)(d + o_has), (const double*)(d + o_mult), ctx->mean, ctx->cov,
                        ctx->kf, fr, (double*)o, (uint8_t*)(o + o_lost), ops);
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
+    if (!zc) FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     memcpy(tlbr_out, ctx->io1.host<char>(), sizeof(double) * 4 * n);
     memcpy(lost_out, ctx->io1.host<char>() + o_lost, n);
@@ -381,16 +384,17 @@ extern "C" int fm_trk_update_det(fm_ctx* ctx, int n, const int32_t* slots, const
     char* h = ctx->io0.host<char>();
     memcpy(h + o_det, det_tlbr, sizeof(double) * 4 * n);
     memcpy(h + o_slots, slots, sizeof(int32_t) * n);
-    FM_HIP(hipMemcpyAsync(ctx->io0.d, h, in_bytes, hipMemcpyHostToDevice, ctx->s_main));
+    const bool zc = n <= FM_ZERO_COPY_TRACKS;
+    if (!zc) FM_HIP(hipMemcpyAsync(ctx->io0.d, h, in_bytes, hipMemcpyHostToDevice, ctx->s_main));
     Rect fr;
     memcpy(fr.r, ctx->frame_rect, sizeof(double) * 4);
-    char* d = ctx->io0.dev<char>();
-    char* o = ctx->io1.dev<char>();
+    char* d = zc ? h : ctx->io0.dev<char>();
+    char* o = zc ? ctx->io1.host<char>() : ctx->io1.dev<char>();
     hipLaunchKernelGGL(kf_update_det_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0,
                        ctx->s_main, n, (const int32_t*)(d + o_slots), (const double*)(d + o_det),
                        ctx->mean, ctx->cov, ctx->kf, fr, (double*)o, (uint8_t*)(o + o_lost));
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
+    if (!zc) FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     memcpy(tlbr_out, ctx->io1.host<char>(), sizeof(double) * 4 * n);
     memcpy(lost_out, ctx->io1.host<char>() + o_lost, n);

@@ -13,6 +13,9 @@ int launch_liteconv(int G, const f16* const* in, const int* in_cs, const int* in
 int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
                      int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
                      int out_cs, int out_coff, hipStream_t s);
+int launch_stemconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
+                    const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad, int cout,
+                    int act, hipStream_t s);
 int launch_spp(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H, int W,
                int C, hipStream_t s);
 int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
@@ -181,6 +184,12 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                                     (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
                                     out, to.c, L.out_coff, s);
         }
+        case FM_OP_STEMCONV:
+            FM_CHECK_ARG(!to.f32 && (ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h &&
+                         (ti.w + 2 * L.pad - L.k) / L.stride + 1 == to.w && L.out_coff + ((L.cout + 7) & ~7) <= to.c);
+            return launch_stemconv(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
+                                   (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                                   B, ti.h, ti.w, to.h, to.w, L.k, L.stride, L.pad, L.cout, L.act, s);
         case FM_OP_SPP:
             FM_CHECK_ARG(to.h == ti.h && to.w == ti.w && L.out_coff + 3 * L.cin <= to.c);
             return launch_spp(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, s);
@@ -326,6 +335,10 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *bytes = ((pin + pout) * L.cin * 2 + (double)L.cin * L.cout * 2) * L.n_in;
             break;
         case FM_OP_GATED_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
+        case FM_OP_STEMCONV:
+            *flops = 2.0 * L.k * L.k * 3 * L.cout * pout;
+            *bytes = pin * 8 + pout * L.cout * 2;
+            break;
         case FM_OP_SPP: *bytes = (pin + 3 * pout) * L.cin * 2; break;
         case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
         case FM_OP_GATE_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;

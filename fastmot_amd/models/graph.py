@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM) = range(12)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV) = range(13)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
@@ -95,6 +95,7 @@ class Graph:
         self.blob = bytearray()
         self.n_gates = 0
         self.gate_c = 8
+        self.use_stem = True   # small-Cin first layers go to the LDS-patch stem kernel
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -135,6 +136,20 @@ class Graph:
         if not bias:
             b = np.zeros_like(b)
         w16 = w.astype(np.float16)
+        if (self.use_stem and x.c <= 4 and x.coff == 0 and cout <= 32 and (k, stride) in ((3, 1), (3, 2), (7, 2))
+                and res is None and not f32_out and up == 1):
+            # stem layer: input patch staged in LDS instead of 16 B gathers per tap (stemconv.hip)
+            kp = ceil_to(k * k * 4, 16)
+            wk = np.zeros((32, k, k, 4), np.float16)
+            wk[:cout, :, :, :x.c] = w16.transpose(0, 2, 3, 1)
+            packed = np.zeros((32, kp), np.float16)
+            packed[:, :k * k * 4] = wk.reshape(32, -1)
+            bias32 = np.zeros(32, np.float32)
+            bias32[:cout] = b
+            self._layer(op=OP_STEMCONV, ins=[x], out=dst, cin=cin_pad, cout=cout, k=k, stride=stride, pad=pad,
+                        act=ACT[act], w_off=self._push(packed), b_off=self._push(bias32), name=name)
+            self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
+            return dst
         # pack [cout_pad32][Kpad64], K order (kh, kw, cin_pad)
         K = k * k * cin_pad
         kpad = ceil_to(K, 64)
@@ -367,7 +382,7 @@ class Graph:
         """2*MAC over conv layers (the 'conv roofline' numerator)."""
         total = 0
         for d in self.layers:
-            if d['op'] == OP_CONV:
+            if d['op'] in (OP_CONV, OP_STEMCONV):
                 o = d['out']
                 total += 2 * d['k'] * d['k'] * d['ins'][0].c * d['cout'] * o.h * o.w * batch
         return total

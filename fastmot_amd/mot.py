@@ -7,6 +7,7 @@ resident: pass a detector.DeviceFrame)."""
 from types import SimpleNamespace
 from enum import Enum
 import logging
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -79,6 +80,10 @@ class MOT:
         self.extractors = [FeatureExtractor(size=self.size, **vars(cfg)) for cfg in feature_extractor_cfgs]
         self.tracker = MultiTracker(self.size, self.extractors[0].metric, **vars(tracker_cfg))
         self.frame_count = 0
+        # KLT + Kalman run on a second host thread while this one drives detector -> ReID network (the
+        # C-ABI calls release the GIL; the stages use separate HIP streams and share no state)
+        self._flow_thread = ThreadPoolExecutor(max_workers=1, thread_name_prefix='fastmot-flow',
+                                               initializer=self.tracker.ctx.bind_thread)
 
     def visible_tracks(self):
         """Confirmed and active tracks (iterator of Track)."""
@@ -110,31 +115,36 @@ class MOT:
             with Profiler('preproc'):
                 self.detector.detect_async(frame)
 
-            # Same stages as mot.py:138-161, interleaved so that the GPU always has work: KLT keypoint
-            # bookkeeping while the detector runs, then the ReID network while the host finishes KLT
-            # (LK read-back + RANSAC) and the Kalman step.  Results are identical (the stages are
-            # independent exactly as in the reference's CPU || GPU overlap).
-            with Profiler('detect'):
-                with Profiler('track'):
-                    self.tracker.compute_flow_begin(frame)
-                detections = self.detector.postprocess()
+            # Same stages as mot.py:138-161.  The reference overlaps its CPU optical flow with the
+            # asynchronous TensorRT detector and its Kalman step with the ReID network; here the whole
+            # KLT + Kalman chain (device pyramid / keypoints / LK, host RANSAC, Kalman launch) runs on a
+            # second host thread and its own HIP streams, so the critical path of a step is
+            # detector -> ReID network -> association.  The stages are independent exactly as in the
+            # reference, so the results are identical.
+            flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
+            try:
+                with Profiler('detect'):
+                    detections = self.detector.postprocess()
 
-            with Profiler('extract'):
-                # every box goes to the first extractor, as in the reference (_split_bboxes_by_cls
-                # with its bisect_right quirk, mot.py:180-189)
-                self.extractors[0].extract_async(frame, detections.tlbr)
-
-                with Profiler('track', aggregate=True):
-                    self.tracker.compute_flow_finish()
-                    self.tracker.apply_kalman()
-
-                embeddings = self.extractors[0].postprocess()
+                with Profiler('extract'):
+                    # every box goes to the first extractor, as in the reference (_split_bboxes_by_cls
+                    # with its bisect_right quirk, mot.py:180-189)
+                    self.extractors[0].extract_async(frame, detections.tlbr)
+                    embeddings = self.extractors[0].postprocess()
+            finally:
+                flow_done.result()
 
             with Profiler('assoc'):
                 self.tracker.update(self.frame_count, detections, embeddings)
         else:
             with Profiler('track'):
                 self.tracker.track(frame)
+
+    def _flow_and_kalman(self, frame):
+        with Profiler('track'):
+            self.tracker.compute_flow_begin(frame)
+            self.tracker.compute_flow_finish()
+            self.tracker.apply_kalman()
 
     @staticmethod
     def print_timing_info():

@@ -40,6 +40,15 @@ const char* fm_last_error(void);
 int fm_device_count(void);
 /* blocks until every stream of the ctx is idle (TRTInference.synchronize, inference.py:119-121) */
 int fm_ctx_synchronize(fm_ctx* ctx);
+/* makes the context's device current for the calling host thread; every additional host thread that
+ * drives the context calls it once (HIP's current device is per thread) */
+int fm_ctx_bind_thread(fm_ctx* ctx);
+/* tunables: "zero_copy_tracks" (default 2048; batches up to this many tracks / boxes exchange kernel
+ * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
+ * "host_lap_elems" (default 16384; LAP cost matrices up to this many elements are solved by the host
+ * solver of the library, larger ones by the device kernels; 0 = always device).  Initial values can be
+ * set with the environment variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP. */
+int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value);
 /* writes "name:gcnArch:CUs:clockMHz:hbmBytes" of the ctx device */
 int fm_device_info(fm_ctx* ctx, char* buf, int buflen);
 
@@ -187,6 +196,9 @@ enum {
                           * independent LightConvs of equal geometry in one launch: group g reads
                           * in[g]/in_coff[g], writes out channels [out_coff + g*cin, +cin) and uses
                           * the g-th slab of the stacked weights                                */
+    FM_OP_STEMCONV = 12, /* k x k conv (k,stride in {3/1, 3/2, 7/2}) of an input with <= 4 real channels,
+                          * cout <= 32, + bias + act: w = fp16 [32][ceil16(k*k*4)] (K order kh,kw,c<4),
+                          * b = f32[32]; patch staged in LDS (stemconv.hip)                     */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

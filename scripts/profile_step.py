@@ -1,0 +1,66 @@
+"""Host-side wall-clock breakdown of MOT.step on the bench workload (no profiler attached): wraps the
+context's C-ABI calls and the pipeline methods with perf_counter accumulators."""
+import sys, time, collections
+import numpy as np
+sys.path.insert(0, '.')
+import bench
+from fastmot_amd import Track
+from fastmot_amd.detector import DeviceFrame
+from fastmot_amd.runtime import get_context
+from fastmot_amd.utils.synthetic import SyntheticVideo
+
+video = SyntheticVideo(bench.SIZE, n_ids=bench.N_DETS, n_frames=bench.RING, seed=100)
+ctx = get_context()
+ctx.frame_configure(bench.SIZE[0], bench.SIZE[1], bench.RING)
+for i, fr in enumerate(video.frames):
+    ctx.frame_ring_store(i, fr)
+mot = bench.build_mot(video)
+Track._count = 0
+mot.reset(1 / 30.)
+
+acc = collections.defaultdict(float)
+cnt = collections.defaultdict(int)
+
+def wrap(obj, name, label=None):
+    fn = getattr(obj, name)
+    label = label or name
+    def w(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            acc[label] += time.perf_counter() - t
+            cnt[label] += 1
+    setattr(obj, name, w)
+
+for n in ('flow_begin', 'flow_prepare', 'flow_lk', 'flow_estimate', 'detect_async', 'detect_sync', 'extract_async',
+          'extract_sync', 'assoc_prepare', 'assoc_stage', 'find_occluded', 'feat_update', 'trk_update_det',
+          'trk_step', 'trk_step_ops', 'emb_upload', 'synchronize', 'trk_create', 'feat_merge', 'frame_ring_select'):
+    if hasattr(ctx, n):
+        wrap(ctx, n, 'ctx.' + n)
+wrap(mot.detector, 'detect_async', 'det.detect_async')
+wrap(mot.detector, 'postprocess', 'det.postprocess')
+wrap(mot.extractors[0], 'extract_async', 'ext.extract_async')
+wrap(mot.extractors[0], 'postprocess', 'ext.postprocess')
+wrap(mot.tracker, 'compute_flow_begin', 'trk.flow_begin')
+wrap(mot.tracker, 'compute_flow_finish', 'trk.flow_finish')
+wrap(mot.tracker, 'apply_kalman', 'trk.apply_kalman')
+wrap(mot.tracker, 'update', 'trk.update')
+wrap(mot, '_step', 'mot._step')
+
+def run(n, start):
+    for s in range(start, start + n):
+        mot.detector._frame_idx = s % bench.RING
+        mot.step(DeviceFrame(s % bench.RING))
+
+run(20, 0)
+ctx.synchronize()
+acc.clear(); cnt.clear()
+N = 200
+t0 = time.perf_counter()
+run(N, 20)
+ctx.synchronize()
+el = time.perf_counter() - t0
+print(f'ms/step {el / N * 1e3:.3f}')
+for k in sorted(acc, key=lambda k: -acc[k]):
+    print(f'{k:<24} {acc[k] / N * 1e3:8.3f} ms/step  calls/step {cnt[k] / N:5.2f}')

@@ -9,8 +9,8 @@ rows = db.execute("select start, end, name, grid_x, grid_y, grid_z, workgroup_x 
 t0, prev_end = rows[0][0], rows[0][0]
 busy = 0
 for i, (s, e, name, gx, gy, gz, wx) in enumerate(rows):
-    short = name[:name.find('(')] if '(' in name else name
-    short = short.replace('(anonymous namespace)::', '').replace('void ', '')
+    short = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    short = short[:short.find('(')] if '(' in short else short
     print(f'{i:3d} t={(s - t0) / 1e3:8.1f} dur={(e - s) / 1e3:7.2f} gap={(s - prev_end) / 1e3:6.2f} grid=({gx // wx},{gy},{gz}) {short[:60]}')
     prev_end = max(prev_end, e)
     busy += e - s

@@ -143,7 +143,18 @@ def _check_lap(ctx, cost):
     np.testing.assert_array_equal(c, ec)
 
 
-def test_lap_matches_scipy_exactly(ctx):
+@pytest.mark.parametrize('host_lap_elems', [16384, 0])
+def test_lap_matches_scipy_exactly(ctx, host_lap_elems):
+    """Host solver for small matrices (default) and the device kernels (lap64_kernel: n <= 64 in
+    registers, lap_kernel: LDS / global work arrays) all reproduce SciPy's (rows, cols) exactly."""
+    ctx.set_option('host_lap_elems', host_lap_elems)
+    try:
+        _lap_cases(ctx)
+    finally:
+        ctx.set_option('host_lap_elems', 16384)
+
+
+def _lap_cases(ctx):
     rng = np.random.default_rng(0)
     for trial in range(200):
         nr, nc = rng.integers(1, 40, 2)
@@ -159,6 +170,11 @@ def test_lap_matches_scipy_exactly(ctx):
             cost = np.full((nr, nc), 1e5)                                # everything gated
             cost[rng.random((nr, nc)) < 0.1] = 0.3
         _check_lap(ctx, cost)
+    # register-resident kernel boundary (n <= 64) with massive ties
+    for shape in ((64, 64), (64, 30), (30, 64), (63, 64), (64, 65), (65, 64), (50, 50), (64, 1), (1, 64)):
+        for ties in (False, True):
+            cost = rng.integers(0, 3, shape).astype(float) if ties else rng.uniform(0, 1, shape)
+            _check_lap(ctx, cost)
     for shape in ((1, 1), (1, 300), (300, 1), (128, 128), (300, 300), (150, 420), (420, 150), (700, 700)):
         cost = rng.uniform(0, 1, shape)
         cost[rng.random(shape) < 0.3] = 1e5

@@ -58,6 +58,34 @@ def test_single_conv(ctx, cin, cout, k, stride, act, h, w, n):
     net.close()
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,act,h,w,n', [
+    (3, 32, 3, 1, 'mish', 40, 37, 1),        # YOLOv4 layer 0
+    (3, 16, 7, 2, 'relu', 64, 32, 3),        # OSNet conv1
+    (3, 64, 7, 2, 'relu', 32, 16, 1),        # OSNet x1.0 conv1: cout > 32 -> generic kernel
+    (4, 24, 3, 2, 'leaky', 33, 18, 2),
+    (1, 8, 3, 1, 'linear', 16, 16, 1),
+])
+def test_stem_conv(ctx, cin, cout, k, stride, act, h, w, n):
+    """LDS-patch stem kernel == generic implicit-GEMM kernel (same fp16 weights; different summation
+    order) == torch."""
+    rng = np.random.default_rng(cin + cout)
+    x = rng.normal(0, 1, (n, h, w, cin)).astype(np.float16)
+    outs = []
+    for stem in (True, False):
+        g = Graph(RandomWeights(seed=k + cout), (h, w), cin)
+        g.use_stem = stem
+        y = g.conv('c', g.input, cout, k, stride, act, pad=3 if k == 7 else None)
+        assert (g.layers[0]['op'] == 12) == (stem and cout <= 32)
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        net.write(g.input, x)
+        net.run(n)
+        outs.append(net.read(y, n))
+        bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+        close(outs[-1], nhwc(bufs[y.tid][:, :cout]), what=f'stem conv {cin}->{cout} k{k} stem={stem}')
+        net.close()
+    assert np.abs(outs[0] - outs[1]).max() <= 4e-3 * max(np.abs(outs[1]).max(), 1.0)
+
+
 def test_splitk_repeated_runs(ctx):
     """Split-K layers hand their fp32 partials to the last-arriving workgroup through a workspace that
     every layer and every run reuses: results must track the inputs run after run (no stale cached
@@ -312,7 +340,7 @@ def test_yolov4_small_input(ctx):
     class Small(YOLO.get_model('YOLOv4')):
         INPUT_SHAPE = (3, 96, 96)
     g, heads = Small.build_graph(RandomWeights(seed=21))
-    assert sum(d['op'] == 0 for d in g.layers) == 110
+    assert sum(d['op'] in (0, 12) for d in g.layers) == 110 and g.layers[0]['op'] == 12
     net = HipNet(ctx, NET_DETECTOR, g, 1)
     rng = np.random.default_rng(22)
     x = rng.uniform(0, 1, (1, 96, 96, 3)).astype(np.float16)

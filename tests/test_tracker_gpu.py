@@ -10,8 +10,27 @@ import scenes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name', list(scenes.SCENES))
-def test_scene_matches_reference(golden_dir, name):
+# default configuration on every scene + the all-device configuration (device LAP kernels, blit copies
+# instead of pinned zero-copy I/O) on two of them
+CONFIGS = [(name, None) for name in scenes.SCENES] + [
+    ('s50_skip1_cosine', dict(host_lap_elems=0, zero_copy_tracks=0)),
+    ('s300_4k_multiclass', dict(host_lap_elems=0)),
+]
+
+
+@pytest.mark.parametrize('name,options', CONFIGS)
+def test_scene_matches_reference(golden_dir, ctx, name, options):
+    from fastmot_amd import MultiTracker, Track
+    for key, value in (options or {}).items():
+        ctx.set_option(key, value)
+    try:
+        _run_scene(golden_dir, name)
+    finally:
+        ctx.set_option('host_lap_elems', 16384)
+        ctx.set_option('zero_copy_tracks', 2048)
+
+
+def _run_scene(golden_dir, name):
     from fastmot_amd import MultiTracker, Track
     g = np.load(golden_dir / f'tracker_{name}.npz')
     scene = scenes.Scene(name)
