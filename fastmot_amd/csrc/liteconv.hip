@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void liteconv_kernel(
     const LiteGroups grp, f16* __restrict__ out, int out_cs, int out_coff_base,
     const f16* __restrict__ wpw_base, int kpad, const f16* __restrict__ wdw_base,
     const float* __restrict__ bias_base, int H, int W, int C, int th, int tw, int tiles_x, int tiles_y,
-    int act) {
+    int act, float* __restrict__ gap_out) {
     const int grp_id = blockIdx.y;
     const f16* __restrict__ in = pick4(grp.in, grp_id);
     const int in_cs = pick4(grp.in_cs, grp_id), in_coff = pick4(grp.in_coff, grp_id);
@@ -103,30 +103,61 @@ __global__ __launch_bounds__(256) void liteconv_kernel(
     }
     __syncthreads();
 
-    // ---- phase B
-    const int c8n = C / 8, total = th * tw * c8n;
+    // ---- phase B: a thread keeps ONE channel group (cg) and walks pixels, so that the per-channel sums
+    // of the tile (the OSNet gate's average pool, fused here: phase C) accumulate in registers
+    const int c8n = C / 8, lanes_px = 256 / c8n;          // pixel lanes; 256 % c8n threads idle
+    const int cg = tid % c8n, pl = tid / c8n;
+    const bool active = pl < lanes_px;
     f16* dst = out + n * (long)H * W * out_cs + out_coff;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int cg = idx % c8n, pix = idx / c8n;
-        const int oy = pix / tw, ox = pix % tw;
-        const int gy = ty0 + oy, gx = tx0 + ox;
-        if (gy >= H || gx >= W) continue;
-        float acc[8];
+    float gsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        float b8[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = bias[cg * 8 + e];
+        for (int e = 0; e < 8; ++e) b8[e] = bias[cg * 8 + e];
+        for (int pix = pl; pix < th * tw; pix += lanes_px) {
+            const int oy = pix / tw, ox = pix % tw;
+            const int gy = ty0 + oy, gx = tx0 + ox;
+            if (gy >= H || gx >= W) continue;
+            float acc[8];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+            for (int e = 0; e < 8; ++e) acc[e] = b8[e];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                float v[8], k[8];
-                unpack8(*reinterpret_cast<const uint4*>(&ys[((oy + dy) * hw + ox + dx) * S + cg * 8]), v);
-                unpack8(*reinterpret_cast<const uint4*>(&wd[(dy * 3 + dx) * C + cg * 8]), k);
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], k[e], acc[e]);
+                for (int dx = 0; dx < 3; ++dx) {
+                    float v[8], k[8];
+                    unpack8(*reinterpret_cast<const uint4*>(&ys[((oy + dy) * hw + ox + dx) * S + cg * 8]), v);
+                    unpack8(*reinterpret_cast<const uint4*>(&wd[(dy * 3 + dx) * C + cg * 8]), k);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], k[e], acc[e]);
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = lc_act(acc[e], act);
+            const uint4 o = pack8(acc);
+            *reinterpret_cast<uint4*>(dst + ((long)gy * W + gx) * out_cs + cg * 8) = o;
+            if (gap_out) {   // sums of the STORED (fp16-rounded) activations, as a separate GAP would see them
+                float r[8];
+                unpack8(o, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gsum[e] += r[e];
             }
+        }
+    }
+    // ---- phase C (stream ends only: group 0): per-tile channel sums -> gap_out[n][tile][C], summed over
+    // the pixel lanes in a fixed order (deterministic); the gated-sum kernel adds the tiles
+    if (gap_out && grp_id == 0) {
+        __syncthreads();                                  // ys is dead: reuse it as float red[lanes_px][C]
+        float* red = reinterpret_cast<float*>(ys);
+        if (active) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = lc_act(acc[e], act);
-        *reinterpret_cast<uint4*>(dst + ((long)gy * W + gx) * out_cs + cg * 8) = pack8(acc);
+            for (int e = 0; e < 8; ++e) red[pl * C + cg * 8 + e] = gsum[e];
+        }
+        __syncthreads();
+        if (tid < C) {
+            float s = 0.f;
+            for (int q = 0; q < lanes_px; ++q) s += red[q * C + tid];
+            gap_out[((size_t)n * (tiles_x * tiles_y) + tile) * C + tid] = s;
+        }
     }
 }
 
@@ -135,9 +166,19 @@ __global__ __launch_bounds__(256) void liteconv_kernel(
 // in/out: NHWC fp16 with channel strides in_cs/out_cs and channel offsets; per group g < G: wpw packed
 // pointwise weights [ceil32(C)][kpad] (same packing as launch_conv); wdw: [9][C]; bias: f32[C] (folded BN
 // of the depthwise), the G slabs stacked contiguously.
+void liteconv_tiling(int C, int W, int H, int* th, int* tw, int* tiles_x, int* tiles_y) {
+    const int nt = (C + 31) / 32;
+    if (nt == 1) { *th = 16; *tw = W > 8 ? 16 : 8; }
+    else if (W > 8) { *th = 8; *tw = 16; }
+    else { *th = 16; *tw = 8; }
+    *tiles_x = (W + *tw - 1) / *tw;
+    *tiles_y = (H + *th - 1) / *th;
+}
+
+// gap_out (optional): fp32 [N][tiles][C] per-tile channel sums of group 0's output (see phase C)
 int launch_liteconv(int G, const f16* const* in, const int* in_cs, const int* in_coff, f16* out, int out_cs,
                     int out_coff, const f16* wpw, int kpad, const f16* wdw, const float* bias, int N, int H,
-                    int W, int C, int act, hipStream_t s) {
+                    int W, int C, int act, float* gap_out, hipStream_t s) {
     FM_CHECK_ARG(G >= 1 && G <= 4 && C % 8 == 0 && C >= 8 && C <= 128 && out_cs % 8 == 0 && out_coff % 8 == 0);
     LiteGroups grp{};
     for (int g = 0; g < 4; ++g) {
@@ -146,15 +187,12 @@ int launch_liteconv(int G, const f16* const* in, const int* in_cs, const int* in
         grp.in[g] = in[q]; grp.in_cs[g] = in_cs[q]; grp.in_coff[g] = in_coff[q];
     }
     const int nt = (C + 31) / 32, ks = (C + 15) / 16;
-    int th, tw;
-    if (nt == 1) { th = 16; tw = W > 8 ? 16 : 8; }
-    else if (W > 8) { th = 8; tw = 16; }
-    else { th = 16; tw = 8; }
-    const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    int th, tw, tiles_x, tiles_y;
+    liteconv_tiling(C, W, H, &th, &tw, &tiles_x, &tiles_y);
     const dim3 grid((unsigned)((long)N * tiles_x * tiles_y), G), block(256);
 #define LC_LAUNCH(NT_, KS_, MAXPOS_, SMAX_)                                                                  \
     hipLaunchKernelGGL((liteconv_kernel<NT_, KS_, MAXPOS_, SMAX_>), grid, block, 0, s, grp, out, out_cs,       \
-                       out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act)
+                       out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act, gap_out)
     if (ks == 1) LC_LAUNCH(1, 1, 324, 40);
     else if (nt == 1) LC_LAUNCH(1, 2, 324, 40);
     else if (nt == 2) { if (ks <= 3) LC_LAUNCH(2, 3, 180, 72); else LC_LAUNCH(2, 4, 180, 72); }

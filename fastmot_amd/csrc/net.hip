@@ -9,10 +9,13 @@ int launch_dwconv3(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, 
                    const float* bias, int N, int H, int W, int C, int act, hipStream_t s);
 int launch_liteconv(int G, const f16* const* in, const int* in_cs, const int* in_coff, f16* out, int out_cs,
                     int out_coff, const f16* wpw, int kpad, const f16* wdw, const float* bias, int N, int H,
-                    int W, int C, int act, hipStream_t s);
+                    int W, int C, int act, float* gap_out, hipStream_t s);
+void liteconv_tiling(int C, int W, int H, int* th, int* tw, int* tiles_x, int* tiles_y);
 int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
                      int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
-                     int out_cs, int out_coff, hipStream_t s);
+                     int out_cs, int out_coff, const float* const* part, int tiles, hipStream_t s);
+// one gate slot: [max_batch][GATE_SLOT_TILES][gate_c] fp32 (gate values use the first [max_batch][gate_c])
+constexpr int GATE_SLOT_TILES = 32;
 int launch_stemconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
                     const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad, int cout,
                     int act, hipStream_t s);
@@ -108,7 +111,7 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
     FM_HIP(hipMalloc(&net->ws, net->ws_floats * sizeof(float)));
     if (n_gates > 0) {
         FM_CHECK_ARG(gate_channels > 0);
-        FM_HIP(hipMalloc(&net->gates, sizeof(float) * (size_t)n_gates * max_batch * gate_channels));
+        FM_HIP(hipMalloc(&net->gates, sizeof(float) * (size_t)n_gates * max_batch * gate_channels * GATE_SLOT_TILES));
     }
     if (which == FM_NET_EXTRACTOR) {
         FM_HIP(hipStreamSynchronize(ctx->s_main));
@@ -165,10 +168,17 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                 cs[i] = tg.c;
                 co[i] = L.in_coff[i];
             }
+            float* gap_out = nullptr;
+            if (L.gate[0] >= 0) {   // group 0 ends a stream: leave per-tile channel sums for FM_OP_GATED_SUM
+                int th, tw, tx, ty;
+                liteconv_tiling(L.cin, ti.w, ti.h, &th, &tw, &tx, &ty);
+                FM_CHECK_ARG(L.gate[0] < net->n_gates && L.cin <= net->gate_c && tx * ty <= GATE_SLOT_TILES);
+                gap_out = net->gates + (size_t)L.gate[0] * net->max_batch * net->gate_c * GATE_SLOT_TILES;
+            }
             return launch_liteconv(L.n_in, ins, cs, co, out, to.c, L.out_coff,
                                    (const f16*)(net->weights + L.w_off), (L.cin + 63) & ~63,
                                    (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b_off),
-                                   B, ti.h, ti.w, L.cin, L.act, s);
+                                   B, ti.h, ti.w, L.cin, L.act, gap_out, s);
         }
         case FM_OP_GATED_SUM: {
             const f16* ins[4];
@@ -179,10 +189,21 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                 cs[i] = net->tensors[L.in[i]].c;
                 co[i] = L.in_coff[i];
             }
+            const float* parts[4] = {nullptr, nullptr, nullptr, nullptr};
+            int tiles = 0;
+            if (L.gate[0] >= 0) {   // producers left per-tile channel sums (FM_OP_LITECONV with gate[0] >= 0)
+                int th, tw, tx, ty;
+                liteconv_tiling(L.cin, ti.w, ti.h, &th, &tw, &tx, &ty);
+                tiles = tx * ty;
+                for (int i = 0; i < L.n_in; ++i) {
+                    FM_CHECK_ARG(L.gate[i] >= 0 && L.gate[i] < net->n_gates);
+                    parts[i] = net->gates + (size_t)L.gate[i] * net->max_batch * net->gate_c * GATE_SLOT_TILES;
+                }
+            }
             return launch_gated_sum(L.n_in, ins, cs, co, B, ti.h * ti.w, L.cin, L.hid,
                                     (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                     (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
-                                    out, to.c, L.out_coff, s);
+                                    out, to.c, L.out_coff, L.gate[0] >= 0 ? parts : nullptr, tiles, s);
         }
         case FM_OP_STEMCONV:
             FM_CHECK_ARG(!to.f32 && (ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h &&
@@ -207,7 +228,7 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             return launch_gate(in0, ti.c, L.in_coff[0], B, ti.h * ti.w, L.cin, L.hid,
                                (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
-                               net->gates + (size_t)L.gate[0] * net->max_batch * net->gate_c, s);
+                               net->gates + (size_t)L.gate[0] * net->max_batch * net->gate_c * GATE_SLOT_TILES, s);
         case FM_OP_GATE_SUM: {
             const f16* ins[4];
             int cs[4], co[4];
@@ -217,7 +238,7 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                 cs[i] = net->tensors[L.in[i]].c;
                 co[i] = L.in_coff[i];
                 FM_CHECK_ARG(L.gate[i] >= 0 && L.gate[i] < net->n_gates);
-                gs[i] = net->gates + (size_t)L.gate[i] * net->max_batch * net->gate_c;
+                gs[i] = net->gates + (size_t)L.gate[i] * net->max_batch * net->gate_c * GATE_SLOT_TILES;
             }
             return launch_gate_sum(L.n_in, ins, cs, co, gs, out, to.c, L.out_coff, B, ti.h * ti.w, L.cin, s);
         }

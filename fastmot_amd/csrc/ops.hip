@@ -315,6 +315,73 @@ __global__ __launch_bounds__(GS_THREADS) void gated_sum_kernel(GateSumArgs a, in
     }
 }
 
+// Same operation when the producers already left per-tile channel sums (liteconv.hip phase C):
+// part[t] = fp32 [N][tiles][C].  The average pool is then a sum of <= 32 numbers per channel, every
+// workgroup recomputes the tiny gate MLP for its sample and the gated sum itself runs with full
+// parallelism over pixels (grid = pixel chunks x samples) instead of one workgroup per sample.
+struct GatedSumPartArgs {
+    const f16* in[4];
+    int in_cs[4], in_coff[4];
+    const float* part[4];
+    int nstreams;
+};
+constexpr int GS2_PIX = 256;   // pixels per workgroup
+__global__ __launch_bounds__(256) void gated_sum_part_kernel(GatedSumPartArgs a, int HW, int C, int hid, int tiles,
+                                                             const f16* __restrict__ w1,
+                                                             const float* __restrict__ b1,
+                                                             const f16* __restrict__ w2,
+                                                             const float* __restrict__ b2,
+                                                             f16* __restrict__ out, int out_cs, int out_coff) {
+    extern __shared__ float sm[];            // gap[4][C] | hidden[4][hid] | gate[4][C]
+    const int n = blockIdx.y, tid = threadIdx.x;
+    float* gap = sm;
+    float* hidden = gap + 4 * C;
+    float* gate = hidden + 4 * hid;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t >= a.nstreams) break;
+        const float* p = a.part[t] + (size_t)n * tiles * C;
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (int q = 0; q < tiles; ++q) s += p[q * C + c];
+            gap[t * C + c] = s / (float)HW;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < a.nstreams * hid; i += 256) {
+        const int t = i / hid, h = i % hid;
+        float s = b1[h];
+        for (int c = 0; c < C; ++c) s = fmaf((float)w1[h * C + c], gap[t * C + c], s);
+        hidden[t * hid + h] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.nstreams * C; i += 256) {
+        const int t = i / C, c = i % C;
+        float s = b2[c];
+        for (int h = 0; h < hid; ++h) s = fmaf((float)w2[c * hid + h], hidden[t * hid + h], s);
+        gate[t * C + c] = 1.f / (1.f + __expf(-s));
+    }
+    __syncthreads();
+    const int c8n = C / 8;
+    const int p0 = blockIdx.x * GS2_PIX;
+    for (int idx = tid; idx < GS2_PIX * c8n; idx += 256) {
+        const int px = p0 + idx / c8n, cg = idx % c8n;
+        if (px >= HW) break;
+        const size_t pix = (size_t)n * HW + px;
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < a.nstreams) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(a.in[t] + pix * a.in_cs[t] + a.in_coff[t] + cg * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaf(v[e], gate[t * C + cg * 8 + e], o[e]);
+            }
+        }
+        *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + cg * 8) = pack8(o);
+    }
+}
+
 // OSNet head: global average pool -> Linear(C -> D) + folded BN1d + ReLU -> L2 normalise
 // (models/reid.py OUTPUT_LAYOUT = 512; feature_extractor.py:73).  One block per sample.
 __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
@@ -439,11 +506,25 @@ int launch_gate(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int
     return 0;
 }
 
+// part (optional): per stream, fp32 [N][tiles][C] channel sums left by the producing liteconv launches
 int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
                      int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
-                     int out_cs, int out_coff, hipStream_t s) {
+                     int out_cs, int out_coff, const float* const* part, int tiles, hipStream_t s) {
     FM_CHECK_ARG(nstreams >= 1 && nstreams <= 4 && C % 8 == 0 && C / 8 <= GS_THREADS && out_cs % 8 == 0 &&
                  out_coff % 8 == 0 && hid >= 1);
+    if (part) {
+        GatedSumPartArgs a{};
+        a.nstreams = nstreams;
+        for (int t = 0; t < nstreams; ++t) {
+            FM_CHECK_ARG(in_cs[t] % 8 == 0 && in_coff[t] % 8 == 0 && part[t]);
+            a.in[t] = in[t]; a.in_cs[t] = in_cs[t]; a.in_coff[t] = in_coff[t]; a.part[t] = part[t];
+        }
+        const size_t shmem = ((size_t)8 * C + 4 * hid) * sizeof(float);
+        hipLaunchKernelGGL(gated_sum_part_kernel, dim3((HW + GS2_PIX - 1) / GS2_PIX, N), dim3(256), shmem, s, a, HW,
+                           C, hid, tiles, w1, b1, w2, b2, out, out_cs, out_coff);
+        FM_HIP(hipGetLastError());
+        return 0;
+    }
     GateSumArgs a{};
     a.nstreams = nstreams;
     for (int t = 0; t < nstreams; ++t) {

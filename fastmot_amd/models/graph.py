@@ -122,7 +122,7 @@ class Graph:
 
     # ---------------------------------------------------------------- ops
     def conv(self, name, x, cout, k=1, stride=1, act='linear', bn=True, dst=None, res=None,
-             res_mode=RES_AFTER_ACT, f32_out=False, pad=None, bias=True, up=1):
+             res_mode=RES_AFTER_ACT, f32_out=False, pad=None, bias=True, up=1, wb=None):
         cin_pad = x.cpad
         pad = k // 2 if pad is None else pad
         ho = (x.h + 2 * pad - k) // stride + 1
@@ -131,8 +131,11 @@ class Graph:
             dst = self.new(ho * up, wo * up, cout, f32=f32_out)
         assert dst.h == ho * up and dst.w == wo * up and dst.c == cout, (name, dst.h, ho, dst.c, cout)
         assert up in (1, 2) and not (up == 2 and f32_out)
-        p = self.wsrc.conv(name, cout, x.c, k, bn=bn)
-        w, b = fold_bn(p)
+        if wb is not None:      # pre-folded (weight [cout, x.c, k, k], bias [cout]) supplied by the caller
+            w, b = (np.asarray(a, np.float32) for a in wb)
+            assert w.shape == (cout, x.c, k, k) and b.shape == (cout,)
+        else:
+            w, b = fold_bn(self.wsrc.conv(name, cout, x.c, k, bn=bn))
         if not bias:
             b = np.zeros_like(b)
         w16 = w.astype(np.float16)
@@ -197,7 +200,7 @@ class Graph:
         bias[:c] = bd
         return dict(pw=packed, dw=wk, bias=bias, ref=(pw.astype(np.float32), wd16.astype(np.float32), bd))
 
-    def lightconv_group(self, name, xs, params, act='relu', dst=None):
+    def lightconv_group(self, name, xs, params, act='relu', dst=None, gap_slot=False):
         """G = len(xs) <= 4 independent fused LightConv3x3 of equal geometry in ONE launch
         (FM_OP_LITECONV, blockIdx.y = group): group i reads view xs[i] and writes channels
         [i*c, (i+1)*c) of the returned view.  c == xs[i].c <= 128 and c % 8 == 0 when G > 1."""
@@ -207,7 +210,14 @@ class Graph:
         if dst is None:
             dst = self.new(xs[0].h, xs[0].w, G * c)
         assert dst.c == G * c
+        gates = []
+        if gap_slot:       # group 0's per-tile channel sums go to a gate slot (input of gated_sum(parts=...))
+            gates = [self.n_gates]
+            self.n_gates += 1
+            self.gate_c = max(self.gate_c, xs[0].cpad)
+        self.last_gap_slot = gates[0] if gates else None
         self._layer(op=OP_LITECONV, ins=list(xs), out=dst, cin=xs[0].cpad, cout=c, k=3, stride=1, pad=1, act=ACT[act],
+                    gates=gates,
                     w_off=self._push(np.stack([p['pw'] for p in params])),
                     w2_off=self._push(np.stack([p['dw'] for p in params])),
                     b_off=self._push(np.stack([p['bias'] for p in params])), name=name,
@@ -279,7 +289,7 @@ class Graph:
                     **{k: gate_params[k] for k in ('w_off', 'b_off', 'w2_off', 'b2_off')})
         return gid, gate_params
 
-    def gated_sum(self, name, xs, hid, dst=None):
+    def gated_sum(self, name, xs, hid, dst=None, parts=None):
         """OSNet unified aggregation gate fused: out = sum_i xs[i] * ChannelGate(xs[i]) with one shared
         gate (fc1: c -> hid, ReLU, fc2: hid -> c, sigmoid) -- FM_OP_GATED_SUM, one launch."""
         x = xs[0]
@@ -295,7 +305,9 @@ class Graph:
         b2[:c] = p2['bias']
         if dst is None:
             dst = self.new(x.h, x.w, c)
+        assert parts is None or len(parts) == len(xs)    # gate slots holding the producers' channel sums
         self._layer(op=OP_GATED_SUM, ins=list(xs), out=dst, cin=x.cpad, cout=c, hid=hid, name=name,
+                    gates=list(parts) if parts is not None else [],
                     w_off=self._push(w1), b_off=self._push(p1['bias'].astype(np.float32)),
                     w2_off=self._push(w2), b2_off=self._push(b2),
                     gate_ref=(w1[:, :c].astype(np.float32), p1['bias'], w2[:c].astype(np.float32), p2['bias']))

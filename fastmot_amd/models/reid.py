@@ -3,7 +3,9 @@ OSNet layer table for the HIP conv engine (torchreid osnet_x1_0 / osnet_x0_25 to
 SURVEY.md appendix A: 978.9 / 82.3 MMAC per 256x128 crop)."""
 from pathlib import Path
 
-from .graph import Graph, RandomWeights, RES_BEFORE_ACT
+import numpy as np
+
+from .graph import Graph, RandomWeights, RES_BEFORE_ACT, fold_bn
 
 
 class ReID:
@@ -42,7 +44,10 @@ def osnet_graph(model, weights, fuse_lightconv=True):
     c0, c1, c2, c3 = model.CHANNELS
     g = Graph(weights, (H, W), 3)
 
-    def osblock(name, x, cout):
+    def osblock(name, x, cout, cat=None):
+        """cat: [mid + x.c]-channel tensor whose upper slice already is x (the producer wrote it there):
+        the gated sum goes to the lower slice and the block tail relu(conv3(x2) + downsample(x)) becomes
+        ONE 1x1 conv over the concatenated channels with weights [W3 | Wd], bias b3 + bd."""
         mid = cout // 4
         x1 = g.conv(name + '.conv1', x, mid, 1, 1, 'relu')
         hid = max(mid // 16, 1)
@@ -51,13 +56,15 @@ def osnet_graph(model, weights, fuse_lightconv=True):
             # streams that reach it runs as ONE grouped launch (4, 3, 2, 1 groups) and the four gates +
             # the gated sum as one more: 5 launches per block tail instead of 10 + 4 + 1.
             params = {(t, i): g.lightconv_params(f'{name}.s{t}.{i}', mid) for t in range(1, 5) for i in range(t)}
-            streams, prev = [], None
+            streams, parts, prev = [], [], None
             for i in range(4):
                 ts = list(range(i + 1, 5))                       # streams alive at depth i
                 xs = [x1] * len(ts) if i == 0 else [prev.slice((t - i) * mid, mid) for t in ts]
-                prev = g.lightconv_group(f'{name}.depth{i}', xs, [params[(t, i)] for t in ts], 'relu')
-                streams.append(prev.slice(0, mid))               # stream i+1 ends at depth i
-            x2 = g.gated_sum(name + '.gate', streams, hid)
+                prev = g.lightconv_group(f'{name}.depth{i}', xs, [params[(t, i)] for t in ts], 'relu', gap_slot=True)
+                streams.append(prev.slice(0, mid))               # stream i+1 ends at depth i (group 0)
+                parts.append(g.last_gap_slot)
+            x2 = g.gated_sum(name + '.gate', streams, hid, parts=parts,
+                             dst=cat.slice(0, mid) if cat is not None else None)
         else:
             streams, gids = [], []
             gp = None
@@ -70,23 +77,32 @@ def osnet_graph(model, weights, fuse_lightconv=True):
                 gid, gp = g.gate(name + '.gate', s, hid, gp)
                 gids.append(gid)
             x2 = g.gate_sum(streams, gids)
+        if cat is not None:
+            wd, bd = fold_bn(weights.conv(name + '.down', cout, x.c, 1, bn=True))
+            w3, b3 = fold_bn(weights.conv(name + '.conv3', cout, mid, 1, bn=True))
+            return g.conv(name + '.conv3+down', cat, cout, 1, 1, 'relu', wb=(np.concatenate([w3, wd], axis=1), b3 + bd))
         if x.c != cout:
             ident = g.conv(name + '.down', x, cout, 1, 1, 'linear')
         else:
             ident = x
         return g.conv(name + '.conv3', x2, cout, 1, 1, 'relu', res=ident, res_mode=RES_BEFORE_ACT)
 
-    x = g.conv('conv1', g.input, c0, 7, 2, 'relu', pad=3)
-    x = g.pool(x, 3, 2, 1)
-    x = osblock('conv2.0', x, c1)
+    def down_block(name, make_x, cin, cout, h, w):
+        """First block of a stage (cin != cout).  make_x(dst) emits the layer producing the block input."""
+        mid = cout // 4
+        if fuse_lightconv and mid % 8 == 0 and mid <= 128:
+            cat = g.new(h, w, mid + cin)
+            return osblock(name, make_x(cat.slice(mid, cin)), cout, cat=cat)
+        return osblock(name, make_x(None), cout)
+
+    s = g.conv('conv1', g.input, c0, 7, 2, 'relu', pad=3)
+    x = down_block('conv2.0', lambda dst: g.pool(s, 3, 2, 1, dst=dst), c0, c1, H // 4, W // 4)
     x = osblock('conv2.1', x, c1)
-    x = g.conv('conv2.t', x, c1, 1, 1, 'relu')
-    x = g.pool(x, 2, 2, 0, avg=True)
-    x = osblock('conv3.0', x, c2)
+    t2 = g.conv('conv2.t', x, c1, 1, 1, 'relu')
+    x = down_block('conv3.0', lambda dst: g.pool(t2, 2, 2, 0, avg=True, dst=dst), c1, c2, H // 8, W // 8)
     x = osblock('conv3.1', x, c2)
-    x = g.conv('conv3.t', x, c2, 1, 1, 'relu')
-    x = g.pool(x, 2, 2, 0, avg=True)
-    x = osblock('conv4.0', x, c3)
+    t3 = g.conv('conv3.t', x, c2, 1, 1, 'relu')
+    x = down_block('conv4.0', lambda dst: g.pool(t3, 2, 2, 0, avg=True, dst=dst), c2, c3, H // 16, W // 16)
     x = osblock('conv4.1', x, c3)
     x = g.conv('conv5', x, c3, 1, 1, 'relu')
     g.head('fc', x, model.OUTPUT_LAYOUT)
