@@ -674,15 +674,15 @@ extern "C" int fm_find_occluded(fm_ctx* ctx, int n, const double* tlbr, double t
     std::vector<size_t> offs;
     char* src = nullptr;
     const bool small = n <= FM_ZERO_COPY_TRACKS / 2;
-    int rc = upload(ctx, ctx->io0, {{tlbr, sizeof(double) * 4 * n}}, offs, &src, small);
+    int rc = upload(ctx, ctx->occ_in, {{tlbr, sizeof(double) * 4 * n}}, offs, &src, small);
     if (rc) return rc;
-    if ((rc = ctx->io1.reserve(n))) return rc;
+    if ((rc = ctx->occ_out.reserve(n))) return rc;
     hipLaunchKernelGGL(occluded_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->s_main, n,
-                       (const double*)src, thresh, small ? ctx->io1.host<uint8_t>() : ctx->io1.dev<uint8_t>());
+                       (const double*)src, thresh, small ? ctx->occ_out.host<uint8_t>() : ctx->occ_out.dev<uint8_t>());
     FM_HIP(hipGetLastError());
-    if (!small) FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, n, hipMemcpyDeviceToHost, ctx->s_main));
+    if (!small) FM_HIP(hipMemcpyAsync(ctx->occ_out.h, ctx->occ_out.d, n, hipMemcpyDeviceToHost, ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
-    memcpy(out, ctx->io1.h, n);
+    memcpy(out, ctx->occ_out.h, n);
     return 0;
 }
 

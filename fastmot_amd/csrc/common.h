@@ -90,6 +90,7 @@ struct fm_ctx {
     hipStream_t s_det = nullptr;    // detector network
     hipStream_t s_ext = nullptr;    // ReID network
     hipStream_t s_flow = nullptr;   // KLT
+    hipEvent_t ev_feat = nullptr;   // last reader of ctx->emb on s_main (fm_feat_update); s_ext waits on it
 
     // ---- device-resident track table
     int slot_cap = 0;
@@ -118,6 +119,8 @@ struct fm_ctx {
     DevBuf as_work;     // LAP work arrays
     DevBuf as_out;      // matches
     DevBuf io0, io1;    // generic staging (kalman etc.)
+    DevBuf occ_in, occ_out;   // fm_find_occluded (own buffers: may run concurrently with the Kalman thread)
+    DevBuf feat_in;     // fm_feat_update staging (own buffer: the call returns without synchronising)
 
     // ---- frames (BGR u8) resident on the device
     int frame_w = 0, frame_h = 0, ring_size = 0;

@@ -33,6 +33,7 @@
 // Roofline: per layer max(2*K*Cout*P / 2.5 PFLOP/s, (in + out + weights) * 2 B / 8 TB/s);
 // YOLOv4 @608 = 128.4 GFLOP, 618 MB -> 0.089 ms/frame lower bound.
 #include "net.h"
+#include <cstdlib>
 
 namespace {
 
@@ -375,9 +376,11 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
     const int cout_pad = (p.Cout + 31) & ~31;
     auto tiles = [&](int bmc, int bnp) { return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc); };
     const int nk = p.Kpad / BK;
+    // a split costs a second (reduce) launch, ~5 us: only worth it when it removes >= ~12 K-steps
+    static const int split_min_nk = [] { const char* e = getenv("FASTMOT_SPLIT_MIN_NK"); return e ? atoi(e) : 16; }();
     auto split_for = [&](long t) {
         int S = 1;
-        if (t < 256) {
+        if (t < 256 && nk >= split_min_nk) {
             S = (int)((512 + t - 1) / t);
             S = S < nk / 4 ? S : nk / 4;
             S = S > 16 ? 16 : S;

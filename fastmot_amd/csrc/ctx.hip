@@ -66,6 +66,7 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_lo));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext, hipStreamNonBlocking, prio_hi));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_flow, hipStreamNonBlocking, prio_hi));
+    FM_HIP(hipEventCreateWithFlags(&ctx->ev_feat, hipEventDisableTiming));
     int rc = fm_ensure_slots(ctx, 1024);
     if (rc) return rc;
     *out = ctx;
@@ -88,10 +89,11 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
                     (void*)ctx->feat_cnt, (void*)ctx->emb})
         if (p) (void)hipFree(p);
     for (DevBuf* b : {&ctx->as_in, &ctx->as_pair, &ctx->as_stage_in, &ctx->as_cost, &ctx->as_work,
-                      &ctx->as_out, &ctx->io0, &ctx->io1})
+                      &ctx->as_out, &ctx->io0, &ctx->io1, &ctx->feat_in, &ctx->occ_in, &ctx->occ_out})
         b->release();
     for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_ext, ctx->s_flow})
         if (s) (void)hipStreamDestroy(s);
+    if (ctx->ev_feat) (void)hipEventDestroy(ctx->ev_feat);
     delete ctx;
     return 0;
 }
@@ -352,20 +354,22 @@ extern "C" int fm_feat_update(fm_ctx* ctx, int n, const int32_t* slots, const in
     int rc = fm_ensure_slots(ctx, m + 1);
     if (rc) return rc;
     // NB: a slot may appear only once per call (sequential semantics of the reference loop)
-    if ((rc = ctx->io0.reserve(sizeof(int32_t) * 2 * n))) return rc;
-    int32_t* h = ctx->io0.host<int32_t>();
+    // own staging buffer: wait for the previous update (long finished in practice) instead of for this one,
+    // so the call returns as soon as the kernel is enqueued; every reader of the feature table is on s_main
+    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    if ((rc = ctx->feat_in.reserve(sizeof(int32_t) * 2 * n))) return rc;
+    int32_t* h = ctx->feat_in.host<int32_t>();
     memcpy(h, slots, sizeof(int32_t) * n);
     memcpy(h + n, emb_rows, sizeof(int32_t) * n);
     const bool zc = n <= FM_ZERO_COPY_TRACKS;
-    if (!zc) FM_HIP(hipMemcpyAsync(ctx->io0.d, h, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, ctx->s_main));
-    const int32_t* din = zc ? h : ctx->io0.dev<int32_t>();
+    if (!zc) FM_HIP(hipMemcpyAsync(ctx->feat_in.d, h, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, ctx->s_main));
+    const int32_t* din = zc ? h : ctx->feat_in.dev<int32_t>();
     const int threads = 256, waves_per_block = threads / 64;
     hipLaunchKernelGGL(feat_update_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(threads),
                        0, ctx->s_main, n, din, din + n, ctx->emb,
                        ctx->feat_sum, ctx->feat_avg, ctx->feat_cnt, ctx->feat_dim);
     FM_HIP(hipGetLastError());
-    // io0 host mirror is reused by the next call -> wait for the H2D to be consumed
-    FM_HIP(hipStreamSynchronize(ctx->s_main));
+    FM_HIP(hipEventRecord(ctx->ev_feat, ctx->s_main));   // the extractor must not overwrite ctx->emb before this
     return 0;
 }
 

@@ -117,6 +117,8 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
         FM_HIP(hipHostMalloc(&e->boxes_host, sizeof(double) * 4 * cap, hipHostMallocDefault));
         e->cap = cap;
     }
+    // fm_feat_update (s_main, asynchronous) may still read the previous frame's embeddings
+    FM_HIP(hipStreamWaitEvent(s, ctx->ev_feat, 0));
     if (n > ctx->emb_cap) {
         // association (s_main) may still read the previous embeddings
         FM_HIP(hipStreamSynchronize(ctx->s_main));

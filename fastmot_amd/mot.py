@@ -130,6 +130,7 @@ class MOT:
                     # every box goes to the first extractor, as in the reference (_split_bboxes_by_cls
                     # with its bisect_right quirk, mot.py:180-189)
                     self.extractors[0].extract_async(frame, detections.tlbr)
+                    self.tracker.prepare_detections(detections)
                     embeddings = self.extractors[0].postprocess()
             finally:
                 flow_done.result()

@@ -90,6 +90,7 @@ class MultiTracker:
         self.ctx = get_context()
         self.tracks = {}
         self.hist_tracks = OrderedDict()
+        self._prepared = None
         self.kf = KalmanFilter(**vars(kalman_filter_cfg))
         self.flow = Flow(self.size, **vars(flow_cfg))
         self.frame_rect = _frame_rect(self.size)
@@ -215,6 +216,16 @@ class MultiTracker:
         m_rows, m_cols, gated = self._solve(stage, _lib.SOLVER_LAP, trk_ids, rows, det_ids, det_ids, **kw)
         return self._assignment_matches(len(trk_ids), len(det_ids), trk_ids, det_ids, m_rows, m_cols, gated)
 
+    def prepare_detections(self, detections):
+        """The part of `update` that depends on the detections only (contiguous copies + find_occluded,
+        tracker.py:196).  MOT.step calls it while the ReID network is still running; `update` calls it
+        itself otherwise."""
+        det_tlbr = np.ascontiguousarray(detections.tlbr, np.float64).reshape(-1, 4)
+        det_label = np.ascontiguousarray(detections.label, np.int64).reshape(-1)
+        det_conf = np.asarray(detections.conf, np.float64).reshape(-1)
+        occluded = self.ctx.find_occluded(det_tlbr, self.occlusion_thresh)
+        self._prepared = (detections, det_tlbr, det_label, det_conf, occluded)
+
     def update(self, frame_id, detections, embeddings):
         """Associates detections to tracklets based on motion and feature embeddings
         (tracker.py:185-293).
@@ -223,11 +234,10 @@ class MultiTracker:
         array last returned by FeatureExtractor.postprocess the device copy is used directly."""
         ctx = self.ctx
         n_det = len(detections)
-        det_tlbr = np.ascontiguousarray(detections.tlbr, np.float64).reshape(-1, 4)
-        det_label = np.ascontiguousarray(detections.label, np.int64).reshape(-1)
-        det_conf = np.asarray(detections.conf, np.float64).reshape(-1)
-
-        occluded_det_mask = ctx.find_occluded(det_tlbr, self.occlusion_thresh)
+        if self._prepared is None or self._prepared[0] is not detections:
+            self.prepare_detections(detections)
+        _, det_tlbr, det_label, det_conf, occluded_det_mask = self._prepared
+        self._prepared = None
         confirmed_by_depth, unconfirmed = self._group_tracks_by_depth()
 
         # ---- device: embeddings + every pairwise term of this frame in one launch
