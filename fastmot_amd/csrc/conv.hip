@@ -57,8 +57,8 @@ __device__ __forceinline__ void store_out(const ConvParams& p, long pix, int co,
     }
 }
 
-template <int WC, int WP, int MC, int MP>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p, float* __restrict__ ws) {
+template <int WC, int WP, int MC, int MP, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams p, float* __restrict__ ws) {
     static_assert(WC * WP == 4, "4 waves per block");
     static_assert(WC * MC <= 4 && WP * MP <= 4, "at most 4 chunks per thread and operand");
     constexpr int BMC = WC * MC * 32;
@@ -350,12 +350,12 @@ __global__ void splitk_reduce_kernel(const ConvParams p, const float* __restrict
     }
 }
 
-template <int WC, int WP, int MC, int MP>
+template <int WC, int WP, int MC, int MP, int MINB>
 int launch_cfg(const ConvParams& p, int S, float* ws, hipStream_t s) {
     constexpr int BMC = WC * MC * 32, BNP = WP * MP * 32;
     const int cout_pad = (p.Cout + 31) & ~31;
     dim3 grid((p.P + BNP - 1) / BNP, (cout_pad + BMC - 1) / BMC, S);
-    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, MC, MP>), grid, dim3(256), 0, s, p, ws);
+    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, MC, MP, MINB>), grid, dim3(256), 0, s, p, ws);
     if (S > 1) {
         const long total = (long)p.P * (p.cout_store / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, ws, S);
@@ -366,8 +366,10 @@ int launch_cfg(const ConvParams& p, int S, float* ws, hipStream_t s) {
 
 }  // namespace
 
-// Tile + split selection.  Tiles: 32c x 128p for narrow layers (OSNet x0.25, stems), 64c x 128p when
-// that still gives >= 2 workgroups per CU, otherwise 64c x 64p.  Split-K brings the launch to ~2
+// Tile + split selection.  Tiles: 32c x 128p for narrow layers (OSNet x0.25), otherwise 64c x 64p.
+// (A 64c x 128p tile for the large early layers was measured 1.5-1.7x SLOWER on them -- 55 KB of LDS
+// and 256 VGPRs leave 2 workgroups per CU to hide the load -> LDS -> MFMA -> store chain of a layer
+// with only 1-5 K-steps; the 64 x 64 tile runs 4 per CU.)  Split-K brings the launch to ~2
 // workgroups per CU as long as every split keeps >= 4 K-steps.
 int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s) {
     FM_CHECK_ARG(p.Cin % 8 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0);
@@ -391,8 +393,10 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
         }
         return S;
     };
-    if (cout_pad <= 32) return launch_cfg<1, 4, 1, 1>(p, 1, ws, s);                      //  32c x 128p
-    if (tiles(64, 128) >= 512) return launch_cfg<2, 2, 1, 2>(p, 1, ws, s);               //  64c x 128p
+    static const int minb = [] { const char* e = getenv("FASTMOT_CONV_MINB"); return e ? atoi(e) : 2; }();
+    if (cout_pad <= 32) return launch_cfg<1, 4, 1, 1, 2>(p, 1, ws, s);                   //  32c x 128p
     const long t = tiles(64, 64);
-    return launch_cfg<2, 2, 1, 1>(p, split_for(t), ws, s);                               //  64c x  64p
+    // many short workgroups (early, memory-bound layers): 128 VGPRs -> 4 workgroups per CU
+    if (minb == 4 || (minb == 3 && t >= 1024)) return launch_cfg<2, 2, 1, 1, 4>(p, split_for(t), ws, s);
+    return launch_cfg<2, 2, 1, 1, 2>(p, split_for(t), ws, s);                            //  64c x  64p
 }
