@@ -437,6 +437,16 @@ _bind_device_io(HipContext)
 
 
 # ---------------------------------------------------------------------- optical flow
+class FlowPredictParams(C.Structure):
+    _fields_ = [('feat_density', C.c_double), ('feat_dist_factor', C.c_double),
+                ('opt_scale', C.c_float * 2), ('bg_scale', C.c_float * 2),
+                ('max_error', C.c_double), ('ransac_max_iter', C.c_int32), ('ransac_conf', C.c_double),
+                ('inlier_thresh', C.c_int32), ('frame_w', C.c_int32), ('frame_h', C.c_int32)]
+
+
+FLOW_OK, FLOW_NO_BACKGROUND, FLOW_NO_HOMOGRAPHY = 0, 1, 2
+
+
 class FlowCfg(C.Structure):
     _fields_ = [('small_w', C.c_int32), ('small_h', C.c_int32), ('bg_w', C.c_int32), ('bg_h', C.c_int32),
                 ('win_size', C.c_int32), ('max_level', C.c_int32), ('max_count', C.c_int32),
@@ -490,6 +500,29 @@ def _bind_flow(cls):
                                        _ptr(needy), C.c_int(pts_cap), _ptr(new_pts), _ptr(new_off), _ptr(new_cnt),
                                        C.byref(n_new), C.c_int(bg_cap), _ptr(bg), C.byref(n_bg)))
         return area, keep.astype(bool), needy.astype(bool), new_pts, new_off, new_cnt, bg[:n_bg.value].copy()
+
+    def flow_predict(self, inside_tlbr, full_tlbr, kps, kp_off, params, pts_cap=65536):
+        """fm_flow_predict: -> (status, H, result, est_tlbr, n_matched, prev_pts, cur_pts, trk_off, bg_range);
+        prev/cur are the compacted RANSAC-inlier keypoints (views of per-call arrays)."""
+        r = _as(inside_tlbr, np.float64).reshape(-1, 4)
+        nT = len(r)
+        fb = _as(full_tlbr, np.float64).reshape(nT, 4)
+        off = _as(kp_off, np.int32)
+        k = _as(kps, np.float32).reshape(-1, 2)
+        assert len(off) == nT + 1 and off[-1] == len(k)
+        prev = np.empty((pts_cap, 2), np.float32)
+        cur = np.empty((pts_cap, 2), np.float32)
+        trk_off = np.zeros(nT + 1, np.int32)
+        bg_range = np.zeros(2, np.int32)
+        H = np.zeros((3, 3))
+        status = C.c_int(0)
+        result = np.zeros(nT, np.int32)
+        est = np.zeros((nT, 4))
+        n_matched = np.zeros(nT, np.int32)
+        check(self.lib.fm_flow_predict(self._ctx, C.c_int(nT), _ptr(r), _ptr(fb), _ptr(k), _ptr(off), C.byref(params),
+                                       C.c_int(pts_cap), _ptr(prev), _ptr(cur), _ptr(trk_off), _ptr(bg_range),
+                                       _ptr(H), C.byref(status), _ptr(result), _ptr(est), _ptr(n_matched)))
+        return status.value, H, result, est, n_matched, prev, cur, trk_off, bg_range
 
     def flow_detect(self, track_idx, track_tlbr, min_dist, cap=1000):
         idx = _as(track_idx, np.int32)
@@ -545,7 +578,8 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_read_image(self._ctx, C.c_int(which), _ptr(buf), C.byref(w), C.byref(h)))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 
-    for fn in (flow_configure, flow_init, flow_begin, flow_swap, flow_targets, flow_prepare, flow_detect, flow_background,
+    for fn in (flow_configure, flow_init, flow_begin, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
+               flow_background,
                flow_lk, flow_estimate, flow_read_image):
         setattr(cls, fn.__name__, fn)
 

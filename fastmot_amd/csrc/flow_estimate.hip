@@ -588,3 +588,117 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Flow.predict (flow.py:135-264) in ONE call: pyramid of the new frame, keypoint bookkeeping /
+// detection / background keypoints, pyramidal LK, camera motion + per-track boxes.  The Python side
+// only orders the tracks and scatters the results; the glue arithmetic below reproduces the NumPy
+// expressions of the reference bit for bit (float32 products, see the comments).
+// ---------------------------------------------------------------------------------------------------
+extern "C" int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr,
+                               const float* kps, const int32_t* kp_off, const fm_flow_predict_params* prm,
+                               int pts_cap, float* prev_out, float* cur_out, int32_t* trk_off_out,
+                               int32_t* bg_range_out, double* H_out, int* status_out, int32_t* result_out,
+                               double* est_tlbr_out, int32_t* n_matched_out) {
+    FM_CHECK_ARG(ctx && ctx->flow && nT >= 0 && prm && pts_cap > 0 && prev_out && cur_out && trk_off_out &&
+                 bg_range_out && H_out && status_out);
+    FM_CHECK_ARG(nT == 0 || (inside_tlbr && full_tlbr && kp_off && result_out && est_tlbr_out && n_matched_out));
+    *status_out = FM_FLOW_NO_BACKGROUND;
+    for (int k = 0; k <= nT; ++k) trk_off_out[k] = 0;
+    bg_range_out[0] = bg_range_out[1] = 0;
+    int rc = fm_flow_begin(ctx);
+    if (rc) return rc;
+
+    // ---- keypoint bookkeeping + detection (flow.py:156-200)
+    const int n_kps = nT ? kp_off[nT] : 0;
+    static thread_local std::vector<int32_t> area, new_off, new_cnt, begins, ends;
+    static thread_local std::vector<uint8_t> keep, needy, status, inl;
+    static thread_local std::vector<float> new_pts, bg_pts, prev, scaled, cur, err;
+    const int bg_cap = 8192;
+    area.assign(nT, 0); new_off.assign(nT, 0); new_cnt.assign(nT, 0); needy.assign(nT, 0);
+    keep.assign(n_kps > 0 ? n_kps : 1, 0);
+    new_pts.resize((size_t)pts_cap * 2);
+    bg_pts.resize((size_t)bg_cap * 2);
+    int n_new = 0, n_bg = 0;
+    const int32_t zero_off = 0;
+    rc = fm_flow_prepare(ctx, nT, inside_tlbr, full_tlbr, kps, nT ? kp_off : &zero_off, prm->feat_density,
+                         prm->feat_dist_factor, area.data(), keep.data(), needy.data(), pts_cap, new_pts.data(),
+                         new_off.data(), new_cnt.data(), &n_new, bg_cap, bg_pts.data(), &n_bg);
+    if (rc) return rc;
+    prev.clear();
+    begins.assign(nT, 0); ends.assign(nT, 0);
+    for (int k = 0; k < nT; ++k) {
+        begins[k] = (int32_t)(prev.size() / 2);
+        if (needy[k]) {   // only detect new keypoints when too few are propagated
+            const float* p = new_pts.data() + 2 * (size_t)new_off[k];
+            prev.insert(prev.end(), p, p + 2 * (size_t)new_cnt[k]);
+        } else {
+            for (int i = kp_off[k]; i < kp_off[k + 1]; ++i)
+                if (keep[i]) { prev.push_back(kps[2 * i]); prev.push_back(kps[2 * i + 1]); }
+        }
+        ends[k] = (int32_t)(prev.size() / 2);
+    }
+    if (n_bg == 0) {   // flow.py:191-196
+        return fm_flow_swap(ctx);
+    }
+    const int bg_begin = (int)(prev.size() / 2);
+    // keypoints = keypoints * (1 / bg_scale): float32 reciprocal, float32 product
+    const float ibx = 1.0f / prm->bg_scale[0], iby = 1.0f / prm->bg_scale[1];
+    for (int i = 0; i < n_bg; ++i) {
+        prev.push_back(bg_pts[2 * i] * ibx);
+        prev.push_back(bg_pts[2 * i + 1] * iby);
+    }
+    const int n_pts = (int)(prev.size() / 2);
+    FM_CHECK_ARG(n_pts <= pts_cap);
+
+    // ---- optical flow on the scaled images (flow.py:202-213)
+    scaled.resize(prev.size()); cur.resize(prev.size()); err.resize(n_pts); status.resize(n_pts); inl.resize(n_pts);
+    for (int i = 0; i < n_pts; ++i) {
+        scaled[2 * i] = prev[2 * i] * prm->opt_scale[0];
+        scaled[2 * i + 1] = prev[2 * i + 1] * prm->opt_scale[1];
+    }
+    rc = fm_flow_lk(ctx, n_pts, scaled.data(), cur.data(), status.data(), err.data());
+    if (rc) return rc;
+    const float iox = 1.0f / prm->opt_scale[0], ioy = 1.0f / prm->opt_scale[1];
+    const float max_err = (float)prm->max_error;
+    for (int i = 0; i < n_pts; ++i) {
+        status[i] = (status[i] && err[i] < max_err) ? 1 : 0;
+        if (status[i]) { cur[2 * i] *= iox; cur[2 * i + 1] *= ioy; }
+    }
+
+    // ---- camera motion + per-track boxes (flow.py:215-263)
+    int ok = 0;
+    const int bg_end = n_pts - 1 > bg_begin ? n_pts - 1 : bg_begin;
+    rc = fm_flow_estimate(ctx, n_pts, prev.data(), cur.data(), status.data(), nT, begins.data(), ends.data(),
+                          bg_begin, bg_end, full_tlbr, prm->frame_w, prm->frame_h, prm->ransac_max_iter,
+                          prm->ransac_conf, prm->inlier_thresh, H_out, &ok, result_out, est_tlbr_out, n_matched_out,
+                          inl.data());
+    if (rc) return rc;
+    if (!ok) {
+        *status_out = FM_FLOW_NO_HOMOGRAPHY;
+        return 0;
+    }
+    // ---- compact the inlier keypoints: per track (result != 0), then the background
+    int w = 0;
+    for (int k = 0; k < nT; ++k) {
+        trk_off_out[k] = w;
+        if (result_out[k] == 0) continue;
+        for (int i = begins[k]; i < ends[k]; ++i)
+            if (inl[i]) {
+                prev_out[2 * w] = prev[2 * i]; prev_out[2 * w + 1] = prev[2 * i + 1];
+                cur_out[2 * w] = cur[2 * i]; cur_out[2 * w + 1] = cur[2 * i + 1];
+                ++w;
+            }
+    }
+    trk_off_out[nT] = w;
+    bg_range_out[0] = w;
+    for (int i = bg_begin; i < n_pts; ++i)
+        if (inl[i]) {
+            prev_out[2 * w] = prev[2 * i]; prev_out[2 * w + 1] = prev[2 * i + 1];
+            cur_out[2 * w] = cur[2 * i]; cur_out[2 * w + 1] = cur[2 * i + 1];
+            ++w;
+        }
+    bg_range_out[1] = w;
+    *status_out = FM_FLOW_OK;
+    return 0;
+}

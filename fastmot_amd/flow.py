@@ -1,5 +1,6 @@
 """Flow (API of fastmot/flow.py:16-264): KLT tracking of per-track keypoints + camera motion.
 The numeric pipeline (gray / resize / GFTT / FAST / pyramidal LK / RANSAC) runs in flow.hip."""
+import ctypes as C
 import logging
 
 import numpy as np
@@ -64,6 +65,9 @@ class Flow:
         self._opt_scale = np.array(self.opt_flow_scale_factor, np.float32)
         self._bg_scale = np.array(self.bg_feat_scale_factor, np.float32)
         self._configured = False
+        self._params = _lib.FlowPredictParams(
+            feat_density, feat_dist_factor, (C.c_float * 2)(*self._opt_scale), (C.c_float * 2)(*self._bg_scale),
+            float(max_error), int(ransac_max_iter), float(ransac_conf), int(inlier_thresh), int(size[0]), int(size[1]))
 
     def _configure(self):
         """Allocates the device images / pyramids (flow.py:100-118 preallocates pinned buffers)."""
@@ -101,26 +105,19 @@ class Flow:
     def predict(self, frame, tracks):
         """Predicts tracklet positions in the next frame and estimates camera motion
         (flow.py:135-264).  Returns ({trk_id: tlbr}, 3x3 homography) or ({}, None) on failure;
-        keypoints / inlier ratios of `tracks` are updated in place."""
-        self.predict_begin(frame, tracks)
-        return self.predict_finish()
+        keypoints / inlier ratios of `tracks` are updated in place.
 
-    def predict_begin(self, frame, tracks):
-        """First half of `predict` (flow.py:153-200): images, keypoint bookkeeping / detection and
-        background keypoints -- one device round trip.  MOT.step calls the two halves separately so
-        that the ReID network can be enqueued in between."""
+        One library call (fm_flow_predict): gray / pyramid of the new frame, keypoint bookkeeping and
+        detection, background keypoints, pyramidal LK, RANSAC camera motion and per-track boxes; this
+        method only orders the tracks and scatters the results."""
         ctx = self.ctx
         bind_frame(ctx, frame, self.size)
-        ctx.flow_begin()                       # gray + small + pyramid of the new frame (async)
+        empty = np.empty((0, 2), np.float32)
 
         # order tracks from closest to farthest
         tracks.sort(reverse=True)
         n_trk = len(tracks)
         fr = self.frame_rect
-        empty = np.empty((0, 2), np.float32)
-
-        # detect target feature points + background feature points (one device round trip)
-        all_prev_pts = []
         if n_trk:
             tlbrs = np.array([t.tlbr for t in tracks], np.float64).reshape(n_trk, 4)
             inside = np.concatenate([np.maximum(tlbrs[:, :2], fr[:2]), np.minimum(tlbrs[:, 2:], fr[2:])], axis=1)
@@ -131,67 +128,30 @@ class Flow:
         else:
             tlbrs, inside = np.zeros((0, 4)), np.zeros((0, 4))
             kp_off, kps = np.zeros(1, np.int32), empty
-        areas, keep, needy, new_pts, new_off, new_cnt, keypoints = ctx.flow_prepare(
-            inside, tlbrs, kps, kp_off, self.feat_density, self.feat_dist_factor)
-        for k in range(n_trk):
-            if needy[k]:     # only detect new keypoints when too few are propagated
-                all_prev_pts.append(new_pts[new_off[k]:new_off[k] + new_cnt[k]].copy())
-            else:
-                all_prev_pts.append(kps[kp_off[k]:kp_off[k + 1]][keep[kp_off[k]:kp_off[k + 1]]])
-        target_ends = np.cumsum([len(p) for p in all_prev_pts]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
-        target_begins = np.concatenate([[0], target_ends[:-1]]).astype(np.int32) if n_trk else np.zeros(0, np.int32)
 
-        self._pending = (tracks, tlbrs, all_prev_pts, target_begins, target_ends, keypoints)
-
-    def predict_finish(self):
-        """Second half of `predict` (flow.py:201-264): LK matching, camera motion, target boxes."""
-        ctx = self.ctx
-        tracks, tlbrs, all_prev_pts, target_begins, target_ends, keypoints = self._pending
-        self._pending = None
-        n_trk = len(tracks)
-        empty = np.empty((0, 2), np.float32)
-        if len(keypoints) == 0:
-            self.bg_keypoints = empty
-            ctx.flow_swap()
-            LOGGER.warning('Camera motion estimation failed')
-            return {}, None
-        keypoints = keypoints * (1 / self._bg_scale)
-        bg_begin = int(target_ends[-1]) if n_trk else 0
-        all_prev_pts.append(keypoints)
-
-        # match features using optical flow (frame buffers are swapped inside)
-        all_prev_pts = np.concatenate(all_prev_pts).astype(np.float32)
-        scaled_prev_pts = all_prev_pts * self._opt_scale
-        all_cur_pts, status, err = ctx.flow_lk(scaled_prev_pts)
-        status = status.astype(np.bool_) & (err < self.max_error)
-        all_cur_pts[status] = all_cur_pts[status] * (1 / self._opt_scale)
-
-        # camera motion + per-track boxes (RANSAC; host side of the library)
-        n_pts = len(all_prev_pts)
-        homography, result, est, n_matched, inl = ctx.flow_estimate(
-            all_prev_pts, all_cur_pts, status, target_begins, target_ends, bg_begin, max(n_pts - 1, bg_begin),
-            tlbrs, self.size, self.ransac_max_iter, self.ransac_conf, self.inlier_thresh)
-        if homography is None:
+        status, homography, result, est, n_matched, prev, cur, off, bg = ctx.flow_predict(
+            inside, tlbrs, kps, kp_off, self._params)
+        if status != _lib.FLOW_OK:
             self.bg_keypoints = empty
             LOGGER.warning('Camera motion estimation failed')
             return {}, None
-        bg = slice(bg_begin, n_pts)
-        self.prev_bg_keypoints = all_prev_pts[bg][inl[bg]]
-        self.bg_keypoints = all_cur_pts[bg][inl[bg]]
+        self.prev_bg_keypoints = prev[bg[0]:bg[1]]
+        self.bg_keypoints = cur[bg[0]:bg[1]]
 
         # estimate target bounding boxes
         next_bboxes = {}
+        off = off.tolist()
+        result = result.tolist()
         for k, track in enumerate(tracks):
             code = result[k]
             if code == 0:
                 track.keypoints = empty
                 continue
-            sl = slice(target_begins[k], target_ends[k])
-            track.prev_keypoints = all_prev_pts[sl][inl[sl]]
-            track.keypoints = all_cur_pts[sl][inl[sl]]
+            track.prev_keypoints = prev[off[k]:off[k + 1]]
             if code == 2:
                 track.keypoints = empty
                 continue
+            track.keypoints = cur[off[k]:off[k + 1]]
             next_bboxes[track.trk_id] = est[k].copy()
-            track.inlier_ratio = len(track.keypoints) / n_matched[k]
+            track.inlier_ratio = (off[k + 1] - off[k]) / n_matched[k]
         return next_bboxes, homography

@@ -143,8 +143,7 @@ class MOT:
 
     def _flow_and_kalman(self, frame):
         with Profiler('track'):
-            self.tracker.compute_flow_begin(frame)
-            self.tracker.compute_flow_finish()
+            self.tracker.compute_flow(frame)
             self.tracker.apply_kalman()
 
     @staticmethod

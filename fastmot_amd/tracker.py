@@ -148,17 +148,6 @@ class MultiTracker:
             # clear tracks when camera motion cannot be estimated
             self._clear_tracks()
 
-    def compute_flow_begin(self, frame):
-        """First half of compute_flow (device round trip); see Flow.predict_begin."""
-        active_tracks = [track for track in self.tracks.values() if track.active]
-        self.flow.predict_begin(frame, active_tracks)
-
-    def compute_flow_finish(self):
-        self.klt_bboxes, self.homography = self.flow.predict_finish()
-        if self.homography is None:
-            # clear tracks when camera motion cannot be estimated
-            self._clear_tracks()
-
     def apply_kalman(self):
         """Kalman predict + KLT update of every track in one launch (tracker.py:164-183)."""
         items = list(self.tracks.items())

@@ -384,6 +384,28 @@ int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, const float*
                      int ransac_max_iter, double ransac_conf, int inlier_thresh,
                      double* H_out, int* ok_out, int32_t* result_out, double* est_tlbr_out,
                      int32_t* n_matched_out, uint8_t* inlier_out);
+/* Flow.predict (flow.py:135-264) as ONE call = fm_flow_begin + fm_flow_prepare + the keypoint list
+ * assembly + fm_flow_lk + fm_flow_estimate, with the NumPy glue arithmetic of the reference (float32
+ * scale products) done in the library.  Inputs as fm_flow_prepare (tracks closest-first).
+ * Outputs: status (FM_FLOW_OK / NO_BACKGROUND: no background keypoints, buffers swapped, flow.py:191-196 /
+ * NO_HOMOGRAPHY: flow.py:227-231); H (3x3); per track result code (0 skipped, 1 box estimated, 2 estimated
+ * but rejected), est_tlbr, n_matched; the RANSAC-inlier keypoints compacted in prev_out / cur_out
+ * ([pts_cap][2] f32, frame coordinates): track k owns [trk_off[k], trk_off[k+1]) (empty when result 0),
+ * the background inliers [bg_range[0], bg_range[1]). */
+typedef struct fm_flow_predict_params {
+    double feat_density, feat_dist_factor;
+    float opt_scale[2], bg_scale[2];      /* opt_flow_scale_factor, bg_feat_scale_factor as float32 */
+    double max_error;                     /* compared as float32, like NumPy's err < max_error */
+    int32_t ransac_max_iter;
+    double ransac_conf;
+    int32_t inlier_thresh;
+    int32_t frame_w, frame_h;
+} fm_flow_predict_params;
+enum { FM_FLOW_OK = 0, FM_FLOW_NO_BACKGROUND = 1, FM_FLOW_NO_HOMOGRAPHY = 2 };
+int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr, const float* kps,
+                    const int32_t* kp_off, const fm_flow_predict_params* prm, int pts_cap, float* prev_out,
+                    float* cur_out, int32_t* trk_off_out, int32_t* bg_range_out, double* H_out, int* status_out,
+                    int32_t* result_out, double* est_tlbr_out, int32_t* n_matched_out);
 /* test hooks: read the device images (which: 0 prev gray, 1 cur gray, 2.. pyramid levels of prev
  * (2+l) and cur (10+l), 20 bg image) */
 int fm_flow_read_image(fm_ctx* ctx, int which, uint8_t* out, int* w, int* h);

@@ -33,7 +33,7 @@ def wrap(obj, name, label=None):
             cnt[label] += 1
     setattr(obj, name, w)
 
-for n in ('flow_begin', 'flow_prepare', 'flow_lk', 'flow_estimate', 'detect_async', 'detect_sync', 'extract_async',
+for n in ('flow_predict', 'detect_async', 'detect_sync', 'extract_async',
           'extract_sync', 'assoc_prepare', 'assoc_stage', 'find_occluded', 'feat_update', 'trk_update_det',
           'trk_step', 'trk_step_ops', 'emb_upload', 'synchronize', 'trk_create', 'feat_merge', 'frame_ring_select'):
     if hasattr(ctx, n):
@@ -42,8 +42,7 @@ wrap(mot.detector, 'detect_async', 'det.detect_async')
 wrap(mot.detector, 'postprocess', 'det.postprocess')
 wrap(mot.extractors[0], 'extract_async', 'ext.extract_async')
 wrap(mot.extractors[0], 'postprocess', 'ext.postprocess')
-wrap(mot.tracker, 'compute_flow_begin', 'trk.flow_begin')
-wrap(mot.tracker, 'compute_flow_finish', 'trk.flow_finish')
+wrap(mot.tracker, 'compute_flow', 'trk.compute_flow')
 wrap(mot.tracker, 'apply_kalman', 'trk.apply_kalman')
 wrap(mot.tracker, 'update', 'trk.update')
 wrap(mot, '_step', 'mot._step')
