@@ -99,6 +99,19 @@ def cpu_baseline(video, budget_s=20.0):
                       'NOT the Numba-compiled reference'}
 
 
+def pmc_traffic():
+    """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_conv.json,
+    produced by scripts/collect_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of the detector network;
+    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  PMC counters cannot be collected from
+    inside this process, hence the file; None when it is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_conv.json')
+    try:
+        with open(path) as f:
+            return json.load(f)['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -181,7 +194,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (110 conv launches of YOLOv4 per frame, '
                                                     f'measured with HIP events on the detector stream over {n_launch} launches)',
                          'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_PEAK_TFLOPS, 5), 'traffic': None,
+                         'frac': round(achieved / MFMA_PEAK_TFLOPS, 5), 'traffic': pmc_traffic(),
                          'flop_per_frame': flops, 'net_ms_per_frame': round(net_avg_ms, 4),
                          'avg_launch_us': round(net_avg_ms * 1e3 / n_launch, 3)},
         }

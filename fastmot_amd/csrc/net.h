@@ -23,6 +23,7 @@ struct ConvParams {
     int K, Kpad, P;                         // K = KH*KW*Cin, Kpad = ceil64(K), P = N*Ho*Wo
     int cout_store;                         // ceil8(Cout): channels written
     int act, res_mode;
+    int grid_p, grid_c, grid_z, weight_major;   // tile grid + XCD-aware order (filled by launch_conv)
     int up;                                 // 2: every output pixel is stored to its 2x2 block of a (2Ho, 2Wo) view
 };
 

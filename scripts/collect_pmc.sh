@@ -1,0 +1,33 @@
+#!/bin/bash
+# HBM-side traffic of the detector's conv kernel: two separate rocprofv3 PMC passes (FETCH_SIZE and
+# WRITE_SIZE do not fit one pass on gfx950) over 6 graph replays of YOLOv4@608, summed per kernel.
+# Run on the GPU box from the repo root:  bash scripts/collect_pmc.sh  -> gpurun_out/pmc_*.txt + r01_pmc_conv.json
+set -e
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$c
+    rocprofv3 --pmc $c -d /tmp/pmc_$c -o f -- python scripts/trace_net.py 0 > /dev/null 2>&1
+    python scripts/rocpd_pmc.py "$(find /tmp/pmc_$c -name '*.db' | head -1)" $c > gpurun_out/pmc_$c.txt
+done
+python - <<'PY'
+import json
+def load(c):
+    for line in open(f'gpurun_out/pmc_{c}.txt'):
+        if line.startswith('JSON '):
+            return json.loads(line[5:])
+f, w = load('FETCH_SIZE'), load('WRITE_SIZE')
+conv = [k for k in f if k.startswith('conv_igemm_kernel')]
+calls = sum(f[k]['calls'] for k in conv)
+fetch_kb = sum(f[k]['total'] for k in conv)
+write_kb = sum(w[k]['total'] for k in conv if k in w)
+out = dict(kernel='conv_igemm_kernel (all template instances)', launches=calls, replays=6,
+           fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb,
+           correction='FETCH_SIZE x2 (gfx950: 128 B requests tallied at 64 B for 16 B/lane loads); WRITE_SIZE raw (uncalibrated)',
+           traffic_bytes_per_launch=round((2 * fetch_kb + write_kb) * 1024 / calls),
+           fetch_bytes_per_frame=round(2 * fetch_kb * 1024 / 6), write_bytes_per_frame=round(write_kb * 1024 / 6),
+           splitk_reduce_fetch_kb_raw=f.get('splitk_reduce_kernel', {}).get('total'),
+           splitk_reduce_write_kb_raw=w.get('splitk_reduce_kernel', {}).get('total'))
+json.dump(out, open('gpurun_out/r01_pmc_conv.json', 'w'), indent=1)
+print(json.dumps(out))
+PY
