@@ -420,11 +420,13 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
     const int nk = p.Kpad / BK;
     // a split costs a second (reduce) launch, ~5 us: only worth it when it removes >= ~12 K-steps
     static const int split_min_nk = [] { const char* e = getenv("FASTMOT_SPLIT_MIN_NK"); return e ? atoi(e) : 16; }();
+    static const int split_target = [] { const char* e = getenv("FASTMOT_SPLIT_TARGET"); return e ? atoi(e) : 384; }();
+    static const int split_min_steps = [] { const char* e = getenv("FASTMOT_SPLIT_MIN_STEPS"); return e ? atoi(e) : 4; }();
     auto split_for = [&](long t) {
         int S = 1;
         if (t < 256 && nk >= split_min_nk) {
-            S = (int)((512 + t - 1) / t);
-            S = S < nk / 4 ? S : nk / 4;
+            S = (int)((split_target + t - 1) / t);
+            S = S < nk / split_min_steps ? S : nk / split_min_steps;
             S = S > 16 ? 16 : S;
             if (S < 1) S = 1;
             // every split must own at least one step

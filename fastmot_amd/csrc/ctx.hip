@@ -65,7 +65,8 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, prio_hi));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_lo));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext, hipStreamNonBlocking, prio_hi));
-    FM_HIP(hipStreamCreateWithPriority(&ctx->s_flow, hipStreamNonBlocking, prio_hi));
+    const char* fp = getenv("FASTMOT_FLOW_PRIO");   // experiment knob: 0 = flow stream at the detector's (low) priority
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_flow, hipStreamNonBlocking, fp && atoi(fp) == 0 ? prio_lo : prio_hi));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_feat, hipEventDisableTiming));
     int rc = fm_ensure_slots(ctx, 1024);
     if (rc) return rc;
