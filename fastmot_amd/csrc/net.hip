@@ -25,6 +25,8 @@ int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int
                 int W, int C, int Ho, int Wo, int k, int stride, int pad, int avg, hipStream_t s);
 int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
                      int W, int C, hipStream_t s);
+int launch_add(const f16* a, int a_cs, int a_coff, const f16* b, int b_cs, int b_coff, f16* out, int out_cs,
+               int out_coff, long npix, int C, hipStream_t s);
 int launch_copy(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, long npix, int C,
                 hipStream_t s);
 int launch_gate(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int hid, const f16* w1,
@@ -221,6 +223,13 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
         case FM_OP_UPSAMPLE2:
             FM_CHECK_ARG(to.h == 2 * ti.h && to.w == 2 * ti.w);
             return launch_upsample2(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, s);
+        case FM_OP_ADD: {
+            FM_CHECK_ARG(L.n_in == 2);
+            const fm_tensor& tb = net->tensors[L.in[1]];
+            FM_CHECK_ARG(tb.h == ti.h && tb.w == ti.w && to.h == ti.h && to.w == ti.w);
+            return launch_add(in0, ti.c, L.in_coff[0], (const f16*)net->bufs[L.in[1]], tb.c, L.in_coff[1], out, to.c,
+                              L.out_coff, (long)B * ti.h * ti.w, L.cin, s);
+        }
         case FM_OP_COPY:
             return launch_copy(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, (long)B * ti.h * ti.w, L.cin, s);
         case FM_OP_GATE:

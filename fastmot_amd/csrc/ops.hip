@@ -149,6 +149,23 @@ __global__ void copy_kernel(const f16* __restrict__ in, int in_cs, int in_coff, 
         *reinterpret_cast<const uint4*>(in + pix * in_cs + in_coff + c);
 }
 
+// element-wise sum of two channel slices ([shortcut] whose operand is also read elsewhere, so that it
+// cannot be folded into the producing conv's epilogue; yolo2onnx.py _make_shortcut_node)
+__global__ void add_kernel(const f16* __restrict__ a, int a_cs, int a_coff, const f16* __restrict__ b, int b_cs,
+                           int b_coff, f16* __restrict__ out, int out_cs, int out_coff, long npix, int C) {
+    const int c8n = C / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c8n) return;
+    const int c = (int)(idx % c8n) * 8;
+    const long pix = idx / c8n;
+    float x[8], y[8];
+    unpack8(*reinterpret_cast<const uint4*>(a + pix * a_cs + a_coff + c), x);
+    unpack8(*reinterpret_cast<const uint4*>(b + pix * b_cs + b_coff + c), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+    *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = pack8(x);
+}
+
 // OSNet channel gate: gate[n][c] = sigmoid(fc2(relu(fc1(GAP(x[n])))))   (one block per sample)
 // w1: [hid][C] f16, b1: f32[hid], w2: [C][hid] f16, b2: f32[C]; gate out f32 [N][C]
 __global__ __launch_bounds__(256) void gate_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
@@ -482,6 +499,16 @@ int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     const long total = (long)N * 4 * H * W * (C / 8);
     hipLaunchKernelGGL(upsample2_kernel, grid1d(total), dim3(256), 0, s, in, in_cs, in_coff, out, out_cs,
                        out_coff, N, H, W, C);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_add(const f16* a, int a_cs, int a_coff, const f16* b, int b_cs, int b_coff, f16* out, int out_cs,
+               int out_coff, long npix, int C, hipStream_t s) {
+    FM_CHECK_ARG(C % 8 == 0 && a_cs % 8 == 0 && a_coff % 8 == 0 && b_cs % 8 == 0 && b_coff % 8 == 0 &&
+                 out_cs % 8 == 0 && out_coff % 8 == 0);
+    hipLaunchKernelGGL(add_kernel, grid1d(npix * (C / 8)), dim3(256), 0, s, a, a_cs, a_coff, b, b_cs, b_coff, out,
+                       out_cs, out_coff, npix, C);
     FM_HIP(hipGetLastError());
     return 0;
 }

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV) = range(13)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD) = range(14)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
@@ -82,6 +82,8 @@ def fold_bn(p, eps=1e-5):
         scale = p['gamma'] / np.sqrt(p['var'] + eps)
         w = w * scale.reshape(-1, *([1] * (w.ndim - 1)))
         b = p['beta'] - p['mean'] * scale
+        if 'bias' in p:                  # Linear/Conv with its own bias followed by BN (OSNet fc head)
+            b = b + p['bias'] * scale
     else:
         b = p.get('bias', np.zeros(w.shape[0], np.float32))
     return w.astype(np.float32), b.astype(np.float32)
@@ -233,14 +235,18 @@ class Graph:
             return self.dwconv3(name + '.dw', y, act)
         return self.lightconv_group(name, [x], [self.lightconv_params(name, cout)], act)
 
-    def pool(self, x, k, stride, pad, avg=False, dst=None):
-        ho = (x.h + 2 * pad - k) // stride + 1
-        wo = (x.w + 2 * pad - k) // stride + 1
+    def pool(self, x, k, stride, pad, avg=False, dst=None, pad_end=None):
+        """pad_end: padding at the bottom/right when it differs from `pad` (ONNX SAME_UPPER of darknet
+        [maxpool], yolo2onnx.py:838-863); windows are clipped at the border either way."""
+        pad_end = pad if pad_end is None else pad_end
+        assert avg is False or pad_end == pad
+        ho = (x.h + pad + pad_end - k) // stride + 1
+        wo = (x.w + pad + pad_end - k) // stride + 1
         if dst is None:
             dst = self.new(ho, wo, x.c)
         assert dst.h == ho and dst.w == wo
         self._layer(op=OP_AVGPOOL if avg else OP_MAXPOOL, ins=[x], out=dst, cin=x.cpad, cout=x.c, k=k,
-                    stride=stride, pad=pad)
+                    stride=stride, pad=pad, pad_end=pad_end)
         return dst
 
     def spp(self, x, dst):
@@ -259,6 +265,13 @@ class Graph:
         if dst is None:
             dst = self.new(2 * x.h, 2 * x.w, x.c)
         self._layer(op=OP_UPSAMPLE2, ins=[x], out=dst, cin=x.cpad, cout=x.c)
+        return dst
+
+    def add(self, a, b, dst=None):
+        assert a.c == b.c and (a.h, a.w) == (b.h, b.w)
+        if dst is None:
+            dst = self.new(a.h, a.w, a.c)
+        self._layer(op=OP_ADD, ins=[a, b], out=dst, cin=a.cpad, cout=a.c)
         return dst
 
     def copy(self, x, dst):

@@ -34,9 +34,19 @@ class ReID:
 
     @classmethod
     def build_graph(cls, weights=None, fuse_lightconv=True):
+        """Weights: the explicit source, else the torchreid checkpoint at MODEL_PATH if it exists
+        (models/torchreid_weights.py), else seeded random parameters."""
+        ckpt = None
         if weights is None:
-            weights = RandomWeights(seed=1)
-        return osnet_graph(cls, weights, fuse_lightconv)
+            if cls.MODEL_PATH is not None and Path(cls.MODEL_PATH).is_file():
+                from .torchreid_weights import TorchreidWeights
+                weights = ckpt = TorchreidWeights(cls.MODEL_PATH)
+            else:
+                weights = RandomWeights(seed=1)
+        out = osnet_graph(cls, weights, fuse_lightconv)
+        if ckpt is not None and ckpt.unused():
+            raise ValueError(f'{cls.MODEL_PATH}: parameters not used by {cls.__name__}: {ckpt.unused()[:5]} ...')
+        return out
 
 
 def osnet_graph(model, weights, fuse_lightconv=True):

@@ -10,6 +10,7 @@ point to Darknet weights; without a file the network runs with seeded random wei
 """
 from pathlib import Path
 
+from .darknet import DarknetWeights, darknet_graph
 from .graph import Graph, RandomWeights
 
 
@@ -43,14 +44,38 @@ class YOLO:
         return cls.__registry[name]
 
     @classmethod
+    def cfg_path(cls):
+        """Darknet cfg next to the weights (the reference converts cfg + weights to ONNX offline,
+        scripts/yolo2onnx.py; here the cfg is read directly)."""
+        return cls.MODEL_PATH.with_suffix('.cfg') if cls.MODEL_PATH is not None else None
+
+    @classmethod
     def build_graph(cls, weights=None):
-        """-> (Graph, [head output views])  heads in LAYER_FACTORS order."""
+        """-> (Graph, [head output views])  heads in LAYER_FACTORS order.
+
+        Weights: the explicit `weights` source, else the Darknet file at MODEL_PATH if it exists, else
+        seeded random parameters.  Topology: the Darknet cfg next to MODEL_PATH if it exists (any
+        YOLOv3/v4/-tiny/Scaled-YOLOv4 cfg, models/darknet.py), else the built-in yolov4.cfg table."""
+        real = None
         if weights is None:
-            weights = RandomWeights(seed=0)
-        assert len(cls.LAYER_FACTORS) == len(cls.SCALES) == len(cls.ANCHORS) or cls.TOPOLOGY != 'yolov4'
-        if cls.TOPOLOGY == 'yolov4':
-            return yolov4_graph(cls, weights)
-        raise NotImplementedError(f'topology {cls.TOPOLOGY} has no layer table yet')
+            if cls.MODEL_PATH is not None and Path(cls.MODEL_PATH).is_file():
+                weights = real = DarknetWeights(cls.MODEL_PATH)
+            else:
+                weights = RandomWeights(seed=0)
+        cfg = cls.cfg_path()
+        if cfg is not None and cfg.is_file():
+            g, heads, meta = darknet_graph(cfg.read_text(), weights, in_hw=cls.INPUT_SHAPE[1:])
+            if meta.get('classes') != cls.NUM_CLASSES or len(heads) != len(cls.LAYER_FACTORS) or \
+                    meta.get('strides') != list(cls.LAYER_FACTORS) or meta.get('new_coords') != cls.NEW_COORDS:
+                raise ValueError(f'{cfg} does not describe {cls.__name__}: {meta}')
+        elif cls.TOPOLOGY == 'yolov4':
+            assert len(cls.LAYER_FACTORS) == len(cls.SCALES) == len(cls.ANCHORS)
+            g, heads = yolov4_graph(cls, weights)
+        else:
+            raise NotImplementedError(f'{cls.__name__}: no built-in layer table; put the Darknet cfg at {cfg}')
+        if real is not None and real.remaining() != 0:
+            raise ValueError(f'{cls.MODEL_PATH}: {real.remaining()} bytes left after loading {cls.__name__}')
+        return g, heads
 
 
 def yolov4_graph(model, weights):
@@ -163,34 +188,71 @@ class YOLOv4_608(YOLO):
                [142, 110, 192, 243, 459, 401]]
 
 
-# The following descriptors are supported by the reference "but not provided" (models/yolo.py:166-299);
-# their metadata is kept so configs resolve, the layer tables are future work.
-class YOLOv4CSP(YOLO):
-    ENGINE_PATH = Path(__file__).parent / 'yolov4-csp.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov4-csp.weights'
-    NUM_CLASSES = 1
-    LETTERBOX = True
-    NEW_COORDS = True
-    INPUT_SHAPE = (3, 640, 640)
-    LAYER_FACTORS = [8, 16, 32]
-    SCALES = [2.0, 2.0, 2.0]
-    ANCHORS = [[12, 16, 19, 36, 40, 28],
-               [36, 75, 76, 55, 72, 146],
-               [142, 110, 192, 243, 459, 401]]
-    TOPOLOGY = 'yolov4-csp'
+# The following descriptors are supported by the reference "but not provided" (models/yolo.py:166-299).
+# Their metadata is identical; the topology comes from the Darknet cfg placed next to MODEL_PATH
+# (models/darknet.py builds the layer table from it).
+_COCO_ANCHORS = [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146], [142, 110, 192, 243, 459, 401]]
 
 
-class YOLOv4P6(YOLO):
-    ENGINE_PATH = Path(__file__).parent / 'yolov4-p6.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov4-p6.weights'
+def _scaled(name, input_shape, factors, anchors, scales=2.0):
+    return type(name, (YOLO,), dict(
+        ENGINE_PATH=Path(__file__).parent / f'{_file_name(name)}.hipnet',
+        MODEL_PATH=Path(__file__).parent / f'{_file_name(name)}.weights',
+        NUM_CLASSES=1, LETTERBOX=True, NEW_COORDS=True, INPUT_SHAPE=input_shape, LAYER_FACTORS=factors,
+        SCALES=[scales] * len(factors), ANCHORS=anchors, TOPOLOGY='darknet-cfg', __module__=__name__))
+
+
+def _file_name(name):
+    return {'YOLOv4CSP': 'yolov4-csp', 'YOLOv4xMish': 'yolov4x-mish', 'YOLOv4CSPSwish': 'yolov4-csp-swish',
+            'YOLOv4CSPxSwish': 'yolov4-csp-x-swish', 'YOLOv4P5': 'yolov4-p5', 'YOLOv4P6': 'yolov4-p6'}[name]
+
+
+YOLOv4CSP = _scaled('YOLOv4CSP', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
+YOLOv4xMish = _scaled('YOLOv4xMish', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
+YOLOv4CSPSwish = _scaled('YOLOv4CSPSwish', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
+YOLOv4CSPxSwish = _scaled('YOLOv4CSPxSwish', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
+YOLOv4P5 = _scaled('YOLOv4P5', (3, 896, 896), [8, 16, 32],
+                   [[13, 17, 31, 25, 24, 51, 61, 45], [48, 102, 119, 96, 97, 189, 217, 184],
+                    [171, 384, 324, 451, 616, 618, 800, 800]])
+YOLOv4P6 = _scaled('YOLOv4P6', (3, 1280, 1280), [8, 16, 32, 64],
+                   [[13, 17, 31, 25, 24, 51, 61, 45], [61, 45, 48, 102, 119, 96, 97, 189],
+                    [97, 189, 217, 184, 171, 384, 324, 451], [324, 451, 545, 357, 616, 618, 1024, 1024]])
+
+
+class YOLOv4Tiny(YOLO):
+    ENGINE_PATH = Path(__file__).parent / 'yolov4-tiny.hipnet'
+    MODEL_PATH = Path(__file__).parent / 'yolov4-tiny.weights'
     NUM_CLASSES = 1
-    LETTERBOX = True
-    NEW_COORDS = True
-    INPUT_SHAPE = (3, 1280, 1280)
-    LAYER_FACTORS = [8, 16, 32, 64]
-    SCALES = [2.0, 2.0, 2.0, 2.0]
-    ANCHORS = [[13, 17, 31, 25, 24, 51, 61, 45],
-               [61, 45, 48, 102, 119, 96, 97, 189],
-               [97, 189, 217, 184, 171, 384, 324, 451],
-               [324, 451, 545, 357, 616, 618, 1024, 1024]]
-    TOPOLOGY = 'yolov4-p6'
+    INPUT_SHAPE = (3, 416, 416)
+    LAYER_FACTORS = [32, 16]
+    SCALES = [1.05, 1.05]
+    ANCHORS = [[81, 82, 135, 169, 344, 319], [23, 27, 37, 58, 81, 82]]
+    TOPOLOGY = 'darknet-cfg'
+
+
+class YOLOv3(YOLO):
+    ENGINE_PATH = Path(__file__).parent / 'yolov3.hipnet'
+    MODEL_PATH = Path(__file__).parent / 'yolov3.weights'
+    NUM_CLASSES = 1
+    INPUT_SHAPE = (3, 416, 416)
+    LAYER_FACTORS = [32, 16, 8]
+    SCALES = [1., 1.]                # as in the reference (models/yolo.py:272): two entries for three heads
+    ANCHORS = [[116, 90, 156, 198, 373, 326], [30, 61, 62, 45, 59, 119], [10, 13, 16, 30, 33, 23]]
+    TOPOLOGY = 'darknet-cfg'
+
+
+class YOLOv3SPP(YOLOv3):
+    ENGINE_PATH = Path(__file__).parent / 'yolov3-spp.hipnet'
+    MODEL_PATH = Path(__file__).parent / 'yolov3-spp.weights'
+    INPUT_SHAPE = (3, 608, 608)
+
+
+class YOLOv3Tiny(YOLO):
+    ENGINE_PATH = Path(__file__).parent / 'yolov3-tiny.hipnet'
+    MODEL_PATH = Path(__file__).parent / 'yolov3-tiny.weights'
+    NUM_CLASSES = 1
+    INPUT_SHAPE = (3, 416, 416)
+    LAYER_FACTORS = [32, 16]
+    SCALES = [1., 1.]
+    ANCHORS = [[81, 82, 135, 169, 344, 319], [10, 14, 23, 27, 37, 58]]
+    TOPOLOGY = 'darknet-cfg'

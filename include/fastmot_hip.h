@@ -199,6 +199,7 @@ enum {
     FM_OP_STEMCONV = 12, /* k x k conv (k,stride in {3/1, 3/2, 7/2}) of an input with <= 4 real channels,
                           * cout <= 32, + bias + act: w = fp16 [32][ceil16(k*k*4)] (K order kh,kw,c<4),
                           * b = f32[32]; patch staged in LDS (stemconv.hip)                     */
+    FM_OP_ADD = 13,      /* out = in[0] + in[1] (stand-alone [shortcut])                          */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

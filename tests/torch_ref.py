@@ -86,11 +86,15 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             for i, k in enumerate((13, 9, 5)):
                 wr(d['out'].slice(i * c, c), F.max_pool2d(xin, k, 1, k // 2))
         elif op == G.OP_MAXPOOL:
-            wr(d['out'], F.max_pool2d(xin, d['k'], d['stride'], d['pad']))
+            pe = d.get('pad_end', d['pad'])
+            xp = F.pad(xin, (d['pad'], pe, d['pad'], pe), value=float('-inf'))
+            wr(d['out'], F.max_pool2d(xp, d['k'], d['stride'], 0))
         elif op == G.OP_AVGPOOL:
             wr(d['out'], F.avg_pool2d(xin, d['k'], d['stride'], d['pad']))
         elif op == G.OP_UPSAMPLE2:
             wr(d['out'], F.interpolate(xin, scale_factor=2, mode='nearest'))
+        elif op == G.OP_ADD:
+            wr(d['out'], xin + rd(d['ins'][1]))
         elif op == G.OP_COPY:
             wr(d['out'], xin)
         elif op == G.OP_GATE:
