@@ -1,0 +1,83 @@
+"""End to end through the command line (the reference's app.py flow): image sequence on disk -> VideoIO ->
+MOT (public detections, OSNet with seeded weights, KLT, Kalman, association) -> MOTChallenge result file ->
+CLEAR-MOT / IDF1 against the synthetic ground truth."""
+import json
+
+import numpy as np
+import pytest
+
+from fastmot_amd.utils import motchallenge as mc
+from fastmot_amd.utils.synthetic import SyntheticVideo
+from fastmot_amd.videoio import VideoIO, resize_bgr
+
+
+def test_videoio_sources_and_queue(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, (7, 36, 64, 3), dtype=np.uint8)
+    (tmp_path / 'img1').mkdir()
+    for i, f in enumerate(frames):
+        Image.fromarray(f[:, :, ::-1]).save(tmp_path / 'img1' / f'{i + 1:06d}.png')
+    np.save(tmp_path / 'stack.npy', frames)
+    for uri in (str(tmp_path / 'img1' / '%06d.png'), str(tmp_path / 'stack.npy')):
+        stream = VideoIO((64, 36), uri, frame_rate=25, buffer_size=3)
+        assert stream.cap_dt == 1 / 25 and stream.resolution == (64, 36) and not stream.do_resize
+        stream.start_capture()
+        got = []
+        while True:
+            f = stream.read()
+            if f is None:
+                break
+            got.append(f)
+        stream.release()
+        np.testing.assert_array_equal(np.stack(got), frames)
+    # resizing source: 2x decimation = area average, arbitrary ratio = fixed-point bilinear
+    stream = VideoIO((32, 18), str(tmp_path / 'stack.npy'))
+    f = stream.read()
+    ref = (frames[0].astype(int).reshape(18, 2, 32, 2, 3).sum((1, 3)) + 2) >> 2
+    np.testing.assert_array_equal(f, ref.astype(np.uint8))
+    stream.release()
+    up = resize_bgr(frames[0], (100, 50))
+    assert up.shape == (50, 100, 3) and up.dtype == np.uint8
+    np.testing.assert_array_equal(up[0, 0], frames[0][0, 0])
+    with pytest.raises(NotImplementedError):
+        VideoIO((64, 36), 'rtsp://camera/stream')
+    with pytest.raises(NotImplementedError):
+        VideoIO((64, 36), str(tmp_path / 'movie.mp4'))
+
+
+@pytest.mark.gpu
+def test_app_end_to_end(tmp_path):
+    from PIL import Image
+    from fastmot_amd import app
+    size, n_frames, n_ids = (960, 540), 24, 8
+    video = SyntheticVideo(size, n_ids=n_ids, n_frames=n_frames, seed=5)
+    seq = tmp_path / 'SYN-01'
+    (seq / 'img1').mkdir(parents=True)
+    (seq / 'det').mkdir()
+    (seq / 'seqinfo.ini').write_text(f'[Sequence]\nname=SYN-01\nimDir=img1\nframeRate=30\nseqLength={n_frames}\n'
+                                     f'imWidth={size[0]}\nimHeight={size[1]}\nimExt=.png\n')
+    det_rows, gt = [], {}
+    for f in range(n_frames):
+        Image.fromarray(video.frames[f][:, :, ::-1]).save(seq / 'img1' / f'{f + 1:06d}.png')
+        d = video.detections(f)
+        for box in d.tlbr:
+            det_rows.append(f'{f + 1},-1,{box[0]},{box[1]},{box[2] - box[0] + 1},{box[3] - box[1] + 1},1,-1,-1,-1')
+        gt[f + 1] = [(i + 1, np.array([b[0], b[1], b[2] - b[0] + 1, b[3] - b[1] + 1])) for i, b in enumerate(video.gt[f])]
+    (seq / 'det' / 'det.txt').write_text('\n'.join(det_rows) + '\n')
+
+    cfg = json.load(open(app.Path(app.__file__).parent / 'cfg' / 'mot.json'))
+    cfg['resize_to'] = list(size)
+    cfg['stream_cfg']['resolution'] = list(size)
+    cfg['mot_cfg']['detector_type'] = 'PUBLIC'
+    cfg['mot_cfg']['detector_frame_skip'] = 1
+    cfg['mot_cfg']['public_detector_cfg']['sequence_path'] = str(seq)
+    (tmp_path / 'mot.json').write_text(json.dumps(cfg))
+
+    out = tmp_path / 'out' / 'SYN-01.txt'
+    rc = app.main(['-i', str(seq / 'img1' / '%06d.png'), '-c', str(tmp_path / 'mot.json'), '-m', '-t', str(out), '-q'])
+    assert rc == 0
+    res = mc.read_txt(out)
+    score = mc.evaluate({f: v for f, v in gt.items() if f in res or f > 1}, res)
+    # public detections are the ground truth + 1 px jitter: everything is tracked, identities are stable
+    assert score['mota'] > 0.9 and score['idf1'] > 0.9 and score['idsw'] <= 2, score
