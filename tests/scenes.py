@@ -19,6 +19,19 @@ SCENES = {
     's50_skip2_euclid': dict(n_ids=50, size=(1920, 1080), n_frames=60, skip=2, metric='euclidean', n_classes=1, seed=3),
     's300_4k_multiclass': dict(n_ids=300, size=(3840, 2160), n_frames=12, skip=1, metric='euclidean', n_classes=3, seed=4),
     's8_flowfail': dict(n_ids=8, size=(1280, 720), n_frames=30, skip=3, metric='cosine', n_classes=1, seed=5, fail_frame=14),
+    # duplicate tracks: an identity is missed for 3 detector frames (its track turns inactive), then detected
+    # for a while with a foreign appearance (-> a second track is born on top of it), then with its own
+    # appearance again -> MultiTracker._rectify_matches merge / duplicate branches (tracker.py:368-401)
+    's30_impostor_skip2': dict(n_ids=30, size=(1920, 1080), n_frames=90, skip=2, metric='euclidean', n_classes=1,
+                               seed=7, impostor=True),
+    # + a concurrent foreign-looking detection on the same object -> two live tracks on one target ->
+    # the "Duplicate" branch as well (seeds chosen so that the reference logs both branches / a re-ID)
+    's30_ghosts': dict(n_ids=30, size=(1920, 1080), n_frames=90, skip=2, metric='euclidean', n_classes=1,
+                       seed=9, impostor=True, ghosts=True),
+    's30_ghosts_b': dict(n_ids=30, size=(1920, 1080), n_frames=90, skip=2, metric='euclidean', n_classes=1,
+                         seed=19, impostor=True, ghosts=True),
+    's30_ghosts_cosine': dict(n_ids=30, size=(1920, 1080), n_frames=90, skip=2, metric='cosine', n_classes=1,
+                              seed=19, impostor=True, ghosts=True),
 }
 
 TRACKER_CFG = dict(max_age=6, age_penalty=2, motion_weight=0.2, max_assoc_cost=0.8, max_reid_cost=0.6,
@@ -79,6 +92,26 @@ class Scene:
                 start = int(rng.integers(5, self.n_frames - 10))
                 self.hidden[start:start + int(rng.integers(3, 9)) * self.skip, i] = True
         self.camera = rng.normal(0, 1, (self.n_frames, 2)) * s   # per-frame camera translation
+        # impostor spells (see SCENES): hidden for 3 detector frames, foreign appearance for 1-3 more
+        self.impostor = np.zeros((self.n_frames, n), bool)
+        self.ghost = np.zeros((self.n_frames, n), bool)
+        if cfg.get('impostor'):
+            rng2 = np.random.default_rng((self.seed, 77))
+            alt = rng2.normal(0, 1, (n, 512))
+            self.alt_feats = alt / np.linalg.norm(alt, axis=1, keepdims=True)
+            self.hidden[:] = False
+            for i in range(n):
+                if rng2.random() < 0.6:
+                    start = int(rng2.integers(4, self.n_frames - 12 * self.skip))
+                    gone = 3 * self.skip
+                    fake = int(rng2.integers(1, 4)) * self.skip
+                    self.hidden[start:start + gone, i] = True
+                    if cfg.get('ghosts') and rng2.random() < 0.5:
+                        # a second, foreign-looking detection on top of the identity from 3 detector frames
+                        # before it is missed until it is seen again: two concurrent tracks on one object
+                        self.ghost[max(start - 3 * self.skip, 1):start + gone + fake, i] = True
+                    else:
+                        self.impostor[start + gone:start + gone + fake, i] = True
         self._det_cache = {}
 
     def detections(self, frame_id):
@@ -92,6 +125,15 @@ class Scene:
         labels = self.labels[ids]
         conf = rng.uniform(0.3, 1, len(ids))
         feats = self.id_feats[ids] + rng.normal(0, 0.02, (len(ids), 512))
+        fake = self.impostor[frame_id, ids]
+        if fake.any():
+            feats[fake] = self.alt_feats[ids[fake]] + rng.normal(0, 0.02, (int(fake.sum()), 512))
+        g_ids = np.flatnonzero(self.ghost[frame_id])
+        if len(g_ids):
+            boxes = np.concatenate([boxes, np.rint(self.gt[frame_id, g_ids] + rng.normal(0, 1.5, (len(g_ids), 4)))])
+            labels = np.concatenate([labels, self.labels[g_ids]])
+            conf = np.concatenate([conf, rng.uniform(0.6, 1, len(g_ids))])
+            feats = np.concatenate([feats, self.alt_feats[g_ids] + rng.normal(0, 0.02, (len(g_ids), 512))])
         # a few false positives with random appearance
         n_fp = int(rng.integers(0, max(2, self.n_ids // 25)))
         W, H = self.size
