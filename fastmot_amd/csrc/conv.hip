@@ -57,7 +57,10 @@ __device__ __forceinline__ void store_out(const ConvParams& p, long pix, int co,
     }
 }
 
-template <int WC, int WP, int MC, int MP, int MINB>
+// TAPMODE: how the K walk crosses (kh, kw) taps -- 0: 1x1 conv (never), 1: Cin >= BK (at most one tap per
+// K step: branch-free selects), 2: generic (divergent loop; compiled as exec-masked loops that split the
+// pipelined K loop into many basic blocks, which is why the common cases get their own instances)
+template <int WC, int WP, int MC, int MP, int MINB, int TAPMODE>
 __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams p, float* __restrict__ ws) {
     static_assert(WC * WP == 4, "4 waves per block");
     static_assert(WC * MC <= 4 && WP * MP <= 4, "at most 4 chunks per thread and operand");
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
 #define CONV_LOAD_A(S, I, KS)                                                                               \
     if constexpr ((I) < A_IT) {                                                                             \
         const int row = min(c0 + lrow + 32 * (I), arow_max);                                                \
-        ra##S##_##I = *reinterpret_cast<const uint4*>(wbase + (size_t)row * p.Kpad + (KS) * BK);               \
+        ra##S##_##I = *reinterpret_cast<const uint4*>(wbase + (__umul24(row, p.Kpad) + (unsigned)((KS) * BK)));  \
     }
 #define CONV_LOAD_B(S, I)                                                                                   \
     if constexpr ((I) < B_IT) {                                                                             \
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
         m_ |= ok ? (1u << (I)) : 0u;                                                                        \
         const int hc = min(max(hi, 0), p.H - 1), wcl = min(max(wi, 0), p.W - 1);                            \
         const int kcc = kk < p.K ? kc : 0;                                                                  \
-        rb##S##_##I = *reinterpret_cast<const uint4*>(pbase[I] + ((size_t)hc * p.W + wcl) * p.in_cs + kcc);    \
+        rb##S##_##I = *reinterpret_cast<const uint4*>(                                                         \
+            pbase[I] + (__umul24(__umul24(hc, p.W) + wcl, p.in_cs) + (unsigned)kcc));                       \
     }
 #define CONV_LOAD_STAGE(S, KS)                                                                              \
     {                                                                                                       \
@@ -170,9 +174,18 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
         okm##S = m_;                                                                                        \
         kk += BK;                                                                                           \
         kc += BK;                                                                                           \
-        while (kc >= p.Cin) {                                                                               \
-            kc -= p.Cin;                                                                                    \
-            if (++kw == p.KW) { kw = 0; ++kh; }                                                             \
+        if constexpr (TAPMODE == 1) {                                                                       \
+            const bool wr_ = kc >= p.Cin;                                                                   \
+            kc -= wr_ ? p.Cin : 0;                                                                          \
+            kw += wr_ ? 1 : 0;                                                                              \
+            const bool wr2_ = kw == p.KW;                                                                   \
+            kw = wr2_ ? 0 : kw;                                                                             \
+            kh += wr2_ ? 1 : 0;                                                                             \
+        } else if constexpr (TAPMODE == 2) {                                                                \
+            while (kc >= p.Cin) {                                                                           \
+                kc -= p.Cin;                                                                                \
+                if (++kw == p.KW) { kw = 0; ++kh; }                                                         \
+            }                                                                                               \
         }                                                                                                   \
     }
 #define CONV_STORE_A(S, I, BUF)                                                                             \
@@ -381,8 +394,8 @@ __global__ void splitk_reduce_kernel(const ConvParams p, const float* __restrict
     }
 }
 
-template <int WC, int WP, int MC, int MP, int MINB>
-int launch_cfg(const ConvParams& p, int S, float* ws, hipStream_t s) {
+template <int WC, int WP, int MC, int MP, int MINB, int TAPMODE>
+int launch_cfg_tap(const ConvParams& p, int S, float* ws, hipStream_t s) {
     constexpr int BMC = WC * MC * 32, BNP = WP * MP * 32;
     const int cout_pad = (p.Cout + 31) & ~31;
     ConvParams q = p;
@@ -395,13 +408,20 @@ int launch_cfg(const ConvParams& p, int S, float* ws, hipStream_t s) {
     if (force >= 0) q.weight_major = force;
     const int total = q.grid_p * q.grid_c * q.grid_z;
     dim3 grid(((total + 7) / 8) * 8);
-    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, MC, MP, MINB>), grid, dim3(256), 0, s, q, ws);
+    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, MC, MP, MINB, TAPMODE>), grid, dim3(256), 0, s, q, ws);
     if (S > 1) {
         const long total = (long)p.P * (p.cout_store / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, ws, S);
     }
     FM_HIP(hipGetLastError());
     return 0;
+}
+
+template <int WC, int WP, int MC, int MP, int MINB>
+int launch_cfg(const ConvParams& p, int S, float* ws, hipStream_t s) {
+    if (p.KH * p.KW == 1) return launch_cfg_tap<WC, WP, MC, MP, MINB, 0>(p, S, ws, s);
+    if (p.Cin >= BK) return launch_cfg_tap<WC, WP, MC, MP, MINB, 1>(p, S, ws, s);
+    return launch_cfg_tap<WC, WP, MC, MP, MINB, 2>(p, S, ws, s);
 }
 
 }  // namespace
@@ -415,6 +435,10 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
     FM_CHECK_ARG(p.Cin % 8 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0);
     FM_CHECK_ARG(p.out_cs % 8 == 0 && p.out_coff % 8 == 0 && p.Kpad % BK == 0);
     FM_CHECK_ARG(p.res_mode == RES_NONE || (p.res_cs % 8 == 0 && p.res_coff % 8 == 0));
+    // 24-bit multiplies (full-rate VALU) build the operand offsets: element offsets inside one sample / the
+    // weight matrix must fit 32 bits and their factors 24 bits
+    FM_CHECK_ARG((long)p.H * p.W < (1L << 24) && p.in_cs < (1 << 24) && (long)p.H * p.W * p.in_cs < (1L << 32));
+    FM_CHECK_ARG(p.Kpad < (1 << 24) && (long)((p.Cout + 31) & ~31) * p.Kpad < (1L << 32));
     const int cout_pad = (p.Cout + 31) & ~31;
     auto tiles = [&](int bmc, int bnp) { return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc); };
     const int nk = p.Kpad / BK;
