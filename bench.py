@@ -118,6 +118,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prefetch', dest='prefetch', action='store_false',
+                    help='strictly sequential steps: do not start the detector on frame t+1 during frame t')
     args = ap.parse_args()
 
     import torch
@@ -147,13 +149,17 @@ def main():
     Track._count = 0
     mot.reset(1 / 30.)
 
+    frames = [DeviceFrame(i) for i in range(RING)]
+
     def run(n, start):
-        net_ms = []
+        # the next frame is known (resident ring = a capture queue that is never empty): MOT.step starts the
+        # detector on it while this frame is in its ReID / association stages (--no-prefetch disables)
+        mot.detector.net_ms.clear()
         for s in range(start, start + n):
             mot.detector._frame_idx = s % RING
-            mot.step(DeviceFrame(s % RING))
-            net_ms.append(ctx.detect_net_ms())
-        return net_ms
+            nxt = frames[(s + 1) % RING] if args.prefetch and s + 1 < start + n else None
+            mot.step(frames[s % RING], next_frame=nxt)
+        return list(mot.detector.net_ms)
 
     def fence():
         ctx.synchronize()
@@ -188,7 +194,7 @@ def main():
             'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': 'BASELINE config[1]: single 1080p stream, YOLOv4 608x608 (80 cls, seeded random '
                                    'weights) + OSNet-x0.25, detector_frame_skip=1, 50 injected detections/frame, '
-                                   'frames resident in HBM', 'streams_per_gpu': 1, 'parallelism': f'1 stream/GPU x {world}',
+                                   'frames resident in HBM', 'next_frame_prefetch': bool(args.prefetch), 'streams_per_gpu': 1, 'parallelism': f'1 stream/GPU x {world}',
                        'visible_tracks': len(list(mot.visible_tracks())),
                        'yolo_candidates_nms_out': mot.detector.last_real_count},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (110 conv launches of YOLOv4 per frame, '

@@ -47,9 +47,11 @@ def load():
 
 
 def _ptr(arr, ctype=None):
+    """Raw data pointer of a C-contiguous array that the CALLER keeps alive for the duration of the call
+    (`arr.ctypes.data_as` would hold a reference but costs 2.4 us per argument; ~60 arguments per frame)."""
     if arr is None:
         return None
-    return arr.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(arr.__array_interface__['data'][0])
 
 
 def _as(arr, dtype, shape=None):
@@ -370,6 +372,22 @@ def _bind_device_io(cls):
     def frame_ring_select(self, index):
         check(self.lib.fm_frame_ring_select(self._ctx, C.c_int(index)))
 
+    def frame_upload_next(self, frame):
+        w, h = self.frame_size
+        if frame.shape != (h, w, 3) or frame.dtype != np.uint8:
+            raise ValueError(f'frame must be uint8 {h}x{w}x3')
+        f = np.ascontiguousarray(frame)
+        check(self.lib.fm_frame_upload_next(self._ctx, _ptr(f)))
+
+    def frame_ring_select_next(self, index):
+        check(self.lib.fm_frame_ring_select_next(self._ctx, C.c_int(index)))
+
+    def frame_promote_next(self):
+        check(self.lib.fm_frame_promote_next(self._ctx))
+
+    def detect_async_next(self):
+        check(self.lib.fm_detect_async_next(self._ctx))
+
     def frame_read(self):
         w, h = self.frame_size
         out = np.empty((h, w, 3), np.uint8)
@@ -427,7 +445,8 @@ def _bind_device_io(cls):
         check(self.lib.fm_extract_read_input(self._ctx, C.c_int(n), _ptr(out)))
         return out
 
-    for fn in (frame_configure, frame_upload, frame_ring_store, frame_ring_select, frame_read,
+    for fn in (frame_configure, frame_upload, frame_ring_store, frame_ring_select, frame_read, frame_upload_next,
+               frame_ring_select_next, frame_promote_next, detect_async_next,
                detect_configure, detect_async, detect_net_ms, detect_preprocess_only, detect_sync, filter_dets,
                detect_raw_candidates, extract_configure, extract_async, extract_sync, extract_read_input):
         setattr(cls, fn.__name__, fn)

@@ -125,7 +125,10 @@ struct fm_ctx {
     // ---- frames (BGR u8) resident on the device
     int frame_w = 0, frame_h = 0, ring_size = 0;
     uint8_t* frame_cur = nullptr;          // points into frame_own or the ring
-    uint8_t* frame_own = nullptr;
+    uint8_t* frame_own = nullptr;          // upload slot of the current frame
+    uint8_t* frame_own2 = nullptr;         // second upload slot (prefetched next frame); the two swap roles
+    uint8_t* frame_next = nullptr;         // frame the detector was prefetched on (fm_frame_*_next)
+    uint8_t* frame_pinned2 = nullptr;
     uint8_t* frame_ring = nullptr;
     uint8_t* frame_pinned = nullptr;
 

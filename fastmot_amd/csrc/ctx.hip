@@ -80,9 +80,10 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->det) fm_det_free(ctx->det);
     if (ctx->ext) fm_ext_free(ctx->ext);
-    for (void* p : {(void*)ctx->frame_own, (void*)ctx->frame_ring})
+    for (void* p : {(void*)ctx->frame_own, (void*)ctx->frame_own2, (void*)ctx->frame_ring})
         if (p) (void)hipFree(p);
     if (ctx->frame_pinned) (void)hipHostFree(ctx->frame_pinned);
+    if (ctx->frame_pinned2) (void)hipHostFree(ctx->frame_pinned2);
     if (ctx->det_net) fm_net_free(ctx->det_net);
     if (ctx->ext_net) fm_net_free(ctx->ext_net);
     if (ctx->flow) fm_flow_free(ctx->flow);

@@ -394,13 +394,17 @@ int collect(fm_ctx* ctx, DetState* d, hipStream_t s, fm_det48* out, int cap_out,
 extern "C" int fm_frame_configure(fm_ctx* ctx, int width, int height, int ring_size) {
     FM_CHECK_ARG(ctx && width > 0 && height > 0 && ring_size >= 0);
     FM_HIP(hipDeviceSynchronize());
-    for (void* p : {(void*)ctx->frame_own, (void*)ctx->frame_ring})
+    for (void* p : {(void*)ctx->frame_own, (void*)ctx->frame_own2, (void*)ctx->frame_ring})
         if (p) (void)hipFree(p);
-    if (ctx->frame_pinned) (void)hipHostFree(ctx->frame_pinned);
-    ctx->frame_own = ctx->frame_ring = ctx->frame_pinned = nullptr;
+    for (void* p : {(void*)ctx->frame_pinned, (void*)ctx->frame_pinned2})
+        if (p) (void)hipHostFree(p);
+    ctx->frame_own = ctx->frame_own2 = ctx->frame_ring = ctx->frame_pinned = ctx->frame_pinned2 = nullptr;
+    ctx->frame_next = nullptr;
     const size_t bytes = (size_t)width * height * 3;
     FM_HIP(hipMalloc(&ctx->frame_own, bytes));
+    FM_HIP(hipMalloc(&ctx->frame_own2, bytes));
     FM_HIP(hipHostMalloc(&ctx->frame_pinned, bytes, hipHostMallocDefault));
+    FM_HIP(hipHostMalloc(&ctx->frame_pinned2, bytes, hipHostMallocDefault));
     if (ring_size > 0) FM_HIP(hipMalloc(&ctx->frame_ring, bytes * ring_size));
     ctx->frame_w = width;
     ctx->frame_h = height;
@@ -420,6 +424,41 @@ extern "C" int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr) {
     FM_HIP(hipMemcpyAsync(ctx->frame_own, ctx->frame_pinned, bytes, hipMemcpyHostToDevice, ctx->s_det));
     FM_HIP(hipStreamSynchronize(ctx->s_det));   // the other streams read the frame too
     ctx->frame_cur = ctx->frame_own;
+    return 0;
+}
+
+// ---- next-frame prefetch: the detector may be started on frame t+1 while frame t is still being tracked
+// (MOT.step(frame, next_frame)).  The next frame lives in the second upload slot (or the ring) and becomes
+// the current one with fm_frame_promote_next -- no second upload.
+extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
+    FM_CHECK_ARG(ctx && bgr && ctx->frame_own2);
+    const size_t bytes = (size_t)ctx->frame_w * ctx->frame_h * 3;
+    FM_HIP(hipStreamSynchronize(ctx->s_det));        // previous reader of this slot / pinned buffer
+    memcpy(ctx->frame_pinned2, bgr, bytes);
+    FM_HIP(hipMemcpyAsync(ctx->frame_own2, ctx->frame_pinned2, bytes, hipMemcpyHostToDevice, ctx->s_det));
+    ctx->frame_next = ctx->frame_own2;
+    return 0;
+}
+
+extern "C" int fm_frame_ring_select_next(fm_ctx* ctx, int index) {
+    FM_CHECK_ARG(ctx && index >= 0 && index < ctx->ring_size);
+    ctx->frame_next = ctx->frame_ring + (size_t)ctx->frame_w * ctx->frame_h * 3 * index;
+    return 0;
+}
+
+extern "C" int fm_frame_promote_next(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx && ctx->frame_next);
+    if (ctx->frame_next == ctx->frame_own2) {
+        // the upload of the prefetched frame was enqueued on s_det; the other streams read it from now on
+        FM_HIP(hipStreamSynchronize(ctx->s_ext));
+        FM_HIP(hipStreamSynchronize(ctx->s_flow));
+        std::swap(ctx->frame_own, ctx->frame_own2);
+        std::swap(ctx->frame_pinned, ctx->frame_pinned2);
+        ctx->frame_cur = ctx->frame_own;
+    } else {
+        ctx->frame_cur = ctx->frame_next;
+    }
+    ctx->frame_next = nullptr;
     return 0;
 }
 
@@ -458,14 +497,14 @@ extern "C" int fm_detect_configure(fm_ctx* ctx, const fm_yolo_cfg* cfg) {
     return 0;
 }
 
-static int enqueue_preprocess(fm_ctx* ctx, DetState* d, NetState* net) {
+static int enqueue_preprocess(fm_ctx* ctx, DetState* d, NetState* net, const uint8_t* frame) {
     const fm_yolo_cfg& c = d->cfg;
-    FM_CHECK_ARG(ctx->frame_cur != nullptr);
+    FM_CHECK_ARG(frame != nullptr);
     FM_CHECK_ARG(c.input_tensor >= 0 && c.input_tensor < (int)net->tensors.size());
     const fm_tensor& t = net->tensors[c.input_tensor];
     FM_CHECK_ARG(t.h == c.in_h && t.w == c.in_w && !t.f32);
     hipLaunchKernelGGL(preprocess_kernel, dim3((c.in_w + 255) / 256, c.in_h), dim3(256), 0, ctx->s_det,
-                       ctx->frame_cur, ctx->frame_w, ctx->frame_h, (f16*)net->bufs[c.input_tensor], c.in_w,
+                       frame, ctx->frame_w, ctx->frame_h, (f16*)net->bufs[c.input_tensor], c.in_w,
                        c.in_h, t.c, c.roi_x, c.roi_y, c.roi_w, c.roi_h);
     FM_HIP(hipGetLastError());
     return 0;
@@ -473,16 +512,29 @@ static int enqueue_preprocess(fm_ctx* ctx, DetState* d, NetState* net) {
 
 extern "C" int fm_detect_preprocess_only(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx && ctx->det && ctx->det->configured && ctx->det_net);
-    return enqueue_preprocess(ctx, ctx->det, ctx->det_net);
+    return enqueue_preprocess(ctx, ctx->det, ctx->det_net, ctx->frame_cur);
 }
 
+static int detect_async_on(fm_ctx* ctx, const uint8_t* frame);
+
 extern "C" int fm_detect_async(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx);
+    return detect_async_on(ctx, ctx->frame_cur);
+}
+
+// detector on the prefetched next frame (fm_frame_upload_next / fm_frame_ring_select_next)
+extern "C" int fm_detect_async_next(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx && ctx->frame_next);
+    return detect_async_on(ctx, ctx->frame_next);
+}
+
+static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     FM_CHECK_ARG(ctx && ctx->det && ctx->det->configured && ctx->det_net);
     DetState* d = ctx->det;
     NetState* net = ctx->det_net;
     const fm_yolo_cfg& c = d->cfg;
     hipStream_t s = ctx->s_det;
-    int rc = enqueue_preprocess(ctx, d, net);
+    int rc = enqueue_preprocess(ctx, d, net, frame);
     if (rc) return rc;
     if (!d->ev0) {
         FM_HIP(hipEventCreate(&d->ev0));

@@ -36,11 +36,30 @@ def bind_frame(ctx, frame, size, begin_step=False):
         ctx.frame_configure(size[0], size[1], getattr(ctx, 'ring_size', 0))
     if not begin_step and getattr(ctx, 'in_step', False) and getattr(ctx, 'bound_frame', None) is frame:
         return
+    if getattr(ctx, 'next_frame', None) is frame:
+        # the frame was prefetched (prefetch_frame): it is already on the device
+        ctx.frame_promote_next()
+        ctx.next_frame = None
+        ctx.bound_frame = frame
+        return
+    ctx.next_frame = None
     if isinstance(frame, DeviceFrame):
         ctx.frame_ring_select(frame.index)
     else:
         ctx.frame_upload(frame)
     ctx.bound_frame = frame
+
+
+def prefetch_frame(ctx, frame, size):
+    """Puts the NEXT frame on the device (second upload slot / ring) without disturbing the current one;
+    the next bind_frame(frame) promotes it instead of uploading again."""
+    if getattr(ctx, 'frame_size', None) != tuple(size):
+        ctx.frame_configure(size[0], size[1], getattr(ctx, 'ring_size', 0))
+    if isinstance(frame, DeviceFrame):
+        ctx.frame_ring_select_next(frame.index)
+    else:
+        ctx.frame_upload_next(frame)
+    ctx.next_frame = frame
 
 
 class Detector(abc.ABC):
@@ -56,6 +75,10 @@ class Detector(abc.ABC):
     @abc.abstractmethod
     def detect_async(self, frame):
         raise NotImplementedError
+
+    def prefetch(self, frame):
+        """Optional: start detecting on the NEXT frame while the current one is still being tracked
+        (MOT.step(frame, next_frame)).  The following detect_async(frame) is then a no-op."""
 
     @abc.abstractmethod
     def postprocess(self):
@@ -106,6 +129,7 @@ class YOLODetector(Detector):
             raise ValueError('Unsupported class IDs') from err
 
         self.ctx = get_context()
+        self._prefetched = None
         self.graph, self.heads = self.model.build_graph(weights)
         self.backend = HipNet(self.ctx, NET_DETECTOR, self.graph, 1, reuse_buffers=reuse_buffers)
         self.roi, self.upscaled_sz, self.bbox_offset = self._create_letterbox()
@@ -158,8 +182,18 @@ class YOLODetector(Detector):
 
     def detect_async(self, frame):
         """Detects objects asynchronously (preprocess + network + decode + NMS enqueued)."""
+        if self._prefetched is frame and frame is not None:
+            self._prefetched = None              # already enqueued by prefetch()
+            bind_frame(self.ctx, frame, self.size)
+            return
+        self._prefetched = None
         bind_frame(self.ctx, frame, self.size)
         self.ctx.detect_async()
+
+    def prefetch(self, frame):
+        prefetch_frame(self.ctx, frame, self.size)
+        self.ctx.detect_async_next()
+        self._prefetched = frame
 
     def postprocess(self):
         """Synchronizes and returns a record array of detections (DET_DTYPE), sorted in ascending

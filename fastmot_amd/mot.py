@@ -80,6 +80,7 @@ class MOT:
         self.extractors = [FeatureExtractor(size=self.size, **vars(cfg)) for cfg in feature_extractor_cfgs]
         self.tracker = MultiTracker(self.size, self.extractors[0].metric, **vars(tracker_cfg))
         self.frame_count = 0
+        self._next_frame = None
         # KLT + Kalman run on a second host thread while this one drives detector -> ReID network (the
         # C-ABI calls release the GIL; the stages use separate HIP streams and share no state)
         self._flow_thread = ThreadPoolExecutor(max_workers=1, thread_name_prefix='fastmot-flow',
@@ -95,21 +96,35 @@ class MOT:
         self.frame_count = 0
         self.tracker.reset(cap_dt)
 
-    def step(self, frame):
+    def step(self, frame, next_frame=None):
         """Runs multiple object tracker on the next frame (ndarray HxWx3 uint8 BGR, or a
-        detector.DeviceFrame that is already resident on the GPU)."""
+        detector.DeviceFrame that is already resident on the GPU).
+
+        next_frame (optional, not in the reference): the frame the following `step` will receive, when
+        the caller already has it (file sources, a capture queue).  The detector network is then started
+        on it as soon as this frame's ReID network is enqueued, so that it overlaps this frame's ReID and
+        association stages; results are unchanged (the detector is stateless), per-frame latency too."""
         ctx = self.tracker.ctx
         bind_frame(ctx, frame, self.size, begin_step=True)
         ctx.in_step = True
+        self._next_frame = next_frame
         try:
             self._step(frame)
         finally:
             ctx.in_step = False
+            self._next_frame = None
         self.frame_count += 1
+
+    def _prefetch_next(self):
+        nxt = self._next_frame
+        if nxt is not None and (self.frame_count + 1) % self.detector_frame_skip == 0:
+            self._next_frame = None
+            self.detector.prefetch(nxt)
 
     def _step(self, frame):
         if self.frame_count == 0:
             detections = self.detector(frame)
+            self._prefetch_next()
             self.tracker.init(frame, detections)
         elif self.frame_count % self.detector_frame_skip == 0:
             with Profiler('preproc'):
@@ -130,6 +145,7 @@ class MOT:
                     # every box goes to the first extractor, as in the reference (_split_bboxes_by_cls
                     # with its bisect_right quirk, mot.py:180-189)
                     self.extractors[0].extract_async(frame, detections.tlbr)
+                    self._prefetch_next()
                     self.tracker.prepare_detections(detections)
                     embeddings = self.extractors[0].postprocess()
             finally:
@@ -138,6 +154,7 @@ class MOT:
             with Profiler('assoc'):
                 self.tracker.update(self.frame_count, detections, embeddings)
         else:
+            self._prefetch_next()
             with Profiler('track'):
                 self.tracker.track(frame)
 

@@ -69,6 +69,7 @@ class InjectedYOLODetector(YOLODetector):
         self._video, self._label = video, label
         self._frame_idx = 0
         self.last_real_count = 0
+        self.net_ms = []          # HIP-event time of the detector's layer sequence, one entry per postprocess()
 
     def detect_async(self, frame):
         super().detect_async(frame)
@@ -76,6 +77,7 @@ class InjectedYOLODetector(YOLODetector):
     def postprocess(self):
         real = super().postprocess()
         self.last_real_count = len(real)
+        self.net_ms.append(self.ctx.detect_net_ms())      # the events of THIS frame's network are complete here
         dets = self._video.detections(self._frame_idx, self._label)
         self._frame_idx += 1
         return dets

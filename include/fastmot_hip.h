@@ -263,6 +263,15 @@ int fm_net_profile_layers(fm_ctx* ctx, int which, int batch, int iters, double* 
  * also be made resident in HBM up front (bench: inputs resident before the timed region). */
 int fm_frame_configure(fm_ctx* ctx, int width, int height, int ring_size);
 int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr);
+/* Next-frame prefetch (no counterpart in the reference, whose detector is synchronous per step): the
+ * detector network can be started on frame t+1 while frame t is still in the ReID / association stages.
+ * fm_frame_upload_next copies a host frame into the second upload slot (asynchronously, detector stream),
+ * fm_frame_ring_select_next points at a resident frame; fm_detect_async_next = fm_detect_async on that
+ * frame; fm_frame_promote_next makes it the current frame of the next step without another upload. */
+int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr);
+int fm_frame_ring_select_next(fm_ctx* ctx, int index);
+int fm_frame_promote_next(fm_ctx* ctx);
+int fm_detect_async_next(fm_ctx* ctx);
 int fm_frame_ring_store(fm_ctx* ctx, int index, const uint8_t* bgr);
 int fm_frame_ring_select(fm_ctx* ctx, int index);
 int fm_frame_read(fm_ctx* ctx, uint8_t* bgr);   /* current device frame -> host (tests) */

@@ -71,3 +71,39 @@ def test_mot_step_holds_identities(ctx, skip):
     assert all(len(s) >= 1 for s in ids_per_obj)
     assert sum(len(s) == 1 for s in ids_per_obj) >= video.n_ids - 2
     assert mot.tracker.homography is not None
+
+
+@pytest.mark.parametrize('skip,resident', [(1, False), (2, False), (1, True)])
+def test_next_frame_prefetch_changes_nothing(ctx, skip, resident):
+    """MOT.step(frame, next_frame): the detector network of frame t+1 runs during frame t's ReID /
+    association stages.  Tracks (ids, boxes, lifecycle) are bit-identical to strictly sequential steps, for
+    uploaded host frames (second upload slot, promoted without re-upload) and for resident ring frames."""
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from fastmot_amd.detector import DeviceFrame
+    from fastmot_amd import Track
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=10, n_frames=16, seed=11)
+    if resident:
+        ctx.frame_configure(size[0], size[1], video.n_frames)
+        for i, fr in enumerate(video.frames):
+            ctx.frame_ring_store(i, fr)
+        frames = [DeviceFrame(i) for i in range(video.n_frames)]
+    else:
+        frames = video.frames
+    runs = []
+    for prefetch in (False, True):
+        mot = build_mot(size, video, skip)
+        Track._count = 0
+        mot.reset(1 / 30.)
+        det_frame = 0
+        rows = []
+        for f in range(video.n_frames):
+            mot.detector._frame_idx = f
+            nxt = frames[f + 1] if prefetch and f + 1 < video.n_frames else None
+            mot.step(frames[f], next_frame=nxt)
+            rows.append([(t.trk_id, tuple(t.tlbr), t.confirmed, t.active, t.age, t.hits)
+                         for t in mot.tracker.tracks.values()])
+        runs.append(rows)
+        mot.tracker._clear_tracks()
+    assert runs[0] == runs[1]
+    assert len(runs[0][-1]) >= 8
