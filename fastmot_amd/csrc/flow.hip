@@ -518,89 +518,117 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
         for (int i = tid; i < gw * gh * 4; i += 256) cells[i] = -1;
     if (tid == 0) s_acc = 0;
     __syncthreads();
+    // Greedy min-distance selection (featureselect.cpp: candidates in sorted order, one is accepted iff no
+    // already accepted corner is closer than minDistance) by the first wavefront, 64 candidates at a time:
+    //   1. every lane tests its candidate against the corners accepted BEFORE this batch (grid cells, or the
+    //      accepted list when the grid does not fit LDS);
+    //   2. the survivors are resolved in order inside the batch: the first survivor is accepted and knocks
+    //      out the later survivors closer than minDistance, repeat.
+    // Once the crop is covered nearly every candidate dies in step 1, so a batch costs one pass instead of
+    // 64 serial iterations (the kernel was 290 us on the benchmark crops, >80 % of it in this loop).
     if (tid < 64) {
         const int md2 = md * md;
         const int limit = min(max_corners, 1024);
         int nacc = 0;
-        for (int q = 0; q < n && nacc < limit; ++q) {
-            const int ri = (int)(keys[q] & 0xffffffffu);
-            const int x = ri % c.w, y = ri / c.w;
-            bool bad = false;
-            if (use_grid) {
-                // 9 neighbouring cells x 4 slots = 36 lanes
-                if (tid < 36) {
-                    const int cxn = x / md + (tid / 4) % 3 - 1, cyn = y / md + (tid / 12) - 1;
-                    if (cxn >= 0 && cyn >= 0 && cxn < gw && cyn < gh) {
-                        const int p = cells[(cyn * gw + cxn) * 4 + (tid & 3)];
-                        if (p >= 0) {
-                            const int dx = x - (p & 0xffff), dy = y - (p >> 16);
-                            bad = dx * dx + dy * dy < md2;
+        for (int base = 0; base < n && nacc < limit; base += 64) {
+            const int q = base + tid;
+            int x = 0, y = 0;
+            bool alive = q < n;
+            if (alive) {
+                const int ri = (int)(keys[q] & 0xffffffffu);
+                x = ri % c.w;
+                y = ri / c.w;
+                if (use_grid) {
+                    const int cx0 = x / md, cy0 = y / md;
+                    for (int cyn = max(cy0 - 1, 0); cyn <= min(cy0 + 1, gh - 1) && alive; ++cyn)
+                        for (int cxn = max(cx0 - 1, 0); cxn <= min(cx0 + 1, gw - 1) && alive; ++cxn) {
+                            const int* cell = cells + (cyn * gw + cxn) * 4;
+#pragma unroll
+                            for (int sidx = 0; sidx < 4; ++sidx) {
+                                const int p = cell[sidx];
+                                if (p >= 0) {
+                                    const int dx = x - (p & 0xffff), dy = y - (p >> 16);
+                                    if (dx * dx + dy * dy < md2) alive = false;
+                                }
+                            }
                         }
+                } else {
+                    for (int j = 0; j < nacc && alive; ++j) {
+                        const int dx = x - acc_x[j], dy = y - acc_y[j];
+                        if (dx * dx + dy * dy < md2) alive = false;
                     }
                 }
-            } else {
-                for (int j = tid; j < nacc; j += 64) {
-                    const int dx = x - acc_x[j], dy = y - acc_y[j];
-                    if (dx * dx + dy * dy < md2) bad = true;
-                }
             }
-            bad = __any(bad);
-            if (!bad) {
+            unsigned long long mask = __ballot(alive);
+            while (mask != 0ull && nacc < limit) {
+                const int first = __ffsll((long long)mask) - 1;
+                const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);
                 if (tid == 0) {
-                    acc_x[nacc] = (short)x;
-                    acc_y[nacc] = (short)y;
+                    acc_x[nacc] = (short)fx;
+                    acc_y[nacc] = (short)fy;
                     if (use_grid) {
-                        int* cell = cells + ((y / md) * gw + x / md) * 4;
+                        int* cell = cells + ((fy / md) * gw + fx / md) * 4;
                         for (int sidx = 0; sidx < 4; ++sidx)
-                            if (cell[sidx] < 0) { cell[sidx] = (y << 16) | x; break; }
+                            if (cell[sidx] < 0) { cell[sidx] = (fy << 16) | fx; break; }
                     }
                 }
                 ++nacc;
+                if (alive) {
+                    const int dx = x - fx, dy = y - fy;
+                    if (tid == first || dx * dx + dy * dy < md2) alive = false;
+                }
+                mask = __ballot(alive);
             }
             __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            __threadfence_block();          // lane 0's grid / list writes are visible to the next batch
         }
         if (tid == 0) s_acc = nacc;
     }
     __syncthreads();
-    // _ellipse_filter (flow.py:297-306): pts (f32) + offset (f32), then float64 ellipse test
-    if (tid == 0) {
+    // _ellipse_filter (flow.py:297-306): pts (f32) + offset (f32), then float64 ellipse test -- flags in
+    // parallel, order-preserving compaction by ballot ranks
+    const int nacc_all = s_acc;
+    unsigned char* inside = reinterpret_cast<unsigned char*>(keys);       // the sort keys are dead
+    {
         const double* b = full_tlbr + 4 * t;
         const double cx = (b[0] + b[2]) / 2, cy = (b[1] + b[3]) / 2;
         const double ax = (b[2] - b[0] + 1) * 0.5, ay = (b[3] - b[1] + 1) * 0.5;
-        int m = 0;
-        if (compact_total) {               // compacted output: count first, reserve, then write
-            for (int q = 0; q < s_acc; ++q) {
-                const float px = (float)acc_x[q] + (float)c.x0, py = (float)acc_y[q] + (float)c.y0;
-                const double ux = ((double)px - cx) / ax, uy = ((double)py - cy) / ay;
-                m += ux * ux + uy * uy <= 1. ? 1 : 0;
-            }
-            int base = atomicAdd(compact_total, m);
-            if (base + m > cap) { m = max(0, cap - base); }
-            compact_off[t] = base;
-            int w_ = 0;
-            for (int q = 0; q < s_acc && w_ < m; ++q) {
-                const float px = (float)acc_x[q] + (float)c.x0, py = (float)acc_y[q] + (float)c.y0;
-                const double ux = ((double)px - cx) / ax, uy = ((double)py - cy) / ay;
-                if (ux * ux + uy * uy <= 1.) {
-                    pts_out[((size_t)base + w_) * 2] = px;
-                    pts_out[((size_t)base + w_) * 2 + 1] = py;
-                    ++w_;
-                }
-            }
-            counts[t] = m;
-            return;
-        }
-        for (int q = 0; q < s_acc && m < cap; ++q) {
+        for (int q = tid; q < nacc_all; q += 256) {
             const float px = (float)acc_x[q] + (float)c.x0, py = (float)acc_y[q] + (float)c.y0;
             const double ux = ((double)px - cx) / ax, uy = ((double)py - cy) / ay;
-            if (ux * ux + uy * uy <= 1.) {
-                pts_out[((size_t)t * cap + m) * 2] = px;
-                pts_out[((size_t)t * cap + m) * 2 + 1] = py;
-                ++m;
-            }
+            inside[q] = ux * ux + uy * uy <= 1. ? 1 : 0;
         }
-        counts[t] = m;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int m = 0;
+        for (int b0 = 0; b0 < nacc_all; b0 += 64)
+            m += __popcll(__ballot(b0 + tid < nacc_all && inside[b0 + tid]));
+        int base = 0;
+        if (compact_total) {               // compacted output: reserve m slots, clip at the capacity
+            if (tid == 0) {
+                base = atomicAdd(compact_total, m);
+                compact_off[t] = base;
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
+            m = max(0, min(m, cap - base));
+        } else {
+            base = t * cap;
+            m = min(m, cap);
+        }
+        int w_ = 0;
+        for (int b0 = 0; b0 < nacc_all && w_ < m; b0 += 64) {
+            const int q = b0 + tid;
+            const bool in = q < nacc_all && inside[q];
+            const unsigned long long bal = __ballot(in);
+            const int rank = w_ + __popcll(bal & ((1ull << tid) - 1ull));
+            if (in && rank < m) {
+                pts_out[((size_t)base + rank) * 2] = (float)acc_x[q] + (float)c.x0;
+                pts_out[((size_t)base + rank) * 2 + 1] = (float)acc_y[q] + (float)c.y0;
+            }
+            w_ += __popcll(bal);
+        }
+        if (tid == 0) counts[t] = m;
     }
 }
 

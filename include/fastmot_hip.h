@@ -416,6 +416,9 @@ int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
                     const int32_t* kp_off, const fm_flow_predict_params* prm, int pts_cap, float* prev_out,
                     float* cur_out, int32_t* trk_off_out, int32_t* bg_range_out, double* H_out, int* status_out,
                     int32_t* result_out, double* est_tlbr_out, int32_t* n_matched_out);
+/* profiling hook: accumulated host wall time (ms) of the stages of fm_flow_predict -- out5 = {begin, prepare,
+ * lk, estimate, number of calls}; reset != 0 clears the accumulators */
+int fm_flow_timing(double* out5, int reset);
 /* test hooks: read the device images (which: 0 prev gray, 1 cur gray, 2.. pyramid levels of prev
  * (2+l) and cur (10+l), 20 bg image) */
 int fm_flow_read_image(fm_ctx* ctx, int which, uint8_t* out, int* w, int* h);

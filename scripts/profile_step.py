@@ -55,11 +55,17 @@ def run(n, start):
 run(20, 0)
 ctx.synchronize()
 acc.clear(); cnt.clear()
+import ctypes as C0
+ctx.lib.fm_flow_timing((C0.c_double * 5)(), 1)
 N = 200
 t0 = time.perf_counter()
 run(N, 20)
 ctx.synchronize()
 el = time.perf_counter() - t0
 print(f'ms/step {el / N * 1e3:.3f}')
+import ctypes as C
+t5 = (C.c_double * 5)()
+ctx.lib.fm_flow_timing(t5, 0)
+print('flow_predict stages (ms/call): begin %.3f prepare %.3f lk %.3f estimate %.3f' % tuple(t5[i] / max(t5[4], 1) for i in range(4)))
 for k in sorted(acc, key=lambda k: -acc[k]):
     print(f'{k:<24} {acc[k] / N * 1e3:8.3f} ms/step  calls/step {cnt[k] / N:5.2f}')
