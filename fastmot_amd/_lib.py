@@ -6,6 +6,7 @@ RuntimeError when its plugin/engine is missing, fastmot/utils/inference.py:50-63
 """
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -89,6 +90,10 @@ class HipContext:
             self._ctx = C.c_void_p()
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: the orderly path is the atexit hook
+        # registered by runtime.get_context(), which runs while the runtime is still alive
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -593,7 +598,7 @@ def _bind_flow(cls):
 
     def flow_read_image(self, which):
         w, h = C.c_int(0), C.c_int(0)
-        buf = np.empty(self.frame_size[0] * self.frame_size[1], np.uint8)
+        buf = np.empty(self.frame_size[0] * self.frame_size[1] * 4, np.uint8)
         check(self.lib.fm_flow_read_image(self._ctx, C.c_int(which), _ptr(buf), C.byref(w), C.byref(h)))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 

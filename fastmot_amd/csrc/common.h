@@ -86,6 +86,7 @@ struct fm_ctx {
     // tunables (fm_ctx_set_option; initial values from the environment)
     int opt_zero_copy_tracks = 2048;   // FASTMOT_ZERO_COPY: 0 = always blit copies
     int opt_host_lap_elems = 16384;    // FASTMOT_HOST_LAP: cost matrices up to this size use lap_host.hip
+    int opt_use_graphs = 1;            // FASTMOT_GRAPHS: 0 = launch network layers one by one (no hipGraph)
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network
     hipStream_t s_ext = nullptr;    // ReID network
@@ -129,6 +130,7 @@ struct fm_ctx {
     uint8_t* frame_own2 = nullptr;         // second upload slot (prefetched next frame); the two swap roles
     uint8_t* frame_next = nullptr;         // frame the detector was prefetched on (fm_frame_*_next)
     uint8_t* frame_pinned2 = nullptr;
+    hipEvent_t ev_next_upload = nullptr;   // completion of the prefetched frame's H2D copy (detector stream)
     uint8_t* frame_ring = nullptr;
     uint8_t* frame_pinned = nullptr;
 

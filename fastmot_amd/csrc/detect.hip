@@ -436,6 +436,8 @@ extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
     FM_HIP(hipStreamSynchronize(ctx->s_det));        // previous reader of this slot / pinned buffer
     memcpy(ctx->frame_pinned2, bgr, bytes);
     FM_HIP(hipMemcpyAsync(ctx->frame_own2, ctx->frame_pinned2, bytes, hipMemcpyHostToDevice, ctx->s_det));
+    if (!ctx->ev_next_upload) FM_HIP(hipEventCreateWithFlags(&ctx->ev_next_upload, hipEventDisableTiming));
+    FM_HIP(hipEventRecord(ctx->ev_next_upload, ctx->s_det));
     ctx->frame_next = ctx->frame_own2;
     return 0;
 }
@@ -449,9 +451,13 @@ extern "C" int fm_frame_ring_select_next(fm_ctx* ctx, int index) {
 extern "C" int fm_frame_promote_next(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx && ctx->frame_next);
     if (ctx->frame_next == ctx->frame_own2) {
-        // the upload of the prefetched frame was enqueued on s_det; the other streams read it from now on
+        // the upload of the prefetched frame was enqueued on s_det; the other streams read the frame from
+        // now on and must wait for that copy (they never waited for the detector stream otherwise)
         FM_HIP(hipStreamSynchronize(ctx->s_ext));
         FM_HIP(hipStreamSynchronize(ctx->s_flow));
+        FM_HIP(hipStreamWaitEvent(ctx->s_ext, ctx->ev_next_upload, 0));
+        FM_HIP(hipStreamWaitEvent(ctx->s_flow, ctx->ev_next_upload, 0));
+        FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_next_upload, 0));
         std::swap(ctx->frame_own, ctx->frame_own2);
         std::swap(ctx->frame_pinned, ctx->frame_pinned2);
         ctx->frame_cur = ctx->frame_own;

@@ -20,10 +20,12 @@ struct ExtState {
     double* boxes = nullptr;       // device [cap][4]
     double* boxes_host = nullptr;  // pinned
     int cap = 0;
+    DevBuf emb_out;                // pinned read-back buffer of fm_extract_sync
 };
 
 void fm_ext_free(ExtState* e) {
     if (!e) return;
+    e->emb_out.release();
     if (e->boxes) (void)hipFree(e->boxes);
     if (e->boxes_host) (void)hipHostFree(e->boxes_host);
     delete e;
@@ -147,10 +149,19 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
 
 extern "C" int fm_extract_sync(fm_ctx* ctx, int n, float* emb) {
     FM_CHECK_ARG(ctx && n >= 0 && n <= ctx->emb_cap);
+    if (n == 0) {
+        FM_HIP(hipStreamSynchronize(ctx->s_ext));
+        return 0;
+    }
+    FM_CHECK_ARG(emb && ctx->ext);
+    // read back on the extractor's own stream through a pinned buffer: a synchronous hipMemcpy runs on the
+    // legacy NULL stream, which must not be mixed with the other host thread's asynchronous work
+    const size_t bytes = sizeof(float) * (size_t)n * ctx->feat_dim;
+    int rc = ctx->ext->emb_out.reserve(bytes);
+    if (rc) return rc;
+    FM_HIP(hipMemcpyAsync(ctx->ext->emb_out.h, ctx->emb, bytes, hipMemcpyDeviceToHost, ctx->s_ext));
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
-    if (n == 0) return 0;
-    FM_CHECK_ARG(emb);
-    FM_HIP(hipMemcpy(emb, ctx->emb, sizeof(float) * (size_t)n * ctx->feat_dim, hipMemcpyDeviceToHost));
+    memcpy(emb, ctx->ext->emb_out.h, bytes);
     return 0;
 }
 

@@ -17,6 +17,7 @@
 // Roofline: all kernels are HBM/L2 bound pixel passes (gray: 6.2 MB in, 2.1 MB out; pyramid
 // 0.69 MB/img; LK <= 3 KB gathered per point and level, L2 resident).
 #include "common.h"
+#include <cstdlib>
 #include <cmath>
 
 namespace {
@@ -160,21 +161,29 @@ struct LKArgs {
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
+// butterfly sum over the wavefront that owns one point.  The first five steps are the 32-lane butterfly the
+// parity tests were written against; the sixth adds the (all-zero) upper half, so the value is unchanged.
 __device__ __forceinline__ float group_sum32(float v) {
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 
-// 32 lanes per point: lane g < win*win owns window pixel (g / win, g % win); sums over the window
-// are 32-lane butterfly reductions (float32; the summation order differs from OpenCV's scalar loop,
-// results agree to ~1e-4 px).  All lanes of a group follow the same control flow.
+// One wavefront (64 lanes) per point: lane g < win*win owns window pixel (g / win, g % win); sums over the
+// window are butterfly reductions (float32; the summation order differs from OpenCV's scalar loop, results
+// agree to ~1e-4 px).  The control flow (pyramid levels skipped, iteration counts) depends on the point, so
+// it must be WAVE-uniform: with two points per wavefront (32 lanes each, the first version) the two halves
+// diverged, and the results of single points then varied from run to run whenever other streams kept the
+// CUs' LDS pipelines busy (reproduced in isolation: scripts/stress_lk2.py; constant images, constant
+// arguments, no such effect with one point per wavefront or with equal trip counts).  39 idle lanes are
+// the price; the kernel is latency bound anyway.
 __global__ __launch_bounds__(256) void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                  float* __restrict__ err) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int pt = gidx >> 5, g = gidx & 31;
-    if (pt >= n) return;                       // whole 32-lane group exits together
+    const int pt = gidx >> 6, g = gidx & 63;
+    if (pt >= n) return;                       // the whole wavefront exits together
     const int win = a.win;
     const bool lane_on = g < win * win;
     const int wy = lane_on ? g / win : 0, wx = lane_on ? g % win : 0;
@@ -982,7 +991,7 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         a.eps2 = (float)(eps * eps);
         a.min_eig_thresh = 1e-4f;
         char* o = f->lk_out.dev<char>();
-        hipLaunchKernelGGL(lk_kernel, dim3((n * 32 + 255) / 256), dim3(256), 0, s, a, n, f->lk_in.dev<float>(),
+        hipLaunchKernelGGL(lk_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, f->lk_in.dev<float>(),
                            reinterpret_cast<float*>(o), reinterpret_cast<uint8_t*>(o + o_st),
                            reinterpret_cast<float*>(o + o_err));
         FM_HIP(hipGetLastError());
@@ -1162,5 +1171,48 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     if (n_bg) memcpy(bg_pts_out, ho + q_bg, sizeof(float) * 2 * n_bg);
     *n_new_out = n_new;
     *n_bg_out = n_bg;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Diagnostic kernel (scripts/stress_spin.py): a long, fully deterministic computation on the flow stream,
+// used to tell a bug in a kernel of this library from a platform issue when kernels on other streams run
+// concurrently.  mode bit 0: 32-lane butterfly (ds_bpermute) every iteration; bit 1: byte loads from `img`.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void spin_kernel(int iters, int mode, const uint8_t* __restrict__ img, int img_n,
+                                                   unsigned* __restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned x = 2463534242u ^ (unsigned)gid;
+    float acc = 0.f;
+    for (int i = 0; i < iters; ++i) {
+        x = x * 1664525u + 1013904223u;
+        if (mode & 2) x += img[(x >> 8) % (unsigned)img_n];
+        if (mode & 1) {
+            float v = (float)(x & 0xffff);
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+            acc += v * 1e-6f;
+            if ((x & 1023u) == 0u && (gid & 32)) break;      // the two 32-lane halves of a wave diverge
+        }
+    }
+    out[gid] = x ^ __float_as_uint(acc);
+}
+}  // namespace
+
+extern "C" int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsigned* out_host) {
+    FM_CHECK_ARG(ctx && ctx->flow && blocks > 0 && out_host);
+    FlowState* f = ctx->flow;
+    hipStream_t s = ctx->s_flow;
+    const size_t bytes = sizeof(unsigned) * 256 * (size_t)blocks;
+    int rc = f->lk_out.reserve(bytes);
+    if (rc) return rc;
+    FM_HIP(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, s, iters, mode, f->gray[f->prev], f->W * f->H,
+                       f->lk_out.dev<unsigned>());
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(f->lk_out.h, f->lk_out.d, bytes, hipMemcpyDeviceToHost, s));
+    FM_HIP(hipStreamSynchronize(s));
+    memcpy(out_host, f->lk_out.h, bytes);
     return 0;
 }

@@ -280,7 +280,7 @@ extern "C" int fm_net_run(fm_ctx* ctx, int which, int batch) {
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr && batch >= 0 && batch <= net->max_batch);
     if (batch == 0) return 0;
-    if (!net->use_graphs) return run_layers_eager(ctx, net, batch);
+    if (!net->use_graphs || !ctx->opt_use_graphs) return run_layers_eager(ctx, net, batch);
     const long key = ((long)batch << 32) | (unsigned)net->emb_offset;
     for (auto& g : net->graphs)
         if (g.first == key) {

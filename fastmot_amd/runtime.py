@@ -6,6 +6,7 @@ track table, the per-frame embeddings and the frame buffers are visible to all s
 without host round trips.  Multi-GPU = one process per GPU (LOCAL_RANK selects the device),
 which is also what the reference's process-global `Track._count` requires (track.py:130).
 """
+import atexit
 import os
 
 from . import _lib
@@ -49,6 +50,9 @@ def get_context():
         _CTX = _lib.HipContext(device)
         _CTX.slots = SlotAllocator()
         _CTX.device_emb_host = None
+        # destroy the context (streams, graphs, buffers) before the interpreter and the HIP runtime tear down;
+        # registered after concurrent.futures' own hook was, so worker threads are joined first
+        atexit.register(reset_context)
     return _CTX
 
 

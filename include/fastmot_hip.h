@@ -46,8 +46,9 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
 /* tunables: "zero_copy_tracks" (default 2048; batches up to this many tracks / boxes exchange kernel
  * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
  * "host_lap_elems" (default 16384; LAP cost matrices up to this many elements are solved by the host
- * solver of the library, larger ones by the device kernels; 0 = always device).  Initial values can be
- * set with the environment variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP. */
+ * solver of the library, larger ones by the device kernels; 0 = always device), "use_graphs" (default 1;
+ * 0 launches the network layers one by one instead of replaying hipGraphs).  Initial values can be set
+ * with the environment variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP / FASTMOT_GRAPHS. */
 int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value);
 /* writes "name:gcnArch:CUs:clockMHz:hbmBytes" of the ctx device */
 int fm_device_info(fm_ctx* ctx, char* buf, int buflen);
@@ -416,6 +417,9 @@ int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
                     const int32_t* kp_off, const fm_flow_predict_params* prm, int pts_cap, float* prev_out,
                     float* cur_out, int32_t* trk_off_out, int32_t* bg_range_out, double* H_out, int* status_out,
                     int32_t* result_out, double* est_tlbr_out, int32_t* n_matched_out);
+/* diagnostic: a long deterministic kernel on the flow stream (mode bit 0: 32-lane butterflies, bit 1: byte
+ * loads from the previous gray image); out_host: 256 * blocks words.  See scripts/stress_spin.py. */
+int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsigned* out_host);
 /* profiling hook: accumulated host wall time (ms) of the stages of fm_flow_predict -- out5 = {begin, prepare,
  * lk, estimate, number of calls}; reset != 0 clears the accumulators */
 int fm_flow_timing(double* out5, int reset);

@@ -10,6 +10,7 @@ import cv_oracle as cv
 import scenes
 from fastmot_amd import _lib
 from fastmot_amd.flow import Flow
+from fastmot_amd.detector import bind_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -213,3 +214,55 @@ def test_prepare_matches_staged_calls(ctx):
     assert needy.tolist() == [True, True, False, True]
     for i, k in enumerate(idx):
         np.testing.assert_array_equal(new_pts[new_off[k]:new_off[k] + new_cnt[k]], pts0[i, :cnt0[i]])
+
+
+def test_lk_deterministic_while_other_streams_are_busy(ctx):
+    """Regression (found with scripts/stress_lk2.py): with two points per wavefront the two 32-lane halves of
+    lk_kernel followed different control flow, and single points then changed from call to call whenever
+    another host thread kept the GPU busy with LDS-heavy kernels -- constant images, constant arguments.
+    One wavefront per point is immune; 120 calls under load must reproduce the idle result bit for bit."""
+    import threading
+    from fastmot_amd.detector import DeviceFrame
+    from fastmot_amd.engine import HipNet, NET_DETECTOR
+    from fastmot_amd.models.graph import Graph, RandomWeights
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=6, n_frames=2, seed=4)
+    ctx.frame_configure(size[0], size[1], 2)
+    for i in range(2):
+        ctx.frame_ring_store(i, video.frames[i])
+    flow = Flow(size)
+    flow.init(DeviceFrame(0))
+    bind_frame(ctx, DeviceFrame(1), size)
+    ctx.flow_begin()
+    ctx.synchronize()
+    g = Graph(RandomWeights(seed=1), (64, 32), 16)
+    params = [g.lightconv_params(f'p{i}', 16) for i in range(4)]
+    g.lightconv_group('l', [g.input] * 4, params)
+    net = HipNet(ctx, NET_DETECTOR, g, 50, reuse_buffers=True)
+    net.run(50)
+    ctx.synchronize()
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(20, size[0] / 2 - 20, 600), rng.uniform(20, size[1] / 2 - 20, 600)], 1).astype(np.float32)
+    base = [ctx.flow_lk(pts), ctx.flow_lk(pts)]          # the second call tracks in the opposite direction
+    stop = []
+
+    def hammer():
+        ctx.bind_thread()
+        while not stop:
+            net.run(50)
+            ctx.synchronize()
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        bad = 0
+        for r in range(60):
+            for k in range(2):
+                nxt, st, _ = ctx.flow_lk(pts)
+                ok = np.array_equal(st, base[k][1]) and np.array_equal(nxt[st > 0], base[k][0][st > 0])
+                bad += not ok
+    finally:
+        stop.append(1)
+        th.join()
+        net.close()
+    assert bad == 0

@@ -107,3 +107,25 @@ def test_next_frame_prefetch_changes_nothing(ctx, skip, resident):
         mot.tracker._clear_tracks()
     assert runs[0] == runs[1]
     assert len(runs[0][-1]) >= 8
+
+
+def test_pipeline_is_deterministic(ctx):
+    """The two-thread, four-stream pipeline gives the same tracks (ids, boxes, keypoint counts) on every run
+    of the same clip (scripts/stress_determinism.py is the long version of this check)."""
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from fastmot_amd import Track
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=10, n_frames=12, seed=11)
+    runs = []
+    for _ in range(4):
+        mot = build_mot(size, video, 1)
+        Track._count = 0
+        mot.reset(1 / 30.)
+        rows = []
+        for f in range(video.n_frames):
+            mot.detector._frame_idx = f
+            mot.step(video.frames[f], next_frame=video.frames[f + 1] if f + 1 < video.n_frames else None)
+            rows.append([(t.trk_id, tuple(t.tlbr), t.age, t.hits, len(t.keypoints)) for t in mot.tracker.tracks.values()])
+        runs.append(rows)
+        mot.tracker._clear_tracks()
+    assert all(r == runs[0] for r in runs[1:])
