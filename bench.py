@@ -197,8 +197,9 @@ def main():
                                    'frames resident in HBM', 'next_frame_prefetch': bool(args.prefetch), 'streams_per_gpu': 1, 'parallelism': f'1 stream/GPU x {world}',
                        'visible_tracks': len(list(mot.visible_tracks())),
                        'yolo_candidates_nms_out': mot.detector.last_real_count},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (110 conv launches of YOLOv4 per frame, '
-                                                    f'measured with HIP events on the detector stream over {n_launch} launches)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel + resblock_kernel (the 110 conv layers of YOLOv4: '
+                                                    f'{n_launch} launches per frame incl. fused residual units / SPP, '
+                                                    'measured with HIP events on the detector stream)',
                          'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_PEAK_TFLOPS, 5), 'traffic': pmc_traffic(),
                          'flop_per_frame': flops, 'net_ms_per_frame': round(net_avg_ms, 4),

@@ -25,6 +25,10 @@ int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int
                 int W, int C, int Ho, int Wo, int k, int stride, int pad, int avg, hipStream_t s);
 int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
                      int W, int C, hipStream_t s);
+bool resblock_supported(int C, int M);
+int launch_resblock(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, int out_coff, const f16* w1,
+                    const float* b1, const f16* w2, const float* b2, int N, int H, int W, int C, int M, int act1,
+                    int act2, hipStream_t s);
 int launch_add(const f16* a, int a_cs, int a_coff, const f16* b, int b_cs, int b_coff, f16* out, int out_cs,
                int out_coff, long npix, int C, hipStream_t s);
 int launch_copy(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, long npix, int C,
@@ -223,6 +227,13 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
         case FM_OP_UPSAMPLE2:
             FM_CHECK_ARG(to.h == 2 * ti.h && to.w == 2 * ti.w);
             return launch_upsample2(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, s);
+        case FM_OP_RESBLOCK:
+            FM_CHECK_ARG(!to.f32 && to.h == ti.h && to.w == ti.w && L.cin == L.cout &&
+                         L.in_coff[0] + L.cin <= ti.c && L.out_coff + L.cout <= to.c);
+            return launch_resblock(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
+                                   (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                                   (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
+                                   B, ti.h, ti.w, L.cin, L.hid, L.act, L.act, s);
         case FM_OP_ADD: {
             FM_CHECK_ARG(L.n_in == 2);
             const fm_tensor& tb = net->tensors[L.in[1]];
@@ -369,6 +380,10 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *flops = 2.0 * L.k * L.k * 3 * L.cout * pout;
             *bytes = pin * 8 + pout * L.cout * 2;
             break;
+        case FM_OP_RESBLOCK:
+            *flops = 2.0 * 10 * L.cin * L.hid * pout;
+            *bytes = (pin + pout) * L.cin * 2 + 10.0 * L.cin * L.hid * 2;
+            break;
         case FM_OP_SPP: *bytes = (pin + 3 * pout) * L.cin * 2; break;
         case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
         case FM_OP_GATE_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
@@ -386,7 +401,7 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
     FM_CHECK_ARG(net != nullptr);
     double f = 0, b = 0;
     for (const fm_layer& L : net->layers)
-        if (L.op == FM_OP_CONV) {
+        if (L.op == FM_OP_CONV || L.op == FM_OP_RESBLOCK) {
             double lf, lb;
             layer_cost(net, L, batch, &lf, &lb);
             f += lf;
@@ -416,7 +431,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
             FM_HIP(hipEventSynchronize(e1));
             float ms = 0;
             FM_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (L.op == FM_OP_CONV) { tc += ms; ++nc; } else { to += ms; ++no; }
+            if (L.op == FM_OP_CONV || L.op == FM_OP_RESBLOCK) { tc += ms; ++nc; } else { to += ms; ++no; }
         }
     FM_HIP(hipEventDestroy(e0));
     FM_HIP(hipEventDestroy(e1));

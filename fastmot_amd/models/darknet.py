@@ -190,6 +190,25 @@ def darknet_graph(cfg, weights, in_hw=None):
         return (layers[j]['type'] == 'shortcut' and layers[j - 1]['type'] == 'convolutional' and
                 readers[j - 1] == {j})
 
+    def conv_attrs(j):
+        L = layers[j]
+        k = int(L.get('size', 1))
+        return (k, int(L.get('stride', 1)), k // 2 if int(L.get('pad', 0)) else int(L.get('padding', 0)),
+                L.get('activation', 'linear'), int(L.get('batch_normalize', 0)) == 1)
+
+    def fused_resblock(j):
+        """Shortcut j closes a residual unit conv1x1 (j-2) -> conv3x3 (j-1) -> + input of j-2 that the
+        fused kernel covers (resblock.hip): one launch instead of three."""
+        if not (use_resblock and j >= 3 and folded_shortcut(j) and layers[j - 2]['type'] == 'convolutional' and
+                readers[j - 2] == {j - 1} and layers[j].get('activation', 'linear') == 'linear'):
+            return False
+        frm = layers[j]['from']
+        if _resolve(j, int(frm[0] if isinstance(frm, list) else frm)) != j - 3:
+            return False
+        a, b = conv_attrs(j - 2), conv_attrs(j - 1)
+        return (a[:3] == (1, 1, 0) and b[:3] == (3, 1, 1) and a[3] == b[3] and shape[j - 3][0] == shape[j][0] and
+                Graph.resblock_supported(shape[j][0], shape[j - 2][0]))
+
     def producer(j):
         """Layer index whose emitted op writes the tensor of layer j, or None if j is a view."""
         j = base(j)
@@ -235,6 +254,7 @@ def darknet_graph(cfg, weights, in_hw=None):
 
     # ---- pass 3: emit
     g = Graph(weights, (H, W), cin0)
+    use_resblock = g.use_resblock
     out = [None] * n                      # View of every layer's output
     cat = {}                              # concat layer -> tensor view (allocated by its first producer)
     heads, meta_yolo = [], []
@@ -265,6 +285,12 @@ def darknet_graph(cfg, weights, in_hw=None):
             is_head = i + 1 < n and layers[i + 1]['type'] == 'yolo'
             res = None
             up = 1
+            if i + 2 < n and layers[i + 2]['type'] == 'shortcut' and fused_resblock(i + 2):
+                continue                    # the 1x1 of a fused residual unit: emitted with its 3x3
+            if i + 1 < n and layers[i + 1]['type'] == 'shortcut' and fused_resblock(i + 1):
+                out[i] = g.resblock(f'{i - 1:03d}_convolutional', f'{i:03d}_convolutional', src(i - 2), shape[i - 1][0],
+                                    act, dst=dst_of(i, c), bn1=conv_attrs(i - 1)[4], bn2=bn)
+                continue
             if i + 1 < n and folded_shortcut(i + 1):
                 res = out[_resolve(i + 1, int(layers[i + 1]['from'] if not isinstance(layers[i + 1]['from'], list)
                                               else layers[i + 1]['from'][0]))]

@@ -8,10 +8,12 @@ the MFMA kernel's [cout_pad32][K_pad64] fp16 layout.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD) = range(14)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK) = range(15)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
@@ -98,6 +100,8 @@ class Graph:
         self.n_gates = 0
         self.gate_c = 8
         self.use_stem = True   # small-Cin first layers go to the LDS-patch stem kernel
+        # darknet residual units (1x1, 3x3, shortcut) as one fused launch (resblock.hip)
+        self.use_resblock = os.environ.get('FASTMOT_RESBLOCK', '1') != '0'
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -169,6 +173,37 @@ class Graph:
                           act=ACT[act], up=up, w_off=self._push(packed), b_off=self._push(bias),
                           res=res, res_mode=res_mode if res is not None else RES_NONE, name=name)
         self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
+        return dst
+
+    @staticmethod
+    def resblock_supported(c, mid):
+        return c in (64, 128, 256) and mid in (c, c // 2)
+
+    @staticmethod
+    def _pack_frag(w16):
+        """[cout, cin, k, k] -> MFMA A-fragment order [cout/32][K/16][lane][8], K order (kh, kw, cin),
+        lane = (k / 8 % 2) * 32 + cout % 32 (cout % 32 == 0, K % 16 == 0)."""
+        cout, cin, k, _ = w16.shape
+        K = k * k * cin
+        assert cout % 32 == 0 and K % 16 == 0
+        rows = w16.transpose(0, 2, 3, 1).reshape(cout // 32, 32, K // 16, 2, 8)
+        return np.ascontiguousarray(rows.transpose(0, 2, 3, 1, 4))
+
+    def resblock(self, name1, name2, x, mid, act='mish', dst=None, wb1=None, wb2=None, bn1=True, bn2=True):
+        """Darknet residual unit in one launch (resblock.hip): x + act(conv3x3(act(conv1x1(x)))).
+        Parameters are drawn in layer order (1x1 then 3x3), like the unfused layers."""
+        c = x.c
+        assert self.resblock_supported(c, mid) and x.cpad == c
+        if dst is None:
+            dst = self.new(x.h, x.w, c)
+        w1, b1 = wb1 if wb1 is not None else fold_bn(self.wsrc.conv(name1, mid, c, 1, bn=bn1))
+        w2, b2 = wb2 if wb2 is not None else fold_bn(self.wsrc.conv(name2, c, mid, 3, bn=bn2))
+        w1, b1, w2, b2 = (np.asarray(a, np.float32) for a in (w1, b1, w2, b2))
+        w1h, w2h = w1.astype(np.float16), w2.astype(np.float16)
+        self._layer(op=OP_RESBLOCK, ins=[x], out=dst, cin=c, cout=c, k=3, stride=1, pad=1, act=ACT[act], hid=mid,
+                    w_off=self._push(self._pack_frag(w1h)), b_off=self._push(b1),
+                    w2_off=self._push(self._pack_frag(w2h)), b2_off=self._push(b2), name=name2,
+                    res_ref=(w1h.astype(np.float32), b1, w2h.astype(np.float32), b2))
         return dst
 
     def dwconv3(self, name, x, act='relu', dst=None):
@@ -410,4 +445,7 @@ class Graph:
             if d['op'] in (OP_CONV, OP_STEMCONV):
                 o = d['out']
                 total += 2 * d['k'] * d['k'] * d['ins'][0].c * d['cout'] * o.h * o.w * batch
+            elif d['op'] == OP_RESBLOCK:
+                o = d['out']
+                total += 2 * 10 * d['cin'] * d['hid'] * o.h * o.w * batch
         return total

@@ -99,6 +99,9 @@ def yolov4_graph(model, weights):
         conv(d, h, 1, dst=cat.slice(h, h))            # route branch A (second in the concat)
         b = conv(d, h, 1)
         for _ in range(n_res):
+            if g.use_resblock and g.resblock_supported(h, m):
+                b = g.resblock(name(), name(), b, m)   # 1x1 + 3x3 + shortcut in one launch
+                continue
             t = conv(b, m, 1)
             b = conv(t, h, 3, res=b)                   # shortcut (linear) : act(conv) + b
         conv(b, h, 1, dst=cat.slice(0, h))            # most recent tensor first

@@ -201,6 +201,12 @@ enum {
                           * cout <= 32, + bias + act: w = fp16 [32][ceil16(k*k*4)] (K order kh,kw,c<4),
                           * b = f32[32]; patch staged in LDS (stemconv.hip)                     */
     FM_OP_ADD = 13,      /* out = in[0] + in[1] (stand-alone [shortcut])                          */
+    FM_OP_RESBLOCK = 14, /* fused darknet residual unit (1x1 conv, 3x3 conv, [shortcut] from=-3;
+                          * yolo2onnx.py:558-760): out = in[0] + act(conv3x3(act(conv1x1(in[0]))));
+                          * cin = cout in {64,128,256} channels, hid = mid channels (% 32, <= 256);
+                          * w_off/b_off = the 1x1 conv, w2_off/b2_off = the 3x3 conv; weights in MFMA
+                          * fragment order [cout/32][K/16][lane = (k/8%2)*32 + cout%32][k%8], K order
+                          * (kh, kw, cin) (resblock.hip)                                          */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

@@ -357,6 +357,20 @@ new_coords=1
 """
 
 
+def _conv(filters, size, stride=1, act='mish', bn=1):
+    return (f'[convolutional]\n' + ('batch_normalize=1\n' if bn else '') +
+            f'filters={filters}\nsize={size}\nstride={stride}\npad=1\nactivation={act}\n\n')
+
+
+# CSP stage whose residual units are wide enough for the fused kernel (64 channels; mid 32 and 64); the
+# last unit's output is a concat operand (written in place), the second shortcut uses the list form
+MINI_RES = ('[net]\nwidth=48\nheight=40\nchannels=3\n\n' + _conv(64, 3, 2) + _conv(64, 1) + '[route]\nlayers = -2\n\n' +
+            _conv(64, 1) + _conv(32, 1) + _conv(64, 3) + '[shortcut]\nfrom=-3\nactivation=linear\n\n' +
+            _conv(64, 1) + _conv(64, 3) + '[shortcut]\nfrom=-3\nactivation=linear\n\n' +
+            '[route]\nlayers = -1,-9\n\n' + _conv(21, 1, act='linear', bn=0) +
+            '[yolo]\nmask = 0,1,2\nanchors = 10,14, 23,27, 37,58\nclasses=2\nnum=3\n')
+
+
 def conv_sections(cfg_layers):
     """(filters, cin, k, bn) of every [convolutional] in cfg order, by an independent shape walk."""
     net, layers = cfg_layers[0], cfg_layers[1:]

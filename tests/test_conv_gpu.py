@@ -174,6 +174,33 @@ def test_spp_fused(ctx, c, h, w, n):
     net.close()
 
 
+@pytest.mark.parametrize('c,mid,h,w,n', [(64, 32, 19, 27, 2), (64, 64, 40, 40, 1), (128, 128, 76, 76, 1),
+                                         (128, 64, 9, 5, 3), (256, 256, 38, 38, 1), (256, 128, 7, 13, 2)])
+def test_resblock_fused(ctx, c, mid, h, w, n):
+    """Fused residual unit == 1x1 conv -> 3x3 conv + shortcut as separate layers (same parameters), and ==
+    the torch reference; input/output in channel slices of wider tensors."""
+    rng = np.random.default_rng(c + mid)
+    x = rng.normal(0, 1, (n, h, w, c)).astype(np.float16)
+    g = Graph(RandomWeights(seed=5), (h, w), c + 8)
+    xin = g.input.slice(8, c)
+    wide = g.new(h, w, c + 16)
+    fused = g.resblock('a', 'b', xin, mid, dst=wide.slice(16, c))
+    assert g.layers[-1]['op'] == 14
+    w1, b1, w2, b2 = g.layers[-1]['res_ref']
+    t = g.conv('a2', xin, mid, 1, 1, 'mish', wb=(w1, b1))
+    plain = g.conv('b2', t, c, 3, 1, 'mish', res=xin, wb=(w2, b2))
+    net = HipNet(ctx, NET_DETECTOR, g, n)
+    xi = np.zeros((n, h, w, c + 8), np.float16)
+    xi[..., 8:] = x
+    net.write(g.input, xi)
+    net.run(n)
+    a, b = net.read(wide, n)[..., 16:], net.read(plain, n)
+    close(a, b, what='fused vs unfused')
+    bufs, _ = torch_ref.run_graph(g, nchw(xi.astype(np.float32)))
+    close(a, nhwc(bufs[wide.tid][:, 16:16 + c]), what='fused vs torch')
+    net.close()
+
+
 @pytest.mark.parametrize('cin,cout,h,w,n', [(512, 256, 19, 19, 1), (64, 24, 6, 9, 2)])
 def test_conv_fused_upsample(ctx, cin, cout, h, w, n):
     """conv(up=2) == conv followed by the nearest x2 upsample layer (split-K path for the first case)."""
@@ -335,12 +362,18 @@ def test_osnet_embeddings(ctx, model, size, batch):
     net.close()
 
 
-def test_yolov4_small_input(ctx):
-    """Whole YOLOv4 topology (110 convs, SPP, PAN) at 96x96 so the CPU reference finishes in seconds."""
+@pytest.mark.parametrize('resblock', ['1', '0'])
+def test_yolov4_small_input(ctx, monkeypatch, resblock):
+    """Whole YOLOv4 topology (110 convs, SPP, PAN) at 96x96 so the CPU reference finishes in seconds;
+    with the residual units fused (19 of the 23: 64..256 channels) and as separate conv layers."""
+    monkeypatch.setenv('FASTMOT_RESBLOCK', resblock)
+
     class Small(YOLO.get_model('YOLOv4')):
         INPUT_SHAPE = (3, 96, 96)
     g, heads = Small.build_graph(RandomWeights(seed=21))
-    assert sum(d['op'] in (0, 12) for d in g.layers) == 110 and g.layers[0]['op'] == 12
+    n_res = sum(d['op'] == 14 for d in g.layers)
+    assert n_res == (19 if resblock == '1' else 0)
+    assert sum(d['op'] in (0, 12) for d in g.layers) + 2 * n_res == 110 and g.layers[0]['op'] == 12
     net = HipNet(ctx, NET_DETECTOR, g, 1)
     rng = np.random.default_rng(22)
     x = rng.uniform(0, 1, (1, 96, 96, 3)).astype(np.float16)

@@ -12,7 +12,7 @@ import torch_ref
 from fastmot_amd.models import darknet
 from fastmot_amd.models import graph as G
 
-CASES = {'mini_v4': dc.MINI_V4, 'mini_tiny': dc.MINI_TINY}
+CASES = {'mini_v4': dc.MINI_V4, 'mini_tiny': dc.MINI_TINY, 'mini_res': dc.MINI_RES}
 
 
 def build(name, seed=1):
@@ -53,6 +53,21 @@ def test_lowering_mini_v4():
     assert meta['classes'] == 2 and meta['strides'] == [2, 4] and meta['scales'] == [1.2, 1.1]
     assert meta['anchors'] == [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146]] and meta['new_coords'] is False
     assert all(g.tensors[h.tid][3] == 1 for h in heads)          # fp32 heads
+
+
+def test_lowering_mini_res(monkeypatch):
+    """Residual units (1x1, 3x3, shortcut from=-3) of 64 channels lower to one fused launch each; the second
+    one writes straight into the concat tensor.  FASTMOT_RESBLOCK=0 keeps the conv + folded-shortcut form."""
+    _, _, g, heads, _ = build('mini_res')
+    ops = Counter(d['op'] for d in g.layers)
+    assert ops[G.OP_RESBLOCK] == 2 and ops[G.OP_ADD] == 0 and ops[G.OP_COPY] == 0 and len(g.layers) == 6
+    res = [d for d in g.layers if d['op'] == G.OP_RESBLOCK]
+    assert [d['hid'] for d in res] == [32, 64] and res[1]['out'].tid == g.layers[-1]['ins'][0].tid
+    monkeypatch.setenv('FASTMOT_RESBLOCK', '0')
+    _, _, g0, _, _ = build('mini_res')
+    ops0 = Counter(d['op'] for d in g0.layers)
+    assert ops0[G.OP_RESBLOCK] == 0 and len(g0.layers) == 8
+    assert sum(1 for d in g0.layers if d['op'] == G.OP_CONV and d['res'] is not None) == 2
 
 
 def test_lowering_mini_tiny():

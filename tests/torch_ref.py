@@ -60,6 +60,12 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             if d['up'] == 2:
                 y = F.interpolate(y, scale_factor=2, mode='nearest')
             wr(d['out'], y, f32=bool(graph.tensors[d['out'].tid][3]))
+        elif op == G.OP_RESBLOCK:
+            w1, b1, w2, b2 = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['res_ref'])
+            y = act_fn(F.conv2d(xin, w1, b1), d['act'])
+            if emulate_fp16_storage:
+                y = y.half().float()
+            wr(d['out'], act_fn(F.conv2d(y, w2, b2, padding=1), d['act']) + xin)
         elif op == G.OP_DWCONV3:
             w, b = params[idx]
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), padding=1, groups=xin.shape[1])
