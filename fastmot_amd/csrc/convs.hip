@@ -1,0 +1,194 @@
+// Streamed convolution for layers with FEW output pixels and a LONG reduction (YOLOv4 at 19 x 19: K up to
+// 4608, 361 pixels; yolo2onnx.py:558-705 conv + BN + activation).  The LDS-tiled kernel (conv.hip) has only
+// cout/64 x P/64 = 48..96 tiles there and needs a split-K launch plus a separate reduce launch (fp32 partials
+// through HBM) to reach the other CUs; these layers ran at ~80 TFLOP/s.  Here the K split happens INSIDE the
+// workgroup:
+//   * a workgroup owns CT x 32 couts x 32 pixels; its NW waves each take a contiguous 1/NW of the K range and
+//     accumulate a private MFMA tile, both operands straight from L2/HBM in fragment layout:
+//       A: weights pre-packed in fragment order ([cout/32][K/16][lane][8 halfs], lane = (k/8%2)*32 + cout%32):
+//          one fragment load of a wave is one contiguous 1 KB block;
+//       B: NHWC pixels are K-contiguous; a chunk of 4 MFMA steps (64 channels) stays inside one tap because
+//          Cin % 64 == 0, is loaded as full 128 B rows and re-laid into fragments through a wave-private
+//          LDS tile;
+//   * a ring of PD chunks per wave is in flight (nothing else hides the ~1 us L2/HBM round trip: ~1-2 waves
+//     per SIMD);
+//   * the NW partial tiles meet in LDS and all threads run the epilogue (bias, activation, residual, x2
+//     upsample replication, fp32 heads) -- no workspace, no second launch.
+// Data reuse per byte is lower than the LDS-tiled kernel's (every wave loads its own fragments: 2-3 KB per
+// 32x32x16 MFMA), so this path is L1-bandwidth bound (~64 B/clk/CU) and only used where the tiled kernel is
+// parallelism bound (graph.py picks it per layer).
+#include "net.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// stands in for the rows of out-of-image taps (zero padding); walked like a pixel row: Cin + 64 <= 4160
+__device__ __attribute__((aligned(128))) f16 g_zero_page[4160];
+
+template <int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int npt, int ncg) {
+    constexpr int PD = CT == 1 ? 4 : 3;            // chunks in flight per wave: PD * (CT + 1) * 16 VGPRs
+    constexpr int BROW = 64 + 8;                    // halfs per pixel row of a staged chunk (+16 B: conflict-free)
+    constexpr int STAGE = NW * 32 * BROW * 2, RED = NW * CT * 4 * 64 * 16;
+    __shared__ __attribute__((aligned(16))) char smem[STAGE > RED ? STAGE : RED];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    // XCD-aware order (workgroup id % 8 = XCD): each XCD gets a contiguous run of the cout-group-major tile
+    // order, so a cout group's weights are fetched into few L2s
+    const int total = npt * ncg, per_xcd = (total + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int tile_c = logical / npt, tile_p = logical % npt;
+
+    // Pixel fragments.  The MFMA wants lane (pixel = lane % 32, k half) to hold 8 channels of ITS pixel; loaded
+    // that way one instruction touches 32 cache lines for 1 KB (measured: these gathers cost more than twice
+    // the weight stream).  Instead the wave loads a chunk (32 pixels x 64 channels) as 4 instructions of 8
+    // pixels x 128 contiguous bytes (lane -> pixel lane / 8 + 8 u, 16 B segment lane % 8), and turns it into
+    // fragment layout through a wave-private 4.5 KB LDS tile.
+    const int seg = lane & 7;
+    const f16* img[4];
+    int iy0[4], ix0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int pix = min(tile_p * 32 + (lane >> 3) + 8 * u, p.P - 1);        // clamped; masked at the store
+        const int hw = p.Ho * p.Wo, n = pix / hw, rem = pix - n * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        iy0[u] = oy * p.stride - p.pad;
+        ix0[u] = ox * p.stride - p.pad;
+        img[u] = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_coff + seg * 8;
+    }
+    f16* stage = reinterpret_cast<f16*>(smem) + wave * 32 * BROW;
+
+    const int nq = p.K >> 6;                        // chunks of 64 k (4 MFMA steps)
+    const int q0 = wave * nq / NW, q1 = (wave + 1) * nq / NW, nloc = q1 - q0;
+    const size_t wtile = (size_t)(p.K >> 4) * 512;  // halfs per cout tile
+    const f16* ap = p.w + ((size_t)tile_c * CT * (p.K >> 4) * 64 + lane) * 8 + (size_t)q0 * 2048;
+
+    // Loader state: the chunks of a wave are consecutive in K, so inside a tap both streams just advance by a
+    // constant (per-chunk address arithmetic was the bottleneck of the first version: ~60 VALU instructions
+    // against 8 MFMAs).  Pointers are rebuilt only when the walk enters the next (kh, kw) tap; out-of-image
+    // taps read a zero page instead of being masked afterwards.
+    f16x8 fa[PD][CT][4], raw[PD][4];
+    const f16* bp[4];
+    int qnext = q0, left = 0;
+    auto load = [&](int slot) {
+        if (left == 0) {                            // wave-uniform
+            const int k0 = qnext << 6, tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int iy = iy0[u] + kh, ix = ix0[u] + kw;
+                const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                bp[u] = (ok ? img[u] + ((size_t)iy * p.W + ix) * p.in_cs : g_zero_page + seg * 8) + c0;
+            }
+            left = (p.Cin - c0) >> 6;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            raw[slot][u] = *reinterpret_cast<const f16x8*>(bp[u]);
+            bp[u] += 64;
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fa[slot][i][u] = *reinterpret_cast<const f16x8*>(ap + i * wtile + u * 512);
+        ap += 2048;
+        --left;
+        ++qnext;
+    };
+    f32x16 acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < PD; ++r)
+        if (r < nloc) load(r);
+    for (int base = 0; base < nloc; base += PD) {
+#pragma unroll
+        for (int r = 0; r < PD; ++r) {
+            if (base + r < nloc) {                  // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *reinterpret_cast<f16x8*>(stage + ((lane >> 3) + 8 * u) * BROW + seg * 8) = raw[r][u];
+                f16x8 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f16x8*>(stage + frow * BROW + (u * 2 + half) * 8);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < CT; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[r][i][u], b[u], acc[i], 0, 0, 0);
+                if (base + r + PD < nloc) load(r);
+            }
+        }
+    }
+    __syncthreads();                                // staging tiles are dead: the partial tiles reuse the space
+    float4 (*red)[CT * 4][64] = reinterpret_cast<float4 (*)[CT * 4][64]>(smem);
+
+    // ---- partial tiles -> LDS, then every thread finishes 4 couts of one pixel
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            red[wave][i * 4 + g][lane] = make_float4(acc[i][g * 4], acc[i][g * 4 + 1], acc[i][g * 4 + 2], acc[i][g * 4 + 3]);
+    __syncthreads();
+    for (int e = tid; e < CT * 256; e += NW * 64) {
+        const int ig = e >> 6, ln = e & 63;
+        float4 a = red[0][ig][ln];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float4 t = red[w][ig][ln];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        const int co = (tile_c * CT + (ig >> 2)) * 32 + (ig & 3) * 8 + (ln >> 5) * 4;
+        const long opix = (long)tile_p * 32 + (ln & 31);
+        if (opix >= p.P || co >= p.cout_store) continue;
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+        float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.res_mode != RES_NONE) {
+            const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)opix * p.res_cs + p.res_coff + co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p.res_mode == RES_BEFORE_ACT) v[j] += r[j];
+            v[j] = apply_act(v[j], p.act);
+            if (p.res_mode == RES_AFTER_ACT) v[j] += r[j];
+        }
+        if (p.out32) {
+            *reinterpret_cast<float4*>(p.out32 + (size_t)opix * p.out_cs + p.out_coff + co) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            f16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+            store_out(p, opix, co, o);
+        }
+    }
+}
+
+template <int CT, int NW>
+int convs_launch(const ConvParams& p, int ntiles_c, hipStream_t s) {
+    const int npt = (p.P + 31) / 32, ncg = ntiles_c / CT;
+    const int total = npt * ncg;
+    hipLaunchKernelGGL((convs_kernel<CT, NW>), dim3(((total + 7) / 8) * 8), dim3(NW * 64), 0, s, p, npt, ncg);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// p.w: fragment-order weights (see header); p.K = KH * KW * Cin with Cin % 64 == 0; p.Kpad unused
+int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
+    FM_CHECK_ARG(p.Cin % 64 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0 && p.K == p.KH * p.KW * p.Cin);
+    FM_CHECK_ARG(p.out_cs % 4 == 0 && p.out_coff % 4 == 0 && p.cout_store % 4 == 0 && p.Cin <= 4096);
+    FM_CHECK_ARG(p.res_mode == RES_NONE || (p.res_cs % 4 == 0 && p.res_coff % 4 == 0));
+    const int ntiles_c = (p.Cout + 31) / 32, npt = (p.P + 31) / 32, nq = p.K / 64;
+    // two cout tiles per workgroup halve the pixel-fragment traffic; only when that still fills the chip
+    const bool ct2 = ntiles_c % 2 == 0 && (ntiles_c / 2) * npt >= 192;
+    const bool nw8 = nq >= 16;                      // >= 2 chunks per wave
+    if (ct2) return nw8 ? convs_launch<2, 8>(p, ntiles_c, s) : convs_launch<2, 4>(p, ntiles_c, s);
+    return nw8 ? convs_launch<1, 8>(p, ntiles_c, s) : convs_launch<1, 4>(p, ntiles_c, s);
+}

@@ -63,6 +63,23 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return *reinterpret_cast<const uint4*>(&h);
 }
 
+// fp16 store of 4 output channels of output pixel `pix`; with p.up == 2 the pixel is replicated to its
+// 2x2 block of the (2Ho, 2Wo) destination view: the nearest x2 [upsample] layer (yolo2onnx.py:806-836)
+// folded into its producer, one launch fewer per PAN level.
+__device__ __forceinline__ void store_out(const ConvParams& p, long pix, int co, f16x4 o) {
+    if (p.up == 2) {
+        const int hw = p.Ho * p.Wo, rem = (int)(pix % hw);
+        const size_t o00 = ((size_t)(pix / hw) * 2 * p.Ho + 2 * (rem / p.Wo)) * (2 * p.Wo) + 2 * (rem % p.Wo);
+        f16* dst = p.out + o00 * p.out_cs + p.out_coff + co;
+        *reinterpret_cast<f16x4*>(dst) = o;
+        *reinterpret_cast<f16x4*>(dst + p.out_cs) = o;
+        *reinterpret_cast<f16x4*>(dst + (size_t)2 * p.Wo * p.out_cs) = o;
+        *reinterpret_cast<f16x4*>(dst + (size_t)(2 * p.Wo + 1) * p.out_cs) = o;
+    } else {
+        *reinterpret_cast<f16x4*>(p.out + (size_t)pix * p.out_cs + p.out_coff + co) = o;
+    }
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case ACT_LEAKY: return x > 0.f ? x : 0.1f * x;

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK) = range(15)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS) = range(16)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
@@ -102,6 +102,9 @@ class Graph:
         self.use_stem = True   # small-Cin first layers go to the LDS-patch stem kernel
         # darknet residual units (1x1, 3x3, shortcut) as one fused launch (resblock.hip)
         self.use_resblock = os.environ.get('FASTMOT_RESBLOCK', '1') != '0'
+        # convs with at most this many output pixels per sample and a long reduction take the streamed
+        # kernel (K split inside the workgroup, convs.hip) instead of the LDS-tiled one + split-K reduce
+        self.convs_max_pixels = int(os.environ.get('FASTMOT_CONVS_MAXP', '1444'))
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -157,6 +160,16 @@ class Graph:
             bias32[:cout] = b
             self._layer(op=OP_STEMCONV, ins=[x], out=dst, cin=cin_pad, cout=cout, k=k, stride=stride, pad=pad,
                         act=ACT[act], w_off=self._push(packed), b_off=self._push(bias32), name=name)
+            self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
+            return dst
+        if x.c == cin_pad and cin_pad % 64 == 0 and k * k * cin_pad >= 512 and ho * wo <= self.convs_max_pixels:
+            wp = np.zeros((ceil_to(cout, 32), x.c, k, k), np.float16)
+            wp[:cout] = w16
+            bias = np.zeros(wp.shape[0], np.float32)
+            bias[:cout] = b
+            self._layer(op=OP_CONVS, ins=[x], out=dst, cin=cin_pad, cout=cout, k=k, stride=stride, pad=pad,
+                        act=ACT[act], up=up, w_off=self._push(self._pack_frag(wp)), b_off=self._push(bias),
+                        res=res, res_mode=res_mode if res is not None else RES_NONE, name=name)
             self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
             return dst
         # pack [cout_pad32][Kpad64], K order (kh, kw, cin_pad)
@@ -442,7 +455,7 @@ class Graph:
         """2*MAC over conv layers (the 'conv roofline' numerator)."""
         total = 0
         for d in self.layers:
-            if d['op'] in (OP_CONV, OP_STEMCONV):
+            if d['op'] in (OP_CONV, OP_STEMCONV, OP_CONVS):
                 o = d['out']
                 total += 2 * d['k'] * d['k'] * d['ins'][0].c * d['cout'] * o.h * o.w * batch
             elif d['op'] == OP_RESBLOCK:

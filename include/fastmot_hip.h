@@ -207,6 +207,10 @@ enum {
                           * w_off/b_off = the 1x1 conv, w2_off/b2_off = the 3x3 conv; weights in MFMA
                           * fragment order [cout/32][K/16][lane = (k/8%2)*32 + cout%32][k%8], K order
                           * (kh, kw, cin) (resblock.hip)                                          */
+    FM_OP_CONVS = 15,    /* FM_OP_CONV for layers with few output pixels and a long reduction (19 x 19 YOLO
+                          * levels): K split across the waves of a workgroup, no workspace / reduce launch
+                          * (convs.hip).  Same fields and semantics as FM_OP_CONV; cin % 64 == 0; weights in
+                          * MFMA fragment order [ceil32(cout)/32][k*k*cin/16][lane][8] as FM_OP_RESBLOCK   */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

@@ -58,6 +58,41 @@ def test_single_conv(ctx, cin, cout, k, stride, act, h, w, n):
     net.close()
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,act,h,w,n,extra', [
+    (512, 1024, 3, 1, 'leaky', 19, 19, 1, ''),      # 2 cout tiles per workgroup, 8 waves
+    (1024, 255, 1, 1, 'linear', 19, 19, 2, 'f32'),  # YOLO head: ragged cout, fp32 output, batch
+    (256, 512, 3, 2, 'leaky', 38, 38, 1, ''),       # stride-2 downsample into the 19 x 19 level
+    (512, 512, 1, 1, 'mish', 19, 19, 1, 'res'),     # shortcut after the activation
+    (512, 256, 1, 1, 'leaky', 19, 19, 1, 'up'),     # fused nearest x2 upsample into a concat slice
+    (128, 64, 3, 1, 'relu', 7, 5, 3, 'res'),        # 1 cout tile per workgroup, ragged pixel tile, batch
+    (64, 40, 3, 1, 'swish', 9, 9, 1, ''),           # 4 waves (K = 576: 9 chunks), cout padded to 64
+    (2048, 512, 1, 1, 'leaky', 19, 19, 1, ''),
+])
+def test_streamed_conv(ctx, cin, cout, k, stride, act, h, w, n, extra):
+    """Streamed conv (K split inside the workgroup, convs.hip) == LDS-tiled conv + split-K reduce == torch."""
+    rng = np.random.default_rng(cin + cout)
+    x = rng.normal(0, 1, (n, h, w, cin)).astype(np.float16)
+    outs = []
+    for maxp in (10 ** 6, 0):
+        g = Graph(RandomWeights(seed=cin + 3 * cout + k), (h, w), cin)
+        g.convs_max_pixels = maxp
+        ho = (h + 2 * (k // 2) - k) // stride + 1
+        wo = (w + 2 * (k // 2) - k) // stride + 1
+        up = 2 if extra == 'up' else 1
+        wide = g.new(ho * up, wo * up, cout + 16, f32=extra == 'f32')
+        res = g.conv('r', g.input, cout, 1, stride, 'linear') if extra == 'res' else None
+        y = g.conv('c', g.input, cout, k, stride, act, dst=wide.slice(16, cout), res=res, up=up, f32_out=extra == 'f32')
+        assert g.layers[-1]['op'] == (15 if maxp else 0)
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        net.write(g.input, x)
+        net.run(n)
+        outs.append(net.read(wide, n)[..., 16:16 + cout])
+        bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+        close(outs[-1], nhwc(bufs[wide.tid][:, 16:16 + cout]), what=f'conv maxp={maxp}')
+        net.close()
+    close(outs[0], outs[1], rel=1e-2, abs_=2e-3, what='streamed vs tiled')
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,act,h,w,n', [
     (3, 32, 3, 1, 'mish', 40, 37, 1),        # YOLOv4 layer 0
     (3, 16, 7, 2, 'relu', 64, 32, 3),        # OSNet conv1
@@ -373,7 +408,7 @@ def test_yolov4_small_input(ctx, monkeypatch, resblock):
     g, heads = Small.build_graph(RandomWeights(seed=21))
     n_res = sum(d['op'] == 14 for d in g.layers)
     assert n_res == (19 if resblock == '1' else 0)
-    assert sum(d['op'] in (0, 12) for d in g.layers) + 2 * n_res == 110 and g.layers[0]['op'] == 12
+    assert sum(d['op'] in (0, 12, 15) for d in g.layers) + 2 * n_res == 110 and g.layers[0]['op'] == 12
     net = HipNet(ctx, NET_DETECTOR, g, 1)
     rng = np.random.default_rng(22)
     x = rng.uniform(0, 1, (1, 96, 96, 3)).astype(np.float16)

@@ -44,11 +44,11 @@ def test_lowering_mini_v4():
     ops = Counter(d['op'] for d in g.layers)
     # 18 convs (the first one on the stem kernel), SPP fused, shortcut + upsample folded into convs, every
     # concat operand written in place: 29 cfg sections -> 19 launches
-    assert ops[G.OP_CONV] + ops[G.OP_STEMCONV] == 18 and ops[G.OP_STEMCONV] == 1 and len(g.layers) == 19
+    assert ops[G.OP_CONV] + ops[G.OP_CONVS] + ops[G.OP_STEMCONV] == 18 and ops[G.OP_STEMCONV] == 1 and len(g.layers) == 19
     assert ops[G.OP_SPP] == 1 and ops[G.OP_MAXPOOL] == 0
     assert ops[G.OP_ADD] == 0 and ops[G.OP_UPSAMPLE2] == 0
-    assert sum(1 for d in g.layers if d['op'] == G.OP_CONV and d['up'] == 2) == 1
-    assert sum(1 for d in g.layers if d['op'] == G.OP_CONV and d['res'] is not None) == 1
+    assert sum(1 for d in g.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['up'] == 2) == 1
+    assert sum(1 for d in g.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['res'] is not None) == 1
     assert ops[G.OP_COPY] == 0
     assert meta['classes'] == 2 and meta['strides'] == [2, 4] and meta['scales'] == [1.2, 1.1]
     assert meta['anchors'] == [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146]] and meta['new_coords'] is False
@@ -67,7 +67,7 @@ def test_lowering_mini_res(monkeypatch):
     _, _, g0, _, _ = build('mini_res')
     ops0 = Counter(d['op'] for d in g0.layers)
     assert ops0[G.OP_RESBLOCK] == 0 and len(g0.layers) == 8
-    assert sum(1 for d in g0.layers if d['op'] == G.OP_CONV and d['res'] is not None) == 2
+    assert sum(1 for d in g0.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['res'] is not None) == 2
 
 
 def test_lowering_mini_tiny():
