@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM-side traffic of the detector's conv kernel: two separate rocprofv3 PMC passes (FETCH_SIZE and
+# HBM-side traffic of the detector's conv kernels (LDS-tiled, streamed, fused residual unit): two separate rocprofv3 PMC passes (FETCH_SIZE and
 # WRITE_SIZE do not fit one pass on gfx950) over 6 graph replays of YOLOv4@608, summed per kernel.
 # Run on the GPU box from the repo root:  bash scripts/collect_pmc.sh  -> gpurun_out/pmc_*.txt + r01_pmc_conv.json
 set -e
@@ -17,11 +17,11 @@ def load(c):
         if line.startswith('JSON '):
             return json.loads(line[5:])
 f, w = load('FETCH_SIZE'), load('WRITE_SIZE')
-conv = [k for k in f if k.startswith('conv_igemm_kernel')]
+conv = [k for k in f if k.startswith('conv_igemm_kernel') or 'resblock_kernel' in k or k.startswith('convs_kernel')]
 calls = sum(f[k]['calls'] for k in conv)
 fetch_kb = sum(f[k]['total'] for k in conv)
 write_kb = sum(w[k]['total'] for k in conv if k in w)
-out = dict(kernel='conv_igemm_kernel (all template instances)', launches=calls, replays=6,
+out = dict(kernel='conv_igemm_kernel + convs_kernel + resblock_kernel (all template instances)', launches=calls, replays=6,
            fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb,
            correction='FETCH_SIZE x2 (gfx950: 128 B requests tallied at 64 B for 16 B/lane loads); WRITE_SIZE raw (uncalibrated)',
            traffic_bytes_per_launch=round((2 * fetch_kb + write_kb) * 1024 / calls),
