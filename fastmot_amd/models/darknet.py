@@ -18,12 +18,13 @@ independent PyTorch interpretation of the same cfg):
   * the conv before a [yolo] section is an fp32 head.
 """
 import io
+import os
 import re
 from pathlib import Path
 
 import numpy as np
 
-from .graph import Graph, SPP_MAX_HW
+from .graph import Graph, SPP_MAX_HW, fold_bn
 
 SUPPORTED = ('net', 'convolutional', 'maxpool', 'shortcut', 'route', 'upsample', 'yolo')
 
@@ -252,9 +253,36 @@ def darknet_graph(cfg, weights, in_hw=None):
             if pj < i:
                 placed[pj] = (i, o)
 
+    # ---- pass 2b: sibling 1x1 convs of a CSP stage.  conv a (-> concat C at offset o) and conv b = a + 2 read
+    # the same tensor (route -2 in between); when the concat slot right below a's is later filled by a plain
+    # 1x1 conv P that runs after every reader of b, both run as ONE conv with stacked weights writing
+    # [b | a] into C: the input is read once, one launch fewer; b's slot is dead by the time P overwrites it.
+    sibling_of, deferred = {}, set()
+    if os.environ.get('FASTMOT_CSP_MERGE', '1') != '0':
+        slot_owner = {v: k for k, v in placed.items()}
+        for a, (ci, oa) in sorted(placed.items()):
+            b = a + 2
+            if not (layers[a]['type'] == 'convolutional' and a >= 1 and b < n and
+                    layers[b]['type'] == 'convolutional' and layers[a + 1]['type'] == 'route' and
+                    len(layers[a + 1]['layers']) == 1 and 'groups' not in layers[a + 1] and
+                    _resolve(a + 1, int(layers[a + 1]['layers'][0])) == a - 1):
+                continue
+            h = shape[a][0]
+            pj = slot_owner.get((ci, oa - h))
+            if (conv_attrs(a) != conv_attrs(b) or conv_attrs(a)[:3] != (1, 1, 0) or shape[b][0] != h or h % 8 or
+                    b in placed or pj is None or layers[pj]['type'] != 'convolutional' or shape[pj][0] != h or
+                    conv_attrs(pj)[:3] != (1, 1, 0) or base(pj - 1) == b or not all(r < pj for r in readers[b]) or
+                    (pj + 1 < n and (folded_shortcut(pj + 1) or folded_upsample(pj + 1))) or
+                    (b + 1 < n and (folded_shortcut(b + 1) or folded_upsample(b + 1) or layers[b + 1]['type'] == 'yolo')) or
+                    (a + 1 < n and layers[a + 1]['type'] == 'yolo')):
+                continue
+            sibling_of[b] = a
+            deferred.add(a)
+
     # ---- pass 3: emit
     g = Graph(weights, (H, W), cin0)
     use_resblock = g.use_resblock
+    stash = {}
     out = [None] * n                      # View of every layer's output
     cat = {}                              # concat layer -> tensor view (allocated by its first producer)
     heads, meta_yolo = [], []
@@ -285,6 +313,20 @@ def darknet_graph(cfg, weights, in_hw=None):
             is_head = i + 1 < n and layers[i + 1]['type'] == 'yolo'
             res = None
             up = 1
+            if i in deferred:               # sibling merge: parameters are read in file order, emitted with conv i + 2
+                stash[i] = fold_bn(g.wsrc.conv(f'{i:03d}_convolutional', c, shape[i - 1][0] if i else cin0, k, bn=bn))
+                ci, oa = placed[i]
+                out[i] = cat_view(ci).slice(oa, c)
+                continue
+            if i in sibling_of:
+                a = sibling_of[i]
+                ci, oa = placed[a]
+                wa, ba = stash.pop(a)
+                wb_, bb = fold_bn(g.wsrc.conv(f'{i:03d}_convolutional', c, src(i - 1).c, k, bn=bn))
+                g.conv(f'{i:03d}_convolutional', src(i - 1), 2 * c, k, s, act, pad=p, dst=cat_view(ci).slice(oa - c, 2 * c),
+                       wb=(np.concatenate([wb_, wa]), np.concatenate([bb, ba])))
+                out[i] = cat_view(ci).slice(oa - c, c)
+                continue
             if i + 2 < n and layers[i + 2]['type'] == 'shortcut' and fused_resblock(i + 2):
                 continue                    # the 1x1 of a fused residual unit: emitted with its 3x3
             if i + 1 < n and layers[i + 1]['type'] == 'shortcut' and fused_resblock(i + 1):

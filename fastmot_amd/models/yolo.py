@@ -8,10 +8,13 @@ route = concat with the most recent tensor first, maxpool SAME stride 1, nearest
 the decode runs in detect.hip.  MODEL_PATH / ENGINE_PATH are kept as attributes: MODEL_PATH may
 point to Darknet weights; without a file the network runs with seeded random weights.
 """
+import os
 from pathlib import Path
 
+import numpy as np
+
 from .darknet import DarknetWeights, darknet_graph
-from .graph import Graph, RandomWeights
+from .graph import Graph, RandomWeights, fold_bn
 
 
 class YOLO:
@@ -93,11 +96,21 @@ def yolov4_graph(model, weights):
     def conv(x, cout, k=1, stride=1, act='mish', **kw):
         return g.conv(name(), x, cout, k, stride, act, **kw)
 
+    merge_siblings = os.environ.get('FASTMOT_CSP_MERGE', '1') != '0'
+
     def csp(x, c_out, n_res, h, m):
         d = conv(x, c_out, 3, 2)
         cat = g.new(d.h, d.w, 2 * h)
-        conv(d, h, 1, dst=cat.slice(h, h))            # route branch A (second in the concat)
-        b = conv(d, h, 1)
+        if merge_siblings:
+            # the two 1x1 convs that read d (route branch A, second in the concat; residual branch) as ONE
+            # conv with stacked weights: d is read once, one launch fewer.  Its output IS the concat tensor:
+            # [b0 | A]; b0 is dead once the first residual unit has run and the stage's last 1x1 overwrites it.
+            (wa, ba), (wb_, bb) = (fold_bn(g.wsrc.conv(name(), h, c_out, 1, bn=True)) for _ in range(2))
+            conv(d, 2 * h, 1, dst=cat, wb=(np.concatenate([wb_, wa]), np.concatenate([bb, ba])))
+            b = cat.slice(0, h)
+        else:
+            conv(d, h, 1, dst=cat.slice(h, h))        # route branch A (second in the concat)
+            b = conv(d, h, 1)
         for _ in range(n_res):
             if g.use_resblock and g.resblock_supported(h, m):
                 b = g.resblock(name(), name(), b, m)   # 1x1 + 3x3 + shortcut in one launch

@@ -371,6 +371,73 @@ MINI_RES = ('[net]\nwidth=48\nheight=40\nchannels=3\n\n' + _conv(64, 3, 2) + _co
             '[yolo]\nmask = 0,1,2\nanchors = 10,14, 23,27, 37,58\nclasses=2\nnum=3\n')
 
 
+def yolov4_cfg(width=64, height=64, classes=3):
+    """yolov4.cfg (AlexeyAB/darknet: CSPDarknet53 + SPP + PAN, 110 [convolutional] sections) generated
+    section by section; relative route/shortcut indices are computed from the recorded section indices."""
+    out, idx = [f'[net]\nwidth={width}\nheight={height}\nchannels=3\n\n'], [-1]
+
+    def add(text):
+        out.append(text)
+        idx[0] += 1
+        return idx[0]
+
+    def conv(f, k, s=1, act='mish', bn=1):
+        return add(_conv(f, k, s, act, bn))
+
+    def route(*targets):          # absolute section indices -> relative
+        cur = idx[0] + 1
+        return add('[route]\nlayers = ' + ','.join(str(t - cur) for t in targets) + '\n\n')
+
+    conv(32, 3)
+    stage_out = []
+    for down, h, m, n in ((64, 64, 32, 1), (128, 64, 64, 2), (256, 128, 128, 8), (512, 256, 256, 8), (1024, 512, 512, 4)):
+        d = conv(down, 3, 2)
+        a = conv(h, 1)
+        route(d)
+        conv(h, 1)
+        for _ in range(n):
+            conv(m, 1)
+            conv(h, 3)
+            add('[shortcut]\nfrom=-3\nactivation=linear\n\n')
+        post = conv(h, 1)
+        route(post, a)
+        stage_out.append(conv(down, 1))
+    lk = dict(act='leaky')
+    conv(512, 1, **lk); conv(1024, 3, **lk); x = conv(512, 1, **lk)
+    p5 = add('[maxpool]\nstride=1\nsize=5\n\n'); route(x)
+    p9 = add('[maxpool]\nstride=1\nsize=9\n\n'); route(x)
+    p13 = add('[maxpool]\nstride=1\nsize=13\n\n'); route(p13, p9, p5, x)
+    conv(512, 1, **lk); conv(1024, 3, **lk); n19 = conv(512, 1, **lk)
+    tops = [n19]
+    for f, lateral in ((256, stage_out[3]), (128, stage_out[2])):
+        conv(f, 1, **lk)
+        up = add('[upsample]\nstride=2\n\n')
+        route(lateral)
+        lat = conv(f, 1, **lk)
+        route(lat, up)
+        for _ in range(2):
+            conv(f, 1, **lk); conv(2 * f, 3, **lk)
+        tops.append(conv(f, 1, **lk))
+    anchors = 'anchors = 12,16, 19,36, 40,28, 36,75, 76,55, 72,146, 142,110, 192,243, 459,401'
+
+    def head(f, mask, scale):
+        conv(2 * f, 3, **lk)
+        conv((classes + 5) * 3, 1, act='linear', bn=0)
+        add(f'[yolo]\nmask = {mask}\n{anchors}\nclasses={classes}\nnum=9\nscale_x_y = {scale}\n\n')
+
+    head(128, '0,1,2', 1.2)
+    prev = tops[2]
+    for f, lateral, mask, scale in ((256, tops[1], '3,4,5', 1.1), (512, tops[0], '6,7,8', 1.05)):
+        route(prev)
+        dn = conv(f, 3, 2, **lk)
+        route(dn, lateral)
+        for _ in range(2):
+            conv(f, 1, **lk); conv(2 * f, 3, **lk)
+        prev = conv(f, 1, **lk)
+        head(f, mask, scale)
+    return ''.join(out)
+
+
 def conv_sections(cfg_layers):
     """(filters, cin, k, bn) of every [convolutional] in cfg order, by an independent shape walk."""
     net, layers = cfg_layers[0], cfg_layers[1:]
