@@ -3,8 +3,9 @@
     python -m fastmot_amd.app -i 'MOT20-01/img1/%06d.jpg' -c cfg/mot.json -m -t out/MOT20-01.txt
 
 Same arguments, same configuration file format (the reference's cfg/mot.json works unchanged), same result
-rows.  `--show` needs a display toolkit and the drawing code of the reference (out of scope here) and is
-rejected; `--output-uri` writes the unannotated frames (image sequence or .npy)."""
+rows.  `--output-uri` writes the frames with the tracker overlays drawn (image sequence or .npy), as the
+reference does (app.py:70-71: draw = show or output); `--show` needs a display toolkit (no GUI in this image)
+and is rejected."""
 from pathlib import Path
 from types import SimpleNamespace
 import argparse
@@ -36,7 +37,7 @@ def parse_args(argv=None):
     optional.add_argument('-t', '--txt', metavar="FILE",
                           help='path to output MOT Challenge format results (e.g. MOT20-01.txt)')
     optional.add_argument('-m', '--mot', action='store_true', help='run multiple object tracker')
-    optional.add_argument('-s', '--show', action='store_true', help='show visualizations (not supported)')
+    optional.add_argument('-s', '--show', action='store_true', help='show visualizations (needs a display: not supported here)')
     group.add_argument('-q', '--quiet', action='store_true', help='reduce output verbosity')
     group.add_argument('-v', '--verbose', action='store_true', help='increase output verbosity')
     parser._action_groups.append(optional)
@@ -44,7 +45,7 @@ def parse_args(argv=None):
     if args.txt is not None and not args.mot:
         raise parser.error('argument -t/--txt: not allowed without argument -m/--mot')
     if args.show:
-        raise parser.error('argument -s/--show: visualisation is out of scope of the MI355X hot path')
+        raise parser.error('argument -s/--show: no display toolkit in this build; use -o to write annotated frames')
     return args
 
 
@@ -70,7 +71,7 @@ def main(argv=None):
     mot = None
     txt = None
     if args.mot:
-        mot = fastmot_amd.MOT(config.resize_to, **vars(config.mot_cfg), draw=False)
+        mot = fastmot_amd.MOT(config.resize_to, **vars(config.mot_cfg), draw=args.output_uri is not None)
         mot.reset(stream.cap_dt)
     if args.txt is not None:
         Path(args.txt).parent.mkdir(parents=True, exist_ok=True)

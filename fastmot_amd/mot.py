@@ -15,6 +15,7 @@ from .detector import SSDDetector, YOLODetector, PublicDetector, bind_frame
 from .feature_extractor import FeatureExtractor
 from .tracker import MultiTracker
 from .utils import Profiler
+from .utils.visualization import Visualizer
 
 LOGGER = logging.getLogger(__name__)
 
@@ -38,8 +39,8 @@ class MOT:
                  visualizer_cfg=None,
                  draw=False):
         """Top level module that integrates detection, feature extraction and tracking
-        (parameters: fastmot/mot.py:37-67).  `draw=True` is not supported on this path
-        (visualisation is out of scope)."""
+        (parameters: fastmot/mot.py:37-67).  `draw=True` renders the overlays of `visualizer_cfg` onto every
+        frame handed to `step` as a host ndarray, in place, after tracking (mot.py:166-167,191-196)."""
         self.size = size
         self.detector_type = DetectorType[detector_type.upper()]
         assert detector_frame_skip >= 1
@@ -64,8 +65,7 @@ class MOT:
         if len(feature_extractor_cfgs) != 1:
             raise NotImplementedError('one ReID network per context (the reference routes every box '
                                       'to the first extractor anyway: bisect_right quirk, SURVEY Q3)')
-        if draw:
-            raise NotImplementedError('visualisation is out of scope of the MI355X hot path')
+        self.visualizer = Visualizer(**vars(visualizer_cfg))
 
         LOGGER.info('Loading detector model...')
         if self.detector_type == DetectorType.SSD:
@@ -113,6 +113,8 @@ class MOT:
         finally:
             ctx.in_step = False
             self._next_frame = None
+        if self.draw:
+            self._draw(frame, self._last_detections)
         self.frame_count += 1
 
     def _prefetch_next(self):
@@ -122,8 +124,9 @@ class MOT:
             self.detector.prefetch(nxt)
 
     def _step(self, frame):
+        self._last_detections = []          # what _draw shows: this frame's detections, none on skipped frames
         if self.frame_count == 0:
-            detections = self.detector(frame)
+            detections = self._last_detections = self.detector(frame)
             self._prefetch_next()
             self.tracker.init(frame, detections)
         elif self.frame_count % self.detector_frame_skip == 0:
@@ -139,7 +142,7 @@ class MOT:
             flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
             try:
                 with Profiler('detect'):
-                    detections = self.detector.postprocess()
+                    detections = self._last_detections = self.detector.postprocess()
 
                 with Profiler('extract'):
                     # every box goes to the first extractor, as in the reference (_split_bboxes_by_cls
@@ -157,6 +160,14 @@ class MOT:
             self._prefetch_next()
             with Profiler('track'):
                 self.tracker.track(frame)
+
+    def _draw(self, frame, detections):
+        if not isinstance(frame, np.ndarray):
+            raise TypeError('draw=True needs host frames (ndarray): overlays are rendered on the CPU')
+        visible = list(self.visible_tracks())
+        self.visualizer.render(frame, visible, detections, self.tracker.klt_bboxes.values(),
+                               self.tracker.flow.prev_bg_keypoints, self.tracker.flow.bg_keypoints,
+                               caption=f'visible: {len(visible)}')
 
     def _flow_and_kalman(self, frame):
         with Profiler('track'):

@@ -1,2 +1,3 @@
 from .decoder import ConfigDecoder
 from .profiler import Profiler
+from .visualization import Visualizer

@@ -81,3 +81,11 @@ def test_app_end_to_end(tmp_path):
     score = mc.evaluate({f: v for f, v in gt.items() if f in res or f > 1}, res)
     # public detections are the ground truth + 1 px jitter: everything is tracked, identities are stable
     assert score['mota'] > 0.9 and score['idf1'] > 0.9 and score['idsw'] <= 2, score
+
+    # -o: the written frames carry the overlays (reference app.py:70-71 draws whenever an output is requested)
+    out2 = tmp_path / 'out2' / 'SYN-01.txt'
+    rc = app.main(['-i', str(seq / 'img1' / '%06d.png'), '-c', str(tmp_path / 'mot.json'), '-m', '-t', str(out2),
+                   '-o', str(tmp_path / 'annotated' / '%06d.png'), '-q'])
+    assert rc == 0 and out2.read_text() == out.read_text()          # drawing does not change the tracks
+    last = np.asarray(Image.open(tmp_path / 'annotated' / f'{n_frames - 1:06d}.png'))[:, :, ::-1]
+    assert last.shape == video.frames[-1].shape and (last != video.frames[-1]).any(axis=2).sum() > 400

@@ -129,3 +129,49 @@ def test_pipeline_is_deterministic(ctx):
         runs.append(rows)
         mot.tracker._clear_tracks()
     assert all(r == runs[0] for r in runs[1:])
+
+
+def test_draw_overlays_do_not_change_tracking(ctx):
+    """MOT(draw=True) renders the overlays of visualizer_cfg onto the caller's frame in place after each step
+    (mot.py:166-167); the tracks are the same as without drawing, the frames differ from the originals exactly
+    where something was drawn, and device-resident frames are rejected for drawing."""
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from fastmot_amd.utils.visualization import Visualizer, get_color
+    from fastmot_amd.detector import DeviceFrame
+    from fastmot_amd import Track
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=8, n_frames=10, seed=5)
+    runs = []
+    for draw in (False, True):
+        mot = build_mot(size, video, 2)
+        mot.draw = draw
+        # (no detection / KLT boxes: they are drawn after, and mostly on top of, the track boxes checked below)
+        mot.visualizer = Visualizer(draw_obj_flow=True, draw_bg_flow=True, draw_trajectory=True, draw_covariance=True)
+        Track._count = 0
+        mot.reset(1 / 30.)
+        rows, seen_visible = [], False
+        for f in range(video.n_frames):
+            mot.detector._frame_idx = f
+            frame = video.frames[f].copy()
+            mot.step(frame, next_frame=video.frames[f + 1] if f + 1 < video.n_frames else None)
+            rows.append([(t.trk_id, tuple(t.tlbr), t.age, t.hits) for t in mot.tracker.tracks.values()])
+            changed = (frame != video.frames[f]).any(axis=2)
+            if not draw:
+                assert not changed.any()
+            else:
+                vis = list(mot.visible_tracks())
+                seen_visible = seen_visible or bool(vis)
+                assert changed.sum() > 50 * len(vis)
+                for t in vis:                                   # bottom edge of every visible track's box
+                    x0, y0, x1, y1 = np.clip(t.tlbr.astype(int), 0, [size[0] - 1, size[1] - 1] * 2)
+                    if y1 < size[1] - 1 and x1 - x0 > 8:
+                        assert (frame[y1, x0 + 2:x1 - 1] == get_color(t.trk_id)).all(axis=1).mean() > 0.7
+        runs.append(rows)
+        if draw:
+            assert seen_visible
+            with pytest.raises(TypeError):
+                ctx.frame_configure(size[0], size[1], 2)
+                ctx.frame_ring_store(0, video.frames[0])
+                mot.step(DeviceFrame(0))
+        mot.tracker._clear_tracks()
+    assert runs[0] == runs[1]
