@@ -81,16 +81,18 @@ def main(argv=None):
     stream.start_capture()
     try:
         with Profiler('app') as prof:
-            while True:
-                frame = stream.read()
-                if frame is None:
-                    break
+            # one frame of read-ahead: the detector network of frame t+1 then overlaps the ReID / association
+            # stages of frame t (MOT.step's next_frame; results are identical to strictly sequential steps)
+            frame = stream.read()
+            while frame is not None:
+                upcoming = stream.read()
                 if args.mot:
-                    mot.step(frame)
+                    mot.step(frame, next_frame=upcoming)
                     if txt is not None:
                         write_rows(txt, mot.frame_count, mot.visible_tracks(), config.resize_to, stream.resolution)
                 if args.output_uri is not None:
                     stream.write(frame)
+                frame = upcoming
     finally:
         # clean up resources
         if txt is not None:
