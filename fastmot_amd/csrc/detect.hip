@@ -60,9 +60,12 @@ namespace {
 // channel dimension padded to 8 (zeros).  Outside the letterbox ROI the input is 0.5.
 __global__ void preprocess_kernel(const uint8_t* __restrict__ frame, int fw, int fh,
                                   f16* __restrict__ inp, int in_w, int in_h, int cs, int roi_x, int roi_y,
-                                  int roi_w, int roi_h) {
+                                  int roi_w, int roi_h, int32_t* __restrict__ counters) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
+    // candidate counters of this frame's decode (one memset node fewer on the detector stream; the previous
+    // frame's counters were copied to the host earlier on the same stream)
+    if (counters && x < 4 && y == 0) counters[x] = 0;
     if (x >= in_w || y >= in_h) return;
     float rgb[3];
     const int rx = x - roi_x, ry = y - roi_y;
@@ -141,9 +144,19 @@ __device__ __forceinline__ void emit_candidate(const FilterArgs& fa, float bx, f
     r[7] = __int_as_float(orig);
 }
 
-// one thread per (anchor, cell): plugins/yolo_layer.cu:127-173 (classic) / :185-230 (new_coords)
-__global__ void decode_kernel(HeadArgs h, FilterArgs fa, int in_w, int in_h, int new_coords) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+struct HeadSet {
+    HeadArgs h[FM_MAX_HEADS];
+    int first_block[FM_MAX_HEADS + 1];   // head i owns blocks [first_block[i], first_block[i + 1])
+};
+
+// one thread per (head, anchor, cell), all heads in one launch: plugins/yolo_layer.cu:127-173 (classic) /
+// :185-230 (new_coords)
+__global__ void decode_kernel(HeadSet hs, FilterArgs fa, int in_w, int in_h, int new_coords) {
+    int hi = 0;
+#pragma unroll
+    for (int i = 1; i < FM_MAX_HEADS; ++i) hi += (int)blockIdx.x >= hs.first_block[i] ? 1 : 0;
+    const HeadArgs& h = hs.h[hi];
+    const int idx = ((int)blockIdx.x - hs.first_block[hi]) * blockDim.x + threadIdx.x;
     const int cells = h.gw * h.gh;
     if (idx >= cells * h.na) return;
     const int a = idx / cells, cell = idx - a * cells;
@@ -511,7 +524,7 @@ static int enqueue_preprocess(fm_ctx* ctx, DetState* d, NetState* net, const uin
     FM_CHECK_ARG(t.h == c.in_h && t.w == c.in_w && !t.f32);
     hipLaunchKernelGGL(preprocess_kernel, dim3((c.in_w + 255) / 256, c.in_h), dim3(256), 0, ctx->s_det,
                        frame, ctx->frame_w, ctx->frame_h, (f16*)net->bufs[c.input_tensor], c.in_w,
-                       c.in_h, t.c, c.roi_x, c.roi_y, c.roi_w, c.roi_h);
+                       c.in_h, t.c, c.roi_x, c.roi_y, c.roi_w, c.roi_h, filter_args(d).counters);
     FM_HIP(hipGetLastError());
     return 0;
 }
@@ -550,23 +563,26 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
     FM_HIP(hipEventRecord(d->ev1, s));
     d->ev_valid = true;
-    FM_HIP(hipMemsetAsync(d->counters, 0, sizeof(int32_t) * 4, s));
-    FilterArgs fa = filter_args(d);
-    int base = 0;
+    FilterArgs fa = filter_args(d);      // (counters were zeroed by this frame's preprocess kernel)
+    HeadSet hs{};
+    int base = 0, blocks = 0;
+    for (int i = 0; i < FM_MAX_HEADS + 1; ++i) hs.first_block[i] = 0x7fffffff;
     for (int i = 0; i < c.n_heads; ++i) {
         FM_CHECK_ARG(c.head_tensor[i] >= 0 && c.head_tensor[i] < (int)net->tensors.size());
         const fm_tensor& t = net->tensors[c.head_tensor[i]];
         FM_CHECK_ARG(t.f32 && t.h == c.grid_h[i] && t.w == c.grid_w[i] && c.n_anchors[i] <= FM_MAX_ANCHORS);
-        HeadArgs h{};
+        HeadArgs& h = hs.h[i];
         h.data = (const float*)net->bufs[c.head_tensor[i]];
         h.cs = t.c; h.gw = c.grid_w[i]; h.gh = c.grid_h[i]; h.na = c.n_anchors[i];
         h.base_index = base;
         memcpy(h.anchors, c.anchors[i], sizeof(float) * 2 * FM_MAX_ANCHORS);
         h.scale_xy = c.scale_xy[i];
         const int n = h.gw * h.gh * h.na;
-        hipLaunchKernelGGL(decode_kernel, dim3((n + 255) / 256), dim3(256), 0, s, h, fa, c.in_w, c.in_h, c.new_coords);
+        hs.first_block[i] = blocks;
+        blocks += (n + 255) / 256;
         base += n;
     }
+    if (blocks) hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), 0, s, hs, fa, c.in_w, c.in_h, c.new_coords);
     FM_HIP(hipGetLastError());
     return enqueue_post(ctx, d, s);
 }
