@@ -11,6 +11,9 @@ int launch_liteconv(int G, const f16* const* in, const int* in_cs, const int* in
                     int out_coff, const f16* wpw, int kpad, const f16* wdw, const float* bias, int N, int H,
                     int W, int C, int act, float* gap_out, hipStream_t s);
 void liteconv_tiling(int C, int W, int H, int* th, int* tw, int* tiles_x, int* tiles_y);
+int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* wpw,
+                     int kpad, const f16* wdw, const float* bias, int N, int H, int W, int C, int act,
+                     float* const* gap, hipStream_t s);
 int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
                      int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
                      int out_cs, int out_coff, const float* const* part, int tiles, hipStream_t s);
@@ -188,6 +191,22 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                                    (const f16*)(net->weights + L.w_off), (L.cin + 63) & ~63,
                                    (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b_off),
                                    B, ti.h, ti.w, L.cin, L.act, gap_out, s);
+        }
+        case FM_OP_LITECHAIN: {
+            FM_CHECK_ARG(L.cin == ((L.cout + 7) & ~7) && to.h == ti.h && to.w == ti.w && L.in_coff[0] + L.cin <= ti.c &&
+                         L.out_coff + 4 * L.cin <= to.c);
+            int th, tw, tx, ty;
+            liteconv_tiling(L.cin, ti.w, ti.h, &th, &tw, &tx, &ty);
+            FM_CHECK_ARG(L.cin <= net->gate_c && tx * ty <= GATE_SLOT_TILES);
+            float* gaps[4];
+            for (int i = 0; i < 4; ++i) {
+                FM_CHECK_ARG(L.gate[i] >= 0 && L.gate[i] < net->n_gates);
+                gaps[i] = net->gates + (size_t)L.gate[i] * net->max_batch * net->gate_c * GATE_SLOT_TILES;
+            }
+            return launch_litechain(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
+                                    (const f16*)(net->weights + L.w_off), (L.cin + 63) & ~63,
+                                    (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b_off),
+                                    B, ti.h, ti.w, L.cin, L.act, gaps, s);
         }
         case FM_OP_GATED_SUM: {
             const f16* ins[4];
@@ -378,6 +397,10 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
         case FM_OP_LITECONV:
             *flops = 2.0 * (L.cin + 9) * L.cout * pout * L.n_in;
             *bytes = ((pin + pout) * L.cin * 2 + (double)L.cin * L.cout * 2) * L.n_in;
+            break;
+        case FM_OP_LITECHAIN:
+            *flops = 2.0 * (L.cin + 9) * L.cout * pout * 10;
+            *bytes = (pin + 4 * pout) * L.cin * 2 + 10.0 * L.cin * L.cout * 2;
             break;
         case FM_OP_GATED_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
         case FM_OP_STEMCONV:

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS) = range(16)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN) = range(17)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
@@ -102,6 +102,8 @@ class Graph:
         self.use_stem = True   # small-Cin first layers go to the LDS-patch stem kernel
         # darknet residual units (1x1, 3x3, shortcut) as one fused launch (resblock.hip)
         self.use_resblock = os.environ.get('FASTMOT_RESBLOCK', '1') != '0'
+        # the four LightConv streams of an OSNet block as one launch (litechain.hip) instead of one per depth
+        self.use_lightchain = os.environ.get('FASTMOT_LITECHAIN', '1') != '0'
         # convs with at most this many output pixels per sample and a long reduction take the streamed
         # kernel (K split inside the workgroup, convs.hip) instead of the LDS-tiled one + split-K reduce
         self.convs_max_pixels = int(os.environ.get('FASTMOT_CONVS_MAXP', '1444'))
@@ -269,6 +271,37 @@ class Graph:
         self._layer(op=OP_LITECONV, ins=list(xs), out=dst, cin=xs[0].cpad, cout=c, k=3, stride=1, pad=1, act=ACT[act],
                     gates=gates,
                     w_off=self._push(np.stack([p['pw'] for p in params])),
+                    w2_off=self._push(np.stack([p['dw'] for p in params])),
+                    b_off=self._push(np.stack([p['bias'] for p in params])), name=name,
+                    lite_ref=[p['ref'] for p in params])
+        return dst
+
+    @staticmethod
+    def lightchain_fits(c, h, w):
+        """The chain kernel keeps two halo tiles of a block in LDS (litechain.hip: litechain_lds_bytes)."""
+        if c % 8 or not 8 <= c <= 128:
+            return False
+        nt = (c + 31) // 32
+        th, tw = (16, 16 if w > 8 else 8) if nt == 1 else ((8, 16) if w > 8 else (16, 8))
+        s = c + (0 if (c >> 3) & 1 else 8)
+        ys = max((th + 8) * (tw + 8) * s, (256 // (c // 8)) * c * 2)
+        return (ys + (th + 6) * (tw + 6) * s + 9 * 32 * nt) * 2 <= 64 * 1024
+
+    def lightchain(self, name, x, params, act='relu', dst=None):
+        """The four streams of an OSNet block -- chains of 1, 2, 3, 4 LightConv3x3 over x -- in ONE launch
+        (FM_OP_LITECHAIN).  params: the 10 lightconv_params() sets in (stream, level) order.  Returns the
+        4*c-channel view (stream s at [s*c, (s+1)*c)); self.last_gap_slots = the streams' GAP partial slots."""
+        c = x.c
+        assert len(params) == 10 and x.coff % 8 == 0 and self.lightchain_fits(c, x.h, x.w)
+        if dst is None:
+            dst = self.new(x.h, x.w, 4 * c)
+        assert dst.c == 4 * c
+        gates = list(range(self.n_gates, self.n_gates + 4))
+        self.n_gates += 4
+        self.gate_c = max(self.gate_c, x.cpad)
+        self.last_gap_slots = gates
+        self._layer(op=OP_LITECHAIN, ins=[x], out=dst, cin=x.cpad, cout=c, k=3, stride=1, pad=1, act=ACT[act],
+                    gates=gates, w_off=self._push(np.stack([p['pw'] for p in params])),
                     w2_off=self._push(np.stack([p['dw'] for p in params])),
                     b_off=self._push(np.stack([p['bias'] for p in params])), name=name,
                     lite_ref=[p['ref'] for p in params])

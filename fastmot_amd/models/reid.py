@@ -62,12 +62,17 @@ def osnet_graph(model, weights, fuse_lightconv=True):
         x1 = g.conv(name + '.conv1', x, mid, 1, 1, 'relu')
         hid = max(mid // 16, 1)
         if fuse_lightconv and mid % 8 == 0 and mid <= 128:
-            # stream t (1..4) is a chain of t LightConv3x3; the chains are independent, so depth i of all
-            # streams that reach it runs as ONE grouped launch (4, 3, 2, 1 groups) and the four gates +
-            # the gated sum as one more: 5 launches per block tail instead of 10 + 4 + 1.
+            # stream t (1..4) is a chain of t LightConv3x3; the chains are independent: all of them run as
+            # ONE launch when two halo tiles fit in LDS (litechain.hip), otherwise depth i of all streams that
+            # reach it as one grouped launch (4, 3, 2, 1 groups); the four gates + the gated sum are one more.
             params = {(t, i): g.lightconv_params(f'{name}.s{t}.{i}', mid) for t in range(1, 5) for i in range(t)}
             streams, parts, prev = [], [], None
-            for i in range(4):
+            chain = g.use_lightchain and g.lightchain_fits(mid, x1.h, x1.w)
+            if chain:                    # all four chains in one launch: 2 launches per block tail
+                y = g.lightchain(f'{name}.streams', x1, [params[(t, i)] for t in range(1, 5) for i in range(t)], 'relu')
+                streams = [y.slice(t * mid, mid) for t in range(4)]
+                parts = g.last_gap_slots
+            for i in range(0 if chain else 4):
                 ts = list(range(i + 1, 5))                       # streams alive at depth i
                 xs = [x1] * len(ts) if i == 0 else [prev.slice((t - i) * mid, mid) for t in ts]
                 prev = g.lightconv_group(f'{name}.depth{i}', xs, [params[(t, i)] for t in ts], 'relu', gap_slot=True)

@@ -211,6 +211,10 @@ enum {
                           * levels): K split across the waves of a workgroup, no workspace / reduce launch
                           * (convs.hip).  Same fields and semantics as FM_OP_CONV; cin % 64 == 0; weights in
                           * MFMA fragment order [ceil32(cout)/32][k*k*cin/16][lane][8] as FM_OP_RESBLOCK   */
+    FM_OP_LITECHAIN = 16,/* the four streams of an OSNet block (chains of 1..4 FM_OP_LITECONV over in[0]) in one
+                          * launch (litechain.hip): stream s writes out channels [out_coff + s*cin, +cin);
+                          * w_off / w2_off / b_off = the 10 parameter sets stacked in (stream, level) order,
+                          * each laid out as for FM_OP_LITECONV; gate[s] = GAP partial slot of stream s       */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

@@ -295,7 +295,7 @@ def test_osnet_fused_and_arena_reuse_identical(ctx):
     embs = {}
     for fuse, reuse in ((False, False), (True, False), (True, True)):
         g, _ = Small.build_graph(RandomWeights(seed=5), fuse_lightconv=fuse)
-        assert len(g.layers) == (50 if fuse else 173)
+        assert len(g.layers) == (32 if fuse else 173)      # 50 with one launch per stream depth (next test)
         net = HipNet(ctx, NET_EXTRACTOR, g, 6, reuse_buffers=reuse)
         for _ in range(2):                      # second run: stale arena contents must not matter
             net.write(g.input, x)
@@ -333,6 +333,45 @@ def test_gated_sum_fused(ctx, c, hid, h, w, n, k):
         close(outs[-1], nhwc(bufs[y.tid][:, :c]), what=f'gated_sum fused={fused}')
         net.close()
     assert np.abs(outs[0] - outs[1]).max() <= 4e-3 * np.abs(outs[1]).max()
+
+
+@pytest.mark.parametrize('c,h,w,n', [(16, 64, 32, 3), (24, 32, 16, 5), (32, 16, 8, 4), (16, 21, 19, 2), (8, 9, 40, 1)])
+def test_lightconv_chain(ctx, c, h, w, n):
+    """The four LightConv streams of an OSNet block in one launch (litechain.hip) == one grouped launch per
+    depth, BIT FOR BIT (same fp16 rounding points, same MFMA order), incl. the gate's per-tile channel sums
+    (checked through the gated sum that consumes them); and == the torch reference."""
+    rng = np.random.default_rng(c + h)
+    x = rng.normal(0, 1, (n, h, w, c + 8)).astype(np.float16)
+    outs = []
+    for chain in (True, False):
+        g = Graph(RandomWeights(seed=9), (h, w), c + 8)
+        x1 = g.input.slice(8, c)
+        params = {(t, i): g.lightconv_params(f's{t}.{i}', c) for t in range(1, 5) for i in range(t)}
+        if chain:
+            assert Graph.lightchain_fits(c, h, w)
+            y = g.lightchain('streams', x1, [params[(t, i)] for t in range(1, 5) for i in range(t)], 'relu')
+            assert g.layers[-1]['op'] == 16
+            streams, parts = [y.slice(t * c, c) for t in range(4)], g.last_gap_slots
+        else:
+            streams, parts, prev = [], [], None
+            for i in range(4):
+                ts = list(range(i + 1, 5))
+                xs = [x1] * len(ts) if i == 0 else [prev.slice((t - i) * c, c) for t in ts]
+                prev = g.lightconv_group(f'depth{i}', xs, [params[(t, i)] for t in ts], 'relu', gap_slot=True)
+                streams.append(prev.slice(0, c))
+                parts.append(g.last_gap_slot)
+        z = g.gated_sum('gate', streams, max(c // 16, 1), parts=parts)
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        net.write(g.input, x)
+        net.run(n)
+        outs.append([net.read(v, n) for v in streams] + [net.read(z, n)])
+        if chain:
+            bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+            for t, v in enumerate(streams):
+                close(outs[-1][t], nhwc(bufs[v.tid][:, v.coff:v.coff + c]), what=f'stream {t}')
+        net.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_lightconv_grouped(ctx):

@@ -79,6 +79,20 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
                     y = y.half().float()
                 y = F.conv2d(y, wd, bd, padding=1, groups=y.shape[1])
                 wr(d['out'].slice(gi * c, c), act_fn(y, d['act']))
+        elif op == G.OP_LITECHAIN:
+            c = d['cout']
+            refs = iter(d['lite_ref'])
+            for t in range(4):
+                y = xin
+                for _ in range(t + 1):
+                    pw, wd, bd = (torch.from_numpy(np.asarray(a, np.float32)) for a in next(refs))
+                    y = F.conv2d(y, pw)
+                    if emulate_fp16_storage:
+                        y = y.half().float()
+                    y = act_fn(F.conv2d(y, wd, bd, padding=1, groups=y.shape[1]), d['act'])
+                    if emulate_fp16_storage:
+                        y = y.half().float()
+                wr(d['out'].slice(t * c, c), y)
         elif op == G.OP_GATED_SUM:
             w1, b1, w2, b2 = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['gate_ref'])
             y = 0
