@@ -4,7 +4,8 @@ YOLODetector keeps the reference's two-phase protocol (`detect_async(frame)` / `
 but every stage between the frame and the final detections runs on the GPU (detect.hip): the
 frame is uploaded once per step and shared with the ReID extractor and KLT; candidates never
 leave the device.  PublicDetector (MOTChallenge det.txt) is kept as the detector-disabled path.
-SSDDetector (TensorFlow UFF, TensorRT < 8 only) is out of scope.
+SSDDetector keeps the reference's tiling / normalisation / filtering / cross-tile merging stages around
+an inference callable (the SSD networks themselves need a TensorFlow graph reader, see models/ssd.py).
 """
 from collections import defaultdict
 from pathlib import Path
@@ -86,15 +87,164 @@ class Detector(abc.ABC):
 
 
 class SSDDetector(Detector):
-    def __init__(self, size, class_ids, **kwargs):
-        raise NotImplementedError('SSD (TensorFlow UFF / TensorRT < 8) is out of scope of the MI355X '
-                                  'hot path; use detector_type YOLO or PUBLIC')
+    def __init__(self, size,
+                 class_ids,
+                 model='SSDInceptionV2',
+                 tile_overlap=0.25,
+                 tiling_grid=(4, 2),
+                 conf_thresh=0.5,
+                 merge_thresh=0.6,
+                 max_area=120000,
+                 backend=None):
+        """Tiled SSD detector; parameters as fastmot/detector.py:46-75.  The frame is resized to the tiling
+        region, cut into `tiling_grid` overlapping tiles of the network's input size, normalised to [-1, 1]
+        (RGB, CHW) and handed to `backend(batch) -> det_out` as one batch; `det_out` is the output of the SSD
+        engine with its NMS stage: TOPK rows (image id, label, conf, xmin, ymin, xmax, ymax in tile fractions)
+        per tile, sorted by confidence.  `backend` (not in the reference: there it is the TensorRT engine built
+        from the model's .pb file) is required because the SSD networks cannot be built here (models/ssd.py).
+        These stages run on the host, as the reference's Numba versions do."""
+        super().__init__(size)
+        self.model = models.SSD.get_model(model)
+        assert 0 <= tile_overlap <= 1
+        self.tile_overlap = tile_overlap
+        assert tiling_grid[0] >= 1 and tiling_grid[1] >= 1
+        self.tiling_grid = tiling_grid
+        assert 0 <= conf_thresh <= 1
+        self.conf_thresh = conf_thresh
+        assert 0 <= merge_thresh <= 1
+        self.merge_thresh = merge_thresh
+        assert max_area >= 0
+        self.max_area = max_area
+
+        self.label_mask = np.zeros(self.model.NUM_CLASSES, dtype=np.bool_)
+        try:
+            self.label_mask[tuple(class_ids),] = True
+        except IndexError as err:
+            raise ValueError('Unsupported class IDs') from err
+
+        self.batch_size = int(np.prod(self.tiling_grid))
+        self.tiles, self.tiling_region_sz = self._generate_tiles()
+        self.scale_factor = tuple(np.array(self.size) / self.tiling_region_sz)
+        if backend is None:
+            self.model.build_graph()            # raises: explains what is missing
+        self.backend = backend
+        self.inp_handle = np.empty((self.batch_size, *self.model.INPUT_SHAPE), np.float32)
+        self._det_out = None
 
     def detect_async(self, frame):
-        raise NotImplementedError
+        """Preprocesses the frame and runs the inference callable on the batch of tiles."""
+        from .videoio import resize_bgr
+        if not isinstance(frame, np.ndarray):
+            raise TypeError('SSDDetector works on host frames (ndarray)')
+        self.normalize(resize_bgr(frame, self.tiling_region_sz), self.tiles, self.inp_handle)
+        self._det_out = np.asarray(self.backend(self.inp_handle), np.float32).reshape(-1)
 
     def postprocess(self):
-        raise NotImplementedError
+        """Returns a record array of detections (DET_DTYPE) sorted by class ID, duplicates across tiles merged."""
+        assert self._det_out is not None, 'postprocess() without detect_async()'
+        dets, tile_ids = self.filter_dets(self._det_out, self.tiles, self.model.TOPK, self.label_mask,
+                                          self.max_area, self.conf_thresh, self.scale_factor)
+        self._det_out = None
+        return self.merge_dets(dets, tile_ids, self.batch_size, self.merge_thresh)
+
+    def _generate_tiles(self):
+        """Tile rectangles (tlbr, inclusive) in the tiling region and the region's size (detector.py:122-130)."""
+        tile_wh = np.array(self.model.INPUT_SHAPE[:0:-1], float)
+        grid = np.array(self.tiling_grid)
+        step = (1 - self.tile_overlap) * tile_wh
+        region = np.rint((grid - 1) * step + tile_wh).astype(int)
+        tiles = []
+        for row in range(grid[1]):
+            for col in range(grid[0]):
+                x, y = float(col * step[0]), float(row * step[1])
+                tiles.append([round(x, 0), round(y, 0), round(x + tile_wh[0] - 1., 0), round(y + tile_wh[1] - 1., 0)])
+        return np.array(tiles), tuple(region)
+
+    @staticmethod
+    def normalize(frame, tiles, out):
+        """Tile crops (int-truncated, clamped at 0, inclusive corners) -> RGB, CHW, x * 2/255 - 1 (float32)."""
+        t = np.maximum(tiles.astype(np.int_), 0)
+        for i, (x0, y0, x1, y1) in enumerate(t):
+            crop = frame[y0:y1 + 1, x0:x1 + 1, ::-1]
+            out[i] = crop.transpose(2, 0, 1) * (2 / 255.) - 1.
+
+    @staticmethod
+    def filter_dets(det_out, tiles, topk, label_mask, max_area, thresh, scale_factor):
+        """Engine rows -> frame coordinates (detector.py:161-185): per tile the rows up to the first one below
+        `thresh`, classes of `label_mask`, tile fractions scaled by the tile size, shifted by the tile origin,
+        scaled to the frame, rounded half-to-even; 0 < area <= max_area."""
+        rows = np.asarray(det_out, np.float32).reshape(len(tiles), topk, 7)
+        boxes, labels, confs, tile_ids = [], [], [], []
+        for ti, tile in enumerate(tiles):
+            conf = rows[ti, :, 2]
+            below = np.flatnonzero(conf < thresh)
+            n = int(below[0]) if len(below) else topk
+            if n == 0:
+                continue
+            r = rows[ti, :n]
+            label = r[:, 1].astype(int)
+            w, h = tile[2] - tile[0] + 1, tile[3] - tile[1] + 1
+            tlbr = np.rint(np.stack([(r[:, 3].astype(float) * w + tile[0]) * scale_factor[0],
+                                     (r[:, 4].astype(float) * h + tile[1]) * scale_factor[1],
+                                     (r[:, 5].astype(float) * w + tile[0]) * scale_factor[0],
+                                     (r[:, 6].astype(float) * h + tile[1]) * scale_factor[1]], 1))
+            bw, bh = tlbr[:, 2] - tlbr[:, 0] + 1, tlbr[:, 3] - tlbr[:, 1] + 1
+            area = np.where((bw <= 0) | (bh <= 0), 0., bw * bh)
+            ok = label_mask[label] & (area > 0) & (area <= max_area)
+            boxes.append(tlbr[ok]); labels.append(label[ok]); confs.append(r[ok, 2]); tile_ids.append(np.full(ok.sum(), ti))
+        dets = np.zeros(sum(len(b) for b in boxes), DET_DTYPE).view(np.recarray)
+        if len(dets):
+            dets.tlbr, dets.label, dets.conf = np.concatenate(boxes), np.concatenate(labels), np.concatenate(confs)
+        return dets, (np.concatenate(tile_ids) if tile_ids else np.zeros(0, int))
+
+    @staticmethod
+    def merge_dets(dets, tile_ids, num_tile, thresh):
+        """Merges the detections of one object seen by several tiles (detector.py:132-139,187-217).  A detection
+        links to every detection of the same class in ANOTHER tile whose intersection-over-minimum is >= thresh
+        and exceeds every earlier candidate of that tile (scan in index order: running maxima are all kept);
+        connected groups collapse into their first member (enclosing box, maximum confidence); the survivors
+        are returned in index order, then argsorted by class."""
+        n = len(dets)
+        if n == 0:
+            return dets
+        box = np.array(dets.tlbr, float)
+        bw, bh = box[:, 2] - box[:, 0] + 1, box[:, 3] - box[:, 1] + 1
+        area = np.where((bw <= 0) | (bh <= 0), 0., bw * bh)
+        iw = np.minimum(box[:, None, 2], box[None, :, 2]) - np.maximum(box[:, None, 0], box[None, :, 0]) + 1
+        ih = np.minimum(box[:, None, 3], box[None, :, 3]) - np.maximum(box[:, None, 1], box[None, :, 1]) + 1
+        with np.errstate(divide='ignore', invalid='ignore'):
+            iom = np.where((iw <= 0) | (ih <= 0), 0., iw * ih / np.minimum(area[:, None], area[None, :]))
+        linkable = (tile_ids[:, None] != tile_ids[None, :]) & (dets.label[:, None] == dets.label[None, :]) & (iom >= thresh)
+        links = []
+        for i in range(n):
+            best = np.zeros(num_tile)
+            mine = []
+            for j in np.flatnonzero(linkable[i]):
+                if iom[i, j] > best[tile_ids[j]]:
+                    best[tile_ids[j]] = iom[i, j]
+                    mine.append(int(j))
+            links.append(mine)
+        seen = np.zeros(n, bool)
+        keep = np.ones(n, bool)
+        out = dets.copy().view(np.recarray)
+        for i in range(n):
+            if not links[i] or seen[i]:
+                continue
+            seen[i] = True
+            todo, group = [i], []
+            while todo:
+                for j in links[todo.pop()]:
+                    if not seen[j]:
+                        seen[j] = True
+                        group.append(j)
+                        todo.append(j)
+            for k in group:
+                out.tlbr[i] = np.concatenate([np.minimum(out.tlbr[i, :2], out.tlbr[k, :2]),
+                                              np.maximum(out.tlbr[i, 2:], out.tlbr[k, 2:])])
+                out.conf[i] = max(out.conf[i], out.conf[k])
+                keep[k] = False
+        out = out[np.flatnonzero(keep)]
+        return out[np.argsort(out.label)].view(np.recarray)
 
 
 class YOLODetector(Detector):
