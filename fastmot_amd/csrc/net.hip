@@ -59,14 +59,16 @@ void fm_net_free(NetState* n) {
     delete n;
 }
 
-static NetState*& net_slot(fm_ctx* ctx, int which) { return which == FM_NET_DETECTOR ? ctx->det_net : ctx->ext_net; }
+static NetState*& net_slot(fm_ctx* ctx, int which) {
+    return which == FM_NET_DETECTOR ? ctx->det_net : which == FM_NET_EXTRACTOR ? ctx->ext_net : ctx->ext_net_b;
+}
 NetState* fm_net_get(fm_ctx* ctx, int which) { return net_slot(ctx, which); }
 int fm_net_run_internal(fm_ctx* ctx, int which, int batch) { return fm_net_run(ctx, which, batch); }
 
 static size_t elem_size(const fm_tensor& t) { return t.f32 ? 4 : 2; }
 
 extern "C" int fm_net_destroy(fm_ctx* ctx, int which) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1));
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2));
     NetState*& slot = net_slot(ctx, which);
     if (slot) {
         FM_HIP(hipStreamSynchronize(slot->stream));
@@ -79,14 +81,14 @@ extern "C" int fm_net_destroy(fm_ctx* ctx, int which) {
 extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensors, const fm_tensor* tensors,
                              int n_layers, const fm_layer* layers, const void* weights, size_t weight_bytes,
                              int n_gates, int gate_channels, size_t arena_bytes) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && max_batch > 0 && n_tensors > 0 && n_layers > 0);
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && max_batch > 0 && n_tensors > 0 && n_layers > 0);
     FM_CHECK_ARG(tensors && layers && weights && weight_bytes > 0);
     int rc = fm_net_destroy(ctx, which);
     if (rc) return rc;
     std::unique_ptr<NetState, void (*)(NetState*)> net(new NetState(), fm_net_free);
     net->which = which;
     net->max_batch = max_batch;
-    net->stream = which == FM_NET_DETECTOR ? ctx->s_det : ctx->s_ext;
+    net->stream = which == FM_NET_DETECTOR ? ctx->s_det : which == FM_NET_EXTRACTOR ? ctx->s_ext : ctx->s_ext_b;
     net->tensors.assign(tensors, tensors + n_tensors);
     net->layers.assign(layers, layers + n_layers);
     if (arena_bytes) {
@@ -123,7 +125,7 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
         FM_CHECK_ARG(gate_channels > 0);
         FM_HIP(hipMalloc(&net->gates, sizeof(float) * (size_t)n_gates * max_batch * gate_channels * GATE_SLOT_TILES));
     }
-    if (which == FM_NET_EXTRACTOR) {
+    if (which != FM_NET_DETECTOR) {
         FM_HIP(hipStreamSynchronize(ctx->s_main));
         if ((rc = fm_emb_reserve(ctx, max_batch))) return rc;
     }
@@ -309,7 +311,7 @@ static int run_layers_eager(fm_ctx* ctx, NetState* net, int batch) {
 // replayed afterwards: ~160 kernel launches cost ~0.5 ms of host time per frame when issued
 // one by one, which sits on the (serial) host critical path of MOT.step.
 extern "C" int fm_net_run(fm_ctx* ctx, int which, int batch) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1));
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2));
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr && batch >= 0 && batch <= net->max_batch);
     if (batch == 0) return 0;
@@ -346,7 +348,7 @@ extern "C" int fm_net_run(fm_ctx* ctx, int which, int batch) {
 }
 
 extern "C" int fm_net_tensor_write(fm_ctx* ctx, int which, int tensor, const void* host, size_t bytes) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && host);
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && host);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net && tensor >= 0 && tensor < (int)net->tensors.size());
     const fm_tensor& t = net->tensors[tensor];
@@ -357,7 +359,7 @@ extern "C" int fm_net_tensor_write(fm_ctx* ctx, int which, int tensor, const voi
 }
 
 extern "C" int fm_net_tensor_read(fm_ctx* ctx, int which, int tensor, void* host, size_t bytes) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && host);
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && host);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net && tensor >= 0 && tensor < (int)net->tensors.size());
     const fm_tensor& t = net->tensors[tensor];
@@ -423,7 +425,7 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
 }
 
 extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, double* bytes) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && flops && bytes);
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && flops && bytes);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr);
     double f = 0, b = 0;
@@ -441,7 +443,7 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
 
 extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, double* conv_ms,
                               double* other_ms, int* n_conv, int* n_other) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && iters > 0);
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && iters > 0);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr && batch > 0 && batch <= net->max_batch);
     hipEvent_t e0, e1;
@@ -471,7 +473,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
 
 // per-layer HIP-event times (ms), averaged over iters; out[n_layers]
 extern "C" int fm_net_profile_layers(fm_ctx* ctx, int which, int batch, int iters, double* out) {
-    FM_CHECK_ARG(ctx && (which == 0 || which == 1) && iters > 0 && out);
+    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && iters > 0 && out);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr && batch > 0 && batch <= net->max_batch);
     hipEvent_t e0, e1;

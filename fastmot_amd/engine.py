@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 
-NET_DETECTOR, NET_EXTRACTOR = 0, 1
+NET_DETECTOR, NET_EXTRACTOR, NET_EXTRACTOR_B = 0, 1, 2
 
 
 class HipNet:
