@@ -90,8 +90,8 @@ struct fm_ctx {
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network
     hipStream_t s_ext = nullptr;    // ReID network
-    hipStream_t s_ext_b = nullptr;  // second ReID instance (split batches)
-    hipEvent_t ev_ext_in = nullptr, ev_ext_b_done = nullptr;
+    hipStream_t s_ext_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // streams of the extra ReID instances
+    hipEvent_t ev_ext_in = nullptr, ev_ext_x_done[FM_MAX_EXTRA_EXTRACTORS] = {};
     hipStream_t s_flow = nullptr;   // KLT
     hipEvent_t ev_feat = nullptr;   // last reader of ctx->emb on s_main (fm_feat_update); s_ext waits on it
 
@@ -140,7 +140,7 @@ struct fm_ctx {
     ExtState* ext = nullptr;
     NetState* det_net = nullptr;
     NetState* ext_net = nullptr;
-    NetState* ext_net_b = nullptr;   // FM_NET_EXTRACTOR_B: second half of a split batch, on s_ext_b
+    NetState* ext_net_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // FM_NET_EXTRACTOR_B + i: further parts of a split batch
     FlowState* flow = nullptr;
 };
 

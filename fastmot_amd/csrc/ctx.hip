@@ -67,9 +67,11 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, prio_hi));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_lo));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext, hipStreamNonBlocking, prio_hi));
-    FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext_b, hipStreamNonBlocking, prio_hi));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_in, hipEventDisableTiming));
-    FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_b_done, hipEventDisableTiming));
+    for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
+        FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext_x[i], hipStreamNonBlocking, prio_hi));
+        FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_x_done[i], hipEventDisableTiming));
+    }
     const char* fp = getenv("FASTMOT_FLOW_PRIO");   // experiment knob: 0 = flow stream at the detector's (low) priority
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_flow, hipStreamNonBlocking, fp && atoi(fp) == 0 ? prio_lo : prio_hi));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_feat, hipEventDisableTiming));
@@ -91,7 +93,8 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     if (ctx->frame_pinned2) (void)hipHostFree(ctx->frame_pinned2);
     if (ctx->det_net) fm_net_free(ctx->det_net);
     if (ctx->ext_net) fm_net_free(ctx->ext_net);
-    if (ctx->ext_net_b) fm_net_free(ctx->ext_net_b);
+    for (NetState* x : ctx->ext_net_x)
+        if (x) fm_net_free(x);
     if (ctx->flow) fm_flow_free(ctx->flow);
     for (void* p : {(void*)ctx->mean, (void*)ctx->cov, (void*)ctx->feat_sum, (void*)ctx->feat_avg,
                     (void*)ctx->feat_cnt, (void*)ctx->emb})
@@ -99,10 +102,14 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     for (DevBuf* b : {&ctx->as_in, &ctx->as_pair, &ctx->as_stage_in, &ctx->as_cost, &ctx->as_work,
                       &ctx->as_out, &ctx->io0, &ctx->io1, &ctx->feat_in, &ctx->occ_in, &ctx->occ_out})
         b->release();
-    for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_ext, ctx->s_ext_b, ctx->s_flow})
+    for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_ext, ctx->s_flow})
         if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_ext_b_done})
+    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in})
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
+        if (ctx->s_ext_x[i]) (void)hipStreamDestroy(ctx->s_ext_x[i]);
+        if (ctx->ev_ext_x_done[i]) (void)hipEventDestroy(ctx->ev_ext_x_done[i]);
+    }
     delete ctx;
     return 0;
 }
@@ -112,7 +119,7 @@ extern "C" int fm_ctx_synchronize(fm_ctx* ctx) {
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_det));
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
-    FM_HIP(hipStreamSynchronize(ctx->s_ext_b));
+    for (hipStream_t x : ctx->s_ext_x) FM_HIP(hipStreamSynchronize(x));
     FM_HIP(hipStreamSynchronize(ctx->s_flow));
     return 0;
 }

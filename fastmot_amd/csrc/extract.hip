@@ -132,31 +132,35 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
     memcpy(e->boxes_host, tlbr, sizeof(double) * 4 * n);
     FM_HIP(hipMemcpyAsync(e->boxes, e->boxes_host, sizeof(double) * 4 * n, hipMemcpyHostToDevice, s));
     const fm_tensor& t = net->tensors[e->input_tensor];
-    // Two instances of the network (FM_NET_EXTRACTOR_B): the batch is cut in halves that run concurrently on
-    // their own streams.  The ~30 dependent launches of OSNet are latency bound, so two half-size chains
-    // side by side finish sooner than one full-size chain; rows of ctx->emb are written by their owners.
-    NetState* net_b = ctx->ext_net_b;
-    if (net_b && n >= 8 && (n + 1) / 2 <= net->max_batch && (n + 1) / 2 <= net_b->max_batch) {
-        const int n0 = (n + 1) / 2, n1 = n - n0;
-        hipStream_t sb = ctx->s_ext_b;
+    // Several instances of the network (FM_NET_EXTRACTOR_B + i): the batch is cut into parts that run
+    // concurrently on their own streams.  The ~30 dependent launches of OSNet are latency bound, so part-size
+    // chains side by side finish sooner than one full-size chain; rows of ctx->emb are written by their owners.
+    int parts = 1;
+    while (parts <= FM_MAX_EXTRA_EXTRACTORS && ctx->ext_net_x[parts - 1]) ++parts;
+    while (parts > 1 && n < 4 * parts) --parts;                 // at least 4 crops per part
+    if (parts > 1 && (n + parts - 1) / parts <= net->max_batch) {
         FM_HIP(hipEventRecord(ctx->ev_ext_in, s));              // boxes uploaded, ev_feat honoured
-        FM_HIP(hipStreamWaitEvent(sb, ctx->ev_ext_in, 0));
-        hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, n0), dim3(128), 0, s,
-                           ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes, n0,
-                           (f16*)net->bufs[e->input_tensor], e->in_w, e->in_h, t.c);
-        hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, n1), dim3(128), 0, sb,
-                           ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes + (size_t)n0 * 4, n1,
-                           (f16*)net_b->bufs[e->input_tensor], e->in_w, e->in_h, t.c);
-        FM_HIP(hipGetLastError());
-        net->emb_offset = 0;
-        int rc = fm_net_run_internal(ctx, FM_NET_EXTRACTOR, n0);
-        if (rc) return rc;
-        net_b->emb_offset = n0;
-        rc = fm_net_run_internal(ctx, FM_NET_EXTRACTOR_B, n1);
-        net_b->emb_offset = 0;
-        if (rc) return rc;
-        FM_HIP(hipEventRecord(ctx->ev_ext_b_done, sb));
-        FM_HIP(hipStreamWaitEvent(s, ctx->ev_ext_b_done, 0));   // everything downstream orders after s_ext only
+        int off = 0;
+        for (int i = 0; i < parts; ++i) {
+            const int b = n / parts + (i < n % parts ? 1 : 0);
+            NetState* ni = i == 0 ? net : ctx->ext_net_x[i - 1];
+            hipStream_t si = i == 0 ? s : ctx->s_ext_x[i - 1];
+            FM_CHECK_ARG(b <= ni->max_batch);
+            if (i) FM_HIP(hipStreamWaitEvent(si, ctx->ev_ext_in, 0));
+            hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, b), dim3(128), 0, si,
+                               ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes + (size_t)off * 4, b,
+                               (f16*)ni->bufs[e->input_tensor], e->in_w, e->in_h, t.c);
+            FM_HIP(hipGetLastError());
+            ni->emb_offset = off;
+            const int rc = fm_net_run_internal(ctx, i == 0 ? FM_NET_EXTRACTOR : FM_NET_EXTRACTOR_B + i - 1, b);
+            ni->emb_offset = 0;
+            if (rc) return rc;
+            if (i) {                                            // everything downstream orders after s_ext only
+                FM_HIP(hipEventRecord(ctx->ev_ext_x_done[i - 1], si));
+                FM_HIP(hipStreamWaitEvent(s, ctx->ev_ext_x_done[i - 1], 0));
+            }
+            off += b;
+        }
         ctx->emb_n = n;
         return 0;
     }

@@ -60,7 +60,8 @@ void fm_net_free(NetState* n) {
 }
 
 static NetState*& net_slot(fm_ctx* ctx, int which) {
-    return which == FM_NET_DETECTOR ? ctx->det_net : which == FM_NET_EXTRACTOR ? ctx->ext_net : ctx->ext_net_b;
+    return which == FM_NET_DETECTOR ? ctx->det_net : which == FM_NET_EXTRACTOR ? ctx->ext_net
+                                                    : ctx->ext_net_x[which - FM_NET_EXTRACTOR_B];
 }
 NetState* fm_net_get(fm_ctx* ctx, int which) { return net_slot(ctx, which); }
 int fm_net_run_internal(fm_ctx* ctx, int which, int batch) { return fm_net_run(ctx, which, batch); }
@@ -68,7 +69,7 @@ int fm_net_run_internal(fm_ctx* ctx, int which, int batch) { return fm_net_run(c
 static size_t elem_size(const fm_tensor& t) { return t.f32 ? 4 : 2; }
 
 extern "C" int fm_net_destroy(fm_ctx* ctx, int which) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2));
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS));
     NetState*& slot = net_slot(ctx, which);
     if (slot) {
         FM_HIP(hipStreamSynchronize(slot->stream));
@@ -81,14 +82,15 @@ extern "C" int fm_net_destroy(fm_ctx* ctx, int which) {
 extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensors, const fm_tensor* tensors,
                              int n_layers, const fm_layer* layers, const void* weights, size_t weight_bytes,
                              int n_gates, int gate_channels, size_t arena_bytes) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && max_batch > 0 && n_tensors > 0 && n_layers > 0);
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS) && max_batch > 0 && n_tensors > 0 && n_layers > 0);
     FM_CHECK_ARG(tensors && layers && weights && weight_bytes > 0);
     int rc = fm_net_destroy(ctx, which);
     if (rc) return rc;
     std::unique_ptr<NetState, void (*)(NetState*)> net(new NetState(), fm_net_free);
     net->which = which;
     net->max_batch = max_batch;
-    net->stream = which == FM_NET_DETECTOR ? ctx->s_det : which == FM_NET_EXTRACTOR ? ctx->s_ext : ctx->s_ext_b;
+    net->stream = which == FM_NET_DETECTOR ? ctx->s_det : which == FM_NET_EXTRACTOR ? ctx->s_ext
+                                                        : ctx->s_ext_x[which - FM_NET_EXTRACTOR_B];
     net->tensors.assign(tensors, tensors + n_tensors);
     net->layers.assign(layers, layers + n_layers);
     if (arena_bytes) {
@@ -311,7 +313,7 @@ static int run_layers_eager(fm_ctx* ctx, NetState* net, int batch) {
 // replayed afterwards: ~160 kernel launches cost ~0.5 ms of host time per frame when issued
 // one by one, which sits on the (serial) host critical path of MOT.step.
 extern "C" int fm_net_run(fm_ctx* ctx, int which, int batch) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2));
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS));
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr && batch >= 0 && batch <= net->max_batch);
     if (batch == 0) return 0;
@@ -348,7 +350,7 @@ extern "C" int fm_net_run(fm_ctx* ctx, int which, int batch) {
 }
 
 extern "C" int fm_net_tensor_write(fm_ctx* ctx, int which, int tensor, const void* host, size_t bytes) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && host);
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS) && host);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net && tensor >= 0 && tensor < (int)net->tensors.size());
     const fm_tensor& t = net->tensors[tensor];
@@ -359,7 +361,7 @@ extern "C" int fm_net_tensor_write(fm_ctx* ctx, int which, int tensor, const voi
 }
 
 extern "C" int fm_net_tensor_read(fm_ctx* ctx, int which, int tensor, void* host, size_t bytes) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && host);
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS) && host);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net && tensor >= 0 && tensor < (int)net->tensors.size());
     const fm_tensor& t = net->tensors[tensor];
@@ -425,7 +427,7 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
 }
 
 extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, double* bytes) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && flops && bytes);
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS) && flops && bytes);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr);
     double f = 0, b = 0;
@@ -443,7 +445,7 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
 
 extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, double* conv_ms,
                               double* other_ms, int* n_conv, int* n_other) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && iters > 0);
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS) && iters > 0);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr && batch > 0 && batch <= net->max_batch);
     hipEvent_t e0, e1;
@@ -473,7 +475,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
 
 // per-layer HIP-event times (ms), averaged over iters; out[n_layers]
 extern "C" int fm_net_profile_layers(fm_ctx* ctx, int which, int batch, int iters, double* out) {
-    FM_CHECK_ARG(ctx && (which >= 0 && which <= 2) && iters > 0 && out);
+    FM_CHECK_ARG(ctx && (which >= 0 && which < FM_NET_EXTRACTOR_B + FM_MAX_EXTRA_EXTRACTORS) && iters > 0 && out);
     NetState* net = net_slot(ctx, which);
     FM_CHECK_ARG(net != nullptr && batch > 0 && batch <= net->max_batch);
     hipEvent_t e0, e1;

@@ -15,7 +15,7 @@ from .runtime import get_context
 
 class FeatureExtractor:
     def __init__(self, model='OSNet025', batch_size=16, weights=None, size=None, reuse_buffers=True,
-                 split_batches=os.environ.get('FASTMOT_EXT_SPLIT', '1') != '0'):
+                 split_batches=int(os.environ.get('FASTMOT_EXT_SPLIT', '2'))):
         """model : name of a class that inherits `models.ReID`; batch_size : samples per network
         launch (fastmot/feature_extractor.py:12-25).  `size` (frame width, height) is only needed
         when the extractor is used without a detector having bound the frame first."""
@@ -29,12 +29,12 @@ class FeatureExtractor:
         self.ctx.feat_configure(self.feature_dim)
         self.graph, _ = self.model.build_graph(weights)
         self.backend = HipNet(self.ctx, NET_EXTRACTOR, self.graph, self.batch_size, reuse_buffers=reuse_buffers)
-        # a second instance of the network (own buffers, own stream): batches of >= 8 crops run as two
-        # concurrent halves (extract.hip); results are the same rows of the same embedding matrix
-        self.backend_b = None
-        _lib.check(self.ctx.lib.fm_net_destroy(self.ctx.handle, NET_EXTRACTOR_B))      # a previous extractor's
-        if split_batches:
-            self.backend_b = HipNet(self.ctx, NET_EXTRACTOR_B, self.graph, self.batch_size, reuse_buffers=reuse_buffers)
+        # further instances of the network (own buffers, own streams): a batch runs as up to `split_batches`
+        # concurrent parts of >= 4 crops (extract.hip); results are the same rows of the same embedding matrix
+        for which in range(NET_EXTRACTOR_B, NET_EXTRACTOR_B + 3):              # a previous extractor's instances
+            _lib.check(self.ctx.lib.fm_net_destroy(self.ctx.handle, which))
+        self.extra_backends = [HipNet(self.ctx, NET_EXTRACTOR_B + i, self.graph, self.batch_size, reuse_buffers=reuse_buffers)
+                               for i in range(max(0, min(int(split_batches), 4) - 1))]
         self.ctx.extract_configure(self.graph.input.tid, self.model.INPUT_SHAPE[2], self.model.INPUT_SHAPE[1])
         self.last_num_features = 0
 

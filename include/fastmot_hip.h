@@ -179,8 +179,9 @@ int fm_iou_dist(fm_ctx* ctx, int na, const double* a, int nb, const double* b, d
  * NHWC fp16 tensors (channels padded to 8); Conv+BN+activation(+shortcut) layers run on the MFMA
  * implicit-GEMM kernel, concat/route is expressed by channel offsets into shared tensors. */
 enum { FM_NET_DETECTOR = 0, FM_NET_EXTRACTOR = 1,
-       FM_NET_EXTRACTOR_B = 2 /* optional second instance of the ReID network (same layer table, own buffers and
-                               * stream): fm_extract_async then runs the two halves of a batch concurrently */ };
+       FM_NET_EXTRACTOR_B = 2 /* 2, 3, 4: optional further instances of the ReID network (same layer table, own
+                               * buffers and streams): fm_extract_async then runs a batch as 2-4 concurrent parts */ };
+#define FM_MAX_EXTRA_EXTRACTORS 3
 enum {
     FM_OP_CONV = 0,      /* conv k x k, stride, pad + bias + act (+ residual)                    */
     FM_OP_DWCONV3 = 1,   /* depthwise 3x3 s1 p1 + bias + act (OSNet LightConv3x3)                */

@@ -132,7 +132,7 @@ def test_reid_crop_resize_normalise(ctx):
 
 
 def test_reid_split_batches_identical(ctx):
-    """Two network instances running the halves of a batch concurrently (FM_NET_EXTRACTOR_B, extract.hip) give
+    """Two or four network instances running the parts of a batch concurrently (FM_NET_EXTRACTOR_B.., extract.hip) give
     the same embedding rows, bit for bit, as one instance running the whole batch -- for even, odd and
     below-threshold box counts."""
     size = (640, 360)
@@ -141,12 +141,13 @@ def test_reid_split_batches_identical(ctx):
     x0, y0 = rng.uniform(0, 500, 33), rng.uniform(0, 250, 33)
     boxes = np.stack([x0, y0, x0 + rng.uniform(20, 120, 33), y0 + rng.uniform(40, 100, 33)], 1)
     embs = {}
-    for split in (True, False):
+    for split in (4, 2, 1):
         ext = FeatureExtractor('OSNet025', batch_size=32, weights=RandomWeights(seed=3), size=size, split_batches=split)
-        assert (ext.backend_b is not None) == split
+        assert len(ext.extra_backends) == split - 1
         for n in (33, 32, 9, 7, 1):
             ext.extract_async(frame, boxes[:n])
             embs[split, n] = ext.postprocess().copy()
             assert embs[split, n].shape == (n, 512)
     for n in (33, 32, 9, 7, 1):
-        np.testing.assert_array_equal(embs[True, n], embs[False, n])
+        np.testing.assert_array_equal(embs[2, n], embs[1, n])
+        np.testing.assert_array_equal(embs[4, n], embs[1, n])
