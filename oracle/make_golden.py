@@ -31,7 +31,7 @@ def golden_tracker(ns):
     for name in scenes.SCENES:
         scene = scenes.Scene(name)
         ns.track.Track._count = 0
-        tracker = ns.tracker.MultiTracker(scene.size, scene.metric, **scenes.tracker_kwargs())
+        tracker = ns.tracker.MultiTracker(scene.size, scene.metric, **scenes.tracker_kwargs(name))
         records, final = scenes.run_scene(tracker, scene)
         out = scenes.pack_records(records, final)
         np.savez_compressed(GOLDEN / f'tracker_{name}.npz', **out)

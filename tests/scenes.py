@@ -32,6 +32,11 @@ SCENES = {
                          seed=19, impostor=True, ghosts=True),
     's30_ghosts_cosine': dict(n_ids=30, size=(1920, 1080), n_frames=90, skip=2, metric='cosine', n_classes=1,
                               seed=19, impostor=True, ghosts=True),
+    # life-cycle edges: tracks need 3 hits to be confirmed, die after 4 missed detector frames, and the detector
+    # returns NOTHING for 7 consecutive frames (empty association stages, every track ages / is removed / comes
+    # back through the re-identification history)
+    's16_blackout_confirm3': dict(n_ids=16, size=(1280, 720), n_frames=64, skip=2, metric='euclidean', n_classes=1,
+                                  seed=11, blackout=(21, 7), cfg=dict(confirm_hits=3, max_age=4)),
 }
 
 TRACKER_CFG = dict(max_age=6, age_penalty=2, motion_weight=0.2, max_assoc_cost=0.8, max_reid_cost=0.6,
@@ -39,9 +44,12 @@ TRACKER_CFG = dict(max_age=6, age_penalty=2, motion_weight=0.2, max_assoc_cost=0
                    confirm_hits=1, history_size=50)
 
 
-def tracker_kwargs():
-    """cfg/mot.json tracker_cfg (reference cfg/mot.json:43-96) as constructor kwargs."""
+def tracker_kwargs(name=None):
+    """cfg/mot.json tracker_cfg (reference cfg/mot.json:43-96) as constructor kwargs; a scene may override
+    entries through its `cfg` key."""
     kw = dict(TRACKER_CFG)
+    if name is not None:
+        kw.update(SCENES[name].get('cfg', {}))
     kw['kalman_filter_cfg'] = SimpleNamespace(
         std_factor_acc=2.25, std_offset_acc=78.5, std_factor_det=(0.08, 0.08),
         std_factor_klt=(0.14, 0.14), min_std_det=(4.0, 4.0), min_std_klt=(5.0, 5.0),
@@ -117,6 +125,10 @@ class Scene:
     def detections(self, frame_id):
         """(recarray[DET_DTYPE] sorted by label, embeddings float32 [N,512])"""
         if frame_id in self._det_cache:
+            return self._det_cache[frame_id]
+        start, length = getattr(self, 'blackout', None) or (0, 0)
+        if start <= frame_id < start + length:          # the detector sees nothing at all
+            self._det_cache[frame_id] = (np.zeros(0, DET_DTYPE).view(np.recarray), np.zeros((0, 512), np.float32))
             return self._det_cache[frame_id]
         rng = np.random.default_rng((self.seed, 1000 + frame_id))
         keep = ~self.hidden[frame_id] & (rng.random(self.n_ids) > 0.08)

@@ -61,7 +61,8 @@ def test_assoc(golden_dir, tag):
     assert uc == g[f'{tag}_gr_ud'].tolist()
 
 
-@pytest.mark.parametrize('name', ['s20_skip5_euclid', 's50_skip1_cosine', 's50_skip2_euclid', 's8_flowfail'])
+@pytest.mark.parametrize('name', ['s20_skip5_euclid', 's50_skip1_cosine', 's50_skip2_euclid', 's8_flowfail',
+                                  's16_blackout_confirm3'])
 def test_tracker_scenes(golden_dir, name):
     """The restated CPU tracker (oracle/cpu_tracker.py) reproduces the reference MultiTracker's
     golden runs: identical track ids / order / rounded boxes / lifecycle on every frame."""
@@ -69,7 +70,7 @@ def test_tracker_scenes(golden_dir, name):
     import cpu_tracker
     g = np.load(golden_dir / f'tracker_{name}.npz')
     scene = scenes.Scene(name)
-    tracker = cpu_tracker.OracleTracker(scene.size, scene.metric, **scenes.tracker_kwargs())
+    tracker = cpu_tracker.OracleTracker(scene.size, scene.metric, **scenes.tracker_kwargs(name))
     records, final = scenes.run_scene(tracker, scene)
     out = scenes.pack_records(records, final)
     np.testing.assert_array_equal(out['tracks'], g['tracks'])

@@ -35,7 +35,7 @@ def _run_scene(golden_dir, name):
     g = np.load(golden_dir / f'tracker_{name}.npz')
     scene = scenes.Scene(name)
     Track._count = 0
-    tracker = MultiTracker(scene.size, scene.metric, **scenes.tracker_kwargs())
+    tracker = MultiTracker(scene.size, scene.metric, **scenes.tracker_kwargs(name))
     records, final = scenes.run_scene(tracker, scene)
     out = scenes.pack_records(records, final)
     exp, got = g['tracks'], out['tracks']
