@@ -4,7 +4,6 @@ from collections import deque
 from types import SimpleNamespace
 
 import numpy as np
-import pytest
 
 from fastmot_amd.utils.visualization import Visualizer, get_color, covariance_ellipse
 
