@@ -213,3 +213,7 @@ int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     FM_HIP(hipGetLastError());
     return 0;
 }
+
+extern "C" size_t fm_litechain_lds_bytes(int c, int w, int h) {
+    return (c % 8 == 0 && c >= 8 && c <= 128 && w > 0 && h > 0) ? litechain_lds_bytes(c, w, h) : (size_t)-1;
+}

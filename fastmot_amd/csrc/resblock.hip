@@ -257,3 +257,5 @@ int launch_resblock(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, in
 #undef RB
     return FM_ERR_ARG;
 }
+
+extern "C" int fm_resblock_supported(int c, int mid) { return resblock_supported(c, mid) ? 1 : 0; }

@@ -437,6 +437,11 @@ int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
 /* diagnostic: a long deterministic kernel on the flow stream (mode bit 0: 32-lane butterflies, bit 1: byte
  * loads from the previous gray image); out_host: 256 * blocks words.  See scripts/stress_spin.py. */
 int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsigned* out_host);
+/* LDS bytes FM_OP_LITECHAIN needs for c channels on h x w maps (<= 65536 to be launchable): the layer-table
+ * builder decides with the same formula whether an OSNet block can use the chain kernel (no device needed) */
+size_t fm_litechain_lds_bytes(int c, int w, int h);
+/* 1 when FM_OP_RESBLOCK supports c in/out channels with mid hidden channels (no device needed) */
+int fm_resblock_supported(int c, int mid);
 /* profiling hook: accumulated host wall time (ms) of the stages of fm_flow_predict -- out5 = {begin, prepare,
  * lk, estimate, number of calls}; reset != 0 clears the accumulators */
 int fm_flow_timing(double* out5, int reset);

@@ -40,3 +40,19 @@ def test_error_string_is_a_c_string():
     from fastmot_amd import _lib
     lib = _lib.load()
     assert isinstance(lib.fm_last_error(), bytes)
+
+
+def test_layer_table_builder_agrees_with_the_kernels():
+    """graph.py decides per layer whether a fused kernel applies; its predicates must be the kernels' own
+    (LDS budget of the OSNet chain kernel, channel sets of the fused residual unit)."""
+    from fastmot_amd import _lib
+    from fastmot_amd.models.graph import Graph
+    lib = _lib.load()
+    lib.fm_litechain_lds_bytes.restype = ctypes.c_size_t
+    for c in (8, 16, 24, 32, 48, 64, 96, 128):
+        for h, w in ((64, 32), (32, 16), (16, 8), (9, 40), (128, 64)):
+            assert Graph.lightchain_fits(c, h, w) == (lib.fm_litechain_lds_bytes(c, w, h) <= 64 * 1024), (c, h, w)
+    assert not Graph.lightchain_fits(20, 64, 32) and not Graph.lightchain_fits(136, 64, 32)
+    for c in (32, 64, 96, 128, 256, 512):
+        for mid in (16, 32, 64, 128, 256, 512):
+            assert Graph.resblock_supported(c, mid) == bool(lib.fm_resblock_supported(c, mid)), (c, mid)
