@@ -32,6 +32,10 @@ SCENES = {
                          seed=19, impostor=True, ghosts=True),
     's30_ghosts_cosine': dict(n_ids=30, size=(1920, 1080), n_frames=90, skip=2, metric='cosine', n_classes=1,
                               seed=19, impostor=True, ghosts=True),
+    # three classes together with the lost-track history: class-wise gating of the re-identification stage,
+    # duplicate / merge branches across classes
+    's40_multiclass_reid': dict(n_ids=40, size=(1920, 1080), n_frames=80, skip=2, metric='cosine', n_classes=3,
+                                seed=23, impostor=True, ghosts=True),
     # life-cycle edges: tracks need 3 hits to be confirmed, die after 4 missed detector frames, and the detector
     # returns NOTHING for 7 consecutive frames (empty association stages, every track ages / is removed / comes
     # back through the re-identification history)

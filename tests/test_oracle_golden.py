@@ -62,7 +62,7 @@ def test_assoc(golden_dir, tag):
 
 
 @pytest.mark.parametrize('name', ['s20_skip5_euclid', 's50_skip1_cosine', 's50_skip2_euclid', 's8_flowfail',
-                                  's16_blackout_confirm3'])
+                                  's16_blackout_confirm3', 's40_multiclass_reid'])
 def test_tracker_scenes(golden_dir, name):
     """The restated CPU tracker (oracle/cpu_tracker.py) reproduces the reference MultiTracker's
     golden runs: identical track ids / order / rounded boxes / lifecycle on every frame."""
