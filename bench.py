@@ -2,14 +2,20 @@
 """Benchmark of the FastMOT per-frame hot path on MI355X (BASELINE.json metric:
 "end-to-end tracker FPS @1080p/50 dets").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,4}]
 
-A step = one MOT.step() on one synthetic 1920x1080 BGR frame that is already resident in HBM
-(ring of frames uploaded before the timed region): YOLOv4 @608x608 (110 conv layers, 128.4 GFLOP,
-seeded random weights) -> decode -> DIoU-NMS -> [50 injected detections] -> KLT (pyramids, GFTT, FAST,
-LK, RANSAC) -> OSNet-x0.25 on 50 crops -> batched Kalman -> association (cost kernels + LAP).
-detector_frame_skip = 1 (BASELINE config[1]).  For N > 1 every rank tracks its own stream on its
-own GPU (weak scaling, no data-path collective); value = total frames / max-over-ranks time.
+A step = one MOT.step() on one synthetic BGR frame that lies in page-locked HOST memory: the H2D copy of the
+frame (6.2 MB at 1080p) is INSIDE the timed region ("includes H2D of each frame"), then
+detector network (seeded random weights) -> decode -> DIoU-NMS -> [injected detections] -> KLT (pyramids, GFTT,
+FAST, LK, RANSAC) -> OSNet on the crops -> batched Kalman -> association (cost kernels + LAP).
+
+`value` is measured with the next frame handed to MOT.step (a capture queue that already holds it: the
+detector of frame t+1 overlaps the ReID / association stages of frame t; results are bit-identical).
+`variants` reports, on shorter runs of the same build in the same process, the strictly sequential rate
+(no next-frame prefetch) and the rate with the frames already resident in HBM (round-1 definition).
+
+For N > 1 every rank tracks its own stream on its own GPU (weak scaling); the only collective is the opt-out
+ReID-gallery all-gather (RCCL) on a side stream.  value = total frames / max-over-ranks time.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -26,9 +32,23 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
-N_DETS = 50
-SIZE = (1920, 1080)
 RING = 32
+
+# BASELINE.json configs that fit one GPU.  [0] is the detector-disabled CPU plumbing case and [3] is config[1]
+# on 8 GPUs (= --gpus 8 --config 1); both are covered by the parity tests / the scaling run, not bench lines.
+CONFIGS = {
+    1: dict(name='BASELINE config[1]', size=(1920, 1080), n_dets=50, yolo='YOLOv4_608', reid='OSNet025', skip=1,
+            labels=(1,), desc='single 1080p stream, YOLOv4 608x608 (80 cls) + OSNet-x0.25, detector_frame_skip=1'),
+    2: dict(name='BASELINE config[2]', size=(1920, 1080), n_dets=50, yolo='YOLOv4CSP_640', reid='OSNet10', skip=5,
+            labels=(1,), desc='single 1080p stream, YOLOv4-CSP 640x640 (80 cls) + OSNet-x1.0, '
+                              'detector_frame_skip=5 (KLT-heavy)'),
+    4: dict(name='BASELINE config[4]', size=(3840, 2160), n_dets=300, yolo='YOLOv4P6_1280', reid='OSNet025', skip=1,
+            labels=(0, 1, 2), desc='MOT20-style dense 4K stream, YOLOv4-P6 1280x1280, 300 detections/frame, '
+                                   '3 classes (one OSNet-x0.25 per class), detector_frame_skip=1'),
+}
+
+
+SIZE, N_DETS = CONFIGS[1]['size'], CONFIGS[1]['n_dets']      # config[1] shorthands for scripts/
 
 
 def tracker_cfg():
@@ -46,81 +66,98 @@ def tracker_cfg():
                                  opt_flow_params=SimpleNamespace(winSize=(5, 5), maxLevel=5, criteria=(3, 10, 0.03))))
 
 
-def build_mot(video):
+def build_mot(cfg, video, gallery_sync=None):
     import fastmot_amd.mot as mot_mod
     from fastmot_amd.detector import YOLODetector
     from fastmot_amd.utils.synthetic import InjectedYOLODetector
     mot_mod.YOLODetector = InjectedYOLODetector
+    tcfg = tracker_cfg()
+    if gallery_sync is not None:
+        tcfg.gallery_sync = gallery_sync
     try:
-        mot = mot_mod.MOT(SIZE, detector_type='YOLO', detector_frame_skip=1, class_ids=(1,),
-                          yolo_detector_cfg=SimpleNamespace(model='YOLOv4_608', conf_thresh=0.25, nms_thresh=0.5,
+        mot = mot_mod.MOT(cfg['size'], detector_type='YOLO', detector_frame_skip=cfg['skip'], class_ids=cfg['labels'],
+                          yolo_detector_cfg=SimpleNamespace(model=cfg['yolo'], conf_thresh=0.25, nms_thresh=0.5,
                                                             max_area=800000, min_aspect_ratio=1.2,
                                                             max_candidates=8192),
-                          feature_extractor_cfgs=(SimpleNamespace(model='OSNet025', batch_size=64),),
-                          tracker_cfg=tracker_cfg())
+                          feature_extractor_cfgs=tuple(SimpleNamespace(model=cfg['reid'], batch_size=64)
+                                                       for _ in cfg['labels']),
+                          tracker_cfg=tcfg)
     finally:
         mot_mod.YOLODetector = YOLODetector
-    mot.detector.bind_video(video)
+    mot.detector.bind_video(video, labels=cfg['labels'])
     return mot
 
 
-def cpu_baseline(video, budget_s=20.0):
-    """kind=port: the numpy restatement (oracle/cpu_tracker.py + cv_oracle.py) of the reference's
-    CPU tracker path -- KLT + Kalman + association, detector / ReID networks excluded exactly as in
-    the reference's TensorRT-disabled configuration (BASELINE config[0]) -- timed on one host core
-    over a bounded number of frames of the same synthetic video."""
-    sys.path.insert(0, str(ROOT / 'oracle'))
-    import cpu_tracker
-    cfg = tracker_cfg()
-    kw = {k: v for k, v in vars(cfg).items() if k != 'flow_cfg'}
-    trk = cpu_tracker.OracleTracker(SIZE, 'euclidean', **kw)
-    trk.reset(1 / 30.)
-    rng = np.random.default_rng(5)
-    ident = rng.normal(0, 1, (video.n_ids, 512))
-    ident /= np.linalg.norm(ident, axis=1, keepdims=True)
+def ping_pong(s, n):
+    """Frame index of step s over a clip of n frames played forwards and backwards (positions stay
+    continuous; a plain wrap-around would teleport every object once per clip)."""
+    p = 2 * (n - 1)
+    s %= p
+    return s if s < n else p - s
 
-    def embs():
-        e = ident + rng.normal(0, 0.02, ident.shape)
-        return (e / np.linalg.norm(e, axis=1, keepdims=True)).astype(np.float32)
-    trk.init(video.frames[0], video.detections(0))
-    t0 = time.perf_counter()
-    n = 0
-    for f in range(1, video.n_frames):
-        trk.compute_flow(video.frames[f])
-        trk.apply_kalman()
-        trk.update(f, video.detections(f), embs())
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n} frames of the same 1080p/{video.n_ids}-detection synthetic clip; numpy port of '
-                      'KLT+Kalman+association (oracle/), detector+ReID networks excluded (injected), '
-                      'NOT the Numba-compiled reference'}
+
+def cpu_leg(cfg, video, mot, budget_s=20.0):
+    """cpu_baseline + parity in one pass.  kind=port: the numpy restatement (oracle/cpu_tracker.py +
+    cv_oracle.py) of the reference's CPU tracker path -- KLT + Kalman + association, detector / ReID networks
+    excluded exactly as in the reference's TensorRT-disabled configuration (BASELINE config[0]) -- timed on one
+    host core over a bounded number of frames of the same synthetic clip, fed with the embeddings the HIP OSNet
+    produced so that its per-frame output can be compared with the HIP pipeline's (the `parity` object)."""
+    sys.path.insert(0, str(ROOT / 'oracle'))
+    import e2e_check
+    n = min(video.n_frames, RING)
+    hip, emb = e2e_check.hip_pass(mot, video, n, cfg['skip'], prefetch=False)
+    tkw = vars(tracker_cfg())
+    ora, dt, done = e2e_check.oracle_pass(cfg['size'], mot.extractors[0].metric.lower(), tkw, video, n, cfg['skip'],
+                                          emb, budget_s=budget_s, labels=cfg['labels'])
+    parity = e2e_check.compare(hip[:done], ora)
+    parity['oracle'] = 'oracle/cpu_tracker.py + cv_oracle.py on the same frames, detections and HIP embeddings'
+    base = {'value': round(done / dt, 3), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{done} frames of the same {cfg["size"][0]}x{cfg["size"][1]}/{video.n_ids}-detection '
+                      f'synthetic clip (detector_frame_skip={cfg["skip"]}); numpy port of KLT+Kalman+association '
+                      '(oracle/), detector+ReID networks excluded (injected), NOT the Numba-compiled reference'}
+    return base, parity
+
+
+def compiled_baseline(cfg, video, budget_s=10.0):
+    """kind=compiled-port: oracle/c_baseline (plain C, -O3 -march=native, single thread) of the same KLT + Kalman
+    + association stages -- the 'Numba-class proxy' of SURVEY.md section 8d; None when it has not been built."""
+    sys.path.insert(0, str(ROOT / 'oracle'))
+    try:
+        import c_baseline
+    except ImportError:
+        return None
+    return c_baseline.time_clip(cfg, video, tracker_cfg(), budget_s)
 
 
 def pmc_traffic():
-    """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_conv.json,
+    """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (profiles/*_pmc_conv.json,
     produced by scripts/collect_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of the detector network;
     FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  PMC counters cannot be collected from
     inside this process, hence the file; None when it is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_conv.json')
-    try:
-        with open(path) as f:
-            return json.load(f)['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ('r02_pmc_conv.json', 'r01_pmc_conv.json'):
+        try:
+            with open(ROOT / 'profiles' / name) as f:
+                return json.load(f)['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-variants', action='store_true', help='skip the sequential / resident-frames side runs')
     ap.add_argument('--no-prefetch', dest='prefetch', action='store_false',
                     help='strictly sequential steps: do not start the detector on frame t+1 during frame t')
+    ap.add_argument('--resident', action='store_true', help='frames resident in HBM (no H2D in the timed region)')
+    ap.add_argument('--no-gallery-sync', dest='gallery', action='store_false',
+                    help='N > 1: disable the cross-stream ReID-gallery all-gather (RCCL)')
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
@@ -135,30 +172,38 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
-    from fastmot_amd import Track
+    from fastmot_amd import Track, models
     from fastmot_amd.detector import DeviceFrame
+    models.allow_random_weights()          # no weight files offline: seeded random parameters (stated in `data`)
     from fastmot_amd.runtime import get_context
     from fastmot_amd.utils.synthetic import SyntheticVideo
 
-    video = SyntheticVideo(SIZE, n_ids=N_DETS, n_frames=RING, seed=100 + rank)
+    size = cfg['size']
+    video = SyntheticVideo(size, n_ids=cfg['n_dets'], n_frames=RING, seed=100 + rank)
     ctx = get_context()
-    ctx.frame_configure(SIZE[0], SIZE[1], RING)
+    ctx.frame_configure(size[0], size[1], RING)
+    host_frames = ctx.pinned_frames(RING)                 # page-locked host memory = the capture queue
     for i, fr in enumerate(video.frames):
-        ctx.frame_ring_store(i, fr)          # inputs resident in HBM before the timed region
-    mot = build_mot(video)
+        host_frames[i] = fr
+        ctx.frame_ring_store(i, fr)                       # resident copies for the `resident` variant only
+    pinned = [host_frames[i] for i in range(RING)]
+    resident = [DeviceFrame(i) for i in range(RING)]
+
+    sync = None
+    if world > 1 and args.gallery:
+        from fastmot_amd.gallery import GallerySync
+        sync = GallerySync(history_size=tracker_cfg().history_size, feat_dim=512)
+    mot = build_mot(cfg, video, gallery_sync=sync)
     Track._count = 0
     mot.reset(1 / 30.)
 
-    frames = [DeviceFrame(i) for i in range(RING)]
-
-    def run(n, start):
-        # the next frame is known (resident ring = a capture queue that is never empty): MOT.step starts the
-        # detector on it while this frame is in its ReID / association stages (--no-prefetch disables)
+    def run(n, start, frames, prefetch):
         mot.detector.net_ms.clear()
         for s in range(start, start + n):
-            mot.detector._frame_idx = s % RING
-            nxt = frames[(s + 1) % RING] if args.prefetch and s + 1 < start + n else None
-            mot.step(frames[s % RING], next_frame=nxt)
+            i = ping_pong(s, RING)
+            mot.detector._frame_idx = i
+            nxt = frames[ping_pong(s + 1, RING)] if prefetch and s + 1 < start + n else None
+            mot.step(frames[i], next_frame=nxt)
         return list(mot.detector.net_ms)
 
     def fence():
@@ -168,22 +213,40 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(args.warmup, 0)
-    fence()
-    t0 = time.perf_counter()
-    net_ms = run(args.steps, args.warmup)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(n, start, frames, prefetch):
+        fence()
+        t0 = time.perf_counter()
+        net_ms = run(n, start, frames, prefetch)
+        fence()
+        return time.perf_counter() - t0, net_ms
+
+    frames = resident if args.resident else pinned
+    run(args.warmup, 0, frames, args.prefetch)
+    elapsed, net_ms = timed(args.steps, args.warmup, frames, args.prefetch)
     if dist is not None:
         t = torch.tensor([elapsed], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    pos = args.warmup + args.steps
+
+    variants = None
+    if world == 1 and not args.no_variants:
+        nv = max(10, min(args.steps, 100))
+        variants = {'steps_each': nv}
+        for key, fr, pf in (('h2d_sequential_fps', pinned, False), ('resident_prefetch_fps', resident, True),
+                            ('resident_sequential_fps', resident, False)):
+            run(4, pos, fr, pf)
+            dt, _ = timed(nv, pos + 4, fr, pf)
+            pos += nv + 4
+            variants[key] = round(nv / dt, 2)
 
     if rank == 0:
         flops, _ = mot.detector.backend.cost(1)
         n_launch = len(mot.detector.graph.layers)
         net_avg_ms = float(np.mean(net_ms))
         achieved = flops / (net_avg_ms * 1e-3) / 1e12
+        from fastmot_amd.utils import Profiler
+        stages = {k: round(Profiler.get_avg_millis(k), 3) for k in ('preproc', 'detect', 'track', 'extract', 'assoc')}
         out = {
             'metric': 'end-to-end tracker FPS @1080p/50 dets',
             'value': round(world * args.steps / elapsed, 2),
@@ -192,25 +255,35 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE config[1]: single 1080p stream, YOLOv4 608x608 (80 cls, seeded random '
-                                   'weights) + OSNet-x0.25, detector_frame_skip=1, 50 injected detections/frame, '
-                                   'frames resident in HBM', 'next_frame_prefetch': bool(args.prefetch), 'streams_per_gpu': 1, 'parallelism': f'1 stream/GPU x {world}',
+            'config': {'workload': f'{cfg["name"]}: {cfg["desc"]}, seeded random weights, {cfg["n_dets"]} injected '
+                                   'detections/frame, ' +
+                                   ('frames resident in HBM' if args.resident else
+                                    'frames in pinned host memory, H2D per frame included'),
+                       'next_frame_prefetch': bool(args.prefetch), 'streams_per_gpu': 1,
+                       'parallelism': f'1 stream/GPU x {world}',
+                       'gallery_allgather': None if sync is None else sync.stats(),
                        'visible_tracks': len(list(mot.visible_tracks())),
-                       'yolo_candidates_nms_out': mot.detector.last_real_count},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel + resblock_kernel (the 110 conv layers of YOLOv4: '
-                                                    f'{n_launch} launches per frame incl. fused residual units / SPP, '
-                                                    'measured with HIP events on the detector stream)',
+                       'yolo_candidates_nms_out': mot.detector.last_real_count,
+                       'stage_ms': stages},
+            'roofline': {'bound': 'mfma', 'kernel': f'conv kernels of the detector ({cfg["yolo"]}: {n_launch} launches '
+                                                    'per frame incl. fused residual units / SPP, measured with HIP '
+                                                    'events on the detector stream inside the pipeline)',
                          'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_PEAK_TFLOPS, 5), 'traffic': pmc_traffic(),
                          'flop_per_frame': flops, 'net_ms_per_frame': round(net_avg_ms, 4),
                          'avg_launch_us': round(net_avg_ms * 1e3 / n_launch, 3)},
         }
+        if variants is not None:
+            out['variants'] = variants
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(video)
-        from fastmot_amd.utils import Profiler
-        stages = {k: round(Profiler.get_avg_millis(k), 3) for k in ('preproc', 'detect', 'track', 'extract', 'assoc')}
+            out['cpu_baseline'], out['parity'] = cpu_leg(cfg, video, mot)
+            comp = compiled_baseline(cfg, video)
+            if comp is not None:
+                out['cpu_baseline_compiled'] = comp
         print('stage ms (Profiler, incl. warmup):', stages, file=sys.stderr)
         print(json.dumps(out), flush=True)
+    if sync is not None:
+        sync.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

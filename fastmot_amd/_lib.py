@@ -357,6 +357,32 @@ DET_DTYPE = np.dtype([('tlbr', float, 4), ('label', int), ('conf', float)], alig
 assert DET_DTYPE.itemsize == 48
 
 
+class _PinnedBlock:
+    def __init__(self, lib, nbytes):
+        self._lib = lib
+        p = C.c_void_p()
+        check(lib.fm_host_alloc(C.c_size_t(nbytes), C.byref(p)))
+        self.ptr = p.value
+
+    def __del__(self):
+        if getattr(self, 'ptr', None):
+            try:
+                self._lib.fm_host_free(C.c_void_p(self.ptr))
+            except Exception:
+                pass
+            self.ptr = None
+
+
+def pinned_empty(lib, shape, dtype):
+    """ndarray in page-locked host memory obtained from fm_host_alloc (freed with the array)."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    block = _PinnedBlock(lib, nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(block.ptr)
+    buf._pinned_block = block              # keeps the allocation alive as long as any view exists
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 def _bind_device_io(cls):
     def frame_configure(self, width, height, ring_size=0):
         check(self.lib.fm_frame_configure(self._ctx, C.c_int(width), C.c_int(height), C.c_int(ring_size)))
@@ -369,6 +395,12 @@ def _bind_device_io(cls):
             raise ValueError(f'frame must be uint8 {h}x{w}x3')
         f = np.ascontiguousarray(frame)
         check(self.lib.fm_frame_upload(self._ctx, _ptr(f)))
+
+    def pinned_frames(self, n):
+        """n frames (n, H, W, 3) uint8 in page-locked host memory (fm_host_alloc): frames stored here are
+        uploaded without a staging copy.  The buffer lives as long as the returned array's base object."""
+        w, h = self.frame_size
+        return pinned_empty(self.lib, (n, h, w, 3), np.uint8)
 
     def frame_ring_store(self, index, frame):
         f = np.ascontiguousarray(frame, np.uint8)
@@ -450,7 +482,7 @@ def _bind_device_io(cls):
         check(self.lib.fm_extract_read_input(self._ctx, C.c_int(n), _ptr(out)))
         return out
 
-    for fn in (frame_configure, frame_upload, frame_ring_store, frame_ring_select, frame_read, frame_upload_next,
+    for fn in (frame_configure, frame_upload, pinned_frames, frame_ring_store, frame_ring_select, frame_read, frame_upload_next,
                frame_ring_select_next, frame_promote_next, detect_async_next,
                detect_configure, detect_async, detect_net_ms, detect_preprocess_only, detect_sync, filter_dets,
                detect_raw_candidates, extract_configure, extract_async, extract_sync, extract_read_input):

@@ -20,6 +20,8 @@
 // frame 6.2 MB in, 608*608*8*2 B out.
 #include "net.h"
 #include <cmath>
+#include <mutex>
+#include <utility>
 
 struct DetState {
     fm_yolo_cfg cfg{};
@@ -380,7 +382,7 @@ int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
     FM_HIP(hipGetLastError());
     FM_HIP(hipMemcpyAsync(d->counters_host, d->counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, s));
     // detections are few: copy a bounded prefix now, the rest (rare) at sync time
-    FM_HIP(hipMemcpyAsync(d->dets_host, d->dets, sizeof(fm_det48) * 512, hipMemcpyDeviceToHost, s));
+    FM_HIP(hipMemcpyAsync(d->dets_host, d->dets, sizeof(fm_det48) * (cap < 512 ? cap : 512), hipMemcpyDeviceToHost, s));
     return 0;
 }
 
@@ -426,6 +428,45 @@ extern "C" int fm_frame_configure(fm_ctx* ctx, int width, int height, int ring_s
     return 0;
 }
 
+// ---- page-locked frame buffers handed to the caller (process-wide registry of their ranges)
+namespace {
+std::mutex g_host_mu;
+std::vector<std::pair<const uint8_t*, size_t>> g_host_ranges;
+
+bool is_pinned_range(const uint8_t* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (auto& r : g_host_ranges)
+        if (p >= r.first && p + bytes <= r.first + r.second) return true;
+    return false;
+}
+}  // namespace
+
+extern "C" int fm_host_alloc(size_t bytes, void** out) {
+    FM_CHECK_ARG(out && bytes > 0);
+    void* p = nullptr;
+    FM_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        g_host_ranges.emplace_back((const uint8_t*)p, bytes);
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int fm_host_free(void* p) {
+    if (!p) return 0;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        for (size_t i = 0; i < g_host_ranges.size(); ++i)
+            if (g_host_ranges[i].first == (const uint8_t*)p) {
+                g_host_ranges.erase(g_host_ranges.begin() + i);
+                break;
+            }
+    }
+    FM_HIP(hipHostFree(p));
+    return 0;
+}
+
 extern "C" int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr) {
     FM_CHECK_ARG(ctx && bgr && ctx->frame_own);
     const size_t bytes = (size_t)ctx->frame_w * ctx->frame_h * 3;
@@ -433,8 +474,12 @@ extern "C" int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr) {
     FM_HIP(hipStreamSynchronize(ctx->s_det));
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
     FM_HIP(hipStreamSynchronize(ctx->s_flow));
-    memcpy(ctx->frame_pinned, bgr, bytes);
-    FM_HIP(hipMemcpyAsync(ctx->frame_own, ctx->frame_pinned, bytes, hipMemcpyHostToDevice, ctx->s_det));
+    const uint8_t* src = bgr;
+    if (!is_pinned_range(bgr, bytes)) {
+        memcpy(ctx->frame_pinned, bgr, bytes);
+        src = ctx->frame_pinned;
+    }
+    FM_HIP(hipMemcpyAsync(ctx->frame_own, src, bytes, hipMemcpyHostToDevice, ctx->s_det));
     FM_HIP(hipStreamSynchronize(ctx->s_det));   // the other streams read the frame too
     ctx->frame_cur = ctx->frame_own;
     return 0;
@@ -446,9 +491,15 @@ extern "C" int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr) {
 extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
     FM_CHECK_ARG(ctx && bgr && ctx->frame_own2);
     const size_t bytes = (size_t)ctx->frame_w * ctx->frame_h * 3;
-    FM_HIP(hipStreamSynchronize(ctx->s_det));        // previous reader of this slot / pinned buffer
-    memcpy(ctx->frame_pinned2, bgr, bytes);
-    FM_HIP(hipMemcpyAsync(ctx->frame_own2, ctx->frame_pinned2, bytes, hipMemcpyHostToDevice, ctx->s_det));
+    const uint8_t* src = bgr;
+    if (!is_pinned_range(bgr, bytes)) {
+        FM_HIP(hipStreamSynchronize(ctx->s_det));    // previous H2D copy out of the staging buffer
+        memcpy(ctx->frame_pinned2, bgr, bytes);
+        src = ctx->frame_pinned2;
+    }
+    // (the previous readers of frame_own2 -- the stages of the step before the last promote -- were
+    // synchronised by fm_frame_promote_next; the detector stream orders the copy behind its own reads)
+    FM_HIP(hipMemcpyAsync(ctx->frame_own2, src, bytes, hipMemcpyHostToDevice, ctx->s_det));
     if (!ctx->ev_next_upload) FM_HIP(hipEventCreateWithFlags(&ctx->ev_next_upload, hipEventDisableTiming));
     FM_HIP(hipEventRecord(ctx->ev_next_upload, ctx->s_det));
     ctx->frame_next = ctx->frame_own2;

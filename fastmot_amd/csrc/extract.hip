@@ -72,12 +72,22 @@ __global__ void crop_resize_kernel(const uint8_t* __restrict__ frame, int fw, in
         const uint8_t* r0 = frame + ((size_t)(y1 + cy.s) * fw + x1) * 3;
         const uint8_t* r1 = frame + ((size_t)(y1 + sy1) * fw + x1) * 3;
         const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+        // cv::resize routes INTER_LINEAR with an exact 2x decimation in both axes to INTER_AREA (resize.cpp:
+        // `is_area_fast && iscale_x == 2 && iscale_y == 2`): rounded mean of the 2x2 block
+        const bool area2 = cw == 2 * ow && ch == 2 * oh;
+        const uint8_t* q0 = frame + ((size_t)(y1 + 2 * y) * fw + x1 + 2 * x) * 3;
+        const uint8_t* q1 = q0 + (size_t)fw * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const int S0 = r0[cx.s * 3 + c] * cx.a0 + r0[sx1 * 3 + c] * cx.a1;
-            const int S1 = r1[cx.s * 3 + c] * cx.a0 + r1[sx1 * 3 + c] * cx.a1;
-            const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
-            const int u8 = min(max(v, 0), 255);
+            int u8;
+            if (area2) {
+                u8 = (q0[c] + q0[3 + c] + q1[c] + q1[3 + c] + 2) >> 2;
+            } else {
+                const int S0 = r0[cx.s * 3 + c] * cx.a0 + r0[sx1 * 3 + c] * cx.a1;
+                const int S1 = r1[cx.s * 3 + c] * cx.a0 + r1[sx1 * 3 + c] * cx.a1;
+                const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                u8 = min(max(v, 0), 255);
+            }
             const int rc = 2 - c;    // BGR -> RGB
             o[rc] = (f16)(float)(((double)u8 / 255. - mean[rc]) / stdv[rc]);
         }

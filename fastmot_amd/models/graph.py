@@ -7,10 +7,12 @@ BatchNorm is folded into the conv weights (eps 1e-5, scripts/yolo2onnx.py:419-42
 the MFMA kernel's [cout_pad32][K_pad64] fp16 layout.
 """
 import ctypes as C
-
+import logging
 import os
 
 import numpy as np
+
+LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
  OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN) = range(17)
@@ -51,6 +53,28 @@ class View:
     def slice(self, coff, c):
         assert coff % 8 == 0
         return View(self.tid, self.coff + coff, c, self.h, self.w)
+
+
+_ALLOW_RANDOM = [os.environ.get('FASTMOT_RANDOM_WEIGHTS', '0') == '1']
+
+
+def allow_random_weights(flag=True):
+    """Benchmarks / tests without weight files: let model descriptors whose MODEL_PATH is missing fall back to
+    seeded random parameters (also FASTMOT_RANDOM_WEIGHTS=1).  Off by default: like the reference, a missing
+    model file is an error -- tracks computed from random weights look plausible and mean nothing."""
+    _ALLOW_RANDOM[0] = bool(flag)
+
+
+def missing_weights(model, seed):
+    """Policy for a descriptor whose weight file does not exist (called by YOLO/ReID.build_graph)."""
+    if not _ALLOW_RANDOM[0]:
+        raise FileNotFoundError(
+            f'{model.__name__}: weight file {model.MODEL_PATH} not found.  Put the file there, pass weights=..., '
+            'or opt in to seeded random weights with fastmot_amd.models.allow_random_weights() / '
+            'FASTMOT_RANDOM_WEIGHTS=1 (benchmarks and tests only)')
+    LOGGER.warning('%s: %s not found -- running with SEEDED RANDOM weights (outputs are meaningless)',
+                   model.__name__, model.MODEL_PATH)
+    return RandomWeights(seed=seed)
 
 
 class RandomWeights:

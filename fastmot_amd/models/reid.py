@@ -5,7 +5,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .graph import Graph, RandomWeights, RES_BEFORE_ACT, fold_bn
+from .graph import Graph, RES_BEFORE_ACT, fold_bn, missing_weights
 
 
 class ReID:
@@ -35,14 +35,15 @@ class ReID:
     @classmethod
     def build_graph(cls, weights=None, fuse_lightconv=True):
         """Weights: the explicit source, else the torchreid checkpoint at MODEL_PATH if it exists
-        (models/torchreid_weights.py), else seeded random parameters."""
+        (models/torchreid_weights.py); a missing file raises FileNotFoundError unless seeded random
+        parameters were opted into (models.allow_random_weights())."""
         ckpt = None
         if weights is None:
             if cls.MODEL_PATH is not None and Path(cls.MODEL_PATH).is_file():
                 from .torchreid_weights import TorchreidWeights
                 weights = ckpt = TorchreidWeights(cls.MODEL_PATH)
             else:
-                weights = RandomWeights(seed=1)
+                weights = missing_weights(cls, seed=1)
         out = osnet_graph(cls, weights, fuse_lightconv)
         if ckpt is not None and ckpt.unused():
             raise ValueError(f'{cls.MODEL_PATH}: parameters not used by {cls.__name__}: {ckpt.unused()[:5]} ...')

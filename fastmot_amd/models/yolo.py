@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 
 from .darknet import DarknetWeights, darknet_graph
-from .graph import Graph, RandomWeights, fold_bn
+from .graph import Graph, fold_bn, missing_weights
 
 
 class YOLO:
@@ -56,15 +56,16 @@ class YOLO:
     def build_graph(cls, weights=None):
         """-> (Graph, [head output views])  heads in LAYER_FACTORS order.
 
-        Weights: the explicit `weights` source, else the Darknet file at MODEL_PATH if it exists, else
-        seeded random parameters.  Topology: the Darknet cfg next to MODEL_PATH if it exists (any
+        Weights: the explicit `weights` source, else the Darknet file at MODEL_PATH; when that file is
+        missing this raises FileNotFoundError like the reference does, unless seeded random parameters were
+        opted into (models.allow_random_weights(), benchmarks / tests).  Topology: the Darknet cfg next to MODEL_PATH if it exists (any
         YOLOv3/v4/-tiny/Scaled-YOLOv4 cfg, models/darknet.py), else the built-in yolov4.cfg table."""
         real = None
         if weights is None:
             if cls.MODEL_PATH is not None and Path(cls.MODEL_PATH).is_file():
                 weights = real = DarknetWeights(cls.MODEL_PATH)
             else:
-                weights = RandomWeights(seed=0)
+                weights = missing_weights(cls, seed=0)
         cfg = cls.cfg_path()
         if cfg is not None and cfg.is_file():
             g, heads, meta = darknet_graph(cfg.read_text(), weights, in_hw=cls.INPUT_SHAPE[1:])

@@ -62,9 +62,6 @@ class MOT:
             visualizer_cfg = SimpleNamespace()
         if len(feature_extractor_cfgs) != len(class_ids):
             raise ValueError('Number of feature extractors must match length of class IDs')
-        if len(feature_extractor_cfgs) != 1:
-            raise NotImplementedError('one ReID network per context (the reference routes every box '
-                                      'to the first extractor anyway: bisect_right quirk, SURVEY Q3)')
         self.visualizer = Visualizer(**vars(visualizer_cfg))
 
         LOGGER.info('Loading detector model...')
@@ -77,7 +74,8 @@ class MOT:
                                            **vars(public_detector_cfg))
 
         LOGGER.info('Loading feature extractor models...')
-        self.extractors = [FeatureExtractor(size=self.size, **vars(cfg)) for cfg in feature_extractor_cfgs]
+        self.extractors = [FeatureExtractor(size=self.size, resident=(i == 0), **vars(cfg))
+                           for i, cfg in enumerate(feature_extractor_cfgs)]
         self.tracker = MultiTracker(self.size, self.extractors[0].metric, **vars(tracker_cfg))
         self.frame_count = 0
         self._next_frame = None
@@ -145,12 +143,25 @@ class MOT:
                     detections = self._last_detections = self.detector.postprocess()
 
                 with Profiler('extract'):
-                    # every box goes to the first extractor, as in the reference (_split_bboxes_by_cls
-                    # with its bisect_right quirk, mot.py:180-189)
-                    self.extractors[0].extract_async(frame, detections.tlbr)
-                    self._prefetch_next()
-                    self.tracker.prepare_detections(detections)
-                    embeddings = self.extractors[0].postprocess()
+                    if len(self.extractors) == 1:
+                        self.extractors[0].extract_async(frame, detections.tlbr)
+                        self._prefetch_next()
+                        self.tracker.prepare_detections(detections)
+                        embeddings = self.extractors[0].postprocess()
+                    else:
+                        # one extractor per class id (mot.py:147-157); _split_bboxes_by_cls keeps the
+                        # reference's bisect_right, quirk included
+                        cls_bboxes = self._split_bboxes_by_cls(detections.tlbr, detections.label, self.class_ids)
+                        for extractor, bboxes in zip(self.extractors, cls_bboxes):
+                            extractor.extract_async(frame, bboxes)
+                        self._prefetch_next()
+                        self.tracker.prepare_detections(detections)
+                        parts = [extractor.postprocess() for extractor in self.extractors]
+                        filled = [p for p in parts if len(p)]
+                        # (a single non-empty part is passed through as it is: the association kernels then
+                        # read the device-resident copy; the reference's np.concatenate with its float64 empty
+                        # parts only changes the dtype of the same values)
+                        embeddings = filled[0] if len(filled) == 1 else np.concatenate(parts)
             finally:
                 flow_done.result()
 
@@ -160,6 +171,34 @@ class MOT:
             self._prefetch_next()
             with Profiler('track'):
                 self.tracker.track(frame)
+
+    @staticmethod
+    def _bisect_right(arr, val, left=0):
+        """fastmot/utils/numba.py:43-53, verbatim semantics: the test is `arr[mid] >= val` (not `>`), so on
+        the ascending label array every probe moves `left` -- the search returns len(arr) whenever
+        val <= arr[left:] (always true for the first class id, the labels being restricted to class_ids)."""
+        right = len(arr)
+        while left < right:
+            mid = left + (right - left) // 2
+            if arr[mid] >= val:
+                left = mid + 1
+            else:
+                right = mid
+        return left
+
+    @classmethod
+    def _split_bboxes_by_cls(cls, bboxes, labels, class_ids):
+        """mot.py:180-189.  With the reference's bisect_right every box goes to the FIRST class's extractor
+        and the others receive empty slices; reproduced, not repaired, so that embeddings (and with them the
+        association) equal the reference's."""
+        cls_bboxes = []
+        begin = 0
+        labels = np.asarray(labels).tolist()
+        for cls_id in class_ids:
+            end = cls._bisect_right(labels, cls_id, begin)
+            cls_bboxes.append(bboxes[begin:end])
+            begin = end
+        return cls_bboxes
 
     def _draw(self, frame, detections):
         if not isinstance(frame, np.ndarray):

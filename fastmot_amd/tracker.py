@@ -100,6 +100,8 @@ class MultiTracker:
         self.homography = None
         self.gallery_sync = gallery_sync
         self._foreign_slots = []
+        self._foreign_key = None
+        self._gallery_cache = {}
 
     # ------------------------------------------------------------------ lifecycle
     def reset(self, dt):
@@ -367,6 +369,8 @@ class MultiTracker:
             self._new_tracks(frame_id, [det_tlbr[det_id]], [int(det_label[det_id])])
             trk = next(reversed(self.tracks.values()))
             trk.global_id = (entry['rank'], entry['trk_id'])
+            self.gallery_sync.consume(entry['rank'], entry['trk_id'])
+            self._foreign_key = None
             ctx.feat_write([trk.slot], entry['feat'][None], [entry['count']])
             trk.avg_feat.count = entry['count']
             ctx.feat_update([trk.slot], [det_id])
@@ -374,18 +378,30 @@ class MultiTracker:
             trk.hits = self.confirm_hits
 
     def _exchange_gallery(self, hist_ids):
-        """All-gathers {id, label, count, avg feature} of the local history (RCCL via torch.distributed)
-        and parks the foreign features in device slots."""
+        """Hands the local history {id, label, count, avg feature} to the gallery exchange (an asynchronous RCCL
+        all-gather on a side stream, gallery.py) and parks the foreign features it returns -- the result of the
+        PREVIOUS exchange -- in device slots.  A history entry's feature is read from the device once, when the
+        track enters the history (it does not change there); foreign features are re-written only when the
+        foreign set changed."""
         ctx = self.ctx
-        tracks = [self.hist_tracks[t] for t in hist_ids]
-        avg, cnt = ctx.feat_read([t.slot for t in tracks]) if tracks else (np.zeros((0, ctx.feat_dim), np.float32), [])
-        foreign = self.gallery_sync.exchange([(tid, t.label, int(c), a) for tid, t, a, c in
-                                              zip(hist_ids, tracks, avg, cnt)])
-        while len(self._foreign_slots) < len(foreign):
-            self._foreign_slots.append(ctx.slots.alloc())
-        if foreign:
-            ctx.feat_write(self._foreign_slots[:len(foreign)], np.array([e['feat'] for e in foreign]),
-                           [e['count'] for e in foreign])
+        cache = self._gallery_cache
+        for tid in [t for t in cache if t not in self.hist_tracks]:
+            del cache[tid]
+        fresh = [t for t in hist_ids if t not in cache]
+        if fresh:
+            avg, cnt = ctx.feat_read([self.hist_tracks[t].slot for t in fresh])
+            for tid, a, c in zip(fresh, avg, cnt):
+                cache[tid] = (int(c), a.copy())
+        foreign = self.gallery_sync.exchange([(tid, self.hist_tracks[tid].label, cache[tid][0], cache[tid][1])
+                                              for tid in hist_ids])
+        key = [(e['rank'], e['trk_id'], e['count']) for e in foreign]
+        if key != self._foreign_key:
+            while len(self._foreign_slots) < len(foreign):
+                self._foreign_slots.append(ctx.slots.alloc())
+            if foreign:
+                ctx.feat_write(self._foreign_slots[:len(foreign)], np.array([e['feat'] for e in foreign]),
+                               [e['count'] for e in foreign])
+            self._foreign_key = key
         return foreign
 
     def _mark_lost(self, trk_id):

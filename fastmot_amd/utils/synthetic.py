@@ -51,13 +51,20 @@ class SyntheticVideo:
                 pos[:, a] = np.clip(pos[:, a], 0, lim - sz)
         self._rng_seed = seed
 
-    def detections(self, frame_idx, label=1):
-        """Exactly n_ids detections: ground truth + N(0, 1) px jitter, conf U(0.5, 1)."""
+    def detections(self, frame_idx, label=1, labels=None):
+        """Exactly n_ids detections: ground truth + N(0, 1) px jitter, conf U(0.5, 1).  `labels` (several class
+        ids): object i has class labels[i % len(labels)] and the detections come sorted by class id, as
+        YOLODetector._filter_dets delivers them (detector.py:344)."""
         rng = np.random.default_rng((self._rng_seed, 7, frame_idx))
         dets = np.zeros(self.n_ids, DET_DTYPE).view(np.recarray)
         dets.tlbr = np.rint(self.gt[frame_idx % self.n_frames] + rng.normal(0, 1, (self.n_ids, 4)))
         dets.label = label
         dets.conf = rng.uniform(0.5, 1, self.n_ids)
+        if labels is not None and len(labels) > 1:
+            lab = np.sort(np.asarray(labels))[np.arange(self.n_ids) % len(labels)]
+            order = np.argsort(lab, kind='stable')
+            dets = dets[order]
+            dets.label = lab[order]
         return dets
 
 
@@ -65,8 +72,11 @@ class InjectedYOLODetector(YOLODetector):
     """YOLODetector whose postprocess() waits for the real GPU pipeline (network + decode + NMS
     on the seeded-random weights) and then returns the scripted detections of the synthetic video."""
 
-    def bind_video(self, video, label=1):
+    def bind_video(self, video, label=1, labels=None):
         self._video, self._label = video, label
+        self._labels = labels if labels is not None and len(labels) > 1 else None
+        if labels is not None and len(labels) == 1:
+            self._label = labels[0]
         self._frame_idx = 0
         self.last_real_count = 0
         self.net_ms = []          # HIP-event time of the detector's layer sequence, one entry per postprocess()
@@ -78,6 +88,6 @@ class InjectedYOLODetector(YOLODetector):
         real = super().postprocess()
         self.last_real_count = len(real)
         self.net_ms.append(self.ctx.detect_net_ms())      # the events of THIS frame's network are complete here
-        dets = self._video.detections(self._frame_idx, self._label)
+        dets = self._video.detections(self._frame_idx, self._label, self._labels)
         self._frame_idx += 1
         return dets

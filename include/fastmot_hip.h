@@ -281,6 +281,13 @@ int fm_net_profile_layers(fm_ctx* ctx, int which, int batch, int iters, double* 
  * also be made resident in HBM up front (bench: inputs resident before the timed region). */
 int fm_frame_configure(fm_ctx* ctx, int width, int height, int ring_size);
 int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr);
+/* Page-locked host buffers for frames (the reference preallocates pinned HostDeviceMem buffers,
+ * utils/inference.py:7-36, flow.py:100-118).  A frame that lies inside a buffer obtained from
+ * fm_host_alloc is copied to the device straight from where it is (no staging copy); it must stay
+ * unmodified until the step that uses it has returned (next-frame prefetch: until it has been the
+ * current frame).  Any other host pointer is staged through the ctx's own pinned buffer first. */
+int fm_host_alloc(size_t bytes, void** out);
+int fm_host_free(void* p);
 /* Next-frame prefetch (no counterpart in the reference, whose detector is synchronous per step): the
  * detector network can be started on frame t+1 while frame t is still in the ReID / association stages.
  * fm_frame_upload_next copies a host frame into the second upload slot (asynchronously, detector stream),

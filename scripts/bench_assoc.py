@@ -1,4 +1,6 @@
 """Micro-benchmark of one association stage (stage cost + LAP + readback) at the bench size."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')

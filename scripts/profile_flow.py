@@ -1,4 +1,6 @@
 """Wall-clock breakdown of Flow.predict on the synthetic 1080p/50-track clip (no detector running)."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -14,7 +16,7 @@ ctx = get_context()
 ctx.frame_configure(1920, 1080, 16)
 for i, fr in enumerate(video.frames):
     ctx.frame_ring_store(i, fr)
-mot = bench.build_mot(video)
+mot = bench.build_mot(bench.CONFIGS[1], video)
 Track._count = 0
 mot.reset(1 / 30.)
 for s in range(8):

@@ -1,4 +1,6 @@
 """Per-layer HIP-event table of a network: shape, tile-independent roofline time and achieved rate."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys
 import numpy as np
 sys.path.insert(0, '.')

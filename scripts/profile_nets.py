@@ -1,5 +1,7 @@
 """Per-network timing on the GPU: whole-run wall time (stream-synchronised) and per-layer HIP-event
 times of the conv (MFMA) launches -> achieved TFLOP/s against the 2.5 PFLOP/s dense fp16 peak."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys, time, json
 import numpy as np
 sys.path.insert(0, '.')

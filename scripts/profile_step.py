@@ -1,5 +1,7 @@
 """Host-side wall-clock breakdown of MOT.step on the bench workload (no profiler attached): wraps the
 context's C-ABI calls and the pipeline methods with perf_counter accumulators."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys, time, collections
 import numpy as np
 sys.path.insert(0, '.')
@@ -14,7 +16,7 @@ ctx = get_context()
 ctx.frame_configure(bench.SIZE[0], bench.SIZE[1], bench.RING)
 for i, fr in enumerate(video.frames):
     ctx.frame_ring_store(i, fr)
-mot = bench.build_mot(video)
+mot = bench.build_mot(bench.CONFIGS[1], video)
 Track._count = 0
 mot.reset(1 / 30.)
 

@@ -1,4 +1,6 @@
 """cProfile of MultiTracker.update on the bench workload (host-side Python cost of the association)."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import cProfile, pstats, sys, io
 sys.path.insert(0, '.')
 import bench
@@ -12,7 +14,7 @@ ctx = get_context()
 ctx.frame_configure(bench.SIZE[0], bench.SIZE[1], bench.RING)
 for i, fr in enumerate(video.frames):
     ctx.frame_ring_store(i, fr)
-mot = bench.build_mot(video)
+mot = bench.build_mot(bench.CONFIGS[1], video)
 Track._count = 0
 mot.reset(1 / 30.)
 def run(n, start):

@@ -1,5 +1,7 @@
 """Runs the same synthetic clip repeatedly through MOT.step (sequential and next-frame-prefetch modes) and
 reports any run whose tracks differ from the first one -- a race detector for the two-thread pipeline."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')

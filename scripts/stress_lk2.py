@@ -1,4 +1,6 @@
 """LK alone: images are built once, then fm_flow_lk runs repeatedly (every second call has the same roles)."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys, threading
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,5 +1,7 @@
 """Does a long deterministic kernel on the flow stream stay deterministic while grouped LightConv launches
 saturate the GPU from another host thread?  (platform vs. library bug)"""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys, threading, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,5 +1,7 @@
 """Runs one network a few times (graph replay) so that `rocprofv3 --kernel-trace` records per-dispatch
 durations; scripts/rocpd_dispatches.py then lists the last replay dispatch by dispatch."""
+import os as _os
+_os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys
 sys.path.insert(0, '.')
 from fastmot_amd.runtime import get_context

@@ -1,3 +1,4 @@
+import os
 import sys
 from pathlib import Path
 
@@ -9,6 +10,9 @@ for p in (ROOT, ROOT / 'oracle', ROOT / 'tests'):
         sys.path.insert(0, str(p))
 
 GOLDEN = ROOT / 'tests' / 'golden'
+
+# no weight files exist offline: the suites run the networks with seeded random parameters (explicit opt-in)
+os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')
 
 
 def pytest_configure(config):

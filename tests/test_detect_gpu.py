@@ -131,6 +131,24 @@ def test_reid_crop_resize_normalise(ctx):
     np.testing.assert_allclose(emb2[15:20], emb, atol=1e-6)
 
 
+def test_reid_crop_exact_2x_uses_area_average(ctx):
+    """cv2.resize(INTER_LINEAR) switches to the INTER_AREA 2x2 mean when the crop is exactly twice the network
+    input in both axes (256x512 -> 128x256); crops one pixel off stay bilinear."""
+    size = (800, 600)
+    frame = synthetic_frame(*size, seed=6)
+    ext = FeatureExtractor('OSNet025', batch_size=8, weights=RandomWeights(seed=3), size=size)
+    boxes = np.array([[100., 20., 355., 531.], [101., 20., 355., 531.], [300., 60., 555., 571.9]])
+    ext.extract_async(frame, boxes)
+    ext.postprocess()
+    inp = ctx.extract_read_input(3, 128, 256)
+    exp = cv_oracle.reid_preprocess(frame, boxes).transpose(0, 2, 3, 1)
+    np.testing.assert_allclose(inp, exp, rtol=0, atol=2.5e-3)
+    crop = frame[20:532, 100:356].astype(np.int64)
+    area = (crop[0::2, 0::2] + crop[0::2, 1::2] + crop[1::2, 0::2] + crop[1::2, 1::2] + 2) >> 2
+    mean, std = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+    np.testing.assert_allclose(inp[0], (area[..., ::-1] / 255. - mean) / std, rtol=0, atol=2.5e-3)
+
+
 def test_reid_split_batches_identical(ctx):
     """Two or four network instances running the parts of a batch concurrently (FM_NET_EXTRACTOR_B.., extract.hip) give
     the same embedding rows, bit for bit, as one instance running the whole batch -- for even, odd and

@@ -1,0 +1,75 @@
+"""a1 end to end: fastmot_amd.MOT.step (detector network -> injected detections -> real KLT on the frames ->
+OSNet -> Kalman -> association; fastmot/mot.py:125-168, tracker.py:139-293, flow.py:135-264) against the CPU
+oracle (oracle/cpu_tracker.OracleTracker + cv_oracle) on the SAME synthetic clip at the BASELINE sizes.
+
+The oracle consumes the embeddings the HIP OSNet produced (the network itself is checked against PyTorch in
+test_conv_gpu.py / test_fullsize_gpu.py), so every difference seen here comes from KLT / Kalman / association.
+Bar: track IDs, dict order, rounded boxes, life-cycle counters, history and per-track keypoint counts
+IDENTICAL on every frame; KLT boxes and the homography within the float32 LK tolerance stated below."""
+from types import SimpleNamespace
+
+import pytest
+
+import e2e_check
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+KLT_BOX_TOL_PX = 0.02      # LK points agree to ~2e-3 px (float32 summation order), boxes are affine fits of them
+H_TOL = 2e-4               # homography entries (translations are in pixels)
+
+
+def build_mot(size, video, yolo='YOLOv4_608', reid='OSNet025', batch=64):
+    import fastmot_amd.mot as mot_mod
+    from fastmot_amd.detector import YOLODetector
+    from fastmot_amd.utils.synthetic import InjectedYOLODetector
+    kw = scenes.tracker_kwargs()
+    mot_mod.YOLODetector = InjectedYOLODetector
+    try:
+        mot = mot_mod.MOT(size, detector_type='YOLO', detector_frame_skip=1, class_ids=(1,),
+                          yolo_detector_cfg=SimpleNamespace(model=yolo, conf_thresh=0.25, nms_thresh=0.5,
+                                                            max_area=800000, min_aspect_ratio=1.2,
+                                                            max_candidates=8192),
+                          feature_extractor_cfgs=(SimpleNamespace(model=reid, batch_size=batch),),
+                          tracker_cfg=SimpleNamespace(**kw))
+    finally:
+        mot_mod.YOLODetector = YOLODetector
+    mot.detector.bind_video(video)
+    return mot, kw
+
+
+def check(summary):
+    print(summary)
+    assert summary['ids_identical'], summary['first_mismatch']
+    assert summary['all_identical'], summary['first_mismatch']
+    assert summary['klt_box_max_px'] <= KLT_BOX_TOL_PX, summary
+    assert summary['H_max_abs'] <= H_TOL, summary
+
+
+@pytest.mark.parametrize('skip,n_frames,prefetch', [(1, 32, True), (5, 41, False)])
+def test_mot_step_equals_oracle_1080p_50(ctx, skip, n_frames, prefetch):
+    """BASELINE config[1] (skip 1, with the next-frame prefetch bench.py uses) and a config[0]/[2]-style
+    detector_frame_skip=5 run: 1920x1080, 50 objects, YOLOv4@608 + OSNet-x0.25."""
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    size = (1920, 1080)
+    video = SyntheticVideo(size, n_ids=50, n_frames=n_frames, seed=100)
+    mot, kw = build_mot(size, video)
+    hip, emb = e2e_check.hip_pass(mot, video, n_frames, skip, prefetch=prefetch)
+    ora, _, _ = e2e_check.oracle_pass(size, mot.extractors[0].metric.lower(), kw, video, n_frames, skip, emb)
+    summary = e2e_check.compare(hip, ora)
+    mot.tracker._clear_tracks()
+    assert summary['frames'] == n_frames and summary['max_tracks'] >= 45
+    check(summary)
+
+
+def test_mot_step_equals_oracle_small_long(ctx):
+    """A longer clip at 960x540 (objects leave / re-enter, tracks get lost and re-identified)."""
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=14, n_frames=90, seed=21)
+    mot, kw = build_mot(size, video, batch=16)
+    hip, emb = e2e_check.hip_pass(mot, video, 90, 2, prefetch=True)
+    ora, _, _ = e2e_check.oracle_pass(size, mot.extractors[0].metric.lower(), kw, video, 90, 2, emb)
+    summary = e2e_check.compare(hip, ora)
+    mot.tracker._clear_tracks()
+    check(summary)
