@@ -43,6 +43,10 @@ struct FlowState {
     int32_t* ov_idx = nullptr;                      // overlap lists (earlier rects intersecting rect k)
     int32_t* ov_off = nullptr;
     int ov_cap = 0;
+    // what the kernels read: the owned buffers above (staged calls) or the packed upload of fm_flow_prepare
+    const int32_t* v_rects = nullptr;
+    const int32_t* v_ov_idx = nullptr;
+    const int32_t* v_ov_off = nullptr;
     int32_t* bg_flags = nullptr;                    // FAST score / flags
 };
 
@@ -149,6 +153,93 @@ __global__ void scharr_kernel(const uint8_t* __restrict__ src, int w, int h, int
     d[((size_t)y * w + x) * 2 + 1] = (int16_t)dy;
 }
 
+// ---- fused pyramid build (4 launches instead of 13).  Same arithmetic, pixel for pixel, as the stand-alone
+// kernels above (which stay for the general-scale path and the image tests).
+__device__ __forceinline__ uint8_t pyrdown_px(const uint8_t* __restrict__ src, int sw, int sh, int x, int y) {
+    const int wk[5] = {1, 4, 6, 4, 1};
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, sh) * sw;
+        int rs = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) rs += wk[i] * row[reflect101(2 * x + i - 2, sw)];
+        sum += wk[j] * rs;
+    }
+    return (uint8_t)((sum + 128) >> 8);
+}
+
+__device__ __forceinline__ int scharr_px(const uint8_t* __restrict__ src, int w, int h, int x, int y) {
+    const int y0 = y > 0 ? y - 1 : (h > 1 ? 1 : 0), y2 = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+    const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+    const uint8_t* r0 = src + (size_t)y0 * w;
+    const uint8_t* r1 = src + (size_t)y * w;
+    const uint8_t* r2 = src + (size_t)y2 * w;
+    auto t0 = [&](int c) { return (r0[c] + r2[c]) * 3 + r1[c] * 10; };
+    auto t1 = [&](int c) { return r2[c] - r0[c]; };
+    const int dx = t0(xp) - t0(xm);
+    const int dy = (t1(xp) + t1(xm)) * 3 + t1(x) * 10;
+    return (int)(((unsigned)dx & 0xffffu) | ((unsigned)dy << 16));   // int16 pair (dx, dy) as one 32-bit store
+}
+
+// BGR frame -> gray (full resolution) + the half-resolution optical-flow image (cv2.resize's exact-2x path =
+// INTER_AREA 2x2 mean of the gray pixels): one thread per 2x2 block, the frame is read once.
+__global__ __launch_bounds__(256) void gray_half_kernel(const uint8_t* __restrict__ bgr, int W, int H,
+                                                        uint8_t* __restrict__ gray, uint8_t* __restrict__ half) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;      // half-resolution coordinates
+    const int hw = W >> 1;
+    if (x >= hw) return;
+    int g[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint8_t* p = bgr + ((size_t)(2 * y + j) * W + 2 * x) * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            g[j][i] = (p[3 * i] * 3735 + p[3 * i + 1] * 19235 + p[3 * i + 2] * 9798 + (1 << 14)) >> 15;
+        *reinterpret_cast<uint16_t*>(gray + (size_t)(2 * y + j) * W + 2 * x) = (uint16_t)(g[j][0] | (g[j][1] << 8));
+    }
+    half[(size_t)y * hw + x] = (uint8_t)((g[0][0] + g[0][1] + g[1][0] + g[1][1] + 2) >> 2);
+}
+
+// one pyramid level: Scharr derivatives of `src` AND its pyrDown, both read the same image (blockIdx.y < sh:
+// derivative rows, then dh rows of the next level)
+__global__ __launch_bounds__(256) void pyr_level_kernel(const uint8_t* __restrict__ src, int sw, int sh,
+                                                        int* __restrict__ deriv, uint8_t* __restrict__ dst, int dw,
+                                                        int dh) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (y < sh) {
+        if (x < sw) deriv[(size_t)y * sw + x] = scharr_px(src, sw, sh, x, y);
+        return;
+    }
+    y -= sh;
+    if (x < dw && y < dh) dst[(size_t)y * dw + x] = pyrdown_px(src, sw, sh, x, y);
+}
+
+// the small tail of the pyramid (level `first` and above, <= ~33 k pixels at 1080p) in ONE workgroup: each level
+// depends on the complete previous one, so separate launches cost a dependent-launch boundary per level for a
+// few microseconds of work.  Global stores of one workgroup are visible to its own waves after __syncthreads().
+struct PyrTail {
+    uint8_t* img[MAX_LEVELS];
+    int* deriv[MAX_LEVELS];
+    int w[MAX_LEVELS], h[MAX_LEVELS];
+    int first, levels;
+};
+
+__global__ __launch_bounds__(1024) void pyr_tail_kernel(PyrTail t) {
+    const int tid = threadIdx.x;
+    for (int l = t.first; l < t.levels; ++l) {
+        const int w = t.w[l], h = t.h[l];
+        // level l is complete here (previous launch, or the pyrDown below + barrier)
+        for (int i = tid; i < w * h; i += 1024) t.deriv[l][i] = scharr_px(t.img[l], w, h, i % w, i / w);
+        if (l + 1 < t.levels) {
+            const int dw = t.w[l + 1], dh = t.h[l + 1];
+            for (int i = tid; i < dw * dh; i += 1024) t.img[l + 1][i] = pyrdown_px(t.img[l], w, h, i % dw, i / dw);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- pyramidal Lucas-Kanade (video/lkpyramid.cpp LKTrackerInvoker), one thread per point
 struct LKArgs {
     const uint8_t* I[MAX_LEVELS];
@@ -161,33 +252,25 @@ struct LKArgs {
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-// butterfly sum over the wavefront that owns one point.  The first five steps are the 32-lane butterfly the
-// parity tests were written against; the sixth adds the (all-zero) upper half, so the value is unchanged.
-__device__ __forceinline__ float group_sum32(float v) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
-// One wavefront (64 lanes) per point: lane g < win*win owns window pixel (g / win, g % win); sums over the
-// window are butterfly reductions (float32; the summation order differs from OpenCV's scalar loop, results
-// agree to ~1e-4 px).  The control flow (pyramid levels skipped, iteration counts) depends on the point, so
-// it must be WAVE-uniform: with two points per wavefront (32 lanes each, the first version) the two halves
-// diverged, and the results of single points then varied from run to run whenever other streams kept the
-// CUs' LDS pipelines busy (reproduced in isolation: scripts/stress_lk2.py; constant images, constant
-// arguments, no such effect with one point per wavefront or with equal trip counts).  39 idle lanes are
-// the price; the kernel is latency bound anyway.
-__global__ __launch_bounds__(256) void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
-                                                 float* __restrict__ next_pts, uint8_t* __restrict__ status,
-                                                 float* __restrict__ err) {
-    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int pt = gidx >> 6, g = gidx & 63;
-    if (pt >= n) return;                       // the whole wavefront exits together
-    const int win = a.win;
-    const bool lane_on = g < win * win;
-    const int wy = lane_on ? g / win : 0, wx = lane_on ? g % win : 0;
-    const float half = (win - 1) * 0.5f;
+// One LANE per point, the window walked sequentially in (y, x) order by that lane: every float32 sum (A11, A12,
+// A22, b1, b2, the error) is accumulated in exactly the order of LKTrackerInvoker's scalar loops -- bit-identical to
+// oracle/cv_oracle.calc_optical_flow_pyr_lk (the first version reduced over a wavefront with a butterfly: results
+// agreed to ~1e-4 px only, which is enough to flip an inlier decision now and then and let the keypoint sets of the
+// two implementations drift apart over a clip; tests/test_e2e_parity_gpu.py).  There are no cross-lane operations
+// at all, so the point-dependent control flow (levels skipped, iteration counts) is plain predication; the only
+// wave-level construct is the uniform early exit of the iteration loop.  A wavefront carries PTS points (its other
+// lanes idle): the kernel is bound by the latency of scattered byte loads, and the ~6 k points of a frame give
+// only a few hundred wavefronts -- the GPU stays free for the detector network that runs concurrently.
+template <int WIN, int PTS>
+__global__ __launch_bounds__(64) void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+                                                float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                float* __restrict__ err) {
+    const int lane = threadIdx.x;
+    const int pt_raw = blockIdx.x * PTS + lane;
+    const bool lane_valid = lane < PTS && pt_raw < n;
+    const int pt = lane_valid ? pt_raw : (n - 1);          // idle lanes shadow a valid point and never write
+    constexpr int W2 = WIN * WIN;
+    const float half = (WIN - 1) * 0.5f;
     const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
     float nx = 0.f, ny = 0.f;
     bool st = true;
@@ -199,6 +282,7 @@ __global__ __launch_bounds__(256) void lk_kernel(LKArgs a, int n, const float* _
         iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
         iw11 = (1 << 14) - iw00 - iw01 - iw10;
     };
+    int Iv[W2], Ix[W2], Iy[W2];
     for (int level = a.levels - 1; level >= 0; --level) {
         const int w = a.w[level], h = a.h[level];
         const uint8_t* I = a.I[level];
@@ -210,87 +294,124 @@ __global__ __launch_bounds__(256) void lk_kernel(LKArgs a, int n, const float* _
         else { nx *= 2.f; ny *= 2.f; }
         ppx -= half; ppy -= half;
         const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
-        if (ipx < -win || ipx >= w || ipy < -win || ipy >= h) {
+        bool act = lane_valid;
+        if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
             if (level == 0) { st = false; er = 0.f; }
-            continue;
+            act = false;
         }
         int iw00, iw01, iw10, iw11;
-        weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
-        int ival = 0, ixval = 0, iyval = 0;
-        if (lane_on) {
-            const int xx0 = ipx + wx, xx1 = xx0 + 1, yy0 = ipy + wy, yy1 = yy0 + 1;
-            const uint8_t* r0 = I + (size_t)reflect101(yy0, h) * w;
-            const uint8_t* r1 = I + (size_t)reflect101(yy1, h) * w;
-            const int c0 = reflect101(xx0, w), c1 = reflect101(xx1, w);
-            ival = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5);
-            // derivative image is zero outside (BORDER_CONSTANT), lkpyramid.cpp
-            auto dv = [&](int xx, int yy) -> int2 {
-                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return make_int2(0, 0);
-                const int v = *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
-                return make_int2((int)(short)(v & 0xffff), (int)(short)(v >> 16));
+        float A11 = 0.f, A12 = 0.f, A22 = 0.f;
+        if (act) {
+            weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
+            // (WIN+1)^2 source pixels of I and of the derivative image (zero outside: BORDER_CONSTANT)
+            int rowI[WIN + 1], colI[WIN + 1];
+#pragma unroll
+            for (int i = 0; i <= WIN; ++i) {
+                rowI[i] = reflect101(ipy + i, h) * w;
+                colI[i] = reflect101(ipx + i, w);
+            }
+            auto dv = [&](int xx, int yy) -> int {
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return 0;
+                return *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
             };
-            const int2 d00 = dv(xx0, yy0), d01 = dv(xx1, yy0), d10 = dv(xx0, yy1), d11 = dv(xx1, yy1);
-            ixval = LK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
-            iyval = LK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
+#pragma unroll
+            for (int y = 0; y < WIN; ++y) {
+#pragma unroll
+                for (int x = 0; x < WIN; ++x) {
+                    const int i00 = I[rowI[y] + colI[x]], i01 = I[rowI[y] + colI[x + 1]];
+                    const int i10 = I[rowI[y + 1] + colI[x]], i11 = I[rowI[y + 1] + colI[x + 1]];
+                    const int ival = LK_DESCALE(i00 * iw00 + i01 * iw01 + i10 * iw10 + i11 * iw11, 14 - 5);
+                    const int d00 = dv(ipx + x, ipy + y), d01 = dv(ipx + x + 1, ipy + y);
+                    const int d10 = dv(ipx + x, ipy + y + 1), d11 = dv(ipx + x + 1, ipy + y + 1);
+                    const int ixval = LK_DESCALE((int)(short)(d00 & 0xffff) * iw00 + (int)(short)(d01 & 0xffff) * iw01 +
+                                                 (int)(short)(d10 & 0xffff) * iw10 + (int)(short)(d11 & 0xffff) * iw11, 14);
+                    const int iyval = LK_DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 +
+                                                 (d11 >> 16) * iw11, 14);
+                    Iv[y * WIN + x] = ival; Ix[y * WIN + x] = ixval; Iy[y * WIN + x] = iyval;
+                    A11 += (float)(ixval * ixval);
+                    A12 += (float)(ixval * iyval);
+                    A22 += (float)(iyval * iyval);
+                }
+            }
+            A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         }
-        const float A11 = group_sum32((float)(ixval * ixval)) * FLT_SCALE;
-        const float A12 = group_sum32((float)(ixval * iyval)) * FLT_SCALE;
-        const float A22 = group_sum32((float)(iyval * iyval)) * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
-        if (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f) {
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
+        if (act && (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f)) {
             if (level == 0) st = false;
-            continue;
+            act = false;
         }
         Dt = 1.f / Dt;
-        nx -= half; ny -= half;
+        float cx = nx - half, cy = ny - half;
         float pdx = 0.f, pdy = 0.f;
-        float outx = nx + half, outy = ny + half;
-        bool running = true;
+        float outx = nx, outy = ny;
+        if (act) { outx = cx + half; outy = cy + half; }
+        bool running = act;
+        auto sample_J = [&](float fx, float fy, int inx, int iny, int (&diffs)[W2]) {
+            weights(fx - inx, fy - iny, iw00, iw01, iw10, iw11);
+            int rowJ[WIN + 1], colJ[WIN + 1];
+#pragma unroll
+            for (int i = 0; i <= WIN; ++i) {
+                rowJ[i] = reflect101(iny + i, h) * w;
+                colJ[i] = reflect101(inx + i, w);
+            }
+            int jv[(WIN + 1) * (WIN + 1)];
+#pragma unroll
+            for (int y = 0; y <= WIN; ++y)
+#pragma unroll
+                for (int x = 0; x <= WIN; ++x) jv[y * (WIN + 1) + x] = J[rowJ[y] + colJ[x]];
+#pragma unroll
+            for (int y = 0; y < WIN; ++y)
+#pragma unroll
+                for (int x = 0; x < WIN; ++x)
+                    diffs[y * WIN + x] = LK_DESCALE(jv[y * (WIN + 1) + x] * iw00 + jv[y * (WIN + 1) + x + 1] * iw01 +
+                                                    jv[(y + 1) * (WIN + 1) + x] * iw10 + jv[(y + 1) * (WIN + 1) + x + 1] * iw11,
+                                                    14 - 5) - Iv[y * WIN + x];
+        };
         for (int j = 0; j < a.max_count; ++j) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-            if (running && (inx < -win || inx >= w || iny < -win || iny >= h)) {
+            const int inx = (int)floorf(cx), iny = (int)floorf(cy);
+            if (running && (inx < -WIN || inx >= w || iny < -WIN || iny >= h)) {
                 if (level == 0) st = false;
                 running = false;
             }
-            if (!running) break;                 // uniform within the 32-lane group
-            weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
-            int diff = 0;
-            if (lane_on) {
-                const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
-                const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
-                const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
-                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
+            if (__ballot(running) == 0ull) break;            // uniform: every lane of the wavefront is here
+            if (running) {
+                int diffs[W2];
+                sample_J(cx, cy, inx, iny, diffs);
+                float b1 = 0.f, b2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < W2; ++k) {
+                    b1 += (float)(diffs[k] * Ix[k]);
+                    b2 += (float)(diffs[k] * Iy[k]);
+                }
+                b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+                const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+                cx += dx; cy += dy;
+                outx = cx + half; outy = cy + half;
+                if (dx * dx + dy * dy <= a.eps2) running = false;
+                else if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                    outx -= dx * 0.5f; outy -= dy * 0.5f;
+                    running = false;
+                }
+                pdx = dx; pdy = dy;
             }
-            const float b1 = group_sum32((float)(diff * ixval)) * FLT_SCALE;
-            const float b2 = group_sum32((float)(diff * iyval)) * FLT_SCALE;
-            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
-            nx += dx; ny += dy;
-            outx = nx + half; outy = ny + half;
-            if (dx * dx + dy * dy <= a.eps2) break;
-            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
-                outx -= dx * 0.5f; outy -= dy * 0.5f;
-                break;
-            }
-            pdx = dx; pdy = dy;
         }
-        nx = outx; ny = outy;
-        if (st && level == 0) {
+        if (act) { nx = outx; ny = outy; }
+        if (act && st && level == 0) {
             const float ex = nx - half, ey = ny - half;
             const int inx = (int)floorf(ex), iny = (int)floorf(ey);
-            if (inx < -win || inx >= w || iny < -win || iny >= h) { st = false; continue; }
-            weights(ex - inx, ey - iny, iw00, iw01, iw10, iw11);
-            int diff = 0;
-            if (lane_on) {
-                const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
-                const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
-                const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
-                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
+            if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) st = false;
+            else {
+                int diffs[W2];
+                sample_J(ex, ey, inx, iny, diffs);
+                float e = 0.f;
+#pragma unroll
+                for (int k = 0; k < W2; ++k) e += fabsf((float)diffs[k]);
+                er = e * 1.f / (32 * WIN * WIN);
             }
-            er = group_sum32(fabsf((float)diff)) * 1.f / (32 * win * win);
         }
     }
-    if (g == 0) {
+    if (lane_valid) {
         next_pts[2 * pt] = nx;
         next_pts[2 * pt + 1] = ny;
         status[pt] = st ? 1 : 0;
@@ -315,6 +436,24 @@ __device__ __forceinline__ bool covered_any(const int32_t* rects, int n, int x, 
         const int32_t* r = rects + 4 * j;
         if (x >= r[0] && x <= r[2] && y >= r[1] && y <= r[3]) return true;
     }
+    return false;
+}
+
+// i / w for 0 <= i < 2^23 without the ~40-instruction integer division: float estimate + one correction step
+// (the estimate is off by at most one for any w the frame sizes allow; the correction makes it exact).
+__device__ __forceinline__ int fast_div(int i, int w, float inv_w) {
+    int q = (int)(((float)i + 0.5f) * inv_w);
+    const int r = i - q * w;
+    q += r >= w ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
+
+constexpr int OV_LDS = 32;     // overlapping earlier rects of one track kept in LDS (more: global lists)
+
+__device__ __forceinline__ bool covered_lds(const int* s_ov, int cnt, int x, int y) {
+    for (int q = 0; q < cnt; ++q)
+        if (x >= s_ov[4 * q] && x <= s_ov[4 * q + 2] && y >= s_ov[4 * q + 1] && y <= s_ov[4 * q + 3]) return true;
     return false;
 }
 
@@ -361,19 +500,31 @@ __global__ __launch_bounds__(256) void prepare_kernel(const int32_t* __restrict_
                                                       const int32_t* __restrict__ kp_off, double feat_density,
                                                       double feat_dist_factor, int32_t* __restrict__ area,
                                                       uint8_t* __restrict__ keep, uint8_t* __restrict__ needy,
-                                                      int32_t* __restrict__ min_dist) {
+                                                      int32_t* __restrict__ min_dist,
+                                                      uint8_t* __restrict__ needy_host) {
     const int k = blockIdx.x, tid = threadIdx.x;
     const int32_t* r = rects + 4 * k;
-    const int w = r[2] - r[0] + 1, h = r[3] - r[1] + 1;
+    const int r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    const int w = r2 - r0 + 1, h = r3 - r1 + 1;
     const int32_t* list = ov.idx + ov.off[k];
     const int cnt = ov.off[k + 1] - ov.off[k];
+    __shared__ int s_ov[4 * OV_LDS];
+    const bool in_lds = cnt <= OV_LDS;
+    if (in_lds && tid < 4 * cnt) s_ov[tid] = rects[4 * list[tid >> 2] + (tid & 3)];
+    __syncthreads();
+    auto covered = [&](int x, int y) { return in_lds ? covered_lds(s_ov, cnt, x, y) : covered_by(rects, list, cnt, x, y); };
     int c = 0, kept = 0;
     if (cnt == 0) c = tid == 0 ? w * h : 0;
-    else
-        for (int i = tid; i < w * h; i += 256) c += covered_by(rects, list, cnt, r[0] + i % w, r[1] + i / w) ? 0 : 1;
+    else {
+        const float inv_w = 1.f / (float)w;
+        for (int i = tid; i < w * h; i += 256) {
+            const int y = fast_div(i, w, inv_w), x = i - y * w;
+            c += covered(r0 + x, r1 + y) ? 0 : 1;
+        }
+    }
     for (int i = kp_off[k] + tid; i < kp_off[k + 1]; i += 256) {
         const int x = (int)rintf(kps[2 * i]), y = (int)rintf(kps[2 * i + 1]);
-        const bool ok = x >= r[0] && x <= r[2] && y >= r[1] && y <= r[3] && !covered_by(rects, list, cnt, x, y);
+        const bool ok = x >= r0 && x <= r2 && y >= r1 && y <= r3 && !covered(x, y);
         keep[i] = ok ? 1 : 0;
         kept += ok ? 1 : 0;
     }
@@ -387,7 +538,9 @@ __global__ __launch_bounds__(256) void prepare_kernel(const int32_t* __restrict_
     }
     if (tid == 0) {
         area[k] = red[0];
-        needy[k] = (double)red2[0] < feat_density * (double)red[0] ? 1 : 0;
+        const uint8_t nd = (double)red2[0] < feat_density * (double)red[0] ? 1 : 0;
+        needy[k] = nd;
+        if (needy_host) needy_host[k] = nd;
         const int md = (int)rint(sqrt((double)red[0]) * feat_dist_factor);
         min_dist[k] = md > 1 ? md : 1;
     }
@@ -419,7 +572,7 @@ __global__ void eig_kernel(const uint8_t* __restrict__ img, int stride, const Cr
     if (needy && !needy[c.k]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.w * c.h) return;
-    const int x = i % c.w, y = i / c.w;
+    const int y = fast_div(i, c.w, 1.f / (float)c.w), x = i - y * c.w;
     const float scale = 1.f / (4.f * block_size * 255.f);
     float sxx = 0.f, sxy = 0.f, syy = 0.f;
     const int r = block_size / 2;
@@ -438,20 +591,24 @@ __global__ void eig_kernel(const uint8_t* __restrict__ img, int stride, const Cr
 
 // one block per needy track: masked max -> threshold -> 3x3 local maxima -> bitonic sort in LDS ->
 // min-distance selection on a cell grid (cell = minDistance, <= 4 accepted corners per cell, the
-// same 3x3-cell neighbourhood test as featureselect.cpp) -> ellipse filter
+// same 3x3-cell neighbourhood test as featureselect.cpp) -> ellipse filter.
+// The min-eigenvalue crop is staged in LDS first (one coalesced pass; the two scans below read every value
+// ten times): with the map in global memory the scans were a chain of dependent L2 round trips per
+// iteration and the kernel took 180-330 us on the benchmark crops.
 constexpr int GFTT_MAX_CAND = 4096;      // sorted in LDS (32 KB)
 constexpr int GFTT_MAX_CELLS = 1536;     // x 4 slots x 4 B = 24 KB
+constexpr int GFTT_BLK = 1024;
 
-__global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __restrict__ crops,
-                                                          const int32_t* __restrict__ rects, Overlaps ov,
-                                                          const float* __restrict__ eig, float quality,
-                                                          int max_corners, const int32_t* __restrict__ min_dist,
-                                                          const double* __restrict__ full_tlbr,
-                                                          float* __restrict__ pts_out, int cap,
-                                                          int32_t* __restrict__ counts,
-                                                          const uint8_t* __restrict__ needy,
-                                                          int32_t* __restrict__ compact_total,
-                                                          int32_t* __restrict__ compact_off) {
+__global__ __launch_bounds__(GFTT_BLK) void gftt_select_kernel(const CropArgs* __restrict__ crops,
+                                                               const int32_t* __restrict__ rects, Overlaps ov,
+                                                               const float* __restrict__ eig, float quality,
+                                                               int max_corners, const int32_t* __restrict__ min_dist,
+                                                               const double* __restrict__ full_tlbr,
+                                                               float* __restrict__ pts_out, int cap,
+                                                               int32_t* __restrict__ counts,
+                                                               const uint8_t* __restrict__ needy,
+                                                               int32_t* __restrict__ compact_total,
+                                                               int32_t* __restrict__ compact_off, int eig_lds_floats) {
     const int t = blockIdx.x, tid = threadIdx.x;
     const CropArgs c = crops[t];
     if (needy && !needy[c.k]) {            // enough propagated keypoints: nothing to detect
@@ -461,23 +618,40 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
         }
         return;
     }
-    const float* e = eig + c.eig_off;
+    extern __shared__ __attribute__((aligned(16))) float s_eig[];
+    const int npx = c.w * c.h;
+    const bool staged = npx <= eig_lds_floats;
+    const float* eg = eig + c.eig_off;
+    if (staged)
+        for (int i = tid; i < npx; i += GFTT_BLK) s_eig[i] = eg[i];
+    const float* e = staged ? s_eig : eg;
     const int32_t* list = ov.idx + ov.off[c.k];
     const int lcnt = ov.off[c.k + 1] - ov.off[c.k];
-    __shared__ float red[256];
+    __shared__ int s_ov[4 * OV_LDS];
+    const bool ov_lds = lcnt <= OV_LDS;
+    if (ov_lds && tid < 4 * lcnt) s_ov[tid] = rects[4 * list[tid >> 2] + (tid & 3)];
+    __shared__ float red[GFTT_BLK];
     __shared__ int s_n;
     __shared__ unsigned long long keys[GFTT_MAX_CAND];
     __shared__ int cells[GFTT_MAX_CELLS * 4];
+    __syncthreads();
+    auto covered = [&](int x, int y) {
+        return ov_lds ? covered_lds(s_ov, lcnt, x, y) : covered_by(rects, list, lcnt, x, y);
+    };
+    const float inv_w = 1.f / (float)c.w;
     // masked maximum (minMaxLoc with mask)
     float mx = 0.f;
-    for (int i = tid; i < c.w * c.h; i += 256) {
-        const int x = i % c.w, y = i / c.w;
-        if (lcnt == 0 || !covered_by(rects, list, lcnt, c.x0 + x, c.y0 + y)) mx = fmaxf(mx, e[i]);
+    for (int i = tid; i < npx; i += GFTT_BLK) {
+        if (lcnt == 0) mx = fmaxf(mx, e[i]);
+        else {
+            const int y = fast_div(i, c.w, inv_w), x = i - y * c.w;
+            if (!covered(c.x0 + x, c.y0 + y)) mx = fmaxf(mx, e[i]);
+        }
     }
     red[tid] = mx;
     if (tid == 0) s_n = 0;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = GFTT_BLK / 2; off > 0; off >>= 1) {
         if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
         __syncthreads();
     }
@@ -486,16 +660,18 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
     // candidates: val > thr, val >= 8 neighbours (dilate inside the crop), mask set, 1-px border skipped.
     // key = (float bits of val << 32) | raster index : descending 64-bit order == (val desc, index desc),
     // the order of std::sort(..., greaterThanPtr) in featureselect.cpp
-    for (int i = tid; i < c.w * c.h; i += 256) {
-        const int x = i % c.w, y = i / c.w;
-        if (x < 1 || y < 1 || x >= c.w - 1 || y >= c.h - 1) continue;
+    for (int i = tid; i < npx; i += GFTT_BLK) {
         const float v = e[i];
         if (!(v > thr) || v == 0.f) continue;
+        const int y = fast_div(i, c.w, inv_w), x = i - y * c.w;
+        if (x < 1 || y < 1 || x >= c.w - 1 || y >= c.h - 1) continue;
         bool is_max = true;
-        for (int j = -1; j <= 1 && is_max; ++j)
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
             for (int ii = -1; ii <= 1; ++ii)
-                if (e[(y + j) * c.w + x + ii] > v) { is_max = false; break; }
-        if (!is_max || (lcnt && covered_by(rects, list, lcnt, c.x0 + x, c.y0 + y))) continue;
+                if (e[i + j * c.w + ii] > v) is_max = false;
+        if (!is_max || (lcnt && covered(c.x0 + x, c.y0 + y))) continue;
         const int slot = atomicAdd(&s_n, 1);
         if (slot < GFTT_MAX_CAND) keys[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
     }
@@ -503,11 +679,11 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
     const int n = min(s_n, GFTT_MAX_CAND);
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
-    for (int i = n + tid; i < np2; i += 256) keys[i] = 0ull;     // padding sorts last
+    for (int i = n + tid; i < np2; i += GFTT_BLK) keys[i] = 0ull;     // padding sorts last
     __syncthreads();
     for (int k2 = 2; k2 <= np2; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += 256) {
+            for (int i = tid; i < np2; i += GFTT_BLK) {
                 const int l = i ^ j;
                 if (l > i) {
                     const unsigned long long a0 = keys[i], a1 = keys[l];
@@ -524,7 +700,7 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
     __shared__ short acc_x[1024], acc_y[1024];
     __shared__ int s_acc;
     if (use_grid)
-        for (int i = tid; i < gw * gh * 4; i += 256) cells[i] = -1;
+        for (int i = tid; i < gw * gh * 4; i += GFTT_BLK) cells[i] = -1;
     if (tid == 0) s_acc = 0;
     __syncthreads();
     // Greedy min-distance selection (featureselect.cpp: candidates in sorted order, one is accepted iff no
@@ -534,9 +710,10 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
     //   2. the survivors are resolved in order inside the batch: the first survivor is accepted and knocks
     //      out the later survivors closer than minDistance, repeat.
     // Once the crop is covered nearly every candidate dies in step 1, so a batch costs one pass instead of
-    // 64 serial iterations (the kernel was 290 us on the benchmark crops, >80 % of it in this loop).
+    // 64 serial iterations.
     if (tid < 64) {
         const int md2 = md * md;
+        const float inv_md = 1.f / (float)md;
         const int limit = min(max_corners, 1024);
         int nacc = 0;
         for (int base = 0; base < n && nacc < limit; base += 64) {
@@ -545,10 +722,10 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
             bool alive = q < n;
             if (alive) {
                 const int ri = (int)(keys[q] & 0xffffffffu);
-                x = ri % c.w;
-                y = ri / c.w;
+                y = fast_div(ri, c.w, inv_w);
+                x = ri - y * c.w;
                 if (use_grid) {
-                    const int cx0 = x / md, cy0 = y / md;
+                    const int cx0 = fast_div(x, md, inv_md), cy0 = fast_div(y, md, inv_md);
                     for (int cyn = max(cy0 - 1, 0); cyn <= min(cy0 + 1, gh - 1) && alive; ++cyn)
                         for (int cxn = max(cx0 - 1, 0); cxn <= min(cx0 + 1, gw - 1) && alive; ++cxn) {
                             const int* cell = cells + (cyn * gw + cxn) * 4;
@@ -576,7 +753,7 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
                     acc_x[nacc] = (short)fx;
                     acc_y[nacc] = (short)fy;
                     if (use_grid) {
-                        int* cell = cells + ((fy / md) * gw + fx / md) * 4;
+                        int* cell = cells + (fast_div(fy, md, inv_md) * gw + fast_div(fx, md, inv_md)) * 4;
                         for (int sidx = 0; sidx < 4; ++sidx)
                             if (cell[sidx] < 0) { cell[sidx] = (fy << 16) | fx; break; }
                     }
@@ -602,7 +779,7 @@ __global__ __launch_bounds__(256) void gftt_select_kernel(const CropArgs* __rest
         const double* b = full_tlbr + 4 * t;
         const double cx = (b[0] + b[2]) / 2, cy = (b[1] + b[3]) / 2;
         const double ax = (b[2] - b[0] + 1) * 0.5, ay = (b[3] - b[1] + 1) * 0.5;
-        for (int q = tid; q < nacc_all; q += 256) {
+        for (int q = tid; q < nacc_all; q += GFTT_BLK) {
             const float px = (float)acc_x[q] + (float)c.x0, py = (float)acc_y[q] + (float)c.y0;
             const double ux = ((double)px - cx) / ax, uy = ((double)py - cy) / ay;
             inside[q] = ux * ux + uy * uy <= 1. ? 1 : 0;
@@ -694,7 +871,9 @@ __global__ void fast_flag_kernel(const int32_t* __restrict__ score, int w, int h
 // raster-order compaction with ONE block-wide scan: thread t owns a contiguous pixel segment
 __global__ __launch_bounds__(1024) void fast_compact_kernel(const uint8_t* __restrict__ flag, int w, int h,
                                                             float* __restrict__ pts, int cap,
-                                                            int32_t* __restrict__ n_out) {
+                                                            int32_t* __restrict__ n_out,
+                                                            const int32_t* __restrict__ new_total,
+                                                            int32_t* __restrict__ totals_host) {
     __shared__ int s_cnt[1024];
     const int tid = threadIdx.x;
     const int total = w * h;
@@ -719,12 +898,61 @@ __global__ __launch_bounds__(1024) void fast_compact_kernel(const uint8_t* __res
             }
             ++pos;
         }
-    if (tid == 1023) *n_out = s_cnt[1023];
+    if (tid == 1023) {
+        *n_out = s_cnt[1023];
+        if (totals_host) {            // [0] = new keypoints (gftt_select_kernel, earlier on this stream), [1] = background
+            totals_host[0] = new_total[0];
+            totals_host[1] = s_cnt[1023];
+        }
+    }
+}
+
+// dynamic LDS of gftt_select_kernel: the min-eigenvalue crop (up to GFTT_EIG_LDS floats next to ~65 KB of static
+// arrays; 160 KB per workgroup on gfx950).  Larger crops (4K frames) are read from global memory.
+constexpr int GFTT_EIG_LDS = 23 * 1024;
+
+int gftt_lds_bytes(int max_area) {
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gftt_select_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GFTT_EIG_LDS * 4);
+        configured = true;
+    }
+    return (max_area <= GFTT_EIG_LDS ? max_area : 0) * 4;
 }
 
 int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
     hipStream_t s = ctx->s_flow;
     const int n = ctx->frame_w * ctx->frame_h;
+    static const bool fused = !(getenv("FASTMOT_PYR_FUSED") && atoi(getenv("FASTMOT_PYR_FUSED")) == 0);
+    if (fused && f->W == 2 * f->lw[0] && f->H == 2 * f->lh[0] && (f->W & 1) == 0) {
+        // gray + half-resolution image in one pass over the frame; levels 0 and 1 as one launch each
+        // (derivatives + next level); everything from level 2 on in one workgroup
+        hipLaunchKernelGGL(gray_half_kernel, dim3((f->lw[0] + 255) / 256, f->lh[0]), dim3(256), 0, s, ctx->frame_cur,
+                           f->W, f->H, f->gray[set], f->pyr[set][0]);
+        const int tail = f->levels > 2 ? 2 : f->levels;
+        for (int l = 0; l < tail; ++l) {
+            const bool has_next = l + 1 < f->levels;
+            hipLaunchKernelGGL(pyr_level_kernel, dim3((f->lw[l] + 255) / 256, f->lh[l] + (has_next ? f->lh[l + 1] : 0)),
+                               dim3(256), 0, s, f->pyr[set][l], f->lw[l], f->lh[l],
+                               reinterpret_cast<int*>(f->deriv[set][l]), has_next ? f->pyr[set][l + 1] : nullptr,
+                               has_next ? f->lw[l + 1] : 0, has_next ? f->lh[l + 1] : 0);
+        }
+        if (f->levels > 2) {
+            PyrTail t{};
+            for (int l = 0; l < f->levels; ++l) {
+                t.img[l] = f->pyr[set][l];
+                t.deriv[l] = reinterpret_cast<int*>(f->deriv[set][l]);
+                t.w[l] = f->lw[l];
+                t.h[l] = f->lh[l];
+            }
+            t.first = 2;
+            t.levels = f->levels;
+            hipLaunchKernelGGL(pyr_tail_kernel, dim3(1), dim3(1024), 0, s, t);
+        }
+        FM_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(gray_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->frame_cur, f->gray[set], n);
     hipLaunchKernelGGL(resize_linear_kernel, dim3((f->lw[0] + 255) / 256, f->lh[0]), dim3(256), 0, s,
                        f->gray[set], f->W, f->H, f->pyr[set][0], f->lw[0], f->lh[0]);
@@ -743,7 +971,7 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
 
 extern "C" int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg) {
     FM_CHECK_ARG(ctx && cfg && ctx->frame_w > 0);
-    FM_CHECK_ARG(cfg->win_size >= 3 && cfg->win_size * cfg->win_size <= 32 && cfg->max_level >= 0 && cfg->max_level < MAX_LEVELS);
+    FM_CHECK_ARG((cfg->win_size == 3 || cfg->win_size == 5) && cfg->max_level >= 0 && cfg->max_level < MAX_LEVELS);   // LK window instances
     FM_CHECK_ARG(cfg->block_size == 3 || cfg->block_size == 5);
     FM_HIP(hipDeviceSynchronize());
     if (ctx->flow) fm_flow_free(ctx->flow);
@@ -860,6 +1088,7 @@ extern "C" int fm_flow_targets(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     FM_HIP(hipMemcpyAsync(f->rects, f->tgt_in.dev<char>() + o_rect, sizeof(int32_t) * 4 * nT, hipMemcpyDeviceToDevice, s));
     FM_HIP(hipMemcpyAsync(f->ov_off, f->tgt_in.dev<char>() + o_ovoff, sizeof(int32_t) * (nT + 1), hipMemcpyDeviceToDevice, s));
     if (n_ov) FM_HIP(hipMemcpyAsync(f->ov_idx, f->tgt_in.dev<char>() + o_ovidx, sizeof(int32_t) * n_ov, hipMemcpyDeviceToDevice, s));
+    f->v_rects = f->rects; f->v_ov_idx = f->ov_idx; f->v_ov_off = f->ov_off;
     const Overlaps ov{f->ov_idx, f->ov_off};
     int32_t* d_area = f->tgt_out.dev<int32_t>();
     uint8_t* d_keep = reinterpret_cast<uint8_t*>(d_area + nT);
@@ -918,10 +1147,11 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
                        reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, nullptr);
     float* d_pts = f->det_out.dev<float>();
     int32_t* d_cnt = reinterpret_cast<int32_t*>(d_pts + 2 * (size_t)n * cap);
-    hipLaunchKernelGGL(gftt_select_kernel, dim3(n), dim3(256), 0, s, reinterpret_cast<const CropArgs*>(db + o_crop),
-                       f->rects, Overlaps{f->ov_idx, f->ov_off}, f->eig, (float)f->cfg.quality_level,
+    hipLaunchKernelGGL(gftt_select_kernel, dim3(n), dim3(GFTT_BLK), gftt_lds_bytes(max_area), s, reinterpret_cast<const CropArgs*>(db + o_crop),
+                       f->v_rects, Overlaps{f->v_ov_idx, f->v_ov_off}, f->eig, (float)f->cfg.quality_level,
                        f->cfg.max_corners, reinterpret_cast<const int32_t*>(db + o_md),
-                       reinterpret_cast<const double*>(db + o_box), d_pts, cap, d_cnt, nullptr, nullptr, nullptr);
+                       reinterpret_cast<const double*>(db + o_box), d_pts, cap, d_cnt, nullptr, nullptr, nullptr,
+                       gftt_lds_bytes(max_area) / 4);
     FM_HIP(hipGetLastError());
     FM_HIP(hipMemcpyAsync(f->det_out.h, f->det_out.d, out_bytes, hipMemcpyDeviceToHost, s));
     FM_HIP(hipStreamSynchronize(s));
@@ -943,9 +1173,9 @@ extern "C" int fm_flow_background(fm_ctx* ctx, int cap, float* pts_out, int* n_o
                        f->cfg.fast_thresh, f->bg_flags);
     int32_t* d_n = f->bg_flags + (size_t)bw * bh;
     uint8_t* d_flag = reinterpret_cast<uint8_t*>(d_n + 8);
-    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->rects,
+    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->v_rects,
                        f->nT, f->W, f->H, d_flag);
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh, f->bg_out.dev<float>(), cap, d_n);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh, f->bg_out.dev<float>(), cap, d_n, nullptr, nullptr);
     FM_HIP(hipGetLastError());
     FM_HIP(hipMemcpyAsync(f->bg_out.host<char>() + sizeof(float) * 2 * cap, d_n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     FM_HIP(hipMemcpyAsync(f->bg_out.h, f->bg_out.d, sizeof(float) * 2 * cap, hipMemcpyDeviceToHost, s));
@@ -973,8 +1203,9 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const size_t out_bytes = o_err + sizeof(float) * n;
         if ((rc = f->lk_out.reserve(out_bytes))) return rc;
         FM_HIP(hipStreamSynchronize(s));
+        // points in, results out: through device-mapped pinned host memory (no blit copies around a ~50 KB
+        // exchange; every lane reads its 8 bytes once and writes 13)
         memcpy(f->lk_in.h, prev_pts, sizeof(float) * 2 * n);
-        FM_HIP(hipMemcpyAsync(f->lk_in.d, f->lk_in.h, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
         const int p = f->prev, c = p ^ 1;
         LKArgs a{};
         for (int l = 0; l < f->levels; ++l) {
@@ -990,12 +1221,26 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const double eps = std::min(std::max(f->cfg.epsilon, 0.), 10.);
         a.eps2 = (float)(eps * eps);
         a.min_eig_thresh = 1e-4f;
-        char* o = f->lk_out.dev<char>();
-        hipLaunchKernelGGL(lk_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, f->lk_in.dev<float>(),
-                           reinterpret_cast<float*>(o), reinterpret_cast<uint8_t*>(o + o_st),
-                           reinterpret_cast<float*>(o + o_err));
+        char* o = f->lk_out.host<char>();
+        {
+            float* o_pts = reinterpret_cast<float*>(o);
+            uint8_t* o_stat = reinterpret_cast<uint8_t*>(o + o_st);
+            float* o_errp = reinterpret_cast<float*>(o + o_err);
+            static const int pts_per_wave = getenv("FASTMOT_LK_PTS") ? atoi(getenv("FASTMOT_LK_PTS")) : 16;
+#define FM_LK_LAUNCH(WIN_, PTS_)                                                                              \
+    hipLaunchKernelGGL((lk_kernel<WIN_, PTS_>), dim3((n + PTS_ - 1) / PTS_), dim3(64), 0, s, a, n,           \
+                       f->lk_in.host<float>(), o_pts, o_stat, o_errp)
+            if (a.win == 5) {
+                if (pts_per_wave >= 64) FM_LK_LAUNCH(5, 64);
+                else if (pts_per_wave >= 32) FM_LK_LAUNCH(5, 32);
+                else if (pts_per_wave >= 16) FM_LK_LAUNCH(5, 16);
+                else FM_LK_LAUNCH(5, 8);
+            } else {
+                FM_LK_LAUNCH(3, 16);
+            }
+#undef FM_LK_LAUNCH
+        }
         FM_HIP(hipGetLastError());
-        FM_HIP(hipMemcpyAsync(f->lk_out.h, f->lk_out.d, out_bytes, hipMemcpyDeviceToHost, s));
         FM_HIP(hipStreamSynchronize(s));
         const char* ho = f->lk_out.host<char>();
         memcpy(next_pts, ho, sizeof(float) * 2 * n);
@@ -1097,8 +1342,11 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     const size_t o_rect = 0, o_kpoff = al(o_rect + sizeof(int32_t) * 4 * nT), o_kps = al(o_kpoff + sizeof(int32_t) * (nT + 1));
     const size_t o_ovoff = al(o_kps + sizeof(float) * 2 * nk), o_ovidx = al(o_ovoff + sizeof(int32_t) * (nT + 1));
     const size_t o_crop = al(o_ovidx + sizeof(int32_t) * n_ov), o_box = al(o_crop + sizeof(CropArgs) * nT);
-    const size_t in_bytes = al(o_box + sizeof(double) * 4 * nT) + 16;
-    int rc = f->tgt_in.reserve(in_bytes);
+    const size_t o_tot = al(o_box + sizeof(double) * 4 * nT);          // two zeroed counters, uploaded with the rest
+    const size_t in_bytes = o_tot + 16;
+    // device-side scratch behind the upload: needy flags + min distances (read by the eig / select kernels)
+    const size_t o_dneedy = in_bytes, o_dmd = al(o_dneedy + nT);
+    int rc = f->tgt_in.reserve(al(o_dmd + sizeof(int32_t) * nT));
     if (rc) return rc;
     // outputs (device-visible pinned host memory): area | md | counts | off | total,n_bg | needy | keep | pts | bg
     const size_t q_area = 0, q_md = al(q_area + 4 * (size_t)nT), q_cnt = al(q_md + 4 * (size_t)nT);
@@ -1107,6 +1355,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     const size_t out_bytes = al(q_bg + sizeof(float) * 2 * bg_cap);
     if ((rc = f->tgt_out.reserve(out_bytes))) return rc;
     char* hb = f->tgt_in.host<char>();
+    char* db = f->tgt_in.dev<char>();
     if (nT) {
         memcpy(hb + o_rect, irect.data(), sizeof(int32_t) * 4 * nT);
         memcpy(hb + o_kpoff, kp_off, sizeof(int32_t) * (nT + 1));
@@ -1115,31 +1364,34 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         if (n_ov) memcpy(hb + o_ovidx, ov_idx.data(), sizeof(int32_t) * n_ov);
         memcpy(hb + o_crop, crops.data(), sizeof(CropArgs) * nT);
         memcpy(hb + o_box, full_tlbr, sizeof(double) * 4 * nT);
-        FM_HIP(hipMemcpyAsync(f->tgt_in.d, hb, in_bytes, hipMemcpyHostToDevice, s));
-        char* db = f->tgt_in.dev<char>();
-        FM_HIP(hipMemcpyAsync(f->rects, db + o_rect, sizeof(int32_t) * 4 * nT, hipMemcpyDeviceToDevice, s));
-        FM_HIP(hipMemcpyAsync(f->ov_off, db + o_ovoff, sizeof(int32_t) * (nT + 1), hipMemcpyDeviceToDevice, s));
-        if (n_ov) FM_HIP(hipMemcpyAsync(f->ov_idx, db + o_ovidx, sizeof(int32_t) * n_ov, hipMemcpyDeviceToDevice, s));
     }
+    memset(hb + o_tot, 0, 16);
+    // ONE upload; the kernels read rects / overlap lists / counters straight from it (no device-to-device
+    // copies, no memset)
+    FM_HIP(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, s));
+    f->v_rects = reinterpret_cast<const int32_t*>(db + o_rect);
+    f->v_ov_off = reinterpret_cast<const int32_t*>(db + o_ovoff);
+    f->v_ov_idx = reinterpret_cast<const int32_t*>(db + o_ovidx);
     char* ho = f->tgt_out.host<char>();      // pinned, device accessible
     int32_t* tot_host = reinterpret_cast<int32_t*>(ho + q_tot);
-    int32_t* tot = f->bg_flags + (size_t)f->cfg.bg_w * f->cfg.bg_h;    // device counters: [0] new pts, [1] bg pts
-    FM_HIP(hipMemsetAsync(tot, 0, sizeof(int32_t) * 2, s));
+    int32_t* tot = reinterpret_cast<int32_t*>(db + o_tot);             // device counters: [0] new pts, [1] bg pts
     if (nT) {
-        char* db = f->tgt_in.dev<char>();
-        const Overlaps ov{f->ov_idx, f->ov_off};
-        uint8_t* d_needy = reinterpret_cast<uint8_t*>(ho + q_needy);
-        int32_t* d_md = reinterpret_cast<int32_t*>(ho + q_md);
-        hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(256), 0, s, f->rects, ov,
+        const Overlaps ov{f->v_ov_idx, f->v_ov_off};
+        uint8_t* d_needy = reinterpret_cast<uint8_t*>(db + o_dneedy);
+        int32_t* d_md = reinterpret_cast<int32_t*>(db + o_dmd);
+        hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(256), 0, s, f->v_rects, ov,
                            reinterpret_cast<const float*>(db + o_kps), reinterpret_cast<const int32_t*>(db + o_kpoff),
                            feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(ho + q_area),
-                           reinterpret_cast<uint8_t*>(ho + q_keep), d_needy, d_md);
+                           reinterpret_cast<uint8_t*>(ho + q_keep), d_needy, d_md,
+                           reinterpret_cast<uint8_t*>(ho + q_needy));
         hipLaunchKernelGGL(eig_kernel, dim3((max_area + 255) / 256, nT), dim3(256), 0, s, f->gray[f->prev], f->W,
                            reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, d_needy);
-        hipLaunchKernelGGL(gftt_select_kernel, dim3(nT), dim3(256), 0, s, reinterpret_cast<const CropArgs*>(db + o_crop),
-                           f->rects, ov, f->eig, (float)f->cfg.quality_level, f->cfg.max_corners, d_md,
+        hipLaunchKernelGGL(gftt_select_kernel, dim3(nT), dim3(GFTT_BLK), gftt_lds_bytes(max_area), s,
+                           reinterpret_cast<const CropArgs*>(db + o_crop), f->v_rects, ov, f->eig,
+                           (float)f->cfg.quality_level, f->cfg.max_corners, d_md,
                            reinterpret_cast<const double*>(db + o_box), reinterpret_cast<float*>(ho + q_pts), pts_cap,
-                           reinterpret_cast<int32_t*>(ho + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(ho + q_off));
+                           reinterpret_cast<int32_t*>(ho + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(ho + q_off),
+                           gftt_lds_bytes(max_area) / 4);
     }
     // background keypoints under the final mask
     const int bw = f->cfg.bg_w, bh = f->cfg.bg_h;
@@ -1148,12 +1400,12 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_img, bw, bh,
                        f->cfg.fast_thresh, f->bg_flags);
     uint8_t* d_flag = reinterpret_cast<uint8_t*>(f->bg_flags + (size_t)bw * bh + 8);
-    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->rects,
+    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->v_rects,
                        nT, f->W, f->H, d_flag);
+    // the last kernel of the call also publishes both totals to the pinned result block (no D2H copy)
     hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh,
-                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1);
+                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, tot, tot_host);
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(tot_host, tot, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, s));
     FM_HIP(hipStreamSynchronize(s));
     if (nT) {
         memcpy(area_out, ho + q_area, 4 * (size_t)nT);

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 
@@ -501,55 +502,108 @@ double round_half_even(double v) { return std::nearbyint(v); }
 }  // namespace
 
 
-// ---- one persistent helper thread (camera-motion RANSAC runs beside the per-track RANSACs)
+// ---- a small persistent worker pool for the host side of Flow.predict: the camera-motion RANSAC and the per-track
+// RANSACs of one frame are independent jobs (OpenCV seeds a fresh RNG per findHomography / estimateAffinePartial2D
+// call, so a track's estimate does not depend on which thread computes it or when).
+//
+// Wake-up latency matters at this scale (~0.25 ms of work per frame): fm_flow_predict calls prewake() BEFORE it
+// waits for the GPU's LK kernel, the workers then spin (bounded) until the jobs arrive, and go back to sleep on the
+// condition variable afterwards -- no permanently spinning cores.
 namespace {
-struct Helper {
-    std::thread th;
+inline void cpu_relax() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __asm__ __volatile__("pause");
+#endif
+}
+
+struct Pool {
+    std::vector<std::thread> th;
     std::mutex m;
-    std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, busy = false, quit = false;
-    Helper() {
-        th = std::thread([this] {
-            std::unique_lock<std::mutex> lk(m);
-            for (;;) {
-                cv.wait(lk, [this] { return has_job || quit; });
-                if (quit) return;
-                has_job = false;
-                std::function<void()> j = std::move(job);
-                lk.unlock();
-                j();
-                lk.lock();
-                busy = false;
-                cv.notify_all();
-            }
-        });
+    std::condition_variable cv, cv_done;
+    std::function<void(int)> fn;
+    std::atomic<int> next{0};
+    std::atomic<uint64_t> gen{0};          // bumped when a job set is published
+    std::atomic<uint64_t> wake{0};         // bumped by prewake()
+    int n_jobs = 0;
+    std::atomic<int> active{0};
+    bool quit = false;
+
+    explicit Pool(int workers) {
+        for (int i = 0; i < workers; ++i) th.emplace_back([this] { loop(); });
     }
-    ~Helper() {
+    ~Pool() {
         {
             std::lock_guard<std::mutex> lk(m);
             quit = true;
         }
         cv.notify_all();
-        if (th.joinable()) th.join();
+        for (auto& t : th)
+            if (t.joinable()) t.join();
+    }
+    void work() {
+        for (;;) {
+            const int j = next.fetch_add(1, std::memory_order_relaxed);
+            if (j >= n_jobs) break;
+            fn(j);
+        }
+    }
+    void loop() {
+        uint64_t seen_gen = 0, seen_wake = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || gen.load() != seen_gen || wake.load() != seen_wake; });
+                if (quit) return;
+            }
+            seen_wake = wake.load();
+            // spin (bounded) for the job set announced by prewake()
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(3);
+            while (gen.load(std::memory_order_acquire) == seen_gen && std::chrono::steady_clock::now() < t_end)
+                cpu_relax();
+            if (gen.load(std::memory_order_acquire) == seen_gen) continue;       // nothing came: sleep again
+            seen_gen = gen.load(std::memory_order_acquire);
+            work();
+            if (active.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(m);
+                cv_done.notify_all();
+            }
+        }
+    }
+    void prewake() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            wake.fetch_add(1);
+        }
+        cv.notify_all();
+    }
+    // runs fn(0..n-1) on the workers and the calling thread; returns when all jobs are done
+    void run(int n, std::function<void(int)> f) {
+        if (th.empty() || n <= 1) {
+            for (int j = 0; j < n; ++j) f(j);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fn = std::move(f);
+            n_jobs = n;
+            next.store(0);
+            active.store((int)th.size());
+            gen.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return active.load() == 0; });
     }
 };
-Helper& helper() {
-    static Helper h;
-    return h;
-}
-void helper_run(std::function<void()> f) {
-    Helper& h = helper();
-    std::lock_guard<std::mutex> lk(h.m);
-    h.job = std::move(f);
-    h.has_job = true;
-    h.busy = true;
-    h.cv.notify_all();
-}
-void helper_wait() {
-    Helper& h = helper();
-    std::unique_lock<std::mutex> lk(h.m);
-    h.cv.wait(lk, [&h] { return !h.busy; });
+
+Pool& pool() {
+    static Pool p([] {
+        if (const char* e = getenv("FASTMOT_FLOW_THREADS")) return std::max(0, atoi(e) - 1);
+        const int hw = (int)std::thread::hardware_concurrency();
+        return std::max(0, std::min(hw / 4, 6));          // + the calling thread
+    }());
+    return p;
 }
 }  // namespace
 
@@ -575,8 +629,7 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
     const Pt* P = reinterpret_cast<const Pt*>(prev_pts);
     const Pt* C = reinterpret_cast<const Pt*>(cur_pts);
     // ---- camera motion: background matches [bg_begin, bg_end) with status (flow.py:216-232).  It only
-    // decides whether the frame is usable and shares no data with the per-track estimates below, so it runs
-    // on the library's helper thread while this thread does the tracks (0.15 + 0.22 ms -> 0.23 ms).
+    // decides whether the frame is usable and shares no data with the per-track estimates below: job 0 of the pool.
     double H[9];
     bool cam_ok = false;
     auto camera_motion = [&]() {
@@ -603,43 +656,49 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
             if (bmask[i]) inlier_out[bidx[i]] = 1;          // background indices only: disjoint from the tracks'
         cam_ok = true;
     };
-    helper_run(camera_motion);
-    struct CameraJoin {                       // every exit path below waits for the helper
-        ~CameraJoin() { helper_wait(); }
-    };
-    std::vector<Pt> a, b;
-    std::vector<int> gidx;
-    std::vector<uint8_t> mask;
-    {
-    CameraJoin join_guard;
-    (void)join_guard;
 
-    // ---- per-track motion (flow.py:235-263), closest-first order; the foreground mask is the set
-    // of predicted boxes of the tracks accepted so far
-    AffinePartial acb;
-    std::vector<double> boxes;   // accepted est_tlbr, crop() semantics
-    for (int k = 0; k < nT; ++k) {
-        a.clear(); b.clear(); gidx.clear();
+    // ---- per-track motion (flow.py:235-263), closest-first order; the foreground mask is the set of predicted
+    // boxes of the tracks accepted so far.  That mask is the ONLY coupling between tracks (a keypoint that has
+    // moved under an already predicted box is dropped before the fit), and it rarely bites: every track is first
+    // estimated speculatively with no mask, in parallel; the sequential pass below then accepts a speculative
+    // result iff none of the track's candidate points is covered by the boxes accepted before it -- the point set,
+    // hence the RANSAC draw sequence and the result, are then exactly those of the sequential algorithm --
+    // and recomputes the track in place otherwise.
+    struct TrackFit {
+        std::vector<int> cand;        // indices of the candidate points the fit saw
+        std::vector<int> inl;         // indices of the inliers
+        double est[4] = {0, 0, 0, 0};
+        int n = 0, result = 0;
+        bool fitted = false;          // est / inl valid
+    };
+    auto fit_track = [&](int k, const std::vector<double>* boxes, TrackFit& r) {
+        static thread_local std::vector<Pt> a, b;
+        static thread_local std::vector<uint8_t> mask;
+        a.clear(); b.clear();
+        r.cand.clear(); r.inl.clear();
+        r.result = 0; r.fitted = false;
         for (int i = begins[k]; i < ends[k]; ++i) {
             if (!status[i]) continue;
             // _fg_filter: inside the frame and not under an already predicted box
             const int x = (int)std::nearbyint(C[i].x), y = (int)std::nearbyint(C[i].y);
             if (x < 0 || y < 0 || x >= frame_w || y >= frame_h) continue;
-            bool covered = false;
-            for (size_t q = 0; q < boxes.size(); q += 4)
-                if (x >= boxes[q] && x <= boxes[q + 2] && y >= boxes[q + 1] && y <= boxes[q + 3]) { covered = true; break; }
-            if (covered) continue;
-            a.push_back(P[i]); b.push_back(C[i]); gidx.push_back(i);
+            if (boxes) {
+                bool covered = false;
+                for (size_t q = 0; q < boxes->size(); q += 4)
+                    if (x >= (*boxes)[q] && x <= (*boxes)[q + 2] && y >= (*boxes)[q + 1] && y <= (*boxes)[q + 3]) { covered = true; break; }
+                if (covered) continue;
+            }
+            a.push_back(P[i]); b.push_back(C[i]); r.cand.push_back(i);
         }
         const int n = (int)a.size();
-        n_matched_out[k] = n;
-        if (n < 3) continue;
+        r.n = n;
+        if (n < 3) return;
         double M[9];
-        if (!ransac_run(acb, a.data(), b.data(), n, 3.0, ransac_conf, ransac_max_iter, M, mask)) continue;
+        AffinePartial acb;
+        if (!ransac_run(acb, a.data(), b.data(), n, 3.0, ransac_conf, ransac_max_iter, M, mask)) return;
         std::vector<Pt> ia, ib;
-        std::vector<int> ii;
         for (int i = 0; i < n; ++i)
-            if (mask[i]) { ia.push_back(a[i]); ib.push_back(b[i]); ii.push_back(gidx[i]); }
+            if (mask[i]) { ia.push_back(a[i]); ib.push_back(b[i]); r.inl.push_back(r.cand[i]); }
         if (n > 2 && !ia.empty()) lm_refine(acb, ia.data(), ib.data(), (int)ia.size(), M, 10);
         // _estimate_bbox (flow.py:273-280)
         const double* tb = track_tlbr + 4 * k;
@@ -647,25 +706,51 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
         double scale = std::sqrt(M[0] * M[0] + M[3] * M[3]);
         if (scale < 0.9 || scale > 1.1) scale = 1.;
         const double w = tb[2] - tb[0] + 1, h = tb[3] - tb[1] + 1;
-        double est[4] = {round_half_even(tlx), round_half_even(tly), round_half_even(tlx + w * scale - 1.),
-                         round_half_even(tly + h * scale - 1.)};
-        for (int i : ii) inlier_out[i] = 1;
-        memcpy(est_tlbr_out + 4 * k, est, sizeof(est));
-        const double ix1 = std::max(est[0], 0.), iy1 = std::max(est[1], 0.);
-        const double ix2 = std::min(est[2], (double)frame_w - 1), iy2 = std::min(est[3], (double)frame_h - 1);
+        r.est[0] = round_half_even(tlx); r.est[1] = round_half_even(tly);
+        r.est[2] = round_half_even(tlx + w * scale - 1.); r.est[3] = round_half_even(tly + h * scale - 1.);
+        r.fitted = true;
+        const double ix1 = std::max(r.est[0], 0.), iy1 = std::max(r.est[1], 0.);
+        const double ix2 = std::min(r.est[2], (double)frame_w - 1), iy2 = std::min(r.est[3], (double)frame_h - 1);
         const bool outside = ix2 < ix1 || iy2 < iy1;
-        if (outside || (int)ii.size() < inlier_thresh) {
-            result_out[k] = 2;   // estimated but rejected: prev_keypoints updated, keypoints cleared
-            continue;
+        // 2: estimated but rejected (prev_keypoints updated, keypoints cleared); 1: accepted
+        r.result = (outside || (int)r.inl.size() < inlier_thresh) ? 2 : 1;
+    };
+    static thread_local std::vector<TrackFit> fits;
+    if ((int)fits.size() < nT) fits.resize(nT);
+    TrackFit* fp = fits.data();        // (a thread_local named inside the lambda would be the WORKER's instance)
+    pool().run(nT + 1, [&, fp](int job) {
+        if (job == 0) camera_motion();
+        else fit_track(job - 1, nullptr, fp[job - 1]);
+    });
+    {
+    std::vector<double> boxes;   // accepted est_tlbr, crop() semantics
+    int n_redone = 0;
+    for (int k = 0; k < nT; ++k) {
+        TrackFit& r = fp[k];
+        bool valid = true;
+        for (size_t q = 0; q < boxes.size() && valid; q += 4)
+            for (int i : r.cand) {
+                const int x = (int)std::nearbyint(C[i].x), y = (int)std::nearbyint(C[i].y);
+                if (x >= boxes[q] && x <= boxes[q + 2] && y >= boxes[q + 1] && y <= boxes[q + 3]) { valid = false; break; }
+            }
+        if (!valid) {
+            fit_track(k, &boxes, r);
+            ++n_redone;
         }
-        result_out[k] = 1;
+        n_matched_out[k] = r.n;
+        if (!r.fitted) continue;
+        for (int i : r.inl) inlier_out[i] = 1;
+        memcpy(est_tlbr_out + 4 * k, r.est, sizeof(r.est));
+        result_out[k] = r.result;
+        if (r.result != 1) continue;
         // crop(fg_mask, est_tlbr)[:] = 0 : int truncation, clamp at 0 (utils/rect.py:83-89)
-        boxes.push_back(std::max((double)(int)est[0], 0.));
-        boxes.push_back(std::max((double)(int)est[1], 0.));
-        boxes.push_back(std::max((double)(int)est[2], 0.));
-        boxes.push_back(std::max((double)(int)est[3], 0.));
+        boxes.push_back(std::max((double)(int)r.est[0], 0.));
+        boxes.push_back(std::max((double)(int)r.est[1], 0.));
+        boxes.push_back(std::max((double)(int)r.est[2], 0.));
+        boxes.push_back(std::max((double)(int)r.est[3], 0.));
     }
-    }   // joins the camera-motion job
+    g_flow_times[5] += n_redone;
+    }
     g_flow_times[6] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count();
     if (!cam_ok) {                            // flow.py:227-231: nothing of this frame is used
         memset(inlier_out, 0, n_pts);
@@ -689,7 +774,7 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
 extern "C" int fm_flow_timing(double* out5, int reset) {
     for (int i = 0; i < 5; ++i) out5[i] = g_flow_times[i];
     if (getenv("FASTMOT_FLOW_TIMING_VERBOSE"))
-        fprintf(stderr, "flow_estimate: homography %.3f ms, tracks %.3f ms per call\n",
+        fprintf(stderr, "flow_estimate: %.3f tracks re-fitted under the mask, %.3f ms per call\n",
                 g_flow_times[5] / (g_flow_times[4] > 0 ? g_flow_times[4] : 1), g_flow_times[6] / (g_flow_times[4] > 0 ? g_flow_times[4] : 1));
     if (reset) for (double& v : g_flow_times) v = 0;
     return 0;
@@ -767,6 +852,7 @@ extern "C" int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         scaled[2 * i] = prev[2 * i] * prm->opt_scale[0];
         scaled[2 * i + 1] = prev[2 * i + 1] * prm->opt_scale[1];
     }
+    pool().prewake();          // the RANSAC workers wake up while this thread waits for the LK kernel
     rc = fm_flow_lk(ctx, n_pts, scaled.data(), cur.data(), status.data(), err.data());
     if (rc) return rc;
     lap(2);

@@ -44,6 +44,7 @@ def hip_pass(mot, video, n_frames, skip, prefetch=False, frames=None):
     mot.detector_frame_skip = skip
     Track._count = 0
     mot.reset(1 / 30.)
+    mot.tracker.klt_bboxes, mot.tracker.homography = {}, None      # (a reused MOT keeps the last clip's values)
     recs = []
     try:
         for f in range(n_frames):

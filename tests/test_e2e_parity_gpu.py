@@ -4,8 +4,8 @@ oracle (oracle/cpu_tracker.OracleTracker + cv_oracle) on the SAME synthetic clip
 
 The oracle consumes the embeddings the HIP OSNet produced (the network itself is checked against PyTorch in
 test_conv_gpu.py / test_fullsize_gpu.py), so every difference seen here comes from KLT / Kalman / association.
-Bar: track IDs, dict order, rounded boxes, life-cycle counters, history and per-track keypoint counts
-IDENTICAL on every frame; KLT boxes and the homography within the float32 LK tolerance stated below."""
+Bar: track IDs, dict order, rounded boxes, life-cycle counters, history, per-track keypoint counts and KLT
+boxes IDENTICAL on every frame (the LK kernel is bit-identical to the restatement); homography to 1e-6."""
 from types import SimpleNamespace
 
 import pytest
@@ -15,8 +15,8 @@ import scenes
 
 pytestmark = pytest.mark.gpu
 
-KLT_BOX_TOL_PX = 0.02      # LK points agree to ~2e-3 px (float32 summation order), boxes are affine fits of them
-H_TOL = 2e-4               # homography entries (translations are in pixels)
+KLT_BOX_TOL_PX = 0.0       # KLT boxes are rounded (flow.py:273-280): identical
+H_TOL = 1e-6               # homography entries: double-precision host code (Jacobi SVD, LM) vs numpy
 
 
 def build_mot(size, video, yolo='YOLOv4_608', reid='OSNet025', batch=64):
