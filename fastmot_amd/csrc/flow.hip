@@ -419,6 +419,146 @@ __global__ __launch_bounds__(64) void lk_kernel(LKArgs a, int n, const float* __
     }
 }
 
+// float32 sum of lanes 0..N-1 in lane order, starting from 0.f like the scalar loops of lkpyramid.cpp
+template <int N>
+__device__ __forceinline__ float seq_sum(float v) {
+    float acc = 0.f;
+    const int bits = __builtin_bit_cast(int, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, k));
+    return acc;
+}
+
+// Variant with one WAVEFRONT per point: lane g < win*win owns window pixel (g / win, g % win) -- the samples of a
+// window are taken in parallel, and every window sum is then accumulated by all lanes in the same sequential
+// (y, x) order through v_readlane (25 dependent float32 adds; a butterfly reduction would be as fast but only
+// agrees with the scalar order to ~1e-4 px).  The control flow (pyramid levels skipped, iteration counts) depends on the point, so
+// it must be WAVE-uniform: with two points per wavefront (32 lanes each, the first version) the two halves
+// diverged, and the results of single points then varied from run to run whenever other streams kept the
+// CUs' LDS pipelines busy (reproduced in isolation: scripts/stress_lk2.py; constant images, constant
+// arguments, no such effect with one point per wavefront or with equal trip counts).  39 idle lanes are
+// the price; the kernel is latency bound anyway.
+template <int WINC>
+__global__ __launch_bounds__(256) void lk_wave_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+                                                 float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                 float* __restrict__ err) {
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pt = gidx >> 6, g = gidx & 63;
+    if (pt >= n) return;                       // the whole wavefront exits together
+    constexpr int win = WINC;
+    const bool lane_on = g < win * win;
+    const int wy = lane_on ? g / win : 0, wx = lane_on ? g % win : 0;
+    const float half = (win - 1) * 0.5f;
+    const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
+    float nx = 0.f, ny = 0.f;
+    bool st = true;
+    float er = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    auto weights = [](float fa, float fb, int& iw00, int& iw01, int& iw10, int& iw11) {
+        iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
+        iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
+        iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
+        iw11 = (1 << 14) - iw00 - iw01 - iw10;
+    };
+    for (int level = a.levels - 1; level >= 0; --level) {
+        const int w = a.w[level], h = a.h[level];
+        const uint8_t* I = a.I[level];
+        const uint8_t* J = a.J[level];
+        const int16_t* D = a.D[level];
+        const float sc = 1.f / (float)(1 << level);
+        float ppx = px0 * sc, ppy = py0 * sc;
+        if (level == a.levels - 1) { nx = ppx; ny = ppy; }
+        else { nx *= 2.f; ny *= 2.f; }
+        ppx -= half; ppy -= half;
+        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+        if (ipx < -win || ipx >= w || ipy < -win || ipy >= h) {
+            if (level == 0) { st = false; er = 0.f; }
+            continue;
+        }
+        int iw00, iw01, iw10, iw11;
+        weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
+        int ival = 0, ixval = 0, iyval = 0;
+        if (lane_on) {
+            const int xx0 = ipx + wx, xx1 = xx0 + 1, yy0 = ipy + wy, yy1 = yy0 + 1;
+            const uint8_t* r0 = I + (size_t)reflect101(yy0, h) * w;
+            const uint8_t* r1 = I + (size_t)reflect101(yy1, h) * w;
+            const int c0 = reflect101(xx0, w), c1 = reflect101(xx1, w);
+            ival = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5);
+            // derivative image is zero outside (BORDER_CONSTANT), lkpyramid.cpp
+            auto dv = [&](int xx, int yy) -> int2 {
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return make_int2(0, 0);
+                const int v = *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
+                return make_int2((int)(short)(v & 0xffff), (int)(short)(v >> 16));
+            };
+            const int2 d00 = dv(xx0, yy0), d01 = dv(xx1, yy0), d10 = dv(xx0, yy1), d11 = dv(xx1, yy1);
+            ixval = LK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
+            iyval = LK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
+        }
+        const float A11 = seq_sum<WINC * WINC>((float)(ixval * ixval)) * FLT_SCALE;
+        const float A12 = seq_sum<WINC * WINC>((float)(ixval * iyval)) * FLT_SCALE;
+        const float A22 = seq_sum<WINC * WINC>((float)(iyval * iyval)) * FLT_SCALE;
+        float Dt = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
+        if (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f) {
+            if (level == 0) st = false;
+            continue;
+        }
+        Dt = 1.f / Dt;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        float outx = nx + half, outy = ny + half;
+        bool running = true;
+        for (int j = 0; j < a.max_count; ++j) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (running && (inx < -win || inx >= w || iny < -win || iny >= h)) {
+                if (level == 0) st = false;
+                running = false;
+            }
+            if (!running) break;                 // uniform within the 32-lane group
+            weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
+            int diff = 0;
+            if (lane_on) {
+                const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
+                const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
+                const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
+                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
+            }
+            const float b1 = seq_sum<WINC * WINC>((float)(diff * ixval)) * FLT_SCALE;
+            const float b2 = seq_sum<WINC * WINC>((float)(diff * iyval)) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+            nx += dx; ny += dy;
+            outx = nx + half; outy = ny + half;
+            if (dx * dx + dy * dy <= a.eps2) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        nx = outx; ny = outy;
+        if (st && level == 0) {
+            const float ex = nx - half, ey = ny - half;
+            const int inx = (int)floorf(ex), iny = (int)floorf(ey);
+            if (inx < -win || inx >= w || iny < -win || iny >= h) { st = false; continue; }
+            weights(ex - inx, ey - iny, iw00, iw01, iw10, iw11);
+            int diff = 0;
+            if (lane_on) {
+                const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
+                const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
+                const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
+                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
+            }
+            er = seq_sum<WINC * WINC>(fabsf((float)diff)) * 1.f / (32 * win * win);
+        }
+    }
+    if (g == 0) {
+        next_pts[2 * pt] = nx;
+        next_pts[2 * pt + 1] = ny;
+        status[pt] = st ? 1 : 0;
+        err[pt] = er;
+    }
+}
+
 // ---- foreground-mask bookkeeping: rect k sees pixel p as foreground iff no rect j<k covers p.
 // Only earlier rects that intersect rect k can cover its pixels: the host passes that (short) list.
 struct Overlaps { const int32_t* idx; const int32_t* off; };   // idx[off[k] .. off[k+1]) = j < k intersecting k
@@ -926,11 +1066,11 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
     const int n = ctx->frame_w * ctx->frame_h;
     static const bool fused = !(getenv("FASTMOT_PYR_FUSED") && atoi(getenv("FASTMOT_PYR_FUSED")) == 0);
     if (fused && f->W == 2 * f->lw[0] && f->H == 2 * f->lh[0] && (f->W & 1) == 0) {
-        // gray + half-resolution image in one pass over the frame; levels 0 and 1 as one launch each
-        // (derivatives + next level); everything from level 2 on in one workgroup
+        // gray + half-resolution image in one pass over the frame; levels 0-2 as one launch each
+        // (derivatives + next level); everything from level 3 on in one workgroup
         hipLaunchKernelGGL(gray_half_kernel, dim3((f->lw[0] + 255) / 256, f->lh[0]), dim3(256), 0, s, ctx->frame_cur,
                            f->W, f->H, f->gray[set], f->pyr[set][0]);
-        const int tail = f->levels > 2 ? 2 : f->levels;
+        const int tail = f->levels > 3 ? 3 : f->levels;        // levels >= 3 (<= ~8 k pixels at 1080p): one workgroup
         for (int l = 0; l < tail; ++l) {
             const bool has_next = l + 1 < f->levels;
             hipLaunchKernelGGL(pyr_level_kernel, dim3((f->lw[l] + 255) / 256, f->lh[l] + (has_next ? f->lh[l + 1] : 0)),
@@ -938,7 +1078,7 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
                                reinterpret_cast<int*>(f->deriv[set][l]), has_next ? f->pyr[set][l + 1] : nullptr,
                                has_next ? f->lw[l + 1] : 0, has_next ? f->lh[l + 1] : 0);
         }
-        if (f->levels > 2) {
+        if (f->levels > 3) {
             PyrTail t{};
             for (int l = 0; l < f->levels; ++l) {
                 t.img[l] = f->pyr[set][l];
@@ -946,7 +1086,7 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
                 t.w[l] = f->lw[l];
                 t.h[l] = f->lh[l];
             }
-            t.first = 2;
+            t.first = 3;
             t.levels = f->levels;
             hipLaunchKernelGGL(pyr_tail_kernel, dim3(1), dim3(1024), 0, s, t);
         }
@@ -1203,8 +1343,8 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const size_t out_bytes = o_err + sizeof(float) * n;
         if ((rc = f->lk_out.reserve(out_bytes))) return rc;
         FM_HIP(hipStreamSynchronize(s));
-        // points in, results out: through device-mapped pinned host memory (no blit copies around a ~50 KB
-        // exchange; every lane reads its 8 bytes once and writes 13)
+        // points in: read once per point straight from device-mapped pinned memory; results out: device buffer +
+        // one D2H copy (13 scattered bytes per point written over PCIe cost more than the whole kernel)
         memcpy(f->lk_in.h, prev_pts, sizeof(float) * 2 * n);
         const int p = f->prev, c = p ^ 1;
         LKArgs a{};
@@ -1221,16 +1361,26 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const double eps = std::min(std::max(f->cfg.epsilon, 0.), 10.);
         a.eps2 = (float)(eps * eps);
         a.min_eig_thresh = 1e-4f;
-        char* o = f->lk_out.host<char>();
+        char* o = f->lk_out.dev<char>();
         {
             float* o_pts = reinterpret_cast<float*>(o);
             uint8_t* o_stat = reinterpret_cast<uint8_t*>(o + o_st);
             float* o_errp = reinterpret_cast<float*>(o + o_err);
-            static const int pts_per_wave = getenv("FASTMOT_LK_PTS") ? atoi(getenv("FASTMOT_LK_PTS")) : 16;
+            const float* in_pts = f->lk_in.host<float>();
+            // FASTMOT_LK_PTS = 0: one wavefront per point (window samples in parallel, sequential sums through
+            // v_readlane); > 0: one lane per point, that many points per wavefront.  Both are bit-identical.
+            static const int pts_per_wave = getenv("FASTMOT_LK_PTS") ? atoi(getenv("FASTMOT_LK_PTS")) : 0;
 #define FM_LK_LAUNCH(WIN_, PTS_)                                                                              \
-    hipLaunchKernelGGL((lk_kernel<WIN_, PTS_>), dim3((n + PTS_ - 1) / PTS_), dim3(64), 0, s, a, n,           \
-                       f->lk_in.host<float>(), o_pts, o_stat, o_errp)
-            if (a.win == 5) {
+    hipLaunchKernelGGL((lk_kernel<WIN_, PTS_>), dim3((n + PTS_ - 1) / PTS_), dim3(64), 0, s, a, n, in_pts, o_pts, \
+                       o_stat, o_errp)
+            if (pts_per_wave <= 0) {
+                if (a.win == 5)
+                    hipLaunchKernelGGL(lk_wave_kernel<5>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
+                                       o_stat, o_errp);
+                else
+                    hipLaunchKernelGGL(lk_wave_kernel<3>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
+                                       o_stat, o_errp);
+            } else if (a.win == 5) {
                 if (pts_per_wave >= 64) FM_LK_LAUNCH(5, 64);
                 else if (pts_per_wave >= 32) FM_LK_LAUNCH(5, 32);
                 else if (pts_per_wave >= 16) FM_LK_LAUNCH(5, 16);
@@ -1241,6 +1391,7 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
 #undef FM_LK_LAUNCH
         }
         FM_HIP(hipGetLastError());
+        FM_HIP(hipMemcpyAsync(f->lk_out.h, f->lk_out.d, out_bytes, hipMemcpyDeviceToHost, s));
         FM_HIP(hipStreamSynchronize(s));
         const char* ho = f->lk_out.host<char>();
         memcpy(next_pts, ho, sizeof(float) * 2 * n);
@@ -1372,25 +1523,28 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     f->v_rects = reinterpret_cast<const int32_t*>(db + o_rect);
     f->v_ov_off = reinterpret_cast<const int32_t*>(db + o_ovoff);
     f->v_ov_idx = reinterpret_cast<const int32_t*>(db + o_ovidx);
+    // results: the small per-track / per-keypoint arrays are produced in device memory and fetched with ONE copy
+    // (thousands of scattered byte stores over PCIe cost more than the kernels); the two variable-length point
+    // lists are written by their compaction steps, in order, straight into the pinned block
     char* ho = f->tgt_out.host<char>();      // pinned, device accessible
+    char* dbo = f->tgt_out.dev<char>();
     int32_t* tot_host = reinterpret_cast<int32_t*>(ho + q_tot);
     int32_t* tot = reinterpret_cast<int32_t*>(db + o_tot);             // device counters: [0] new pts, [1] bg pts
     if (nT) {
         const Overlaps ov{f->v_ov_idx, f->v_ov_off};
-        uint8_t* d_needy = reinterpret_cast<uint8_t*>(db + o_dneedy);
-        int32_t* d_md = reinterpret_cast<int32_t*>(db + o_dmd);
+        uint8_t* d_needy = reinterpret_cast<uint8_t*>(dbo + q_needy);
+        int32_t* d_md = reinterpret_cast<int32_t*>(dbo + q_md);
         hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(256), 0, s, f->v_rects, ov,
                            reinterpret_cast<const float*>(db + o_kps), reinterpret_cast<const int32_t*>(db + o_kpoff),
-                           feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(ho + q_area),
-                           reinterpret_cast<uint8_t*>(ho + q_keep), d_needy, d_md,
-                           reinterpret_cast<uint8_t*>(ho + q_needy));
+                           feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(dbo + q_area),
+                           reinterpret_cast<uint8_t*>(dbo + q_keep), d_needy, d_md, (uint8_t*)nullptr);
         hipLaunchKernelGGL(eig_kernel, dim3((max_area + 255) / 256, nT), dim3(256), 0, s, f->gray[f->prev], f->W,
                            reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, d_needy);
         hipLaunchKernelGGL(gftt_select_kernel, dim3(nT), dim3(GFTT_BLK), gftt_lds_bytes(max_area), s,
                            reinterpret_cast<const CropArgs*>(db + o_crop), f->v_rects, ov, f->eig,
                            (float)f->cfg.quality_level, f->cfg.max_corners, d_md,
                            reinterpret_cast<const double*>(db + o_box), reinterpret_cast<float*>(ho + q_pts), pts_cap,
-                           reinterpret_cast<int32_t*>(ho + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(ho + q_off),
+                           reinterpret_cast<int32_t*>(dbo + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(dbo + q_off),
                            gftt_lds_bytes(max_area) / 4);
     }
     // background keypoints under the final mask
@@ -1402,10 +1556,11 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     uint8_t* d_flag = reinterpret_cast<uint8_t*>(f->bg_flags + (size_t)bw * bh + 8);
     hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->v_rects,
                        nT, f->W, f->H, d_flag);
-    // the last kernel of the call also publishes both totals to the pinned result block (no D2H copy)
+    // the last kernel of the call also puts both totals into the result block
     hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh,
-                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, tot, tot_host);
+                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, tot, reinterpret_cast<int32_t*>(dbo + q_tot));
     FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(ho, dbo, q_pts, hipMemcpyDeviceToHost, s));
     FM_HIP(hipStreamSynchronize(s));
     if (nT) {
         memcpy(area_out, ho + q_area, 4 * (size_t)nT);

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 
 namespace {
@@ -576,12 +577,10 @@ struct Pool {
         }
         cv.notify_all();
     }
-    // runs fn(0..n-1) on the workers and the calling thread; returns when all jobs are done
-    void run(int n, std::function<void(int)> f) {
-        if (th.empty() || n <= 1) {
-            for (int j = 0; j < n; ++j) f(j);
-            return;
-        }
+    int workers() const { return (int)th.size(); }
+    // hands fn(0..n-1) to the WORKERS (jobs are taken in index order) and returns at once; the caller does its own
+    // part and then calls finish()
+    void start(int n, std::function<void(int)> f) {
         {
             std::lock_guard<std::mutex> lk(m);
             fn = std::move(f);
@@ -591,7 +590,9 @@ struct Pool {
             gen.fetch_add(1, std::memory_order_release);
         }
         cv.notify_all();
-        work();
+    }
+    void finish() {
+        work();                                   // (normally nothing is left)
         std::unique_lock<std::mutex> lk(m);
         cv_done.wait(lk, [&] { return active.load() == 0; });
     }
@@ -716,26 +717,56 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
         r.result = (outside || (int)r.inl.size() < inlier_thresh) ? 2 : 1;
     };
     static thread_local std::vector<TrackFit> fits;
-    if ((int)fits.size() < nT) fits.resize(nT);
-    TrackFit* fp = fits.data();        // (a thread_local named inside the lambda would be the WORKER's instance)
-    pool().run(nT + 1, [&, fp](int job) {
-        if (job == 0) camera_motion();
-        else fit_track(job - 1, nullptr, fp[job - 1]);
-    });
+    static thread_local std::vector<std::atomic<int>> ready;
+    if ((int)fits.size() < nT) {
+        fits.resize(nT);
+        ready = std::vector<std::atomic<int>>(nT);
+    }
+    TrackFit* fp = fits.data();        // (a thread_local named inside a worker's lambda would be the WORKER's instance)
+    std::atomic<int>* rdy = ready.data();
+    Pool& pl = pool();
+    const bool parallel = pl.workers() > 0 && nT > 0;
+    if (parallel) {
+        for (int k = 0; k < nT; ++k) rdy[k].store(0, std::memory_order_relaxed);
+        // job 0 = camera motion (the longest job, started first), jobs 1..nT = speculative per-track fits in
+        // closest-first order; this thread validates / commits them in the same order as they become ready
+        pl.start(nT + 1, [&, fp, rdy](int job) {
+            if (job == 0) { camera_motion(); return; }
+            fit_track(job - 1, nullptr, fp[job - 1]);
+            rdy[job - 1].store(1, std::memory_order_release);
+        });
+    } else {
+        camera_motion();
+    }
     {
     std::vector<double> boxes;   // accepted est_tlbr, crop() semantics
     int n_redone = 0;
     for (int k = 0; k < nT; ++k) {
         TrackFit& r = fp[k];
-        bool valid = true;
-        for (size_t q = 0; q < boxes.size() && valid; q += 4)
-            for (int i : r.cand) {
-                const int x = (int)std::nearbyint(C[i].x), y = (int)std::nearbyint(C[i].y);
-                if (x >= boxes[q] && x <= boxes[q + 2] && y >= boxes[q + 1] && y <= boxes[q + 3]) { valid = false; break; }
+        if (!parallel) {
+            fit_track(k, &boxes, r);               // the plain sequential algorithm
+        } else {
+            while (rdy[k].load(std::memory_order_acquire) == 0) cpu_relax();
+            bool valid = true;
+            if (!boxes.empty() && !r.cand.empty()) {
+                // bounding box of the candidate points first: most accepted boxes are nowhere near this track
+                int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
+                for (int i : r.cand) {
+                    const int x = (int)std::nearbyint(C[i].x), y = (int)std::nearbyint(C[i].y);
+                    bx0 = std::min(bx0, x); bx1 = std::max(bx1, x); by0 = std::min(by0, y); by1 = std::max(by1, y);
+                }
+                for (size_t q = 0; q < boxes.size() && valid; q += 4) {
+                    if (boxes[q] > bx1 || boxes[q + 2] < bx0 || boxes[q + 1] > by1 || boxes[q + 3] < by0) continue;
+                    for (int i : r.cand) {
+                        const int x = (int)std::nearbyint(C[i].x), y = (int)std::nearbyint(C[i].y);
+                        if (x >= boxes[q] && x <= boxes[q + 2] && y >= boxes[q + 1] && y <= boxes[q + 3]) { valid = false; break; }
+                    }
+                }
             }
-        if (!valid) {
-            fit_track(k, &boxes, r);
-            ++n_redone;
+            if (!valid) {
+                fit_track(k, &boxes, r);
+                ++n_redone;
+            }
         }
         n_matched_out[k] = r.n;
         if (!r.fitted) continue;
@@ -751,6 +782,7 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
     }
     g_flow_times[5] += n_redone;
     }
+    if (parallel) pl.finish();         // the camera-motion job (and nothing else) may still be running
     g_flow_times[6] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count();
     if (!cam_ok) {                            // flow.py:227-231: nothing of this frame is used
         memset(inlier_out, 0, n_pts);

@@ -97,4 +97,4 @@ def test_flow_estimate_equals_oracle(threads):
     # the overlapping scenes must have exercised the sequential re-fit path
     assert 'tracks re-fitted under the mask' in res.stderr
     redone = float(res.stderr.split('flow_estimate:')[1].split()[0])
-    assert redone > 0, res.stderr[-500:]
+    assert (redone > 0) == (threads > 1), res.stderr[-500:]      # one thread = the plain sequential algorithm
