@@ -19,9 +19,17 @@
 #include "common.h"
 #include <cstdlib>
 #include <cmath>
+#include <chrono>
 
 namespace {
 constexpr int MAX_LEVELS = 8;
+}
+
+// wall-clock split of the two synchronising KLT calls (ms, accumulated; printed by fm_flow_timing when
+// FASTMOT_FLOW_TIMING_VERBOSE is set): prepare {host, first sync, enqueue, last sync}, lk {first sync, enqueue, last sync}
+double g_flow_sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static inline double fm_now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 struct FlowState {
@@ -252,173 +260,6 @@ struct LKArgs {
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-// One LANE per point, the window walked sequentially in (y, x) order by that lane: every float32 sum (A11, A12,
-// A22, b1, b2, the error) is accumulated in exactly the order of LKTrackerInvoker's scalar loops -- bit-identical to
-// oracle/cv_oracle.calc_optical_flow_pyr_lk (the first version reduced over a wavefront with a butterfly: results
-// agreed to ~1e-4 px only, which is enough to flip an inlier decision now and then and let the keypoint sets of the
-// two implementations drift apart over a clip; tests/test_e2e_parity_gpu.py).  There are no cross-lane operations
-// at all, so the point-dependent control flow (levels skipped, iteration counts) is plain predication; the only
-// wave-level construct is the uniform early exit of the iteration loop.  A wavefront carries PTS points (its other
-// lanes idle): the kernel is bound by the latency of scattered byte loads, and the ~6 k points of a frame give
-// only a few hundred wavefronts -- the GPU stays free for the detector network that runs concurrently.
-template <int WIN, int PTS>
-__global__ __launch_bounds__(64) void lk_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
-                                                float* __restrict__ next_pts, uint8_t* __restrict__ status,
-                                                float* __restrict__ err) {
-    const int lane = threadIdx.x;
-    const int pt_raw = blockIdx.x * PTS + lane;
-    const bool lane_valid = lane < PTS && pt_raw < n;
-    const int pt = lane_valid ? pt_raw : (n - 1);          // idle lanes shadow a valid point and never write
-    constexpr int W2 = WIN * WIN;
-    const float half = (WIN - 1) * 0.5f;
-    const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
-    float nx = 0.f, ny = 0.f;
-    bool st = true;
-    float er = 0.f;
-    const float FLT_SCALE = 1.f / (1 << 20);
-    auto weights = [](float fa, float fb, int& iw00, int& iw01, int& iw10, int& iw11) {
-        iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
-        iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
-        iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
-        iw11 = (1 << 14) - iw00 - iw01 - iw10;
-    };
-    int Iv[W2], Ix[W2], Iy[W2];
-    for (int level = a.levels - 1; level >= 0; --level) {
-        const int w = a.w[level], h = a.h[level];
-        const uint8_t* I = a.I[level];
-        const uint8_t* J = a.J[level];
-        const int16_t* D = a.D[level];
-        const float sc = 1.f / (float)(1 << level);
-        float ppx = px0 * sc, ppy = py0 * sc;
-        if (level == a.levels - 1) { nx = ppx; ny = ppy; }
-        else { nx *= 2.f; ny *= 2.f; }
-        ppx -= half; ppy -= half;
-        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
-        bool act = lane_valid;
-        if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
-            if (level == 0) { st = false; er = 0.f; }
-            act = false;
-        }
-        int iw00, iw01, iw10, iw11;
-        float A11 = 0.f, A12 = 0.f, A22 = 0.f;
-        if (act) {
-            weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
-            // (WIN+1)^2 source pixels of I and of the derivative image (zero outside: BORDER_CONSTANT)
-            int rowI[WIN + 1], colI[WIN + 1];
-#pragma unroll
-            for (int i = 0; i <= WIN; ++i) {
-                rowI[i] = reflect101(ipy + i, h) * w;
-                colI[i] = reflect101(ipx + i, w);
-            }
-            auto dv = [&](int xx, int yy) -> int {
-                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return 0;
-                return *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
-            };
-#pragma unroll
-            for (int y = 0; y < WIN; ++y) {
-#pragma unroll
-                for (int x = 0; x < WIN; ++x) {
-                    const int i00 = I[rowI[y] + colI[x]], i01 = I[rowI[y] + colI[x + 1]];
-                    const int i10 = I[rowI[y + 1] + colI[x]], i11 = I[rowI[y + 1] + colI[x + 1]];
-                    const int ival = LK_DESCALE(i00 * iw00 + i01 * iw01 + i10 * iw10 + i11 * iw11, 14 - 5);
-                    const int d00 = dv(ipx + x, ipy + y), d01 = dv(ipx + x + 1, ipy + y);
-                    const int d10 = dv(ipx + x, ipy + y + 1), d11 = dv(ipx + x + 1, ipy + y + 1);
-                    const int ixval = LK_DESCALE((int)(short)(d00 & 0xffff) * iw00 + (int)(short)(d01 & 0xffff) * iw01 +
-                                                 (int)(short)(d10 & 0xffff) * iw10 + (int)(short)(d11 & 0xffff) * iw11, 14);
-                    const int iyval = LK_DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 +
-                                                 (d11 >> 16) * iw11, 14);
-                    Iv[y * WIN + x] = ival; Ix[y * WIN + x] = ixval; Iy[y * WIN + x] = iyval;
-                    A11 += (float)(ixval * ixval);
-                    A12 += (float)(ixval * iyval);
-                    A22 += (float)(iyval * iyval);
-                }
-            }
-            A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
-        }
-        float Dt = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
-        if (act && (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f)) {
-            if (level == 0) st = false;
-            act = false;
-        }
-        Dt = 1.f / Dt;
-        float cx = nx - half, cy = ny - half;
-        float pdx = 0.f, pdy = 0.f;
-        float outx = nx, outy = ny;
-        if (act) { outx = cx + half; outy = cy + half; }
-        bool running = act;
-        auto sample_J = [&](float fx, float fy, int inx, int iny, int (&diffs)[W2]) {
-            weights(fx - inx, fy - iny, iw00, iw01, iw10, iw11);
-            int rowJ[WIN + 1], colJ[WIN + 1];
-#pragma unroll
-            for (int i = 0; i <= WIN; ++i) {
-                rowJ[i] = reflect101(iny + i, h) * w;
-                colJ[i] = reflect101(inx + i, w);
-            }
-            int jv[(WIN + 1) * (WIN + 1)];
-#pragma unroll
-            for (int y = 0; y <= WIN; ++y)
-#pragma unroll
-                for (int x = 0; x <= WIN; ++x) jv[y * (WIN + 1) + x] = J[rowJ[y] + colJ[x]];
-#pragma unroll
-            for (int y = 0; y < WIN; ++y)
-#pragma unroll
-                for (int x = 0; x < WIN; ++x)
-                    diffs[y * WIN + x] = LK_DESCALE(jv[y * (WIN + 1) + x] * iw00 + jv[y * (WIN + 1) + x + 1] * iw01 +
-                                                    jv[(y + 1) * (WIN + 1) + x] * iw10 + jv[(y + 1) * (WIN + 1) + x + 1] * iw11,
-                                                    14 - 5) - Iv[y * WIN + x];
-        };
-        for (int j = 0; j < a.max_count; ++j) {
-            const int inx = (int)floorf(cx), iny = (int)floorf(cy);
-            if (running && (inx < -WIN || inx >= w || iny < -WIN || iny >= h)) {
-                if (level == 0) st = false;
-                running = false;
-            }
-            if (__ballot(running) == 0ull) break;            // uniform: every lane of the wavefront is here
-            if (running) {
-                int diffs[W2];
-                sample_J(cx, cy, inx, iny, diffs);
-                float b1 = 0.f, b2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < W2; ++k) {
-                    b1 += (float)(diffs[k] * Ix[k]);
-                    b2 += (float)(diffs[k] * Iy[k]);
-                }
-                b1 *= FLT_SCALE; b2 *= FLT_SCALE;
-                const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
-                cx += dx; cy += dy;
-                outx = cx + half; outy = cy + half;
-                if (dx * dx + dy * dy <= a.eps2) running = false;
-                else if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
-                    outx -= dx * 0.5f; outy -= dy * 0.5f;
-                    running = false;
-                }
-                pdx = dx; pdy = dy;
-            }
-        }
-        if (act) { nx = outx; ny = outy; }
-        if (act && st && level == 0) {
-            const float ex = nx - half, ey = ny - half;
-            const int inx = (int)floorf(ex), iny = (int)floorf(ey);
-            if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) st = false;
-            else {
-                int diffs[W2];
-                sample_J(ex, ey, inx, iny, diffs);
-                float e = 0.f;
-#pragma unroll
-                for (int k = 0; k < W2; ++k) e += fabsf((float)diffs[k]);
-                er = e * 1.f / (32 * WIN * WIN);
-            }
-        }
-    }
-    if (lane_valid) {
-        next_pts[2 * pt] = nx;
-        next_pts[2 * pt + 1] = ny;
-        status[pt] = st ? 1 : 0;
-        err[pt] = er;
-    }
-}
-
 // float32 sum of lanes 0..N-1 in lane order, starting from 0.f like the scalar loops of lkpyramid.cpp
 template <int N>
 __device__ __forceinline__ float seq_sum(float v) {
@@ -429,10 +270,15 @@ __device__ __forceinline__ float seq_sum(float v) {
     return acc;
 }
 
-// Variant with one WAVEFRONT per point: lane g < win*win owns window pixel (g / win, g % win) -- the samples of a
-// window are taken in parallel, and every window sum is then accumulated by all lanes in the same sequential
-// (y, x) order through v_readlane (25 dependent float32 adds; a butterfly reduction would be as fast but only
-// agrees with the scalar order to ~1e-4 px).  The control flow (pyramid levels skipped, iteration counts) depends on the point, so
+// One WAVEFRONT per point: lane g < win*win owns window pixel (g / win, g % win) -- the samples of a window are
+// taken in parallel, and every window sum (A11, A12, A22, b1, b2, the error) is then accumulated by all lanes in
+// the sequential (y, x) order of LKTrackerInvoker's scalar loops through v_readlane: 25 dependent float32 adds,
+// bit-identical to oracle/cv_oracle.calc_optical_flow_pyr_lk.  (Round 1 reduced with a butterfly: as fast, but it
+// agrees with the scalar order to ~1e-4 px only -- enough to flip an inlier decision now and then and let the
+// keypoint sets of the two implementations drift apart over a clip, tests/test_e2e_parity_gpu.py.  A variant with
+// one LANE per point -- no cross-lane operations, 64x fewer wavefronts -- was also bit-identical when idle but
+// 2 of 120 calls differed while another stream kept the CUs busy, the same symptom as the two-points-per-wavefront
+// kernel of round 1, and it was slower (latency of scattered byte loads with one wave per SIMD): removed.)  The control flow (pyramid levels skipped, iteration counts) depends on the point, so
 // it must be WAVE-uniform: with two points per wavefront (32 lanes each, the first version) the two halves
 // diverged, and the results of single points then varied from run to run whenever other streams kept the
 // CUs' LDS pipelines busy (reproduced in isolation: scripts/stress_lk2.py; constant images, constant
@@ -1342,10 +1188,14 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const size_t o_st = sizeof(float) * 2 * n, o_err = (o_st + n + 15) & ~size_t(15);
         const size_t out_bytes = o_err + sizeof(float) * n;
         if ((rc = f->lk_out.reserve(out_bytes))) return rc;
+        static const int io_mode = getenv("FASTMOT_LK_IO") ? atoi(getenv("FASTMOT_LK_IO")) : 1;
+        double tl0 = fm_now_ms();
         FM_HIP(hipStreamSynchronize(s));
-        // points in: read once per point straight from device-mapped pinned memory; results out: device buffer +
-        // one D2H copy (13 scattered bytes per point written over PCIe cost more than the whole kernel)
+        g_flow_sub[4] += fm_now_ms() - tl0; tl0 = fm_now_ms();
+        // io_mode 1 (default): points in are read once per point straight from device-mapped pinned memory;
+        // results out go to a device buffer + one D2H copy.  0: blit copies both ways.  2: zero-copy both ways.
         memcpy(f->lk_in.h, prev_pts, sizeof(float) * 2 * n);
+        if (io_mode == 0) FM_HIP(hipMemcpyAsync(f->lk_in.d, f->lk_in.h, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
         const int p = f->prev, c = p ^ 1;
         LKArgs a{};
         for (int l = 0; l < f->levels; ++l) {
@@ -1361,38 +1211,24 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const double eps = std::min(std::max(f->cfg.epsilon, 0.), 10.);
         a.eps2 = (float)(eps * eps);
         a.min_eig_thresh = 1e-4f;
-        char* o = f->lk_out.dev<char>();
+        char* o = io_mode == 2 ? f->lk_out.host<char>() : f->lk_out.dev<char>();
         {
             float* o_pts = reinterpret_cast<float*>(o);
             uint8_t* o_stat = reinterpret_cast<uint8_t*>(o + o_st);
             float* o_errp = reinterpret_cast<float*>(o + o_err);
-            const float* in_pts = f->lk_in.host<float>();
-            // FASTMOT_LK_PTS = 0: one wavefront per point (window samples in parallel, sequential sums through
-            // v_readlane); > 0: one lane per point, that many points per wavefront.  Both are bit-identical.
-            static const int pts_per_wave = getenv("FASTMOT_LK_PTS") ? atoi(getenv("FASTMOT_LK_PTS")) : 0;
-#define FM_LK_LAUNCH(WIN_, PTS_)                                                                              \
-    hipLaunchKernelGGL((lk_kernel<WIN_, PTS_>), dim3((n + PTS_ - 1) / PTS_), dim3(64), 0, s, a, n, in_pts, o_pts, \
-                       o_stat, o_errp)
-            if (pts_per_wave <= 0) {
-                if (a.win == 5)
-                    hipLaunchKernelGGL(lk_wave_kernel<5>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
-                                       o_stat, o_errp);
-                else
-                    hipLaunchKernelGGL(lk_wave_kernel<3>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
-                                       o_stat, o_errp);
-            } else if (a.win == 5) {
-                if (pts_per_wave >= 64) FM_LK_LAUNCH(5, 64);
-                else if (pts_per_wave >= 32) FM_LK_LAUNCH(5, 32);
-                else if (pts_per_wave >= 16) FM_LK_LAUNCH(5, 16);
-                else FM_LK_LAUNCH(5, 8);
-            } else {
-                FM_LK_LAUNCH(3, 16);
-            }
-#undef FM_LK_LAUNCH
+            const float* in_pts = io_mode == 0 ? f->lk_in.dev<float>() : f->lk_in.host<float>();
+            if (a.win == 5)
+                hipLaunchKernelGGL(lk_wave_kernel<5>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
+                                   o_stat, o_errp);
+            else
+                hipLaunchKernelGGL(lk_wave_kernel<3>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
+                                   o_stat, o_errp);
         }
         FM_HIP(hipGetLastError());
-        FM_HIP(hipMemcpyAsync(f->lk_out.h, f->lk_out.d, out_bytes, hipMemcpyDeviceToHost, s));
+        if (io_mode != 2) FM_HIP(hipMemcpyAsync(f->lk_out.h, f->lk_out.d, out_bytes, hipMemcpyDeviceToHost, s));
+        g_flow_sub[5] += fm_now_ms() - tl0; tl0 = fm_now_ms();
         FM_HIP(hipStreamSynchronize(s));
+        g_flow_sub[6] += fm_now_ms() - tl0;
         const char* ho = f->lk_out.host<char>();
         memcpy(next_pts, ho, sizeof(float) * 2 * n);
         memcpy(status, ho + o_st, n);
@@ -1443,6 +1279,8 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     hipStream_t s = ctx->s_flow;
     f->nT = nT;
     const int nk = nT ? kp_off[nT] : 0;
+    double tp0 = fm_now_ms();
+    static const int out_mode = getenv("FASTMOT_PREP_OUT") ? atoi(getenv("FASTMOT_PREP_OUT")) : 0;
     // ---- host side: integer rects, overlap lists, crop table
     std::vector<int32_t> irect(4 * (size_t)nT), ov_off(nT + 1, 0), ov_idx;
     std::vector<CropArgs> crops(nT);
@@ -1463,7 +1301,9 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         crops[k] = c;
     }
     const int n_ov = (int)ov_idx.size();
+    g_flow_sub[0] += fm_now_ms() - tp0; tp0 = fm_now_ms();
     FM_HIP(hipStreamSynchronize(s));
+    g_flow_sub[1] += fm_now_ms() - tp0; tp0 = fm_now_ms();
     if (eig_total > f->eig_cap) {
         FM_HIP(hipFree(f->eig));
         f->eig = nullptr;
@@ -1527,7 +1367,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     // (thousands of scattered byte stores over PCIe cost more than the kernels); the two variable-length point
     // lists are written by their compaction steps, in order, straight into the pinned block
     char* ho = f->tgt_out.host<char>();      // pinned, device accessible
-    char* dbo = f->tgt_out.dev<char>();
+    char* dbo = out_mode == 1 ? ho : f->tgt_out.dev<char>();     // (1: zero-copy stores, A/B experiments)
     int32_t* tot_host = reinterpret_cast<int32_t*>(ho + q_tot);
     int32_t* tot = reinterpret_cast<int32_t*>(db + o_tot);             // device counters: [0] new pts, [1] bg pts
     if (nT) {
@@ -1560,8 +1400,10 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh,
                        reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, tot, reinterpret_cast<int32_t*>(dbo + q_tot));
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(ho, dbo, q_pts, hipMemcpyDeviceToHost, s));
+    if (out_mode != 1) FM_HIP(hipMemcpyAsync(ho, dbo, q_pts, hipMemcpyDeviceToHost, s));
+    g_flow_sub[2] += fm_now_ms() - tp0; tp0 = fm_now_ms();
     FM_HIP(hipStreamSynchronize(s));
+    g_flow_sub[3] += fm_now_ms() - tp0;
     if (nT) {
         memcpy(area_out, ho + q_area, 4 * (size_t)nT);
         memcpy(needy_out, ho + q_needy, nT);

@@ -803,12 +803,23 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
 // only orders the tracks and scatters the results; the glue arithmetic below reproduces the NumPy
 // expressions of the reference bit for bit (float32 products, see the comments).
 // ---------------------------------------------------------------------------------------------------
+extern double g_flow_sub[8];
+
 extern "C" int fm_flow_timing(double* out5, int reset) {
     for (int i = 0; i < 5; ++i) out5[i] = g_flow_times[i];
+    if (getenv("FASTMOT_FLOW_TIMING_VERBOSE")) {
+        const double nc = g_flow_times[4] > 0 ? g_flow_times[4] : 1;
+        fprintf(stderr, "flow sub-stages (ms/call): prepare host %.3f sync0 %.3f enqueue %.3f sync1 %.3f | lk sync0 %.3f enqueue %.3f sync1 %.3f\n",
+                g_flow_sub[0] / nc, g_flow_sub[1] / nc, g_flow_sub[2] / nc, g_flow_sub[3] / nc, g_flow_sub[4] / nc,
+                g_flow_sub[5] / nc, g_flow_sub[6] / nc);
+    }
     if (getenv("FASTMOT_FLOW_TIMING_VERBOSE"))
         fprintf(stderr, "flow_estimate: %.3f tracks re-fitted under the mask, %.3f ms per call\n",
                 g_flow_times[5] / (g_flow_times[4] > 0 ? g_flow_times[4] : 1), g_flow_times[6] / (g_flow_times[4] > 0 ? g_flow_times[4] : 1));
-    if (reset) for (double& v : g_flow_times) v = 0;
+    if (reset) {
+        for (double& v : g_flow_times) v = 0;
+        for (double& v : g_flow_sub) v = 0;
+    }
     return 0;
 }
 

@@ -13,6 +13,7 @@ from pathlib import Path
 
 import numpy as np
 
+from . import scaled_yolov4
 from .darknet import DarknetWeights, darknet_graph
 from .graph import Graph, fold_bn, missing_weights
 
@@ -37,6 +38,7 @@ class YOLO:
     SCALES = None
     ANCHORS = None
     TOPOLOGY = 'yolov4'
+    BUILTIN_CFG = None          # name of a generator in models/scaled_yolov4.py (used when no .cfg file is present)
 
     def __init_subclass__(cls, **kwargs):
         super().__init_subclass__(**kwargs)
@@ -75,6 +77,11 @@ class YOLO:
         elif cls.TOPOLOGY == 'yolov4':
             assert len(cls.LAYER_FACTORS) == len(cls.SCALES) == len(cls.ANCHORS)
             g, heads = yolov4_graph(cls, weights)
+        elif cls.BUILTIN_CFG is not None:
+            # Scaled-YOLOv4 topologies generated section by section (models/scaled_yolov4.py)
+            text = getattr(scaled_yolov4, cls.BUILTIN_CFG)(cls.INPUT_SHAPE[2], cls.INPUT_SHAPE[1], cls.NUM_CLASSES)
+            g, heads, meta = darknet_graph(text, weights, in_hw=cls.INPUT_SHAPE[1:])
+            assert meta['strides'] == list(cls.LAYER_FACTORS) and meta['new_coords'] == cls.NEW_COORDS
         else:
             raise NotImplementedError(f'{cls.__name__}: no built-in layer table; put the Darknet cfg at {cfg}')
         if real is not None and real.remaining() != 0:
@@ -211,8 +218,9 @@ class YOLOv4_608(YOLO):
 _COCO_ANCHORS = [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146], [142, 110, 192, 243, 459, 401]]
 
 
-def _scaled(name, input_shape, factors, anchors, scales=2.0):
+def _scaled(name, input_shape, factors, anchors, scales=2.0, builtin=None):
     return type(name, (YOLO,), dict(
+        BUILTIN_CFG=builtin,
         ENGINE_PATH=Path(__file__).parent / f'{_file_name(name)}.hipnet',
         MODEL_PATH=Path(__file__).parent / f'{_file_name(name)}.weights',
         NUM_CLASSES=1, LETTERBOX=True, NEW_COORDS=True, INPUT_SHAPE=input_shape, LAYER_FACTORS=factors,
@@ -224,7 +232,7 @@ def _file_name(name):
             'YOLOv4CSPxSwish': 'yolov4-csp-x-swish', 'YOLOv4P5': 'yolov4-p5', 'YOLOv4P6': 'yolov4-p6'}[name]
 
 
-YOLOv4CSP = _scaled('YOLOv4CSP', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
+YOLOv4CSP = _scaled('YOLOv4CSP', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS, builtin='yolov4_csp_cfg')
 YOLOv4xMish = _scaled('YOLOv4xMish', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
 YOLOv4CSPSwish = _scaled('YOLOv4CSPSwish', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
 YOLOv4CSPxSwish = _scaled('YOLOv4CSPxSwish', (3, 640, 640), [8, 16, 32], _COCO_ANCHORS)
@@ -233,7 +241,20 @@ YOLOv4P5 = _scaled('YOLOv4P5', (3, 896, 896), [8, 16, 32],
                     [171, 384, 324, 451, 616, 618, 800, 800]])
 YOLOv4P6 = _scaled('YOLOv4P6', (3, 1280, 1280), [8, 16, 32, 64],
                    [[13, 17, 31, 25, 24, 51, 61, 45], [61, 45, 48, 102, 119, 96, 97, 189],
-                    [97, 189, 217, 184, 171, 384, 324, 451], [324, 451, 545, 357, 616, 618, 1024, 1024]])
+                    [97, 189, 217, 184, 171, 384, 324, 451], [324, 451, 545, 357, 616, 618, 1024, 1024]],
+                   builtin='yolov4_p6_cfg')
+
+
+class YOLOv4CSP_640(YOLOv4CSP):
+    """BASELINE.json config[2]: Scaled-YOLOv4 CSP at 640x640 with the 80 COCO classes (52.9 M parameters,
+    121 GFLOP), seeded random weights unless yolov4-csp.weights is present."""
+    NUM_CLASSES = 80
+
+
+class YOLOv4P6_1280(YOLOv4P6):
+    """BASELINE.json config[4]: Scaled-YOLOv4 P6 at 1280x1280, 80 classes, 4 heads x 4 anchors
+    (127.5 M parameters, 722 GFLOP)."""
+    NUM_CLASSES = 80
 
 
 class YOLOv4Tiny(YOLO):
