@@ -1188,12 +1188,14 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const size_t o_st = sizeof(float) * 2 * n, o_err = (o_st + n + 15) & ~size_t(15);
         const size_t out_bytes = o_err + sizeof(float) * n;
         if ((rc = f->lk_out.reserve(out_bytes))) return rc;
-        static const int io_mode = getenv("FASTMOT_LK_IO") ? atoi(getenv("FASTMOT_LK_IO")) : 1;
+        static const int io_mode = getenv("FASTMOT_LK_IO") ? atoi(getenv("FASTMOT_LK_IO")) : 2;
         double tl0 = fm_now_ms();
         FM_HIP(hipStreamSynchronize(s));
         g_flow_sub[4] += fm_now_ms() - tl0; tl0 = fm_now_ms();
-        // io_mode 1 (default): points in are read once per point straight from device-mapped pinned memory;
-        // results out go to a device buffer + one D2H copy.  0: blit copies both ways.  2: zero-copy both ways.
+        // io_mode 2 (default): points in and results out through device-mapped pinned host memory (each wavefront
+        // reads 8 bytes and writes 13: no blit copies around the kernel; measured 0.127 ms per call against 0.147 ms
+        // with H2D + D2H copies, mode 0).  Mode 1 (zero-copy in, D2H copy out) stalls the following stream
+        // synchronisations by ~0.4 ms on this runtime and is kept only as a record of that measurement.
         memcpy(f->lk_in.h, prev_pts, sizeof(float) * 2 * n);
         if (io_mode == 0) FM_HIP(hipMemcpyAsync(f->lk_in.d, f->lk_in.h, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
         const int p = f->prev, c = p ^ 1;
@@ -1280,7 +1282,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     f->nT = nT;
     const int nk = nT ? kp_off[nT] : 0;
     double tp0 = fm_now_ms();
-    static const int out_mode = getenv("FASTMOT_PREP_OUT") ? atoi(getenv("FASTMOT_PREP_OUT")) : 0;
+    static const int out_mode = getenv("FASTMOT_PREP_OUT") ? atoi(getenv("FASTMOT_PREP_OUT")) : 1;
     // ---- host side: integer rects, overlap lists, crop table
     std::vector<int32_t> irect(4 * (size_t)nT), ov_off(nT + 1, 0), ov_idx;
     std::vector<CropArgs> crops(nT);
@@ -1363,21 +1365,23 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     f->v_rects = reinterpret_cast<const int32_t*>(db + o_rect);
     f->v_ov_off = reinterpret_cast<const int32_t*>(db + o_ovoff);
     f->v_ov_idx = reinterpret_cast<const int32_t*>(db + o_ovidx);
-    // results: the small per-track / per-keypoint arrays are produced in device memory and fetched with ONE copy
-    // (thousands of scattered byte stores over PCIe cost more than the kernels); the two variable-length point
-    // lists are written by their compaction steps, in order, straight into the pinned block
+    // results: written by the kernels straight into the pinned, device-mapped block (out_mode 1, default); out_mode 0
+    // keeps the small per-track / per-keypoint arrays in device memory and fetches them with one D2H copy (same
+    // speed, measured; the consumers of needy / min-distance read the device copy either way)
     char* ho = f->tgt_out.host<char>();      // pinned, device accessible
     char* dbo = out_mode == 1 ? ho : f->tgt_out.dev<char>();     // (1: zero-copy stores, A/B experiments)
     int32_t* tot_host = reinterpret_cast<int32_t*>(ho + q_tot);
     int32_t* tot = reinterpret_cast<int32_t*>(db + o_tot);             // device counters: [0] new pts, [1] bg pts
     if (nT) {
         const Overlaps ov{f->v_ov_idx, f->v_ov_off};
-        uint8_t* d_needy = reinterpret_cast<uint8_t*>(dbo + q_needy);
-        int32_t* d_md = reinterpret_cast<int32_t*>(dbo + q_md);
+        // needy flags / min distances are consumed by the eig / select kernels: device copies (behind the upload)
+        uint8_t* d_needy = reinterpret_cast<uint8_t*>(db + o_dneedy);
+        int32_t* d_md = reinterpret_cast<int32_t*>(db + o_dmd);
         hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(256), 0, s, f->v_rects, ov,
                            reinterpret_cast<const float*>(db + o_kps), reinterpret_cast<const int32_t*>(db + o_kpoff),
                            feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(dbo + q_area),
-                           reinterpret_cast<uint8_t*>(dbo + q_keep), d_needy, d_md, (uint8_t*)nullptr);
+                           reinterpret_cast<uint8_t*>(dbo + q_keep), d_needy, d_md,
+                           reinterpret_cast<uint8_t*>(dbo + q_needy));
         hipLaunchKernelGGL(eig_kernel, dim3((max_area + 255) / 256, nT), dim3(256), 0, s, f->gray[f->prev], f->W,
                            reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, d_needy);
         hipLaunchKernelGGL(gftt_select_kernel, dim3(nT), dim3(GFTT_BLK), gftt_lds_bytes(max_area), s,
