@@ -119,12 +119,14 @@ def cpu_leg(cfg, video, mot, budget_s=20.0):
 
 
 def compiled_baseline(cfg, video, budget_s=10.0):
-    """kind=compiled-port: oracle/c_baseline (plain C, -O3 -march=native, single thread) of the same KLT + Kalman
-    + association stages -- the 'Numba-class proxy' of SURVEY.md section 8d; None when it has not been built."""
+    """kind=compiled-port: the same CPU path with the parts the reference runs as compiled code (OpenCV KLT / RANSAC)
+    in plain C (oracle/c_baseline.c, -O3, single thread) under the same Python orchestration -- the 'Numba-class
+    proxy' of SURVEY.md section 8d; None when gcc / the library is unavailable."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     try:
         import c_baseline
-    except ImportError:
+        c_baseline.lib()
+    except (ImportError, OSError, RuntimeError):
         return None
     return c_baseline.time_clip(cfg, video, tracker_cfg(), budget_s)
 

@@ -32,13 +32,19 @@ struct DetState {
     int32_t* counters = nullptr;  // [0]=n_cand [1]=overflow [2]=n_det
     uint64_t* mask = nullptr;     // [cap][cap/64]
     fm_det48* dets = nullptr;     // [cap]
-    fm_det48* dets_host = nullptr;
-    int32_t* counters_host = nullptr;
+    // Results are double buffered on the host side and completed by events, so that the pass on the NEXT frame
+    // can already be queued behind this one (MOT.step with next_frame: the detector stream never idles) while the
+    // host still has to collect this frame's detections: passes are collected in the order they were enqueued.
+    static constexpr int NSLOT = 2;
+    static constexpr int PREFIX = 2048;        // detections copied back with the pass (more: synchronous fallback)
+    fm_det48* dets_host[NSLOT] = {nullptr, nullptr};
+    int32_t* counters_host[NSLOT] = {nullptr, nullptr};
+    hipEvent_t ev_done[NSLOT] = {nullptr, nullptr};
+    hipEvent_t ev0[NSLOT] = {nullptr, nullptr}, ev1[NSLOT] = {nullptr, nullptr};   // bracket the network launches
+    int wr = 0, rd = 0, pending = 0, last = -1;   // slot written next / collected next / passes in flight / last collected
     uint8_t* label_mask = nullptr;
     float* rows_in = nullptr;     // test hook upload
     int rows_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the network launches of detect_async
-    bool ev_valid = false;
 };
 
 void fm_det_free(DetState* d) {
@@ -46,10 +52,12 @@ void fm_det_free(DetState* d) {
     for (void* p : {(void*)d->cand, (void*)d->sorted, (void*)d->counters, (void*)d->mask, (void*)d->dets,
                     (void*)d->label_mask, (void*)d->rows_in})
         if (p) (void)hipFree(p);
-    if (d->dets_host) (void)hipHostFree(d->dets_host);
-    if (d->counters_host) (void)hipHostFree(d->counters_host);
-    if (d->ev0) (void)hipEventDestroy(d->ev0);
-    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    for (int i = 0; i < DetState::NSLOT; ++i) {
+        if (d->dets_host[i]) (void)hipHostFree(d->dets_host[i]);
+        if (d->counters_host[i]) (void)hipHostFree(d->counters_host[i]);
+        for (hipEvent_t e : {d->ev_done[i], d->ev0[i], d->ev1[i]})
+            if (e) (void)hipEventDestroy(e);
+    }
     delete d;
 }
 
@@ -342,17 +350,28 @@ int alloc_post(DetState* d, int cap) {
     if (d->cand && cap == d->cap) return 0;
     for (void* p : {(void*)d->cand, (void*)d->sorted, (void*)d->mask, (void*)d->dets})
         if (p) (void)hipFree(p);
-    if (d->dets_host) (void)hipHostFree(d->dets_host);
-    d->cand = d->sorted = nullptr; d->mask = nullptr; d->dets = nullptr; d->dets_host = nullptr;
+    for (int i = 0; i < DetState::NSLOT; ++i) {
+        if (d->dets_host[i]) (void)hipHostFree(d->dets_host[i]);
+        d->dets_host[i] = nullptr;
+    }
+    d->cand = d->sorted = nullptr; d->mask = nullptr; d->dets = nullptr;
     d->cap = cap;
+    d->wr = d->rd = d->pending = 0;
+    d->last = -1;
     FM_HIP(hipMalloc(&d->cand, sizeof(float) * 8 * cap));
     FM_HIP(hipMalloc(&d->sorted, sizeof(float) * 8 * cap));
     FM_HIP(hipMalloc(&d->mask, sizeof(uint64_t) * (size_t)cap * (cap / 64)));
     FM_HIP(hipMalloc(&d->dets, sizeof(fm_det48) * cap));
-    FM_HIP(hipHostMalloc(&d->dets_host, sizeof(fm_det48) * cap, hipHostMallocDefault));
+    for (int i = 0; i < DetState::NSLOT; ++i)
+        FM_HIP(hipHostMalloc(&d->dets_host[i], sizeof(fm_det48) * cap, hipHostMallocDefault));
     if (!d->counters) {
         FM_HIP(hipMalloc(&d->counters, sizeof(int32_t) * 4));
-        FM_HIP(hipHostMalloc(&d->counters_host, sizeof(int32_t) * 4, hipHostMallocDefault));
+        for (int i = 0; i < DetState::NSLOT; ++i) {
+            FM_HIP(hipHostMalloc(&d->counters_host[i], sizeof(int32_t) * 4, hipHostMallocDefault));
+            FM_HIP(hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming));
+            FM_HIP(hipEventCreate(&d->ev0[i]));
+            FM_HIP(hipEventCreate(&d->ev1[i]));
+        }
         FM_HIP(hipMalloc(&d->label_mask, 128));
     }
     return 0;
@@ -380,25 +399,49 @@ int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), sizeof(uint64_t) * (cap / 64), s, d->sorted,
                        d->counters, cap, d->mask, d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets);
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(d->counters_host, d->counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, s));
-    // detections are few: copy a bounded prefix now, the rest (rare) at sync time
-    FM_HIP(hipMemcpyAsync(d->dets_host, d->dets, sizeof(fm_det48) * (cap < 512 ? cap : 512), hipMemcpyDeviceToHost, s));
+    if (d->pending >= DetState::NSLOT) {      // never collected (a caller that only ever enqueues): drop the oldest
+        d->rd = (d->rd + 1) % DetState::NSLOT;
+        --d->pending;
+    }
+    const int slot = d->wr;
+    FM_HIP(hipMemcpyAsync(d->counters_host[slot], d->counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, s));
+    // detections are few: copy a bounded prefix with the pass, the rest (rare) at collection time
+    FM_HIP(hipMemcpyAsync(d->dets_host[slot], d->dets, sizeof(fm_det48) * (cap < DetState::PREFIX ? cap : DetState::PREFIX),
+                          hipMemcpyDeviceToHost, s));
+    FM_HIP(hipEventRecord(d->ev_done[slot], s));
+    d->wr = (slot + 1) % DetState::NSLOT;
+    ++d->pending;
     return 0;
 }
 
 int collect(fm_ctx* ctx, DetState* d, hipStream_t s, fm_det48* out, int cap_out, int* n) {
-    FM_HIP(hipStreamSynchronize(s));
-    if (d->counters_host[1]) {
-        fm_set_error("candidate list overflow (%d > %d): raise max_candidates", d->counters_host[0], d->cap);
+    if (d->pending == 0) {
+        fm_set_error("no detector pass in flight (fm_detect_async first)");
         return FM_ERR_STATE;
     }
-    const int nd = d->counters_host[2];
-    if (nd > 512) FM_HIP(hipMemcpy(d->dets_host, d->dets, sizeof(fm_det48) * nd, hipMemcpyDeviceToHost));
+    const int slot = d->rd;
+    FM_HIP(hipEventSynchronize(d->ev_done[slot]));
+    d->rd = (slot + 1) % DetState::NSLOT;
+    --d->pending;
+    d->last = slot;
+    if (d->counters_host[slot][1]) {
+        fm_set_error("candidate list overflow (%d > %d): raise max_candidates", d->counters_host[slot][0], d->cap);
+        return FM_ERR_STATE;
+    }
+    const int nd = d->counters_host[slot][2];
+    if (nd > DetState::PREFIX) {
+        if (d->pending) {       // the device list already belongs to the next pass
+            fm_set_error("%d detections exceed the %d copied back with the pass while another pass is in flight",
+                         nd, DetState::PREFIX);
+            return FM_ERR_STATE;
+        }
+        FM_HIP(hipMemcpy(d->dets_host[slot], d->dets, sizeof(fm_det48) * nd, hipMemcpyDeviceToHost));
+    }
     if (nd > cap_out) {
         fm_set_error("output capacity %d < %d detections", cap_out, nd);
         return FM_ERR_ARG;
     }
-    memcpy(out, d->dets_host, sizeof(fm_det48) * nd);
+    memcpy(out, d->dets_host[slot], sizeof(fm_det48) * nd);
     *n = nd;
     return 0;
 }
@@ -493,7 +536,8 @@ extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
     const size_t bytes = (size_t)ctx->frame_w * ctx->frame_h * 3;
     const uint8_t* src = bgr;
     if (!is_pinned_range(bgr, bytes)) {
-        FM_HIP(hipStreamSynchronize(ctx->s_det));    // previous H2D copy out of the staging buffer
+        // previous H2D copy out of a staging buffer: its event, not the stream (a detector pass may be running)
+        if (ctx->ev_next_upload) FM_HIP(hipEventSynchronize(ctx->ev_next_upload));
         memcpy(ctx->frame_pinned2, bgr, bytes);
         src = ctx->frame_pinned2;
     }
@@ -560,6 +604,8 @@ extern "C" int fm_detect_configure(fm_ctx* ctx, const fm_yolo_cfg* cfg) {
     if (rc) return rc;
     DetState* d = ctx->det;
     FM_HIP(hipStreamSynchronize(ctx->s_det));
+    d->rd = d->wr;            // a new detector: nothing of the previous one is collected any more
+    d->pending = 0;
     d->cfg = *cfg;
     if ((rc = alloc_post(d, cfg->max_candidates > 0 ? cfg->max_candidates : 8192))) return rc;
     FM_HIP(hipMemcpy(d->label_mask, cfg->label_mask, 128, hipMemcpyHostToDevice));
@@ -606,14 +652,9 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     hipStream_t s = ctx->s_det;
     int rc = enqueue_preprocess(ctx, d, net, frame);
     if (rc) return rc;
-    if (!d->ev0) {
-        FM_HIP(hipEventCreate(&d->ev0));
-        FM_HIP(hipEventCreate(&d->ev1));
-    }
-    FM_HIP(hipEventRecord(d->ev0, s));
+    FM_HIP(hipEventRecord(d->ev0[d->wr], s));
     if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
-    FM_HIP(hipEventRecord(d->ev1, s));
-    d->ev_valid = true;
+    FM_HIP(hipEventRecord(d->ev1[d->wr], s));
     FilterArgs fa = filter_args(d);      // (counters were zeroed by this frame's preprocess kernel)
     HeadSet hs{};
     int base = 0, blocks = 0;
@@ -648,6 +689,8 @@ extern "C" int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* o
     DetState* d = ctx->det;
     hipStream_t s = ctx->s_det;
     FM_HIP(hipStreamSynchronize(s));
+    d->rd = d->wr;            // (test hook: passes nobody collected are dropped; the stream is idle here)
+    d->pending = 0;
     if (n > d->rows_cap) {
         if (d->rows_in) FM_HIP(hipFree(d->rows_in));
         d->rows_in = nullptr;
@@ -678,8 +721,9 @@ extern "C" int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* 
 // HIP-event time (ms) of the network launches of the last fm_detect_async, measured on the
 // detector stream itself (bench.py roofline: conv FLOPs / this time).
 extern "C" int fm_detect_net_ms(fm_ctx* ctx, float* ms) {
-    FM_CHECK_ARG(ctx && ctx->det && ms && ctx->det->ev_valid);
-    FM_HIP(hipEventSynchronize(ctx->det->ev1));
-    FM_HIP(hipEventElapsedTime(ms, ctx->det->ev0, ctx->det->ev1));
+    FM_CHECK_ARG(ctx && ctx->det && ms && ctx->det->last >= 0);      // the pass collected last
+    const int slot = ctx->det->last;
+    FM_HIP(hipEventSynchronize(ctx->det->ev1[slot]));
+    FM_HIP(hipEventElapsedTime(ms, ctx->det->ev0[slot], ctx->det->ev1[slot]));
     return 0;
 }

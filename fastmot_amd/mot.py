@@ -100,8 +100,8 @@ class MOT:
 
         next_frame (optional, not in the reference): the frame the following `step` will receive, when
         the caller already has it (file sources, a capture queue).  The detector network is then started
-        on it as soon as this frame's ReID network is enqueued, so that it overlaps this frame's ReID and
-        association stages; results are unchanged (the detector is stateless), per-frame latency too."""
+        on it right behind this frame's own pass, so that it overlaps this frame's KLT, ReID and association
+        stages; results are unchanged (the detector is stateless), per-frame latency too."""
         ctx = self.tracker.ctx
         bind_frame(ctx, frame, self.size, begin_step=True)
         ctx.in_step = True
@@ -139,13 +139,15 @@ class MOT:
             # reference, so the results are identical.
             flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
             try:
+                # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
+                # detector stream never idles; results are collected in order, detect.hip)
+                self._prefetch_next()
                 with Profiler('detect'):
                     detections = self._last_detections = self.detector.postprocess()
 
                 with Profiler('extract'):
                     if len(self.extractors) == 1:
                         self.extractors[0].extract_async(frame, detections.tlbr)
-                        self._prefetch_next()
                         self.tracker.prepare_detections(detections)
                         embeddings = self.extractors[0].postprocess()
                     else:
@@ -154,7 +156,6 @@ class MOT:
                         cls_bboxes = self._split_bboxes_by_cls(detections.tlbr, detections.label, self.class_ids)
                         for extractor, bboxes in zip(self.extractors, cls_bboxes):
                             extractor.extract_async(frame, bboxes)
-                        self._prefetch_next()
                         self.tracker.prepare_detections(detections)
                         parts = [extractor.postprocess() for extractor in self.extractors]
                         filled = [p for p in parts if len(p)]

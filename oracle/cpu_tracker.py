@@ -61,7 +61,8 @@ class OracleFlow:
     """Flow.init / Flow.predict on real frames with cv_oracle (flow.py:121-264)."""
 
     def __init__(self, size, bg_scale=(0.1, 0.1), opt_scale=(0.5, 0.5), feat_density=0.005, feat_dist_factor=0.06,
-                 ransac_max_iter=500, ransac_conf=0.99, max_error=100, inlier_thresh=4, bg_feat_thresh=10):
+                 ransac_max_iter=500, ransac_conf=0.99, max_error=100, inlier_thresh=4, bg_feat_thresh=10, cv_impl=None):
+        self.cv = cv_impl if cv_impl is not None else cv      # cv_oracle (numpy) or c_baseline (compiled C)
         self.size = size
         self.bg_scale, self.opt_scale = bg_scale, opt_scale
         self.feat_density, self.feat_dist_factor = feat_density, feat_dist_factor
@@ -73,12 +74,12 @@ class OracleFlow:
         self.bg_keypoints = self.prev_bg_keypoints = np.empty((0, 2), np.float32)
 
     def init(self, frame):
-        self.prev_gray = cv.bgr2gray(frame)
-        self.prev_small = cv.resize_linear_u8(self.prev_gray, self.small_sz)
+        self.prev_gray = self.cv.bgr2gray(frame)
+        self.prev_small = self.cv.resize_linear_u8(self.prev_gray, self.small_sz)
 
     def predict(self, frame, tracks):
-        gray = cv.bgr2gray(frame)
-        small = cv.resize_linear_u8(gray, self.small_sz)
+        gray = self.cv.bgr2gray(frame)
+        small = self.cv.resize_linear_u8(gray, self.small_sz)
         tracks.sort(reverse=True)
         empty = np.empty((0, 2), np.float32)
         fg = np.full(gray.shape, 255, np.uint8)
@@ -96,7 +97,7 @@ class OracleFlow:
                 kp = kp[fg[p2[:, 1], p2[:, 0]] == 255] if len(kp) else kp
             if len(kp) < self.feat_density * area:
                 md = max(round(np.sqrt(area) * self.feat_dist_factor), 1)
-                kp = cv.good_features_to_track(self.prev_gray[ins[1]:ins[3] + 1, ins[0]:ins[2] + 1], tm, 1000, 0.06, md)
+                kp = self.cv.good_features_to_track(self.prev_gray[ins[1]:ins[3] + 1, ins[0]:ins[2] + 1], tm, 1000, 0.06, md)
                 if len(kp):
                     kp = kp + ins[:2].astype(np.float32)
                     c = (t.tlbr[:2] + t.tlbr[2:]) / 2
@@ -106,9 +107,9 @@ class OracleFlow:
             tm[:] = 0
         ends = np.cumsum([len(p) for p in all_prev]).astype(np.int32) if tracks else np.zeros(0, np.int32)
         begins = np.concatenate([[0], ends[:-1]]).astype(np.int32) if tracks else np.zeros(0, np.int32)
-        bg_img = cv.resize_linear_u8(self.prev_gray, self.bg_sz)
-        mask_small = cv.resize_nearest(fg, self.bg_sz)
-        kp = cv.fast_detect(bg_img, self.bg_feat_thresh)
+        bg_img = self.cv.resize_linear_u8(self.prev_gray, self.bg_sz)
+        mask_small = self.cv.resize_nearest(fg, self.bg_sz)
+        kp = self.cv.fast_detect(bg_img, self.bg_feat_thresh)
         kp = kp[[mask_small[int(p[1] + 0.5), int(p[0] + 0.5)] != 0 for p in kp]] if len(kp) else kp
         if len(kp) == 0:
             self.bg_keypoints = empty
@@ -119,12 +120,12 @@ class OracleFlow:
         all_prev.append(kp)
         P = np.concatenate(all_prev).astype(np.float32)
         sp = P * np.array(self.opt_scale, np.float32)
-        C, st, err = cv.calc_optical_flow_pyr_lk(self.prev_small, small, sp)
+        C, st, err = self.cv.calc_optical_flow_pyr_lk(self.prev_small, small, sp)
         st = st.astype(bool) & (err < self.max_error)
         C[st] = C[st] * (1 / np.array(self.opt_scale, np.float32))
         self.prev_gray, self.prev_small = gray, small
         tl = np.array([t.tlbr for t in tracks], float).reshape(-1, 4)
-        H, res, est, nm, inl = cv.flow_estimate(P, C, st, begins, ends, bg_begin, max(len(P) - 1, bg_begin), tl,
+        H, res, est, nm, inl = self.cv.flow_estimate(P, C, st, begins, ends, bg_begin, max(len(P) - 1, bg_begin), tl,
                                                 self.size, self.ransac_max_iter, self.ransac_conf, self.inlier_thresh)
         if H is None:
             self.bg_keypoints = empty
@@ -148,7 +149,7 @@ class OracleFlow:
 class OracleTracker:
     def __init__(self, size, metric, max_age=6, age_penalty=2, motion_weight=0.2, max_assoc_cost=0.9,
                  max_reid_cost=0.45, iou_thresh=0.4, duplicate_thresh=0.8, occlusion_thresh=0.7, conf_thresh=0.5,
-                 confirm_hits=1, history_size=50, kalman_filter_cfg=None, flow_cfg=None):
+                 confirm_hits=1, history_size=50, kalman_filter_cfg=None, flow_cfg=None, cv_impl=None):
         self.size, self.metric = size, metric.lower()
         self.max_age, self.age_penalty, self.motion_weight = max_age, age_penalty, motion_weight
         self.max_assoc_cost, self.max_reid_cost, self.iou_thresh = max_assoc_cost, max_reid_cost, iou_thresh
@@ -157,7 +158,7 @@ class OracleTracker:
         self.p = o.KFParams(**(vars(kalman_filter_cfg) if kalman_filter_cfg is not None else {}))
         self.tracks, self.hist_tracks = {}, OrderedDict()
         self.frame_rect = np.array([0., 0., size[0] - 1., size[1] - 1.])
-        self.flow = OracleFlow(size)
+        self.flow = OracleFlow(size, cv_impl=cv_impl)
         self.klt_bboxes, self.homography = {}, None
 
     def reset(self, dt):

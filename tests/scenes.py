@@ -263,3 +263,101 @@ def pack_records(records, final):
         out['final_mean'] = np.array([final[i][0] for i in ids]).reshape(-1, 8)
         out['final_cov'] = np.array([final[i][1] for i in ids]).reshape(-1, 8, 8)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# MOT-level scenes: the same scripted inputs behind the Detector / FeatureExtractor interfaces, so that MOT.step
+# itself (mot.py:125-168: schedule, one extractor per class id, _split_bboxes_by_cls, embedding concatenation) can be
+# run -- by the reference (oracle/make_golden_mot.py) and by fastmot_amd (tests/test_mot_multiclass_gpu.py).
+# ------------------------------------------------------------------------------------------------
+class FakeDetector:
+    """Detector interface (detector.py:26-43) returning the scene's scripted detections.  It is called on frame 0
+    and then on every detector frame, in order: the frame id follows from the call count."""
+    scene = None
+    state = None
+
+    def __init__(self, size, class_ids=None, *args, **kwargs):
+        self.size = size
+        self.calls = 0
+
+    def __call__(self, frame):
+        self.detect_async(frame)
+        return self.postprocess()
+
+    def detect_async(self, frame):
+        self.state['frame_id'] = self.calls * self.scene.skip
+        self.calls += 1
+
+    def prefetch(self, frame):
+        pass
+
+    def postprocess(self):
+        dets, _ = self.scene.detections(self.state['frame_id'])
+        return dets
+
+
+class FakeExtractor:
+    """FeatureExtractor interface (feature_extractor.py:39-74): embeddings of the boxes it is handed, looked up in the
+    scene by box (first unused exact match); no boxes -> np.empty((0, dim)) float64, as the reference returns."""
+    scene = None
+    state = None
+    log = None                    # [(frame_id, extractor index, number of boxes)] -- which extractor got what
+
+    def __init__(self, *args, **kwargs):
+        self.index = len(FakeExtractor.instances)
+        FakeExtractor.instances.append(self)
+        self.rows = []
+
+    instances = []
+
+    @property
+    def metric(self):
+        return self.scene.metric
+
+    def extract_async(self, frame, tlbrs):
+        dets, _ = self.scene.detections(self.state['frame_id'])
+        used = self.state.setdefault(('used', self.state['frame_id']), set())
+        self.rows = []
+        for box in np.asarray(tlbrs, float).reshape(-1, 4):
+            for i in range(len(dets)):
+                if i not in used and np.array_equal(dets.tlbr[i], box):
+                    used.add(i)
+                    self.rows.append(i)
+                    break
+            else:
+                raise AssertionError('box handed to the extractor is not a detection of this frame')
+        FakeExtractor.log.append((self.state['frame_id'], self.index, len(self.rows)))
+
+    def postprocess(self):
+        _, embs = self.scene.detections(self.state['frame_id'])
+        if not self.rows:
+            return np.empty((0, embs.shape[1]))
+        return embs[self.rows]
+
+    def __call__(self, frame, tlbrs):
+        self.extract_async(frame, tlbrs)
+        return self.postprocess()
+
+
+def bind_fakes(scene):
+    state = {}
+    FakeDetector.scene = FakeExtractor.scene = scene
+    FakeDetector.state = FakeExtractor.state = state
+    FakeExtractor.instances = []
+    FakeExtractor.log = []
+    return state
+
+
+def run_scene_mot(mot, scene, frame_for=lambda f: f):
+    """Drives a MOT object (reference or fastmot_amd, built with the fakes above) over the scene; same record
+    format as run_scene."""
+    mot.tracker.flow = scene.make_flow()
+    mot.reset(1 / 30.)
+    records = []
+    for frame_id in range(scene.n_frames):
+        mot.step(frame_for(frame_id))
+        tracker = mot.tracker
+        rows = [(int(tid), np.asarray(t.tlbr, float).copy(), bool(t.confirmed), bool(t.active),
+                 int(t.age), int(t.hits)) for tid, t in tracker.tracks.items()]
+        records.append((frame_id, rows, [int(k) for k in tracker.hist_tracks.keys()]))
+    return records
