@@ -77,6 +77,15 @@ void fm_flow_free(FlowState* f) {
 
 namespace {
 
+// FM_SGPR_CAP: kernels of the KLT stream run beside the ReID network's kernels on the same CUs.  Measured on MI355X
+// (scripts/stress_lk4.py, stress_lk5.py): while grouped LightConv launches (liteconv_kernel) or the OSNet graph run on
+// another stream, 15-30 % of the calls of this kernel returned one or two of 600 points off by 1e-5 .. 0.2 px --
+// constant inputs, images intact afterwards, never when idle or beside conv / YOLOv4 launches, never when this kernel
+// had its CUs to itself (150 KB LDS request).  The effect follows the SCALAR register budget of the victim: 106 and 78
+// SGPRs per wave were hit (73 and 59 of 400 calls), 46 SGPRs never (0 of 400).  The cause inside the part was not
+// established; the budget of the KLT kernels is therefore capped (the compiler spills the rest to VGPR lanes).
+#define FM_SGPR_CAP __attribute__((amdgpu_num_sgpr(48)))
+
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
@@ -285,7 +294,7 @@ __device__ __forceinline__ float seq_sum(float v) {
 // arguments, no such effect with one point per wavefront or with equal trip counts).  39 idle lanes are
 // the price; the kernel is latency bound anyway.
 template <int WINC>
-__global__ __launch_bounds__(256) void lk_wave_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+__device__ __forceinline__ void lk_wave_body(const LKArgs& a, int n, const float* __restrict__ prev_pts,
                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                  float* __restrict__ err) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,6 +414,14 @@ __global__ __launch_bounds__(256) void lk_wave_kernel(LKArgs a, int n, const flo
     }
 }
 
+
+template <int WINC>
+__global__ __launch_bounds__(1024) FM_SGPR_CAP void lk_wave_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+                                                      float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                      float* __restrict__ err) {
+    lk_wave_body<WINC>(a, n, prev_pts, next_pts, status, err);
+}
+
 // ---- foreground-mask bookkeeping: rect k sees pixel p as foreground iff no rect j<k covers p.
 // Only earlier rects that intersect rect k can cover its pixels: the host passes that (short) list.
 struct Overlaps { const int32_t* idx; const int32_t* off; };   // idx[off[k] .. off[k+1]) = j < k intersecting k
@@ -481,7 +498,7 @@ __global__ void kp_filter_kernel(const int32_t* __restrict__ rects, Overlaps ov,
 
 // fused bookkeeping of flow.py:163-169 for one track per block: mask area, _rect_filter of the
 // propagated keypoints, the "too few keypoints" decision and the GFTT minDistance (flow.py:267-271)
-__global__ __launch_bounds__(256) void prepare_kernel(const int32_t* __restrict__ rects, Overlaps ov,
+__global__ __launch_bounds__(256) FM_SGPR_CAP void prepare_kernel(const int32_t* __restrict__ rects, Overlaps ov,
                                                       const float* __restrict__ kps,
                                                       const int32_t* __restrict__ kp_off, double feat_density,
                                                       double feat_dist_factor, int32_t* __restrict__ area,
@@ -552,7 +569,7 @@ __device__ __forceinline__ void sobel_at(const uint8_t* img, int stride, const C
     dy = gy * scale;
 }
 
-__global__ void eig_kernel(const uint8_t* __restrict__ img, int stride, const CropArgs* __restrict__ crops,
+__global__ FM_SGPR_CAP void eig_kernel(const uint8_t* __restrict__ img, int stride, const CropArgs* __restrict__ crops,
                            float* __restrict__ eig, int block_size, const uint8_t* __restrict__ needy) {
     const CropArgs c = crops[blockIdx.y];
     if (needy && !needy[c.k]) return;
@@ -585,7 +602,7 @@ constexpr int GFTT_MAX_CAND = 4096;      // sorted in LDS (32 KB)
 constexpr int GFTT_MAX_CELLS = 1536;     // x 4 slots x 4 B = 24 KB
 constexpr int GFTT_BLK = 1024;
 
-__global__ __launch_bounds__(GFTT_BLK) void gftt_select_kernel(const CropArgs* __restrict__ crops,
+__global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const CropArgs* __restrict__ crops,
                                                                const int32_t* __restrict__ rects, Overlaps ov,
                                                                const float* __restrict__ eig, float quality,
                                                                int max_corners, const int32_t* __restrict__ min_dist,
@@ -1219,12 +1236,25 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
             uint8_t* o_stat = reinterpret_cast<uint8_t*>(o + o_st);
             float* o_errp = reinterpret_cast<float*>(o + o_err);
             const float* in_pts = io_mode == 0 ? f->lk_in.dev<float>() : f->lk_in.host<float>();
+            // CU isolation: the launch requests (and never touches) 150 KB of dynamic LDS per 16-wavefront workgroup, so
+            // exactly one of its workgroups fits a CU and no LDS-using workgroup of another stream (the ReID network's
+            // fused LightConv kernels: the ones that disturb this kernel, see FM_SGPR_CAP) can be resident beside it.
+            // 16 wavefronts per CU still hide the latency of the scattered byte loads; FASTMOT_LK_LDS=0 disables.
+            static const int lds_req = getenv("FASTMOT_LK_LDS") ? atoi(getenv("FASTMOT_LK_LDS")) : 150000;
+            static bool lds_set = false;
+            if (lds_req > 65536 && !lds_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lk_wave_kernel<5>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lk_wave_kernel<3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
+                lds_set = true;
+            }
+            const int threads = lds_req > 0 ? 1024 : 256;
+            const dim3 grid((unsigned)(((size_t)n * 64 + threads - 1) / threads));
             if (a.win == 5)
-                hipLaunchKernelGGL(lk_wave_kernel<5>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
-                                   o_stat, o_errp);
+                hipLaunchKernelGGL(lk_wave_kernel<5>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
             else
-                hipLaunchKernelGGL(lk_wave_kernel<3>, dim3((n * 64 + 255) / 256), dim3(256), 0, s, a, n, in_pts, o_pts,
-                                   o_stat, o_errp);
+                hipLaunchKernelGGL(lk_wave_kernel<3>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
         }
         FM_HIP(hipGetLastError());
         if (io_mode != 2) FM_HIP(hipMemcpyAsync(f->lk_out.h, f->lk_out.d, out_bytes, hipMemcpyDeviceToHost, s));

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of the detector's conv kernels (LDS-tiled, streamed, fused residual unit): two separate rocprofv3 PMC passes (FETCH_SIZE and
 # WRITE_SIZE do not fit one pass on gfx950) over 6 graph replays of YOLOv4@608, summed per kernel.
-# Run on the GPU box from the repo root:  bash scripts/collect_pmc.sh  -> gpurun_out/pmc_*.txt + r01_pmc_conv.json
+# Run on the GPU box from the repo root:  bash scripts/collect_pmc.sh  -> gpurun_out/pmc_*.txt + r02_pmc_conv.json
 set -e
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -28,6 +28,6 @@ out = dict(kernel='conv_igemm_kernel + convs_kernel + resblock_kernel (all templ
            fetch_bytes_per_frame=round(2 * fetch_kb * 1024 / 6), write_bytes_per_frame=round(write_kb * 1024 / 6),
            splitk_reduce_fetch_kb_raw=f.get('splitk_reduce_kernel', {}).get('total'),
            splitk_reduce_write_kb_raw=w.get('splitk_reduce_kernel', {}).get('total'))
-json.dump(out, open('gpurun_out/r01_pmc_conv.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/r02_pmc_conv.json', 'w'), indent=1)
 print(json.dumps(out))
 PY

@@ -218,19 +218,24 @@ def test_prepare_matches_staged_calls(ctx):
         np.testing.assert_array_equal(new_pts[new_off[k]:new_off[k] + new_cnt[k]], pts0[i, :cnt0[i]])
 
 
-def test_lk_deterministic_while_other_streams_are_busy(ctx):
-    """Regression (found with scripts/stress_lk2.py in round 1): with two points per wavefront the two 32-lane halves
-    of lk_kernel followed different control flow, and single points then changed in 50-80 % of the calls whenever
-    another host thread kept the GPU busy with LDS-heavy kernels -- constant images, constant arguments.
+@pytest.mark.parametrize('hammer', ['liteconv', 'osnet'])
+def test_lk_deterministic_while_other_streams_are_busy(ctx, hammer):
+    """LK on constant inputs must reproduce its idle result bit for bit while another host thread keeps the CUs busy
+    with the ReID network's kernels.
 
-    With one wavefront per point the idle result is reproduced bit for bit; what remains under load, measured in
-    round 2 with scripts/stress_lk3.py for every I/O path (blit copies, zero-copy): about one call in 600 returns
-    ONE of its 600 points 1e-5 .. 4e-3 px away (3e-6 per point and call; no dependence on the kernel variant or
-    on how inputs / outputs travel).  The bound below keeps the regression visible (hundreds of points in most calls)
-    without failing on that residue."""
+    History: round 1 found single points changing in 50-80 % of the calls with two points per wavefront and blamed
+    the diverging halves.  Round 2 (scripts/stress_lk4.py .. stress_lk6.py) narrowed it down: only the two fused
+    LightConv kernels (liteconv_kernel, litechain_kernel -- the only kernels of the library with SGPR spill code,
+    v_writelane / v_readlane) disturb the LK kernel, only when their workgroups are resident on the same CU, and the
+    scalar register budget of the LK kernel matters (106 / 78 SGPRs: 15-18 % of the calls, 46: 2.5 % beside
+    litechain, 0 beside liteconv).  Conv / YOLOv4 / pool / gate / head launches never do, the images stay intact, the
+    networks themselves and the Kalman / cost kernels reproduce bit for bit under the same load
+    (scripts/stress_nets.py).  The LK launch therefore (a) caps its SGPR budget at 48 and (b) requests 150 KB of
+    LDS per 16-wavefront workgroup so that no LDS-using workgroup shares its CU: 0 of 600 calls differ."""
     import threading
     from fastmot_amd.detector import DeviceFrame
-    from fastmot_amd.engine import HipNet, NET_DETECTOR
+    from fastmot_amd.engine import HipNet, NET_EXTRACTOR
+    from fastmot_amd.models import ReID
     from fastmot_amd.models.graph import Graph, RandomWeights
     from fastmot_amd.utils.synthetic import SyntheticVideo
     size = (960, 540)
@@ -243,42 +248,37 @@ def test_lk_deterministic_while_other_streams_are_busy(ctx):
     bind_frame(ctx, DeviceFrame(1), size)
     ctx.flow_begin()
     ctx.synchronize()
-    g = Graph(RandomWeights(seed=1), (64, 32), 16)
-    params = [g.lightconv_params(f'p{i}', 16) for i in range(4)]
-    g.lightconv_group('l', [g.input] * 4, params)
-    net = HipNet(ctx, NET_DETECTOR, g, 50, reuse_buffers=True)
-    net.run(50)
+    ctx.feat_configure(512)
+    if hammer == 'liteconv':
+        g = Graph(RandomWeights(seed=1), (64, 32), 16)
+        params = [g.lightconv_params(f'p{i}', 16) for i in range(4)]
+        g.lightconv_group('l', [g.input] * 4, params)
+    else:
+        g, _ = ReID.get_model('OSNet025').build_graph(RandomWeights(seed=1))
+    net = HipNet(ctx, NET_EXTRACTOR, g, 50, reuse_buffers=True)
+    net.run(50)                                          # (graph capture happens here, not beside the copies below)
     ctx.synchronize()
     rng = np.random.default_rng(0)
     pts = np.stack([rng.uniform(20, size[0] / 2 - 20, 600), rng.uniform(20, size[1] / 2 - 20, 600)], 1).astype(np.float32)
     base = [ctx.flow_lk(pts), ctx.flow_lk(pts)]          # the second call tracks in the opposite direction
-    for k in range(2):                                   # idle: bit for bit
-        nxt, st, _ = ctx.flow_lk(pts)
-        np.testing.assert_array_equal(st, base[k][1])
-        np.testing.assert_array_equal(nxt[st > 0], base[k][0][st > 0])
     stop = []
 
-    def hammer():
+    def hammer_loop():
         ctx.bind_thread()
         while not stop:
             net.run(50)
             ctx.synchronize()
-    th = threading.Thread(target=hammer)
+    th = threading.Thread(target=hammer_loop)
     th.start()
     try:
-        bad_calls, bad_points, worst = 0, 0, 0.
+        bad = 0
         for r in range(100):
             for k in range(2):
                 nxt, st, _ = ctx.flow_lk(pts)
-                assert np.array_equal(st, base[k][1])
-                ok = st > 0
-                d = np.abs(nxt[ok] - base[k][0][ok]).max(axis=1)
-                if (d > 0).any():
-                    bad_calls += 1
-                    bad_points += int((d > 0).sum())
-                    worst = max(worst, float(d.max()))
+                ok = np.array_equal(st, base[k][1]) and np.array_equal(nxt[st > 0], base[k][0][st > 0])
+                bad += not ok
     finally:
         stop.append(1)
         th.join()
         net.close()
-    assert bad_calls <= 4 and bad_points <= 8 and worst < 0.02, (bad_calls, bad_points, worst)
+    assert bad == 0
