@@ -13,7 +13,25 @@ sys.path.insert(0, '.')
 from fastmot_amd.models import YOLO
 
 P_PEAK, BW = 2.5e15, 8.0e12
-db = sqlite3.connect(sys.argv[1])
+import glob
+import os
+
+
+def open_trace(path):
+    """path: a rocpd database or a rocprofv3 output directory (the database with kernel dispatches is picked)."""
+    cands = [path] if os.path.isfile(path) else sorted(glob.glob(os.path.join(path, '**', '*.db'), recursive=True),
+                                                       key=os.path.getsize, reverse=True)
+    for c in cands:
+        d = sqlite3.connect(c)
+        try:
+            d.execute('select count(*) from kernels').fetchone()
+            return d
+        except sqlite3.OperationalError:
+            continue
+    raise SystemExit(f'no rocpd database with a kernels table under {path}: {cands}')
+
+
+db = open_trace(sys.argv[1])
 model = sys.argv[2] if len(sys.argv) > 2 else 'YOLOv4_608'
 g, _ = YOLO.get_model(model).build_graph()
 n = len(g.layers)

@@ -88,6 +88,9 @@ def test_foreign_gallery_reid(ctx):
             self.local = list(local)
             return self.entries
 
+        def consume(self, rank, trk_id):          # a re-identified foreign identity is not offered again
+            self.entries = [e for e in self.entries if (e['rank'], e['trk_id']) != (rank, trk_id)]
+
     rng = np.random.default_rng(0)
     feat = rng.normal(0, 1, 512).astype(np.float32)
     feat /= np.linalg.norm(feat)
@@ -109,5 +112,5 @@ def test_foreign_gallery_reid(ctx):
     tagged = [t for t in trk.tracks.values() if getattr(t, 'global_id', None) == (3, 17)]
     assert len(tagged) == 1 and tagged[0].avg_feat.count == 5 and tagged[0].confirmed
     np.testing.assert_array_equal(tagged[0].tlbr, dets.tlbr[0])
-    assert len(trk.tracks) == 2
+    assert len(trk.tracks) == 2 and sync.entries == []
     trk._clear_tracks()
