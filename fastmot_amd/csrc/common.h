@@ -85,7 +85,8 @@ struct fm_ctx {
     int device = 0;
     // tunables (fm_ctx_set_option; initial values from the environment)
     int opt_zero_copy_tracks = 2048;   // FASTMOT_ZERO_COPY: 0 = always blit copies
-    int opt_host_lap_elems = 16384;    // FASTMOT_HOST_LAP: cost matrices up to this size use lap_host.hip
+    int opt_host_lap_elems = 262144;   // FASTMOT_HOST_LAP: cost matrices up to this size use lap_host.hip (measured: the
+                                       // host solver is ~5x faster at every size up to 400 x 400, profiles/r02_lap_crossover.txt)
     int opt_use_graphs = 1;            // FASTMOT_GRAPHS: 0 = launch network layers one by one (no hipGraph)
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network

@@ -35,4 +35,4 @@ for n in (8, 16, 32, 50, 64, 100, 128, 200, 300, 400):
         o.lsa(cost)
     res['scipy'] = (time.perf_counter() - t) / 20 * 1e6
     print(f'{n:>4} x {n:<4} {res["host"]:>10.1f} {res["device"]:>10.1f} {res["scipy"]:>10.1f}')
-ctx.set_option('host_lap_elems', 16384)
+ctx.set_option('host_lap_elems', 262144)

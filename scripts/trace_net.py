@@ -3,7 +3,7 @@ durations; scripts/rocpd_dispatches.py then lists the last replay dispatch by di
 import os as _os
 _os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')   # no weight files offline
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from fastmot_amd.runtime import get_context
 from fastmot_amd.engine import HipNet
 from fastmot_amd.models import YOLO, ReID

@@ -143,7 +143,7 @@ def _check_lap(ctx, cost):
     np.testing.assert_array_equal(c, ec)
 
 
-@pytest.mark.parametrize('host_lap_elems', [16384, 0])
+@pytest.mark.parametrize('host_lap_elems', [262144, 0])
 def test_lap_matches_scipy_exactly(ctx, host_lap_elems):
     """Host solver for small matrices (default) and the device kernels (lap64_kernel: n <= 64 in
     registers, lap_kernel: LDS / global work arrays) all reproduce SciPy's (rows, cols) exactly."""
@@ -151,7 +151,7 @@ def test_lap_matches_scipy_exactly(ctx, host_lap_elems):
     try:
         _lap_cases(ctx)
     finally:
-        ctx.set_option('host_lap_elems', 16384)
+        ctx.set_option('host_lap_elems', 262144)
 
 
 def _lap_cases(ctx):

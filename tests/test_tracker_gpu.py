@@ -26,7 +26,7 @@ def test_scene_matches_reference(golden_dir, ctx, name, options):
     try:
         _run_scene(golden_dir, name)
     finally:
-        ctx.set_option('host_lap_elems', 16384)
+        ctx.set_option('host_lap_elems', 262144)
         ctx.set_option('zero_copy_tracks', 2048)
 
 
