@@ -116,16 +116,17 @@ class Flow:
 
         # order tracks from closest to farthest: same order as `tracks.sort(reverse=True)` with Track.__lt__
         # (track.py:160-162 compares exactly this tuple), without ~6 Python-level comparisons per track
-        tracks.sort(key=lambda t: (t.tlbr[-1], -t.age), reverse=True)
+        tracks.sort(key=lambda t: (t.bboxes[-1][3], -t.age), reverse=True)
         n_trk = len(tracks)
         fr = self.frame_rect
         if n_trk:
-            tlbrs = np.array([t.tlbr for t in tracks], np.float64).reshape(n_trk, 4)
+            tlbrs = np.array([t.bboxes[-1] for t in tracks], np.float64).reshape(n_trk, 4)
             inside = np.concatenate([np.maximum(tlbrs[:, :2], fr[:2]), np.minimum(tlbrs[:, 2:], fr[2:])], axis=1)
-            assert (inside[:, 2] >= inside[:, 0]).all() and (inside[:, 3] >= inside[:, 1]).all()
+            assert (inside[:, 2:] >= inside[:, :2]).all()
+            kp_list = [t.keypoints for t in tracks]
             kp_off = np.zeros(n_trk + 1, np.int32)
-            np.cumsum([len(t.keypoints) for t in tracks], out=kp_off[1:])
-            kps = np.concatenate([t.keypoints for t in tracks]).astype(np.float32) if kp_off[-1] else empty
+            np.cumsum([len(k) for k in kp_list], out=kp_off[1:])
+            kps = np.concatenate(kp_list).astype(np.float32, copy=False) if kp_off[-1] else empty
         else:
             tlbrs, inside = np.zeros((0, 4)), np.zeros((0, 4))
             kp_off, kps = np.zeros(1, np.int32), empty
@@ -139,20 +140,23 @@ class Flow:
         self.prev_bg_keypoints = prev[bg[0]:bg[1]]
         self.bg_keypoints = cur[bg[0]:bg[1]]
 
-        # estimate target bounding boxes
+        # estimate target bounding boxes: the per-track keypoint arrays are views cut in one call each
         next_bboxes = {}
-        off = off.tolist()
-        result = result.tolist()
-        for k, track in enumerate(tracks):
-            code = result[k]
-            if code == 0:
-                track.keypoints = empty
-                continue
-            track.prev_keypoints = prev[off[k]:off[k + 1]]
-            if code == 2:
-                track.keypoints = empty
-                continue
-            track.keypoints = cur[off[k]:off[k + 1]]
-            next_bboxes[track.trk_id] = est[k].copy()
-            track.inlier_ratio = (off[k + 1] - off[k]) / n_matched[k]
+        if n_trk:
+            cuts = off[1:-1]
+            prev_parts, cur_parts = np.split(prev[:off[-1]], cuts), np.split(cur[:off[-1]], cuts)
+            counts = (off[1:] - off[:-1]).tolist()
+            result, n_matched, est_rows = result.tolist(), n_matched.tolist(), list(est)
+            for k, track in enumerate(tracks):
+                code = result[k]
+                if code == 0:
+                    track.keypoints = empty
+                    continue
+                track.prev_keypoints = prev_parts[k]
+                if code == 2:
+                    track.keypoints = empty
+                    continue
+                track.keypoints = cur_parts[k]
+                next_bboxes[track.trk_id] = est_rows[k]
+                track.inlier_ratio = counts[k] / n_matched[k]
         return next_bboxes, homography

@@ -156,23 +156,27 @@ class MultiTracker:
         n = len(items)
         if n == 0:
             return
-        slots = np.empty(n, np.int32)
+        slots = np.fromiter((track.slot for _, track in items), np.int32, n)
         klt = np.zeros((n, 4))
         has_klt = np.zeros(n, np.uint8)
         mult = np.ones(n)
         klt_bboxes = self.klt_bboxes
-        for i, (trk_id, track) in enumerate(items):
-            slots[i] = track.slot
-            box = klt_bboxes.get(trk_id)
-            if box is not None:
-                klt[i] = box
-                has_klt[i] = 1
+        if klt_bboxes:
+            age_penalty = self.age_penalty
+            hit = [(i, klt_bboxes[trk_id], track) for i, (trk_id, track) in enumerate(items) if trk_id in klt_bboxes]
+            if hit:
+                idx = [h[0] for h in hit]
+                klt[idx] = [h[1] for h in hit]
+                has_klt[idx] = 1
                 # give large KLT uncertainty for occluded tracks (large age / low inlier ratio)
-                mult[i] = max(self.age_penalty * track.age, 1) / track.inlier_ratio
+                mult[idx] = [max(age_penalty * h[2].age, 1) / h[2].inlier_ratio for h in hit]
         next_tlbrs, lost = self.kf.step_slots(slots, self.homography, klt, has_klt, mult)
-        for i, (trk_id, track) in enumerate(items):
-            track.update(next_tlbrs[i])
-            if lost[i]:
+        rows = list(next_tlbrs)
+        for (trk_id, track), row in zip(items, rows):
+            track.bboxes.append(row)
+        if lost.any():
+            for i in np.flatnonzero(lost).tolist():
+                trk_id, track = items[i]
                 if track.confirmed:
                     LOGGER.info(f"{'Out:':<14}{track}")
                 self._mark_lost(trk_id)
