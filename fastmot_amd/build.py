@@ -14,8 +14,9 @@ OUT = PKG / 'libfastmot_hip.so'
 HIPCC = '/opt/rocm/bin/hipcc'
 # -ffp-contract=off: association/Kalman decisions compare doubles produced with separate IEEE
 # mul/add like NumPy (see assoc.hip header); conv kernels use explicit MFMA/fma intrinsics.
+import os
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-         '-Wno-unused-result']
+         '-Wno-unused-result'] + os.environ.get('FASTMOT_EXTRA_HIPCC_FLAGS', '').split()   # profiling builds (-DFM_*_TIMING)
 
 
 def sources():

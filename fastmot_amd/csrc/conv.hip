@@ -315,8 +315,11 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
             for (int e = 0; e < 8; ++e) {
                 v[e] += bias8[e];
                 if (p.res_mode == RES_BEFORE_ACT) v[e] += r[e];
-                v[e] = apply_act(v[e], p.act);
-                if (p.res_mode == RES_AFTER_ACT) v[e] += r[e];
+            }
+            apply_act_n<8>(v, p.act);
+            if (p.res_mode == RES_AFTER_ACT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
             }
             if (p.out32) {
                 float* dst = p.out32 + (size_t)pix * p.out_cs + p.out_coff + co;
@@ -361,11 +364,14 @@ __global__ void splitk_reduce_kernel(const ConvParams p, const float* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = (float)rv[e];
     }
+    if (p.res_mode == RES_BEFORE_ACT) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (p.res_mode == RES_BEFORE_ACT) v[e] += r[e];
-        v[e] = apply_act(v[e], p.act);
-        if (p.res_mode == RES_AFTER_ACT) v[e] += r[e];
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    apply_act_n<4>(v, p.act);
+    if (p.res_mode == RES_AFTER_ACT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
     }
     if (p.out32) {
         *reinterpret_cast<float4*>(p.out32 + (size_t)pix * p.out_cs + p.out_coff + co) = make_float4(v[0], v[1], v[2], v[3]);

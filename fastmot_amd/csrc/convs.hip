@@ -152,11 +152,14 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
         }
+        if (p.res_mode == RES_BEFORE_ACT) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (p.res_mode == RES_BEFORE_ACT) v[j] += r[j];
-            v[j] = apply_act(v[j], p.act);
-            if (p.res_mode == RES_AFTER_ACT) v[j] += r[j];
+            for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        apply_act_n<4>(v, p.act);
+        if (p.res_mode == RES_AFTER_ACT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j];
         }
         if (p.out32) {
             *reinterpret_cast<float4*>(p.out32 + (size_t)opix * p.out_cs + p.out_coff + co) = make_float4(v[0], v[1], v[2], v[3]);

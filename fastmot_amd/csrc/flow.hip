@@ -269,14 +269,44 @@ struct LKArgs {
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-// float32 sum of lanes 0..N-1 in lane order, starting from 0.f like the scalar loops of lkpyramid.cpp
+// float32 sum of lanes 0..N-1 in lane order, starting from 0.f like the scalar loops of lkpyramid.cpp.
+// Sequential inclusive scan over the lanes: every step adds the left neighbour's running value (DPP wave_shr:1,
+// lane 0 reads 0) to the lane's own term, a(s)[i] = a(s-1)[i-1] + v[i].  By induction lane i holds
+// ((v0 + v1) + ...) + vi after step i and keeps it, so N-1 steps leave the scalar-order sum in lane N-1: the
+// same N-1 dependent float32 adds as the scalar loop, one VALU instruction each (round 2's first version walked
+// the lanes with v_readlane: 2 instructions + an SGPR round trip per term).
+__device__ __forceinline__ float seq_step(float acc, float v) {
+    const int left = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, left) + v;
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 template <int N>
 __device__ __forceinline__ float seq_sum(float v) {
-    float acc = 0.f;
-    const int bits = __builtin_bit_cast(int, v);
+    float acc = v;
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, k));
-    return acc;
+    for (int k = 1; k < N; ++k) acc = seq_step(acc, v);
+    return lane_value(acc, N - 1);
+}
+// two / three independent sums, their scans interleaved step by step (a DPP read of a VGPR written by the previous
+// VALU instruction costs wait states; the neighbouring chain fills them)
+template <int N>
+__device__ __forceinline__ void seq_sum2(float v0, float v1, float& s0, float& s1) {
+    float a0 = v0, a1 = v1;
+#pragma unroll
+    for (int k = 1; k < N; ++k) { a0 = seq_step(a0, v0); a1 = seq_step(a1, v1); }
+    s0 = lane_value(a0, N - 1);
+    s1 = lane_value(a1, N - 1);
+}
+template <int N>
+__device__ __forceinline__ void seq_sum3(float v0, float v1, float v2, float& s0, float& s1, float& s2) {
+    float a0 = v0, a1 = v1, a2 = v2;
+#pragma unroll
+    for (int k = 1; k < N; ++k) { a0 = seq_step(a0, v0); a1 = seq_step(a1, v1); a2 = seq_step(a2, v2); }
+    s0 = lane_value(a0, N - 1);
+    s1 = lane_value(a1, N - 1);
+    s2 = lane_value(a2, N - 1);
 }
 
 // One WAVEFRONT per point: lane g < win*win owns window pixel (g / win, g % win) -- the samples of a window are
@@ -349,9 +379,9 @@ __device__ __forceinline__ void lk_wave_body(const LKArgs& a, int n, const float
             ixval = LK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
             iyval = LK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
         }
-        const float A11 = seq_sum<WINC * WINC>((float)(ixval * ixval)) * FLT_SCALE;
-        const float A12 = seq_sum<WINC * WINC>((float)(ixval * iyval)) * FLT_SCALE;
-        const float A22 = seq_sum<WINC * WINC>((float)(iyval * iyval)) * FLT_SCALE;
+        float A11, A12, A22;
+        seq_sum3<WINC * WINC>((float)(ixval * ixval), (float)(ixval * iyval), (float)(iyval * iyval), A11, A12, A22);
+        A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
         if (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f) {
@@ -378,8 +408,9 @@ __device__ __forceinline__ void lk_wave_body(const LKArgs& a, int n, const float
                 const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
                 diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
             }
-            const float b1 = seq_sum<WINC * WINC>((float)(diff * ixval)) * FLT_SCALE;
-            const float b2 = seq_sum<WINC * WINC>((float)(diff * iyval)) * FLT_SCALE;
+            float b1, b2;
+            seq_sum2<WINC * WINC>((float)(diff * ixval), (float)(diff * iyval), b1, b2);
+            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
             nx += dx; ny += dy;
             outx = nx + half; outy = ny + half;

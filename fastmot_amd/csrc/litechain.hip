@@ -14,6 +14,8 @@
 //   same: results are bit-identical to the per-level path (tests/test_conv_gpu.py).  The halo makes the deepest
 //   stream recompute (24^2 + 22^2 + 20^2 + 18^2) / (4 * 18^2) = 1.38x of the pointwise work of a 16 x 16 tile.
 #include "net.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -23,8 +25,45 @@ struct ChainGaps {
     float* p[4];
 };
 
-template <int NT, int KS>
-__global__ __launch_bounds__(256) void litechain_kernel(
+// profiling build only (-DFM_LCH_TIMING, scripts/lch_timing.py): s_memtime stamps of workgroup (0, deepest stream)
+#ifdef FM_LCH_TIMING
+__device__ long long g_lch_stamps[32];
+#define LCH_STAMP(i) if (blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0) g_lch_stamps[i] = __builtin_readcyclecounter();
+#define LCH_WALL(i) if (blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0) g_lch_stamps[i] = wall_clock64();
+#else
+#define LCH_STAMP(i)
+#define LCH_WALL(i)
+#endif
+
+// EPT halfs from LDS / to LDS or HBM as one access
+template <int EPT> struct HalfVec;
+template <> struct HalfVec<8> { typedef uint4 T; };
+template <> struct HalfVec<4> { typedef uint2 T; };
+template <> struct HalfVec<2> { typedef uint32_t T; };
+template <int EPT>
+__device__ __forceinline__ void unpack_n(const typename HalfVec<EPT>::T& v, float* f) {
+    typedef f16 hv __attribute__((ext_vector_type(EPT)));
+    const hv h = *reinterpret_cast<const hv*>(&v);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) f[e] = (float)h[e];
+}
+template <int EPT>
+__device__ __forceinline__ typename HalfVec<EPT>::T pack_n(const float* f) {
+    typedef f16 hv __attribute__((ext_vector_type(EPT)));
+    hv h;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) h[e] = (f16)f[e];
+    return *reinterpret_cast<const typename HalfVec<EPT>::T*>(&h);
+}
+
+// NTHR = 256 SUB threads: launches with few workgroups (small maps, small batches) leave most CUs idle while every
+// workgroup walks its chain alone, so they run with 512 threads (1024 measured slower: the per-item index
+// arithmetic is repeated by every thread that shares the item).  The pointwise tiles are dealt to NTHR / 64
+// waves; in the depthwise phase SUB threads share a (pixel lane, 8-channel group) item, each taking 8 / SUB of its
+// channels -- the pixel sequence of every channel, and with it the order of the gate's partial sums, is the same
+// for every SUB: results do not depend on the launch shape.
+template <int NT, int KS, int NTHR>
+__global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 3 : 1) void litechain_kernel(
     const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out, int out_cs, int out_coff_base,
     const f16* __restrict__ wpw_base, int kpad, const f16* __restrict__ wdw_base,
     const float* __restrict__ bias_base, int H, int W, int C, int th, int tw, int tiles_x, int tiles_y, int act,
@@ -32,7 +71,8 @@ __global__ __launch_bounds__(256) void litechain_kernel(
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
     f16* ys = lds;                       // pointwise output of the current level (halo region)
     f16* zb = lds + ys_elems;            // depthwise output of the previous level = operand of this one
-    f16* wd = zb + zb_elems;             // depthwise weights of the current level [9][C]
+    f16* wd = zb + zb_elems;             // depthwise weights of ALL levels of this stream [D][9][C] ...
+    float* bs = reinterpret_cast<float*>(wd + 4 * 9 * 32 * NT);   // ... and their biases [D][C]
     const int stream = blockIdx.y, D = stream + 1, pset0 = stream * (stream + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fk = (lane >> 5) * 8;
@@ -43,31 +83,51 @@ __global__ __launch_bounds__(256) void litechain_kernel(
     const int out_coff = out_coff_base + stream * C;
     f16* dst = out + n * (long)H * W * out_cs + out_coff;
 
-    const int c8n = C / 8, lanes_px = 256 / c8n;          // phase B: a thread keeps one 8-channel group
-    const int cg = tid % c8n, pl = tid / c8n;
+    constexpr int SUB = NTHR / 256, EPT = 8 / SUB, NWAVES = NTHR / 64;
+    typedef typename HalfVec<EPT>::T hvec;
+    const int c8n = C / 8, lanes_px = 256 / c8n;          // phase B: SUB threads keep one 8-channel group
+    const int t256 = tid & 255, sub = tid >> 8;
+    const int cg = t256 % c8n, pl = t256 / c8n, ch0 = cg * 8 + sub * EPT;
     const bool active = pl < lanes_px;
-    float gsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gsum[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) gsum[e] = 0.f;
+    LCH_STAMP(0)
+    LCH_WALL(30)
+
+    // Every level used to begin with three dependent HBM/L2 round trips (depthwise weights -> LDS, pointwise
+    // fragments, biases) in a workgroup that has nothing else to run meanwhile.  The depthwise weights and biases of
+    // the whole chain (consecutive parameter sets) go to LDS once, next to the level-0 operand fetch; the pointwise
+    // fragments of level l + 1 are requested while level l runs its depthwise phase.
+    {
+        const f16* wdw = wdw_base + (size_t)pset0 * 9 * C;
+        for (int i = tid; i < D * 9 * C / 8; i += NTHR)
+            *reinterpret_cast<uint4*>(&wd[i * 8]) = *reinterpret_cast<const uint4*>(wdw + i * 8);
+        for (int i = tid; i < D * C; i += NTHR) bs[i] = bias_base[(size_t)pset0 * C + i];
+    }
+    constexpr bool PREFETCH = NT * KS <= 4;     // wider chains keep one fragment set (register budget)
+    f16x8 afr[NT][KS], afr_next[PREFETCH ? NT : 1][PREFETCH ? KS : 1];
+#define LCH_LOAD_FRAGS(DST, LVL)                                                                              \
+    {                                                                                                         \
+        const f16* wpw_ = wpw_base + (size_t)(pset0 + (LVL)) * (32 * NT) * kpad;                              \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                     \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                 \
+                DST[nt][ks] = *reinterpret_cast<const f16x8*>(wpw_ + (long)(nt * 32 + frow) * kpad + ks * 16 + fk); \
+    }
+    LCH_LOAD_FRAGS(afr, 0)
 
     for (int lvl = 0; lvl < D; ++lvl) {
         const int hl = D - lvl;                           // halo of this level's pointwise region
         const int wp = tw + 2 * hl, hp = th + 2 * hl, npos = wp * hp;
-        const f16* wpw = wpw_base + (size_t)(pset0 + lvl) * (32 * NT) * kpad;
-        const f16* wdw = wdw_base + (size_t)(pset0 + lvl) * 9 * C;
-        const float* bias = bias_base + (size_t)(pset0 + lvl) * C;
-        for (int i = tid; i < 9 * C / 8; i += 256)        // (the previous level's phase B is behind a barrier)
-            *reinterpret_cast<uint4*>(&wd[i * 8]) = *reinterpret_cast<const uint4*>(wdw + i * 8);
+        // floor(i / d) = (i * ceil(2^16 / d)) >> 16 for i < 2048, d <= 32 (regions are at most 24 x 24)
+        const unsigned rcp_wp = (65536u + wp - 1) / wp, rcp_wz = (65536u + wp - 3) / (wp - 2);
 
         // ---- phase A
-        f16x8 afr[NT][KS];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                afr[nt][ks] = *reinterpret_cast<const f16x8*>(wpw + (long)(nt * 32 + frow) * kpad + ks * 16 + fk);
         const int mtiles = (npos + 31) / 32;
-        for (int mt = wave; mt < mtiles; mt += 4) {
+        for (int mt = wave; mt < mtiles; mt += NWAVES) {
             const int pos = mt * 32 + frow, posc = min(pos, npos - 1);
-            const int py = ty0 - hl + posc / wp, px = tx0 - hl + posc % wp;
+            const int prow = (int)(((unsigned)posc * rcp_wp) >> 16);
+            const int py = ty0 - hl + prow, px = tx0 - hl + (posc - prow * wp);
             const bool inside = pos < npos && py >= 0 && py < H && px >= 0 && px < W;
             // operand rows: the block input in HBM/L2 at level 0, the previous level's LDS tile afterwards (it
             // covers exactly this region and is zero outside the image).  (Requesting all of a wave's level-0
@@ -107,49 +167,70 @@ __global__ __launch_bounds__(256) void litechain_kernel(
                 }
             }
         }
+        LCH_STAMP(16 + lvl)
         __syncthreads();
+        LCH_STAMP(1 + 2 * lvl)
+        if constexpr (PREFETCH) {
+            if (lvl + 1 < D) LCH_LOAD_FRAGS(afr_next, lvl + 1)    // lands during phase B
+        }
 
         // ---- phase B
         const int wz = wp - 2, hz = hp - 2;
         const bool last = lvl == D - 1;
+        const f16* wdl = wd + lvl * 9 * C;
         if (active) {
-            float b8[8];
+            float b8[EPT], kf[9][EPT];                 // this thread's bias and depthwise taps of the level, as floats
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b8[e] = bias[cg * 8 + e];
+            for (int e = 0; e < EPT; ++e) b8[e] = bs[lvl * C + ch0 + e];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) unpack_n<EPT>(*reinterpret_cast<const hvec*>(&wdl[t * C + ch0]), kf[t]);
             for (int pix = pl; pix < wz * hz; pix += lanes_px) {
-                const int oy = pix / wz, ox = pix % wz;
+                const int oy = (int)(((unsigned)pix * rcp_wz) >> 16), ox = pix - oy * wz;
                 const int gy = ty0 - (hl - 1) + oy, gx = tx0 - (hl - 1) + ox;
                 const bool in_img = gy >= 0 && gy < H && gx >= 0 && gx < W;
                 if (last && !in_img) continue;
-                float acc[8];
+                float acc[EPT];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = b8[e];
+                for (int e = 0; e < EPT; ++e) acc[e] = b8[e];
+                const f16* yp = &ys[(oy * wp + ox) * S + ch0];
+                hvec raw[9];                                // all nine taps requested before the first FMA
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        float v[8], k[8];
-                        unpack8(*reinterpret_cast<const uint4*>(&ys[((oy + dy) * wp + ox + dx) * S + cg * 8]), v);
-                        unpack8(*reinterpret_cast<const uint4*>(&wd[(dy * 3 + dx) * C + cg * 8]), k);
+                    for (int dx = 0; dx < 3; ++dx)
+                        raw[dy * 3 + dx] = *reinterpret_cast<const hvec*>(yp + (dy * wp + dx) * S);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], k[e], acc[e]);
-                    }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = apply_act(acc[e], act);
-                const uint4 o = pack8(acc);
+                for (int t = 0; t < 9; ++t) fma_mix_n<EPT>(reinterpret_cast<const uint32_t*>(&raw[t]), kf[t], acc);
+                apply_act_n<EPT>(acc, act);
+                hvec o = pack_n<EPT>(acc);
                 if (!last) {
-                    *reinterpret_cast<uint4*>(&zb[pix * S + cg * 8]) = in_img ? o : make_uint4(0, 0, 0, 0);
+                    if (!in_img) memset(&o, 0, sizeof(o));
+                    *reinterpret_cast<hvec*>(&zb[pix * S + ch0]) = o;
                 } else {
-                    *reinterpret_cast<uint4*>(dst + ((long)gy * W + gx) * out_cs + cg * 8) = o;
-                    float r[8];     // sums of the STORED (fp16-rounded) activations, as a separate GAP would see them
-                    unpack8(o, r);
+                    *reinterpret_cast<hvec*>(dst + ((long)gy * W + gx) * out_cs + ch0) = o;
+                    float r[EPT];   // sums of the STORED (fp16-rounded) activations, as a separate GAP would see them
+                    unpack_n<EPT>(o, r);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gsum[e] += r[e];
+                    for (int e = 0; e < EPT; ++e) gsum[e] += r[e];
                 }
             }
         }
+        LCH_STAMP(20 + lvl)
         __syncthreads();
+        LCH_STAMP(2 + 2 * lvl)
+        LCH_WALL(31)
+        if (lvl + 1 < D) {
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) afr[nt][ks] = afr_next[nt][ks];
+            } else {
+                LCH_LOAD_FRAGS(afr, lvl + 1)
+            }
+        }
     }
+#undef LCH_LOAD_FRAGS
 
     // ---- per-tile channel sums -> gaps.p[stream][n][tile][C], summed over the pixel lanes in a fixed order
     float* gap_out = gaps.p[stream];
@@ -157,7 +238,7 @@ __global__ __launch_bounds__(256) void litechain_kernel(
         float* red = reinterpret_cast<float*>(ys);          // ys is dead (barrier above)
         if (active) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[pl * C + cg * 8 + e] = gsum[e];
+            for (int e = 0; e < EPT; ++e) red[pl * C + ch0 + e] = gsum[e];
         }
         __syncthreads();
         if (tid < C) {
@@ -179,7 +260,8 @@ size_t litechain_lds_bytes(int C, int W, int H) {
     const int S = C + (((C >> 3) & 1) ? 0 : 8), nt = (C + 31) / 32;
     const size_t ys = (size_t)(th + 8) * (tw + 8) * S, zb = (size_t)(th + 6) * (tw + 6) * S;
     const size_t red = (size_t)(256 / (C / 8)) * C * 2;                  // phase-C floats, in halfs
-    return ((ys > red ? ys : red) + zb + 9 * 32 * nt) * sizeof(f16);
+    // + depthwise weights [4][9][32 nt] (halfs) and biases [4][32 nt] (floats) of the whole chain
+    return ((ys > red ? ys : red) + zb + 4 * 9 * 32 * nt + 4 * 2 * 32 * nt) * sizeof(f16);
 }
 
 // in: the block's conv1 output (C channels); out: 4 C channels, stream s (depth s + 1) at [s C, (s + 1) C);
@@ -199,20 +281,41 @@ int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     const int ys_elems = (int)(ys > red ? ys : red), zb_elems = (th + 6) * (tw + 6) * S;
     ChainGaps gaps{};
     for (int i = 0; i < 4; ++i) gaps.p[i] = gap ? gap[i] : nullptr;
-    const dim3 grid((unsigned)((long)N * tiles_x * tiles_y), 4), block(256);
+    const long wgs = (long)N * tiles_x * tiles_y * 4;
+    const dim3 grid((unsigned)(wgs / 4), 4);
+    // few workgroups: wider ones (see the kernel); FASTMOT_LCH_THREADS forces a width (A/B runs, tests)
+    static const int forced = [] { const char* e = getenv("FASTMOT_LCH_THREADS"); return e ? atoi(e) : 0; }();
+    const int nthr = forced ? forced : wgs <= 384 ? 512 : 256;
+#define LCH_LAUNCH_T(NT_, KS_, NTHR_)                                                                             \
+    hipLaunchKernelGGL((litechain_kernel<NT_, KS_, NTHR_>), grid, dim3(NTHR_), shmem, s, in, in_cs, in_coff, out, \
+                       out_cs, out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act, gaps, S,   \
+                       ys_elems, zb_elems)
 #define LCH_LAUNCH(NT_, KS_)                                                                                      \
-    hipLaunchKernelGGL((litechain_kernel<NT_, KS_>), grid, block, shmem, s, in, in_cs, in_coff, out, out_cs,      \
-                       out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act, gaps, S, ys_elems, \
-                       zb_elems)
-    if (ks == 1) LCH_LAUNCH(1, 1);
-    else if (nt == 1) LCH_LAUNCH(1, 2);
-    else if (nt == 2) { if (ks <= 3) LCH_LAUNCH(2, 3); else LCH_LAUNCH(2, 4); }
-    else if (nt == 3) { if (ks <= 5) LCH_LAUNCH(3, 5); else LCH_LAUNCH(3, 6); }
-    else { if (ks <= 7) LCH_LAUNCH(4, 7); else LCH_LAUNCH(4, 8); }
+    {                                                                                                             \
+        bool done_ = false;                                                                                       \
+        if constexpr ((NT_) * (KS_) <= 4) {                                                                       \
+            if (!done_ && nthr >= 512) { LCH_LAUNCH_T(NT_, KS_, 512); done_ = true; }                             \
+        }                                                                                                         \
+        if (!done_) LCH_LAUNCH_T(NT_, KS_, 256);                                                                  \
+    }
+    if (ks == 1) LCH_LAUNCH(1, 1)
+    else if (nt == 1) LCH_LAUNCH(1, 2)
+    else if (nt == 2) { if (ks <= 3) LCH_LAUNCH(2, 3) else LCH_LAUNCH(2, 4) }
+    else if (nt == 3) { if (ks <= 5) LCH_LAUNCH(3, 5) else LCH_LAUNCH(3, 6) }
+    else { if (ks <= 7) LCH_LAUNCH(4, 7) else LCH_LAUNCH(4, 8) }
 #undef LCH_LAUNCH
+#undef LCH_LAUNCH_T
     FM_HIP(hipGetLastError());
     return 0;
 }
+
+#ifdef FM_LCH_TIMING
+extern "C" int fm_debug_lch_stamps(long long* out32) {
+    FM_HIP(hipDeviceSynchronize());
+    FM_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_lch_stamps), sizeof(long long) * 32));
+    return 0;
+}
+#endif
 
 extern "C" size_t fm_litechain_lds_bytes(int c, int w, int h) {
     return (c % 8 == 0 && c >= 8 && c <= 128 && w > 0 && h > 0) ? litechain_lds_bytes(c, w, h) : (size_t)-1;

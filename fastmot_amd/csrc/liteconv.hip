@@ -16,7 +16,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float lc_act(float v, int act) { return apply_act(v, act); }
 
 // blockIdx.y selects one of up to 4 independent LightConvs of the same geometry (the parallel streams
 // of an OSNet block at the same depth): group g reads view in[g], writes channels
@@ -114,25 +113,27 @@ __global__ __launch_bounds__(256) void liteconv_kernel(
         float b8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) b8[e] = bias[cg * 8 + e];
+        float kf[9][8];                                    // this thread's depthwise taps, as floats
+#pragma unroll
+        for (int t = 0; t < 9; ++t) unpack8(*reinterpret_cast<const uint4*>(&wd[t * C + cg * 8]), kf[t]);
+        const int tw_shift = tw == 16 ? 4 : 3;             // liteconv_tiling: tw is 16 or 8
         for (int pix = pl; pix < th * tw; pix += lanes_px) {
-            const int oy = pix / tw, ox = pix % tw;
+            const int oy = pix >> tw_shift, ox = pix & (tw - 1);
             const int gy = ty0 + oy, gx = tx0 + ox;
             if (gy >= H || gx >= W) continue;
             float acc[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = b8[e];
+            const f16* yp = &ys[(oy * hw + ox) * S + cg * 8];
+            uint4 raw[9];                                   // all nine taps requested before the first FMA
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    float v[8], k[8];
-                    unpack8(*reinterpret_cast<const uint4*>(&ys[((oy + dy) * hw + ox + dx) * S + cg * 8]), v);
-                    unpack8(*reinterpret_cast<const uint4*>(&wd[(dy * 3 + dx) * C + cg * 8]), k);
+                for (int dx = 0; dx < 3; ++dx)
+                    raw[dy * 3 + dx] = *reinterpret_cast<const uint4*>(yp + (dy * hw + dx) * S);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], k[e], acc[e]);
-                }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = lc_act(acc[e], act);
+            for (int t = 0; t < 9; ++t) fma_mix_n<8>(reinterpret_cast<const uint32_t*>(&raw[t]), kf[t], acc);
+            apply_act_n<8>(acc, act);
             const uint4 o = pack8(acc);
             *reinterpret_cast<uint4*>(dst + ((long)gy * W + gx) * out_cs + cg * 8) = o;
             if (gap_out) {   // sums of the STORED (fp16-rounded) activations, as a separate GAP would see them

@@ -63,6 +63,28 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return *reinterpret_cast<const uint4*>(&h);
 }
 
+// acc + (float)h * k, h = the low (HI = 0) or high half of a packed fp16 pair: v_fma_mix_f32 extends the half exactly
+// inside the FMA -- the same value as convert + fmaf, one VALU instruction instead of two (hipcc picks it or not
+// depending on the surrounding code; the depthwise loops of the LightConv kernels are 72 of these per 8 outputs).
+template <int HI>
+__device__ __forceinline__ float fma_mix_h(uint32_t packed, float k, float acc) {
+    float d;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(k), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(k), "v"(acc));
+    return d;
+}
+// acc[e] += (float)h[e] * k[e] for the N halfs packed in `raw` (N / 2 dwords)
+template <int N>
+__device__ __forceinline__ void fma_mix_n(const uint32_t* raw, const float* k, float* acc) {
+    // (convert + fmaf, which hipcc pairs into v_pk_fma_f32, measured slower here: 8000 vs 6240 cycles for the first
+    // depthwise phase of a 16 x 8 chain, scripts/lch_timing.py)
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+        acc[e] = fma_mix_h<0>(raw[e >> 1], k[e], acc[e]);
+        acc[e + 1] = fma_mix_h<1>(raw[e >> 1], k[e + 1], acc[e + 1]);
+    }
+}
+
 // fp16 store of 4 output channels of output pixel `pix`; with p.up == 2 the pixel is replicated to its
 // 2x2 block of the (2Ho, 2Wo) destination view: the nearest x2 [upsample] layer (yolo2onnx.py:806-836)
 // folded into its producer, one launch fewer per PAN level.
@@ -80,18 +102,56 @@ __device__ __forceinline__ void store_out(const ConvParams& p, long pix, int co,
     }
 }
 
+// Activations.  The divisions are v_rcp_f32 (1 ulp) instead of IEEE divides: ~10 VALU less per element, far below
+// the fp16 rounding of every stored activation (Mish runs on up to 11.8 M outputs per layer of YOLOv4).
+__device__ __forceinline__ float act_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float act_leaky(float x) { return x > 0.f ? x : 0.1f * x; }
+__device__ __forceinline__ float act_relu(float x) { return x > 0.f ? x : 0.f; }
+__device__ __forceinline__ float act_mish(float x) {   // x * tanh(softplus(x)),  tanh(log(1+e^x)) = t/(t+2), t = n^2+2n, n = e^x
+    const float n = __expf(x);
+    const float t = n * (n + 2.f);
+    return x > 20.f ? x : x * (t * act_rcp(t + 2.f));
+}
+__device__ __forceinline__ float act_logistic(float x) { return act_rcp(1.f + __expf(-x)); }
+__device__ __forceinline__ float act_swish(float x) { return x * act_rcp(1.f + __expf(-x)); }
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
-        case ACT_LEAKY: return x > 0.f ? x : 0.1f * x;
-        case ACT_MISH: {   // x * tanh(softplus(x)),  tanh(log(1+e^x)) = (n^2+2n)/(n^2+2n+2), n = e^x
-            if (x > 20.f) return x;
-            const float n = __expf(x);
-            const float t = n * (n + 2.f);
-            return x * (t / (t + 2.f));
-        }
-        case ACT_RELU: return x > 0.f ? x : 0.f;
-        case ACT_LOGISTIC: return 1.f / (1.f + __expf(-x));
-        case ACT_SWISH: return x / (1.f + __expf(-x));
+        case ACT_LEAKY: return act_leaky(x);
+        case ACT_MISH: return act_mish(x);
+        case ACT_RELU: return act_relu(x);
+        case ACT_LOGISTIC: return act_logistic(x);
+        case ACT_SWISH: return act_swish(x);
         default: return x;
+    }
+}
+
+// N values at once: ONE (wave-uniform) branch on the activation per group.  With apply_act() per element the
+// compiler kept a switch per element (litechain.hip's depthwise phase: 8 x ~25 scalar/branch instructions per
+// 8 outputs, more than the 72 FMAs they followed).
+template <int N>
+__device__ __forceinline__ void apply_act_n(float* v, int act) {
+    switch (act) {
+        case ACT_LEAKY:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = act_leaky(v[e]);
+            break;
+        case ACT_MISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = act_mish(v[e]);
+            break;
+        case ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = act_relu(v[e]);
+            break;
+        case ACT_LOGISTIC:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = act_logistic(v[e]);
+            break;
+        case ACT_SWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = act_swish(v[e]);
+            break;
+        default: break;
     }
 }

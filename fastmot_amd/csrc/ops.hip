@@ -37,8 +37,7 @@ __global__ void dwconv3_kernel(const f16* __restrict__ in, int in_cs, int in_cof
             for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], k[e], acc[e]);
         }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = apply_act(acc[e], act);
+    apply_act_n<8>(acc, act);
     *reinterpret_cast<uint4*>(out + pix * out_cs + out_coff + c) = pack8(acc);
 }
 

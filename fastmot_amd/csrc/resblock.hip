@@ -111,10 +111,11 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(
                 for (int g = 0; g < 4; ++g) {
                     const float4 bv = bias1[p][g];
                     union { f16 h[4]; uint2 u; } pk;
-                    pk.h[0] = (f16)(inside ? apply_act(acc[g * 4 + 0] + bv.x, act1) : 0.f);
-                    pk.h[1] = (f16)(inside ? apply_act(acc[g * 4 + 1] + bv.y, act1) : 0.f);
-                    pk.h[2] = (f16)(inside ? apply_act(acc[g * 4 + 2] + bv.z, act1) : 0.f);
-                    pk.h[3] = (f16)(inside ? apply_act(acc[g * 4 + 3] + bv.w, act1) : 0.f);
+                    float a4[4] = {acc[g * 4 + 0] + bv.x, acc[g * 4 + 1] + bv.y, acc[g * 4 + 2] + bv.z,
+                                   acc[g * 4 + 3] + bv.w};
+                    apply_act_n<4>(a4, act1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk.h[e] = (f16)(inside ? a4[e] : 0.f);
                     *reinterpret_cast<uint2*>(&mid[pos * S + mt * 32 + g * 8 + (lane >> 5) * 4]) = pk.u;
                 }
             }
@@ -199,10 +200,11 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(
             const int co = ct * 32 + g * 8 + (lane >> 5) * 4;
             const f16x4 rv = *reinterpret_cast<const f16x4*>(rsrc + co);
             f16x4 o;
-            o[0] = (f16)(apply_act(acc[g * 4 + 0] + bias2[g].x, act2) + (float)rv[0]);
-            o[1] = (f16)(apply_act(acc[g * 4 + 1] + bias2[g].y, act2) + (float)rv[1]);
-            o[2] = (f16)(apply_act(acc[g * 4 + 2] + bias2[g].z, act2) + (float)rv[2]);
-            o[3] = (f16)(apply_act(acc[g * 4 + 3] + bias2[g].w, act2) + (float)rv[3]);
+            float a4[4] = {acc[g * 4 + 0] + bias2[g].x, acc[g * 4 + 1] + bias2[g].y, acc[g * 4 + 2] + bias2[g].z,
+                           acc[g * 4 + 3] + bias2[g].w};
+            apply_act_n<4>(a4, act2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (f16)(a4[e] + (float)rv[e]);
             *reinterpret_cast<f16x4*>(out + gp * out_cs + out_coff + co) = o;
         }
     }

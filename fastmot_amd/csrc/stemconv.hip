@@ -69,10 +69,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const f16* __restrict__ 
                 if (co < cout_store) {
                     const float4 bv = *reinterpret_cast<const float4*>(bias + co);
                     f16x4 o;
-                    o[0] = (f16)apply_act(acc[4 * g + 0] + bv.x, act);
-                    o[1] = (f16)apply_act(acc[4 * g + 1] + bv.y, act);
-                    o[2] = (f16)apply_act(acc[4 * g + 2] + bv.z, act);
-                    o[3] = (f16)apply_act(acc[4 * g + 3] + bv.w, act);
+                    float a4[4] = {acc[4 * g + 0] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z,
+                                   acc[4 * g + 3] + bv.w};
+                    apply_act_n<4>(a4, act);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (f16)a4[e];
                     *reinterpret_cast<f16x4*>(dst + co) = o;
                 }
             }

@@ -336,7 +336,11 @@ class YOLODetector(Detector):
             self._prefetched = None              # already enqueued by prefetch()
             bind_frame(self.ctx, frame, self.size)
             return
-        self._prefetched = None
+        if self._prefetched is not None:
+            # the caller announced another frame than the one it passes now: collect and drop that pass, so that
+            # postprocess() returns THIS frame's detections (passes are collected in the order they were enqueued)
+            self._prefetched = None
+            self.ctx.detect_sync()
         bind_frame(self.ctx, frame, self.size)
         self.ctx.detect_async()
 

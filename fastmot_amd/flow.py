@@ -116,11 +116,11 @@ class Flow:
 
         # order tracks from closest to farthest: same order as `tracks.sort(reverse=True)` with Track.__lt__
         # (track.py:160-162 compares exactly this tuple), without ~6 Python-level comparisons per track
-        tracks.sort(key=lambda t: (t.bboxes[-1][3], -t.age), reverse=True)
+        tracks.sort(key=lambda t: (t.tlbr[3], -t.age), reverse=True)
         n_trk = len(tracks)
         fr = self.frame_rect
         if n_trk:
-            tlbrs = np.array([t.bboxes[-1] for t in tracks], np.float64).reshape(n_trk, 4)
+            tlbrs = np.array([t.tlbr for t in tracks], np.float64).reshape(n_trk, 4)
             inside = np.concatenate([np.maximum(tlbrs[:, :2], fr[:2]), np.minimum(tlbrs[:, 2:], fr[2:])], axis=1)
             assert (inside[:, 2:] >= inside[:, :2]).all()
             kp_list = [t.keypoints for t in tracks]

@@ -309,7 +309,7 @@ class Graph:
         th, tw = (16, 16 if w > 8 else 8) if nt == 1 else ((8, 16) if w > 8 else (16, 8))
         s = c + (0 if (c >> 3) & 1 else 8)
         ys = max((th + 8) * (tw + 8) * s, (256 // (c // 8)) * c * 2)
-        return (ys + (th + 6) * (tw + 6) * s + 9 * 32 * nt) * 2 <= 64 * 1024
+        return (ys + (th + 6) * (tw + 6) * s + 4 * 9 * 32 * nt + 4 * 2 * 32 * nt) * 2 <= 64 * 1024
 
     def lightchain(self, name, x, params, act='relu', dst=None):
         """The four streams of an OSNet block -- chains of 1, 2, 3, 4 LightConv3x3 over x -- in ONE launch

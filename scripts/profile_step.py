@@ -22,6 +22,10 @@ mot.reset(1 / 30.)
 
 acc = collections.defaultdict(float)
 cnt = collections.defaultdict(int)
+tl0 = collections.defaultdict(float)     # sum of (start - step start), (end - step start): the timeline of a step
+tl1 = collections.defaultdict(float)
+step_t0 = [0.0]
+PREFETCH = _os.environ.get('PROFILE_PREFETCH', '0') == '1'
 
 def wrap(obj, name, label=None):
     fn = getattr(obj, name)
@@ -31,13 +35,16 @@ def wrap(obj, name, label=None):
         try:
             return fn(*a, **k)
         finally:
-            acc[label] += time.perf_counter() - t
+            e = time.perf_counter()
+            acc[label] += e - t
             cnt[label] += 1
+            tl0[label] += t - step_t0[0]
+            tl1[label] += e - step_t0[0]
     setattr(obj, name, w)
 
 for n in ('flow_predict', 'detect_async', 'detect_sync', 'extract_async',
           'extract_sync', 'assoc_prepare', 'assoc_stage', 'find_occluded', 'feat_update', 'trk_update_det',
-          'trk_step', 'trk_step_ops', 'emb_upload', 'synchronize', 'trk_create', 'feat_merge', 'frame_ring_select'):
+          'trk_step', 'trk_step_ops', 'detect_async_next', 'frame_ring_select_next', 'frame_upload_next', 'frame_upload', 'frame_promote_next', 'emb_upload', 'synchronize', 'trk_create', 'feat_merge', 'frame_ring_select'):
     if hasattr(ctx, n):
         wrap(ctx, n, 'ctx.' + n)
 wrap(mot.detector, 'detect_async', 'det.detect_async')
@@ -49,14 +56,26 @@ wrap(mot.tracker, 'apply_kalman', 'trk.apply_kalman')
 wrap(mot.tracker, 'update', 'trk.update')
 wrap(mot, '_step', 'mot._step')
 
+DFRAMES = [DeviceFrame(i) for i in range(bench.RING)]    # the detector recognises a prefetched frame by identity
+if _os.environ.get('PROFILE_H2D', '0') == '1':            # frames in pinned host memory, uploaded every step (bench.py)
+    _host = ctx.pinned_frames(bench.RING)
+    for _i, _fr in enumerate(video.frames):
+        _host[_i] = _fr
+    DFRAMES = [_host[_i] for _i in range(bench.RING)]
+
+
 def run(n, start):
     for s in range(start, start + n):
         mot.detector._frame_idx = s % bench.RING
-        mot.step(DeviceFrame(s % bench.RING))
+        step_t0[0] = time.perf_counter()
+        if PREFETCH:
+            mot.step(DFRAMES[s % bench.RING], next_frame=DFRAMES[(s + 1) % bench.RING])
+        else:
+            mot.step(DFRAMES[s % bench.RING])
 
 run(20, 0)
 ctx.synchronize()
-acc.clear(); cnt.clear()
+acc.clear(); cnt.clear(); tl0.clear(); tl1.clear()
 import ctypes as C0
 ctx.lib.fm_flow_timing((C0.c_double * 5)(), 1)
 N = 200
@@ -70,4 +89,6 @@ t5 = (C.c_double * 5)()
 ctx.lib.fm_flow_timing(t5, 0)
 print('flow_predict stages (ms/call): begin %.3f prepare %.3f lk %.3f estimate %.3f' % tuple(t5[i] / max(t5[4], 1) for i in range(4)))
 for k in sorted(acc, key=lambda k: -acc[k]):
-    print(f'{k:<24} {acc[k] / N * 1e3:8.3f} ms/step  calls/step {cnt[k] / N:5.2f}')
+    c = max(cnt[k], 1)
+    print(f'{k:<24} {acc[k] / N * 1e3:8.3f} ms/step  calls/step {cnt[k] / N:5.2f}   '
+          f'mean start +{tl0[k] / c * 1e3:6.3f}  end +{tl1[k] / c * 1e3:6.3f} ms after the step began')

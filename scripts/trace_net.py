@@ -14,7 +14,7 @@ if which == 0:
     g, _ = YOLO.get_model('YOLOv4_608').build_graph(); batch = 1
 else:
     ctx.feat_configure(512)
-    g, _ = ReID.get_model('OSNet025').build_graph(); batch = 50
+    g, _ = ReID.get_model('OSNet025').build_graph(); batch = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 net = HipNet(ctx, which, g, batch, reuse_buffers=True)
 for _ in range(6):
     net.run(batch)

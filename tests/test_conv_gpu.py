@@ -335,7 +335,8 @@ def test_gated_sum_fused(ctx, c, hid, h, w, n, k):
     assert np.abs(outs[0] - outs[1]).max() <= 4e-3 * np.abs(outs[1]).max()
 
 
-@pytest.mark.parametrize('c,h,w,n', [(16, 64, 32, 3), (24, 32, 16, 5), (32, 16, 8, 4), (16, 21, 19, 2), (8, 9, 40, 1)])
+@pytest.mark.parametrize('c,h,w,n', [(16, 64, 32, 3), (24, 32, 16, 5), (32, 16, 8, 4), (16, 21, 19, 2), (8, 9, 40, 1),
+                                     (16, 64, 32, 13), (16, 64, 32, 8), (24, 32, 16, 40)])
 def test_lightconv_chain(ctx, c, h, w, n):
     """The four LightConv streams of an OSNet block in one launch (litechain.hip) == one grouped launch per
     depth, BIT FOR BIT (same fp16 rounding points, same MFMA order), incl. the gate's per-tile channel sums
@@ -372,6 +373,29 @@ def test_lightconv_chain(ctx, c, h, w, n):
         net.close()
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_lightconv_chain_launch_shape_independent(ctx):
+    """litechain.hip runs launches with few workgroups as 512- or 1024-thread workgroups (256 otherwise): a
+    sample's streams and gated sum are bit-identical whatever the batch it is part of."""
+    c, h, w, nmax = 16, 64, 32, 13                      # 8 tiles x 4 streams per sample
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 1, (nmax, h, w, c + 8)).astype(np.float16)
+    g = Graph(RandomWeights(seed=9), (h, w), c + 8)
+    x1 = g.input.slice(8, c)
+    params = [g.lightconv_params(f's{t}.{i}', c) for t in range(1, 5) for i in range(t)]
+    y = g.lightchain('streams', x1, params, 'relu')
+    z = g.gated_sum('gate', [y.slice(t * c, c) for t in range(4)], 1, parts=g.last_gap_slots)
+    net = HipNet(ctx, NET_DETECTOR, g, nmax)
+    outs = {}
+    for n in (13, 8, 2):                                 # 416 / 256 / 64 workgroups -> 256 / 512 / 1024 threads
+        net.write(g.input, x[:n])
+        net.run(n)
+        outs[n] = (net.read(y, n)[:2].copy(), net.read(z, n)[:2].copy())
+    net.close()
+    for n in (8, 2):
+        np.testing.assert_array_equal(outs[13][0], outs[n][0])
+        np.testing.assert_array_equal(outs[13][1], outs[n][1])
 
 
 def test_lightconv_grouped(ctx):

@@ -110,6 +110,32 @@ def test_preprocess_decode_end_to_end(ctx, model):
     np.testing.assert_allclose(dets.conf[order], cf, rtol=5e-6)
 
 
+def test_stale_prefetch_is_dropped(ctx):
+    """prefetch(f_x) followed by detect_async(f_1) with another frame: postprocess() returns f_1's detections
+    (detector passes are collected in the order they were enqueued, so the announced-but-unused pass is
+    collected and dropped first); the announced frame itself is recognised by identity and not run twice."""
+    size = (320, 180)
+    det = YOLODetector(size, (0, 1, 2), model='TinyYOLO', conf_thresh=0.1, nms_thresh=0.5,
+                       weights=RandomWeights(seed=4), max_candidates=16384, reuse_buffers=False)
+    f0, f1, fx = (synthetic_frame(*size, seed=s) for s in (1, 2, 3))
+    want0, want1 = det(f0).copy(), det(f1).copy()
+    assert len(want0) and len(want1) and (len(want0) != len(want1) or (want0.tlbr != want1.tlbr).any())
+    det.detect_async(f0)
+    det.prefetch(fx)
+    got0 = det.postprocess().copy()
+    det.detect_async(f1)                      # not the announced frame
+    got1 = det.postprocess().copy()
+    det.detect_async(f0)
+    det.prefetch(f1)
+    det.postprocess()
+    det.detect_async(f1)                      # the announced frame: no second pass
+    got1b = det.postprocess().copy()
+    for got, want in ((got0, want0), (got1, want1), (got1b, want1)):
+        assert len(got) == len(want)
+        np.testing.assert_array_equal(got.tlbr, want.tlbr)
+        np.testing.assert_array_equal(got.label, want.label)
+
+
 def test_reid_crop_resize_normalise(ctx):
     size = (640, 360)
     frame = synthetic_frame(*size, seed=2)
