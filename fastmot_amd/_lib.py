@@ -520,6 +520,19 @@ def _bind_flow(cls):
     def flow_begin(self):
         check(self.lib.fm_flow_begin(self._ctx))
 
+    def flow_arm(self):
+        """This step's fm_flow_predict is about to run on another thread (LK / ReID exclusion, fastmot_hip.h)."""
+        check(self.lib.fm_flow_arm(self._ctx))
+
+    def flow_release(self):
+        check(self.lib.fm_flow_release(self._ctx))
+
+    def flow_wait_lk(self, timeout_us=200):
+        """True once the armed prediction has finished its LK launch (or nothing is armed)."""
+        done = C.c_int(0)
+        check(self.lib.fm_flow_wait_lk(self._ctx, C.c_int(int(timeout_us)), C.byref(done)))
+        return bool(done.value)
+
     def flow_swap(self):
         check(self.lib.fm_flow_swap(self._ctx))
 
@@ -634,7 +647,7 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_read_image(self._ctx, C.c_int(which), _ptr(buf), C.byref(w), C.byref(h)))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 
-    for fn in (flow_configure, flow_init, flow_begin, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
+    for fn in (flow_configure, flow_init, flow_begin, flow_arm, flow_release, flow_wait_lk, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
                flow_background,
                flow_lk, flow_estimate, flow_read_image):
         setattr(cls, fn.__name__, fn)

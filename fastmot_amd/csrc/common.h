@@ -1,6 +1,7 @@
 // Internal definitions shared by the libfastmot_hip.so translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -88,6 +89,9 @@ struct fm_ctx {
     int opt_host_lap_elems = 262144;   // FASTMOT_HOST_LAP: cost matrices up to this size use lap_host.hip (measured: the
                                        // host solver is ~5x faster at every size up to 400 x 400, profiles/r02_lap_crossover.txt)
     int opt_use_graphs = 1;            // FASTMOT_GRAPHS: 0 = launch network layers one by one (no hipGraph)
+    int opt_lk_isolation = 1;          // FASTMOT_LK_ISOLATION: the LK launch takes whole CUs (flow.hip); a pipeline that
+                                       // never runs the ReID network beside it (fm_flow_arm / fm_flow_wait_lk) clears it
+    std::atomic<int> flow_phase{0};    // 0 idle, 1 armed (a KLT prediction of this step has not finished its LK launch), 2 LK done
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network
     hipStream_t s_ext = nullptr;    // ReID network

@@ -1270,8 +1270,12 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
             // CU isolation: the launch requests (and never touches) 150 KB of dynamic LDS per 16-wavefront workgroup, so
             // exactly one of its workgroups fits a CU and no LDS-using workgroup of another stream (the ReID network's
             // fused LightConv kernels: the ones that disturb this kernel, see FM_SGPR_CAP) can be resident beside it.
-            // 16 wavefronts per CU still hide the latency of the scattered byte loads; FASTMOT_LK_LDS=0 disables.
-            static const int lds_req = getenv("FASTMOT_LK_LDS") ? atoi(getenv("FASTMOT_LK_LDS")) : 150000;
+            // It is expensive inside a busy pipeline -- a workgroup waits until a CU has drained completely while
+            // the other streams keep filling the gaps (LK stage 0.17 ms alone, 0.5 ms beside the detector + ReID) --
+            // so a caller that keeps the ReID network off the GPU while this kernel runs (fastmot_amd/mot.py:
+            // fm_flow_arm / fm_flow_wait_lk) clears the "lk_isolation" option and gets ordinary 4-point workgroups.
+            static const int lds_env = getenv("FASTMOT_LK_LDS") ? atoi(getenv("FASTMOT_LK_LDS")) : 150000;
+            const int lds_req = ctx->opt_lk_isolation ? lds_env : 0;
             static bool lds_set = false;
             if (lds_req > 65536 && !lds_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lk_wave_kernel<5>),

@@ -805,6 +805,36 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
 // ---------------------------------------------------------------------------------------------------
 extern double g_flow_sub[8];
 
+// ---- LK / ReID exclusion (see the isolation note at the LK launch in flow.hip).  fm_flow_arm: the caller is about
+// to hand this step's fm_flow_predict to another thread; fm_flow_wait_lk: blocks until that prediction has finished
+// its LK launch (or was released / never armed); fm_flow_release: the prediction thread is done, however it ended.
+extern "C" int fm_flow_arm(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx);
+    ctx->flow_phase.store(1, std::memory_order_release);
+    return 0;
+}
+extern "C" int fm_flow_release(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx);
+    ctx->flow_phase.store(0, std::memory_order_release);
+    return 0;
+}
+extern "C" int fm_flow_wait_lk(fm_ctx* ctx, int timeout_us, int* done) {
+    FM_CHECK_ARG(ctx && done && timeout_us >= 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (ctx->flow_phase.load(std::memory_order_acquire) == 1) {
+        if (++spins < 2000) { cpu_relax(); continue; }
+        spins = 0;
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_us) {
+            *done = 0;
+            return 0;
+        }
+        std::this_thread::yield();
+    }
+    *done = 1;
+    return 0;
+}
+
 extern "C" int fm_flow_timing(double* out5, int reset) {
     for (int i = 0; i < 5; ++i) out5[i] = g_flow_times[i];
     if (getenv("FASTMOT_FLOW_TIMING_VERBOSE")) {
@@ -897,6 +927,7 @@ extern "C" int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     }
     pool().prewake();          // the RANSAC workers wake up while this thread waits for the LK kernel
     rc = fm_flow_lk(ctx, n_pts, scaled.data(), cur.data(), status.data(), err.data());
+    ctx->flow_phase.store(2, std::memory_order_release);      // (fm_flow_lk returns after the kernel has finished)
     if (rc) return rc;
     lap(2);
     const float iox = 1.0f / prm->opt_scale[0], ioy = 1.0f / prm->opt_scale[1];

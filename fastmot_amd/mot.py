@@ -4,6 +4,7 @@ Same stage schedule as the reference's MOT.step (mot.py:125-168) -- detector enq
 extractor enqueue || Kalman, then association -- but every stage is a set of kernels on its own HIP
 stream of one shared device context, and the frame is uploaded once per step (or is already
 resident: pass a detector.DeviceFrame)."""
+import os
 from types import SimpleNamespace
 from enum import Enum
 import logging
@@ -79,6 +80,10 @@ class MOT:
         self.tracker = MultiTracker(self.size, self.extractors[0].metric, **vars(tracker_cfg))
         self.frame_count = 0
         self._next_frame = None
+        # LK / ReID exclusion (fastmot_hip.h: fm_flow_arm): inside step() the ReID network is launched only after the
+        # KLT thread's LK kernel has finished, so the LK launch need not take whole CUs.  FASTMOT_LK_EXCLUSION=0 keeps
+        # the isolated launch instead (needed when ANOTHER process runs a ReID network on the same GPU).
+        self._lk_exclusion = os.environ.get('FASTMOT_LK_EXCLUSION', '1') != '0'
         # KLT + Kalman run on a second host thread while this one drives detector -> ReID network (the
         # C-ABI calls release the GIL; the stages use separate HIP streams and share no state)
         self._flow_thread = ThreadPoolExecutor(max_workers=1, thread_name_prefix='fastmot-flow',
@@ -106,11 +111,15 @@ class MOT:
         bind_frame(ctx, frame, self.size, begin_step=True)
         ctx.in_step = True
         self._next_frame = next_frame
+        if self._lk_exclusion:
+            ctx.set_option('lk_isolation', 0)       # only while this pipeline orders LK and ReID itself
         try:
             self._step(frame)
         finally:
             ctx.in_step = False
             self._next_frame = None
+            if self._lk_exclusion:
+                ctx.set_option('lk_isolation', 1)
         if self.draw:
             self._draw(frame, self._last_detections)
         self.frame_count += 1
@@ -122,6 +131,7 @@ class MOT:
             self.detector.prefetch(nxt)
 
     def _step(self, frame):
+        ctx = self.tracker.ctx
         self._last_detections = []          # what _draw shows: this frame's detections, none on skipped frames
         if self.frame_count == 0:
             detections = self._last_detections = self.detector(frame)
@@ -137,6 +147,8 @@ class MOT:
             # second host thread and its own HIP streams, so the critical path of a step is
             # detector -> ReID network -> association.  The stages are independent exactly as in the
             # reference, so the results are identical.
+            if self._lk_exclusion:
+                ctx.flow_arm()
             flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
             try:
                 # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
@@ -144,6 +156,13 @@ class MOT:
                 self._prefetch_next()
                 with Profiler('detect'):
                     detections = self._last_detections = self.detector.postprocess()
+
+                # LK / ReID exclusion: the ReID network starts once the KLT thread's LK kernel has finished (the two
+                # must not share compute units; ordering them is far cheaper than giving the LK launch
+                # whole CUs inside the busy pipeline).  The ReID launch still overlaps the host RANSAC + Kalman step.
+                if self._lk_exclusion:
+                    while not ctx.flow_wait_lk(200) and not flow_done.done():
+                        pass
 
                 with Profiler('extract'):
                     if len(self.extractors) == 1:
@@ -210,9 +229,13 @@ class MOT:
                                caption=f'visible: {len(visible)}')
 
     def _flow_and_kalman(self, frame):
-        with Profiler('track'):
-            self.tracker.compute_flow(frame)
-            self.tracker.apply_kalman()
+        try:
+            with Profiler('track'):
+                self.tracker.compute_flow(frame)
+                self.tracker.apply_kalman()
+        finally:
+            if self._lk_exclusion:
+                self.tracker.ctx.flow_release()
 
     @staticmethod
     def print_timing_info():

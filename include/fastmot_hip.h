@@ -47,8 +47,9 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
  * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
  * "host_lap_elems" (default 262144; LAP cost matrices up to this many elements are solved by the host
  * solver of the library, larger ones by the device kernels; 0 = always device), "use_graphs" (default 1;
- * 0 launches the network layers one by one instead of replaying hipGraphs).  Initial values can be set
- * with the environment variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP / FASTMOT_GRAPHS. */
+ * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_isolation" (default 1, see
+ * fm_flow_arm).  Initial values can be set with the environment variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP /
+ * FASTMOT_GRAPHS / FASTMOT_LK_ISOLATION. */
 int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value);
 /* writes "name:gcnArch:CUs:clockMHz:hbmBytes" of the ctx device */
 int fm_device_info(fm_ctx* ctx, char* buf, int buflen);
@@ -441,6 +442,16 @@ int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
                     const int32_t* kp_off, const fm_flow_predict_params* prm, int pts_cap, float* prev_out,
                     float* cur_out, int32_t* trk_off_out, int32_t* bg_range_out, double* H_out, int* status_out,
                     int32_t* result_out, double* est_tlbr_out, int32_t* n_matched_out);
+/* LK / ReID exclusion for pipelines that run fm_flow_predict on a second host thread (fastmot_amd/mot.py; the
+ * reference overlaps its optical flow with the asynchronous detector the same way, mot.py:138-145).  The LK
+ * kernel must not share compute units with the ReID network's fused LightConv kernels;
+ * by default its launch therefore takes whole CUs (option "lk_isolation" = 1), which is slow beside busy streams.
+ * A pipeline that orders the two instead -- fm_flow_arm before handing the prediction to its thread,
+ * fm_flow_wait_lk (done = 1: the prediction has finished its LK launch or is not armed; 0: timeout) before
+ * fm_extract_async, fm_flow_release when the prediction thread is through -- may set "lk_isolation" to 0. */
+int fm_flow_arm(fm_ctx* ctx);
+int fm_flow_wait_lk(fm_ctx* ctx, int timeout_us, int* done);
+int fm_flow_release(fm_ctx* ctx);
 /* diagnostic: a long deterministic kernel on the flow stream (mode bit 0: 32-lane butterflies, bit 1: byte
  * loads from the previous gray image); out_host: 256 * blocks words.  See scripts/stress_spin.py. */
 int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsigned* out_host);
