@@ -98,6 +98,9 @@ struct fm_ctx {
     hipStream_t s_ext_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // streams of the extra ReID instances
     hipEvent_t ev_ext_in = nullptr, ev_ext_x_done[FM_MAX_EXTRA_EXTRACTORS] = {};
     hipStream_t s_flow = nullptr;   // KLT
+    hipStream_t s_flow2 = nullptr;  // KLT: pyramid of the new frame (independent of the keypoint preparation on s_flow)
+    hipEvent_t ev_pyr = nullptr;    // completion of that pyramid; s_flow waits on it before its first reader (LK)
+    bool pyr_pending = false;
     hipEvent_t ev_feat = nullptr;   // last reader of ctx->emb on s_main (fm_feat_update); s_ext waits on it
 
     // ---- device-resident track table

@@ -91,6 +91,8 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     }
     const char* fp = getenv("FASTMOT_FLOW_PRIO");   // experiment knob: 0 = flow stream at the detector's (low) priority
     if ((rc_s = make_stream(&ctx->s_flow, "FASTMOT_CU_MASK_FLOW", fp && atoi(fp) == 0 ? prio_lo : prio_hi))) return rc_s;
+    if ((rc_s = make_stream(&ctx->s_flow2, "FASTMOT_CU_MASK_FLOW", fp && atoi(fp) == 0 ? prio_lo : prio_hi))) return rc_s;
+    FM_HIP(hipEventCreateWithFlags(&ctx->ev_pyr, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_feat, hipEventDisableTiming));
     int rc = fm_ensure_slots(ctx, 1024);
     if (rc) return rc;
@@ -119,9 +121,9 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     for (DevBuf* b : {&ctx->as_in, &ctx->as_pair, &ctx->as_stage_in, &ctx->as_cost, &ctx->as_work,
                       &ctx->as_out, &ctx->io0, &ctx->io1, &ctx->feat_in, &ctx->occ_in, &ctx->occ_out})
         b->release();
-    for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_ext, ctx->s_flow})
+    for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_ext, ctx->s_flow, ctx->s_flow2})
         if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in})
+    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr})
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
         if (ctx->s_ext_x[i]) (void)hipStreamDestroy(ctx->s_ext_x[i]);
@@ -138,6 +140,7 @@ extern "C" int fm_ctx_synchronize(fm_ctx* ctx) {
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
     for (hipStream_t x : ctx->s_ext_x) FM_HIP(hipStreamSynchronize(x));
     FM_HIP(hipStreamSynchronize(ctx->s_flow));
+    FM_HIP(hipStreamSynchronize(ctx->s_flow2));
     return 0;
 }
 

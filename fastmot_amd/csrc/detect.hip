@@ -510,6 +510,32 @@ extern "C" int fm_host_free(void* p) {
     return 0;
 }
 
+// H2D frame copy as a kernel reading the page-locked (device-mapped) source (FASTMOT_UPLOAD_KERNEL=1; experiment: the
+// 0.09-0.15 ms the hipMemcpyAsync call takes in front of the prefetched detector pass turned out to be runtime lock
+// contention with the KLT thread's launches -- a kernel launch waits just as long -- so the copy engine stays the default).
+__global__ __launch_bounds__(256) void frame_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                                         const uint8_t* __restrict__ src8, uint8_t* __restrict__ dst8,
+                                                         size_t bytes) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if (i < n16) reinterpret_cast<u32x4*>(dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + i);
+    if (i == 0)
+        for (size_t b = n16 * 16; b < bytes; ++b) dst8[b] = src8[b];
+}
+
+static int enqueue_frame_copy(uint8_t* dst, const uint8_t* src_pinned, size_t bytes, hipStream_t s) {
+    static const int use_kernel = [] { const char* e = getenv("FASTMOT_UPLOAD_KERNEL"); return e ? atoi(e) : 0; }();
+    if (use_kernel && ((uintptr_t)src_pinned & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        hipLaunchKernelGGL(frame_copy_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const uint4*>(src_pinned), reinterpret_cast<uint4*>(dst), n16, src_pinned, dst, bytes);
+        FM_HIP(hipGetLastError());
+        return 0;
+    }
+    FM_HIP(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
 extern "C" int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr) {
     FM_CHECK_ARG(ctx && bgr && ctx->frame_own);
     const size_t bytes = (size_t)ctx->frame_w * ctx->frame_h * 3;
@@ -517,12 +543,14 @@ extern "C" int fm_frame_upload(fm_ctx* ctx, const uint8_t* bgr) {
     FM_HIP(hipStreamSynchronize(ctx->s_det));
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
     FM_HIP(hipStreamSynchronize(ctx->s_flow));
+    FM_HIP(hipStreamSynchronize(ctx->s_flow2));
     const uint8_t* src = bgr;
     if (!is_pinned_range(bgr, bytes)) {
         memcpy(ctx->frame_pinned, bgr, bytes);
         src = ctx->frame_pinned;
     }
-    FM_HIP(hipMemcpyAsync(ctx->frame_own, src, bytes, hipMemcpyHostToDevice, ctx->s_det));
+    int rc_copy = enqueue_frame_copy(ctx->frame_own, src, bytes, ctx->s_det);
+    if (rc_copy) return rc_copy;
     FM_HIP(hipStreamSynchronize(ctx->s_det));   // the other streams read the frame too
     ctx->frame_cur = ctx->frame_own;
     return 0;
@@ -543,7 +571,8 @@ extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
     }
     // (the previous readers of frame_own2 -- the stages of the step before the last promote -- were
     // synchronised by fm_frame_promote_next; the detector stream orders the copy behind its own reads)
-    FM_HIP(hipMemcpyAsync(ctx->frame_own2, src, bytes, hipMemcpyHostToDevice, ctx->s_det));
+    int rc_copy = enqueue_frame_copy(ctx->frame_own2, src, bytes, ctx->s_det);
+    if (rc_copy) return rc_copy;
     if (!ctx->ev_next_upload) FM_HIP(hipEventCreateWithFlags(&ctx->ev_next_upload, hipEventDisableTiming));
     FM_HIP(hipEventRecord(ctx->ev_next_upload, ctx->s_det));
     ctx->frame_next = ctx->frame_own2;
@@ -563,8 +592,10 @@ extern "C" int fm_frame_promote_next(fm_ctx* ctx) {
         // now on and must wait for that copy (they never waited for the detector stream otherwise)
         FM_HIP(hipStreamSynchronize(ctx->s_ext));
         FM_HIP(hipStreamSynchronize(ctx->s_flow));
+        FM_HIP(hipStreamSynchronize(ctx->s_flow2));
         FM_HIP(hipStreamWaitEvent(ctx->s_ext, ctx->ev_next_upload, 0));
         FM_HIP(hipStreamWaitEvent(ctx->s_flow, ctx->ev_next_upload, 0));
+        FM_HIP(hipStreamWaitEvent(ctx->s_flow2, ctx->ev_next_upload, 0));
         FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_next_upload, 0));
         std::swap(ctx->frame_own, ctx->frame_own2);
         std::swap(ctx->frame_pinned, ctx->frame_pinned2);

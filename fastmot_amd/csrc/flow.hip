@@ -955,8 +955,19 @@ int gftt_lds_bytes(int max_area) {
     return (max_area <= GFTT_EIG_LDS ? max_area : 0) * 4;
 }
 
-int build_pyramid(fm_ctx* ctx, FlowState* f, int set) {
-    hipStream_t s = ctx->s_flow;
+// The KLT stream, for every launch that may read the pyramid of the newest frame: that pyramid is built on s_flow2
+// (fm_flow_begin) so that the keypoint preparation -- which only reads the PREVIOUS frame's images -- runs beside
+// it; the first such reader makes s_flow wait for it.
+int flow_stream(fm_ctx* ctx, hipStream_t* out) {
+    if (ctx->pyr_pending) {
+        FM_HIP(hipStreamWaitEvent(ctx->s_flow, ctx->ev_pyr, 0));
+        ctx->pyr_pending = false;
+    }
+    *out = ctx->s_flow;
+    return 0;
+}
+
+int build_pyramid(fm_ctx* ctx, FlowState* f, int set, hipStream_t s) {
     const int n = ctx->frame_w * ctx->frame_h;
     static const bool fused = !(getenv("FASTMOT_PYR_FUSED") && atoi(getenv("FASTMOT_PYR_FUSED")) == 0);
     if (fused && f->W == 2 * f->lw[0] && f->H == 2 * f->lh[0] && (f->W & 1) == 0) {
@@ -1042,7 +1053,7 @@ extern "C" int fm_flow_init(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx && ctx->flow && ctx->frame_cur);
     FlowState* f = ctx->flow;
     f->prev = 0;
-    int rc = build_pyramid(ctx, f, 0);
+    int rc = build_pyramid(ctx, f, 0, ctx->s_flow);
     if (rc) return rc;
     f->nT = 0;
     return 0;
@@ -1050,11 +1061,26 @@ extern "C" int fm_flow_init(fm_ctx* ctx) {
 
 extern "C" int fm_flow_begin(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx && ctx->flow && ctx->frame_cur);
-    return build_pyramid(ctx, ctx->flow, ctx->flow->prev ^ 1);
+    static const bool side = !(getenv("FASTMOT_PYR_STREAM") && atoi(getenv("FASTMOT_PYR_STREAM")) == 0);
+    if (!side) return build_pyramid(ctx, ctx->flow, ctx->flow->prev ^ 1, ctx->s_flow);
+    hipStream_t s;
+    int rc = flow_stream(ctx, &s);          // (a pyramid nobody read: order this one behind it)
+    if (rc) return rc;
+    // the side stream starts behind whatever s_flow still does with the buffers of this set (nothing inside
+    // fm_flow_predict, which ends synchronised; the step functions used by tests may have work queued)
+    FM_HIP(hipEventRecord(ctx->ev_pyr, ctx->s_flow));
+    FM_HIP(hipStreamWaitEvent(ctx->s_flow2, ctx->ev_pyr, 0));
+    if ((rc = build_pyramid(ctx, ctx->flow, ctx->flow->prev ^ 1, ctx->s_flow2))) return rc;
+    FM_HIP(hipEventRecord(ctx->ev_pyr, ctx->s_flow2));
+    ctx->pyr_pending = true;
+    return 0;
 }
 
 extern "C" int fm_flow_swap(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx && ctx->flow);
+    hipStream_t s;
+    int rc = flow_stream(ctx, &s);          // from now on the new pyramid is the "previous" one every launch reads
+    if (rc) return rc;
     ctx->flow->prev ^= 1;
     return 0;
 }
@@ -1063,7 +1089,8 @@ extern "C" int fm_flow_targets(fm_ctx* ctx, int nT, const double* inside_tlbr, c
                                const int32_t* kp_off, int32_t* area_out, uint8_t* keep_out) {
     FM_CHECK_ARG(ctx && ctx->flow && nT >= 0);
     FlowState* f = ctx->flow;
-    hipStream_t s = ctx->s_flow;
+    hipStream_t s;
+    { int rc_s_ = flow_stream(ctx, &s); if (rc_s_) return rc_s_; }
     f->nT = nT;
     if (nT == 0) return 0;
     FM_CHECK_ARG(inside_tlbr && kp_off && area_out);
@@ -1145,7 +1172,8 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
     if (n == 0) return 0;
     FM_CHECK_ARG(track_idx && track_tlbr && min_dist && pts_out && counts_out);
     FlowState* f = ctx->flow;
-    hipStream_t s = ctx->s_flow;
+    hipStream_t s;
+    { int rc_s_ = flow_stream(ctx, &s); if (rc_s_) return rc_s_; }
     FM_HIP(hipStreamSynchronize(s));
     const int32_t* hrects = reinterpret_cast<const int32_t*>(f->tgt_in.host<char>());
     std::vector<CropArgs> crops(n);
@@ -1197,7 +1225,8 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
 extern "C" int fm_flow_background(fm_ctx* ctx, int cap, float* pts_out, int* n_out) {
     FM_CHECK_ARG(ctx && ctx->flow && cap > 0 && pts_out && n_out);
     FlowState* f = ctx->flow;
-    hipStream_t s = ctx->s_flow;
+    hipStream_t s;
+    { int rc_s_ = flow_stream(ctx, &s); if (rc_s_) return rc_s_; }
     const int bw = f->cfg.bg_w, bh = f->cfg.bg_h;
     int rc = f->bg_out.reserve(sizeof(float) * 2 * cap + 16);
     if (rc) return rc;
@@ -1228,7 +1257,8 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
                           float* err) {
     FM_CHECK_ARG(ctx && ctx->flow && n >= 0);
     FlowState* f = ctx->flow;
-    hipStream_t s = ctx->s_flow;
+    hipStream_t s;
+    { int rc_s_ = flow_stream(ctx, &s); if (rc_s_) return rc_s_; }
     if (n > 0) {
         FM_CHECK_ARG(prev_pts && next_pts && status && err);
         int rc = f->lk_in.reserve(sizeof(float) * 2 * n);
@@ -1343,7 +1373,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
                                int* n_bg_out) {
     FM_CHECK_ARG(ctx && ctx->flow && nT >= 0 && pts_cap > 0 && bg_cap > 0 && n_new_out && n_bg_out && bg_pts_out);
     FlowState* f = ctx->flow;
-    hipStream_t s = ctx->s_flow;
+    hipStream_t s = ctx->s_flow;            // (reads only the previous frame: no wait for the new pyramid)
     f->nT = nT;
     const int nk = nT ? kp_off[nT] : 0;
     double tp0 = fm_now_ms();
@@ -1369,7 +1399,11 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     }
     const int n_ov = (int)ov_idx.size();
     g_flow_sub[0] += fm_now_ms() - tp0; tp0 = fm_now_ms();
-    FM_HIP(hipStreamSynchronize(s));
+    // (no synchronisation here: the staging block was consumed by the previous call, which ended with one, and the
+    // kernels of fm_flow_begin that may still be running touch none of the buffers below -- only a reallocation
+    // needs an idle stream)
+    if (eig_total > f->eig_cap || nT > f->rect_cap || nT + 1 > f->ov_cap || n_ov > f->ov_cap * 8)
+        FM_HIP(hipStreamSynchronize(s));
     g_flow_sub[1] += fm_now_ms() - tp0; tp0 = fm_now_ms();
     if (eig_total > f->eig_cap) {
         FM_HIP(hipFree(f->eig));
@@ -1521,7 +1555,8 @@ __global__ __launch_bounds__(256) void spin_kernel(int iters, int mode, const ui
 extern "C" int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsigned* out_host) {
     FM_CHECK_ARG(ctx && ctx->flow && blocks > 0 && out_host);
     FlowState* f = ctx->flow;
-    hipStream_t s = ctx->s_flow;
+    hipStream_t s;
+    { int rc_s_ = flow_stream(ctx, &s); if (rc_s_) return rc_s_; }
     const size_t bytes = sizeof(unsigned) * 256 * (size_t)blocks;
     int rc = f->lk_out.reserve(bytes);
     if (rc) return rc;

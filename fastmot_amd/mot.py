@@ -19,6 +19,7 @@ from .utils import Profiler
 from .utils.visualization import Visualizer
 
 LOGGER = logging.getLogger(__name__)
+_PREFETCH_FIRST = os.environ.get('FASTMOT_PREFETCH_FIRST', '0') != '0'
 
 
 class DetectorType(Enum):
@@ -149,10 +150,15 @@ class MOT:
             # reference, so the results are identical.
             if self._lk_exclusion:
                 ctx.flow_arm()
+            # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
+            # detector stream never idles; results are collected in order, detect.hip).  Two host threads launching
+            # at once serialise inside the HIP runtime (the upload call takes 0.15 ms beside the KLT thread's burst of
+            # ~15 launches, 0.01 ms before it), but starting the KLT thread later costs as much: measured neutral
+            # (FASTMOT_PREFETCH_FIRST=1 is the other order).
+            if _PREFETCH_FIRST:
+                self._prefetch_next()
             flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
             try:
-                # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
-                # detector stream never idles; results are collected in order, detect.hip)
                 self._prefetch_next()
                 with Profiler('detect'):
                     detections = self._last_detections = self.detector.postprocess()
