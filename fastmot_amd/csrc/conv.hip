@@ -74,21 +74,24 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
         const int logical = p.weight_major == 2 ? (int)blockIdx.x   // natural order (A/B experiments only)
                                                 : (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
         if (logical >= total) return;
+        // (idiv_small: float-reciprocal division, exact below 2^22 -- the integer sequences made up a third of the
+        // ~900 instructions a 1x1 layer's thread executes)
+        const float inv_gp = 1.f / (float)p.grid_p, inv_gc = 1.f / (float)p.grid_c, inv_gz = 1.f / (float)p.grid_z;
         if (p.weight_major == 2) {
-            tile_p = logical % p.grid_p;
-            const int r = logical / p.grid_p;
-            tile_c = r % p.grid_c;
-            split = r / p.grid_c;
+            const int r = idiv_small(logical, p.grid_p, inv_gp);
+            tile_p = logical - r * p.grid_p;
+            split = idiv_small(r, p.grid_c, inv_gc);
+            tile_c = r - split * p.grid_c;
         } else if (p.weight_major) {          // logical = (tile_c * grid_z + split) * grid_p + tile_p
-            tile_p = logical % p.grid_p;
-            const int r = logical / p.grid_p;
-            split = r % p.grid_z;
-            tile_c = r / p.grid_z;
+            const int r = idiv_small(logical, p.grid_p, inv_gp);
+            tile_p = logical - r * p.grid_p;
+            tile_c = idiv_small(r, p.grid_z, inv_gz);
+            split = r - tile_c * p.grid_z;
         } else {                       // logical = (tile_p * grid_c + tile_c) * grid_z + split
-            split = logical % p.grid_z;
-            const int r = logical / p.grid_z;
-            tile_c = r % p.grid_c;
-            tile_p = r / p.grid_c;
+            const int r = idiv_small(logical, p.grid_z, inv_gz);
+            split = logical - r * p.grid_z;
+            tile_p = idiv_small(r, p.grid_c, inv_gc);
+            tile_c = r - tile_p * p.grid_c;
         }
     }
     const int nsplit = p.grid_z;
@@ -105,21 +108,23 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
     // ---- per-thread im2col state of the pixels this thread stages
     const f16* pbase[B_IT];
     int phi0[B_IT], pwi0[B_IT];
+    const int hw_out = p.Ho * p.Wo;
+    const float inv_hw = 1.f / (float)hw_out, inv_wo = 1.f / (float)p.Wo;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int pix = min(p0 + lrow + 32 * i, p.P - 1);    // clamped pixels are never stored
-        const int hw = p.Ho * p.Wo;
-        const int n = pix / hw, rem = pix - n * hw;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int hw = hw_out;
+        const int n = idiv_small(pix, hw, inv_hw), rem = pix - n * hw;
+        const int ho = idiv_small(rem, p.Wo, inv_wo), wo = rem - ho * p.Wo;
         phi0[i] = ho * p.stride - p.pad;
         pwi0[i] = wo * p.stride - p.pad;
         pbase[i] = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_coff;
     }
     // K walk of this thread's 8-channel chunk: k = (k_begin + step) * 64 + lchunk*8 -> (kh, kw, c)
     int kk = k_begin * BK + lchunk * 8;
-    int tap = kk / p.Cin;
+    int tap = idiv_small(kk, p.Cin, 1.f / (float)p.Cin);
     int kc = kk - tap * p.Cin;
-    int kh = tap / p.KW, kw = tap - kh * p.KW;
+    int kh = idiv_small(tap, p.KW, 1.f / (float)p.KW), kw = tap - kh * p.KW;
 
     // Stage registers.  Everything below uses macros with literal stage names: passing stage
     // arrays to lambdas by pointer/reference kept them in scratch memory (no SROA).
@@ -328,8 +333,9 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
             } else {
                 const uint4 o = pack8(v);
                 if (p.up == 2) {   // fused nearest x2 upsample: replicate to the 2x2 block
-                    const int hw = p.Ho * p.Wo, rem = pix % hw;
-                    const size_t o00 = ((size_t)(pix / hw) * 2 * p.Ho + 2 * (rem / p.Wo)) * (2 * p.Wo) + 2 * (rem % p.Wo);
+                    const int hw = hw_out, nn = idiv_small(pix, hw, inv_hw), rem = pix - nn * hw;
+                    const int ry = idiv_small(rem, p.Wo, inv_wo), rx = rem - ry * p.Wo;
+                    const size_t o00 = ((size_t)nn * 2 * p.Ho + 2 * ry) * (2 * p.Wo) + 2 * rx;
                     f16* dst = p.out + o00 * p.out_cs + p.out_coff + co;
                     *reinterpret_cast<uint4*>(dst) = o;
                     *reinterpret_cast<uint4*>(dst + p.out_cs) = o;
@@ -428,6 +434,7 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
     // weight matrix must fit 32 bits and their factors 24 bits
     FM_CHECK_ARG((long)p.H * p.W < (1L << 24) && p.in_cs < (1 << 24) && (long)p.H * p.W * p.in_cs < (1L << 32));
     FM_CHECK_ARG(p.Kpad < (1 << 24) && (long)((p.Cout + 31) & ~31) * p.Kpad < (1L << 32));
+    FM_CHECK_ARG(p.P < (1 << 22) && p.Kpad < (1 << 22));      // idiv_small (prologue index decompositions)
     const int cout_pad = (p.Cout + 31) & ~31;
     auto tiles = [&](int bmc, int bnp) { return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc); };
     const int nk = p.Kpad / BK;

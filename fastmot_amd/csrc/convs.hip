@@ -49,10 +49,12 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     const int seg = lane & 7;
     const f16* img[4];
     int iy0[4], ix0[4];
+    const int hw = p.Ho * p.Wo;
+    const float inv_hw = 1.f / (float)hw, inv_wo = 1.f / (float)p.Wo;           // P < 2^22 (checked at the launch)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int pix = min(tile_p * 32 + (lane >> 3) + 8 * u, p.P - 1);        // clamped; masked at the store
-        const int hw = p.Ho * p.Wo, n = pix / hw, rem = pix - n * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int n = idiv_small(pix, hw, inv_hw), rem = pix - n * hw, oy = idiv_small(rem, p.Wo, inv_wo), ox = rem - oy * p.Wo;
         iy0[u] = oy * p.stride - p.pad;
         ix0[u] = ox * p.stride - p.pad;
         img[u] = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_coff + seg * 8;
@@ -70,11 +72,17 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     // taps read a zero page instead of being masked afterwards.
     f16x8 fa[PD][CT][4], raw[PD][4];
     const f16* bp[4];
-    int qnext = q0, left = 0;
+    // (kh, kw, c0) of the next chunk: divided out once, then walked -- the divisions inside load() were evaluated
+    // for every chunk (if-converted: 46 scalar instructions per 8 MFMAs)
+    int left = 0, kh, kw, c0;
+    {
+        const int k0 = q0 << 6, tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
     auto load = [&](int slot) {
-        if (left == 0) {                            // wave-uniform
-            const int k0 = qnext << 6, tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        if (left == 0) {                            // wave-uniform: the walk enters tap (kh, kw) at channel c0
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int iy = iy0[u] + kh, ix = ix0[u] + kw;
@@ -82,6 +90,8 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
                 bp[u] = (ok ? img[u] + ((size_t)iy * p.W + ix) * p.in_cs : g_zero_page + seg * 8) + c0;
             }
             left = (p.Cin - c0) >> 6;
+            c0 = 0;                                 // the following taps start at their first channel
+            if (++kw == p.KW) { kw = 0; ++kh; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -94,7 +104,6 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
             for (int u = 0; u < 4; ++u) fa[slot][i][u] = *reinterpret_cast<const f16x8*>(ap + i * wtile + u * 512);
         ap += 2048;
         --left;
-        ++qnext;
     };
     f32x16 acc[CT];
 #pragma unroll
@@ -188,6 +197,7 @@ int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
     FM_CHECK_ARG(p.Cin % 64 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0 && p.K == p.KH * p.KW * p.Cin);
     FM_CHECK_ARG(p.out_cs % 4 == 0 && p.out_coff % 4 == 0 && p.cout_store % 4 == 0 && p.Cin <= 4096);
     FM_CHECK_ARG(p.res_mode == RES_NONE || (p.res_cs % 4 == 0 && p.res_coff % 4 == 0));
+    FM_CHECK_ARG(p.P < (1 << 22));                  // idiv_small in the prologue
     const int ntiles_c = (p.Cout + 31) / 32, npt = (p.P + 31) / 32, nq = p.K / 64;
     // two cout tiles per workgroup halve the pixel-fragment traffic; only when that still fills the chip
     const bool ct2 = ntiles_c % 2 == 0 && (ntiles_c / 2) * npt >= 192;

@@ -529,7 +529,10 @@ __global__ void kp_filter_kernel(const int32_t* __restrict__ rects, Overlaps ov,
 
 // fused bookkeeping of flow.py:163-169 for one track per block: mask area, _rect_filter of the
 // propagated keypoints, the "too few keypoints" decision and the GFTT minDistance (flow.py:267-271)
-__global__ __launch_bounds__(256) FM_SGPR_CAP void prepare_kernel(const int32_t* __restrict__ rects, Overlaps ov,
+// (1024 threads per track: a lone wavefront per SIMD issues one instruction every ~8 cycles; 256 threads took 49 us on the
+// benchmark's crops)
+constexpr int PREP_BLK = 1024;
+__global__ __launch_bounds__(PREP_BLK) FM_SGPR_CAP void prepare_kernel(const int32_t* __restrict__ rects, Overlaps ov,
                                                       const float* __restrict__ kps,
                                                       const int32_t* __restrict__ kp_off, double feat_density,
                                                       double feat_dist_factor, int32_t* __restrict__ area,
@@ -551,22 +554,22 @@ __global__ __launch_bounds__(256) FM_SGPR_CAP void prepare_kernel(const int32_t*
     if (cnt == 0) c = tid == 0 ? w * h : 0;
     else {
         const float inv_w = 1.f / (float)w;
-        for (int i = tid; i < w * h; i += 256) {
+        for (int i = tid; i < w * h; i += PREP_BLK) {
             const int y = fast_div(i, w, inv_w), x = i - y * w;
             c += covered(r0 + x, r1 + y) ? 0 : 1;
         }
     }
-    for (int i = kp_off[k] + tid; i < kp_off[k + 1]; i += 256) {
+    for (int i = kp_off[k] + tid; i < kp_off[k + 1]; i += PREP_BLK) {
         const int x = (int)rintf(kps[2 * i]), y = (int)rintf(kps[2 * i + 1]);
         const bool ok = x >= r0 && x <= r2 && y >= r1 && y <= r3 && !covered(x, y);
         keep[i] = ok ? 1 : 0;
         kept += ok ? 1 : 0;
     }
-    __shared__ int red[256], red2[256];
+    __shared__ int red[PREP_BLK], red2[PREP_BLK];
     red[tid] = c;
     red2[tid] = kept;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = PREP_BLK / 2; off > 0; off >>= 1) {
         if (tid < off) { red[tid] += red[tid + off]; red2[tid] += red2[tid + off]; }
         __syncthreads();
     }
@@ -1476,7 +1479,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         // needy flags / min distances are consumed by the eig / select kernels: device copies (behind the upload)
         uint8_t* d_needy = reinterpret_cast<uint8_t*>(db + o_dneedy);
         int32_t* d_md = reinterpret_cast<int32_t*>(db + o_dmd);
-        hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(256), 0, s, f->v_rects, ov,
+        hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(PREP_BLK), 0, s, f->v_rects, ov,
                            reinterpret_cast<const float*>(db + o_kps), reinterpret_cast<const int32_t*>(db + o_kpoff),
                            feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(dbo + q_area),
                            reinterpret_cast<uint8_t*>(dbo + q_keep), d_needy, d_md,

@@ -63,6 +63,15 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return *reinterpret_cast<const uint4*>(&h);
 }
 
+// floor(i / d) for 0 <= i, i < 2^22 and d >= 1 through the float reciprocal inv = 1.f / d (one multiply + convert instead of
+// the ~35-instruction integer division sequence; exact in that range: the quotient's error q * 2^-23 stays below the
+// 0.5 / d margin of (i + 0.5) / d).  Index decompositions in kernel prologues run once per lane, but a 5 us kernel has
+// only a few hundred instructions in total.
+__device__ __forceinline__ int idiv_small(int i, int d, float inv) {
+    (void)d;
+    return (int)(((float)i + 0.5f) * inv);
+}
+
 // acc + (float)h * k, h = the low (HI = 0) or high half of a packed fp16 pair: v_fma_mix_f32 extends the half exactly
 // inside the FMA -- the same value as convert + fmaf, one VALU instruction instead of two (hipcc picks it or not
 // depending on the surrounding code; the depthwise loops of the LightConv kernels are 72 of these per 8 outputs).
