@@ -282,3 +282,26 @@ def test_lk_deterministic_while_other_streams_are_busy(ctx, hammer):
         th.join()
         net.close()
     assert bad == 0
+
+
+def test_lk_reid_ordering_protocol(ctx):
+    """fm_flow_arm / fm_flow_wait_lk / fm_flow_release (the LK / ReID ordering MOT.step relies on): nothing armed ->
+    done at once; armed -> the wait times out until the prediction has passed its LK launch or was released."""
+    assert ctx.flow_wait_lk(0)
+    ctx.flow_arm()
+    try:
+        assert not ctx.flow_wait_lk(300)
+    finally:
+        ctx.flow_release()
+    assert ctx.flow_wait_lk(0)
+    # an armed prediction that runs to its LK kernel flips the flag itself
+    size = (640, 360)
+    flow = make_flow(size)
+    flow.init(textured_frame(*size, 11))
+    ctx.flow_arm()
+    try:
+        boxes, H = flow.predict(textured_frame(*size, 11, shift=(6, -4)), [FakeTrack(1, [100, 100, 170, 300])])
+        assert H is not None
+        assert ctx.flow_wait_lk(0)
+    finally:
+        ctx.flow_release()
