@@ -10,6 +10,7 @@ import sys
 from pathlib import Path
 
 import numpy as np
+from types import SimpleNamespace
 
 LIB_PATH = Path(__file__).parent / 'libfastmot_hip.so'
 
@@ -593,6 +594,49 @@ def _bind_flow(cls):
                                        _ptr(H), C.byref(status), _ptr(result), _ptr(est), _ptr(n_matched)))
         return status.value, H, result, est, n_matched, prev, cur, trk_off, bg_range
 
+    def track_predict_async(self, inside_tlbr, full_tlbr, kps, kp_off, params, slots, ages, sorted_idx, age_penalty,
+                            pts_cap=65536):
+        """fm_track_predict_async: fm_flow_predict + the Kalman step on the library's worker thread.  Returns a job
+        (it owns every buffer the worker reads or writes) for track_predict_wait."""
+        job = SimpleNamespace()
+        job.r = _as(inside_tlbr, np.float64).reshape(-1, 4)
+        nT = len(job.r)
+        job.fb = _as(full_tlbr, np.float64).reshape(nT, 4)
+        job.off = _as(kp_off, np.int32)
+        job.k = _as(kps, np.float32).reshape(-1, 2)
+        assert len(job.off) == nT + 1 and job.off[-1] == len(job.k)
+        job.prev = np.empty((pts_cap, 2), np.float32)
+        job.cur = np.empty((pts_cap, 2), np.float32)
+        job.trk_off = np.zeros(nT + 1, np.int32)
+        job.bg_range = np.zeros(2, np.int32)
+        job.H = np.zeros((3, 3))
+        job.result = np.zeros(nT, np.int32)
+        job.est = np.zeros((nT, 4))
+        job.n_matched = np.zeros(nT, np.int32)
+        job.slots = _as(slots, np.int32)
+        nK = len(job.slots)
+        job.ages = _as(ages, np.int32)
+        job.sorted_idx = _as(sorted_idx, np.int32)
+        assert len(job.ages) == nK and len(job.sorted_idx) == nK
+        job.tlbr = np.empty((nK, 4), np.float64)
+        job.lost = np.zeros(nK, np.uint8)
+        job.params = params
+        check(self.lib.fm_track_predict_async(
+            self._ctx, C.c_int(nT), _ptr(job.r), _ptr(job.fb), _ptr(job.k), _ptr(job.off), C.byref(params),
+            C.c_int(pts_cap), _ptr(job.prev), _ptr(job.cur), _ptr(job.trk_off), _ptr(job.bg_range), _ptr(job.H),
+            _ptr(job.result), _ptr(job.est), _ptr(job.n_matched), C.c_int(nK), _ptr(job.slots), _ptr(job.ages),
+            _ptr(job.sorted_idx), C.c_double(float(age_penalty)), _ptr(job.tlbr), _ptr(job.lost)))
+        return job
+
+    def track_predict_wait(self, job):
+        """-> (the tuple ctx.flow_predict returns, next_tlbrs, lost) ; the last two are None when no Kalman step ran."""
+        status, kalman = C.c_int(0), C.c_int(0)
+        check(self.lib.fm_track_predict_wait(self._ctx, C.byref(status), C.byref(kalman)))
+        pred = (status.value, job.H, job.result, job.est, job.n_matched, job.prev, job.cur, job.trk_off, job.bg_range)
+        if kalman.value:
+            return pred, job.tlbr, job.lost.astype(bool)
+        return pred, None, None
+
     def flow_detect(self, track_idx, track_tlbr, min_dist, cap=1000):
         idx = _as(track_idx, np.int32)
         n = len(idx)
@@ -647,7 +691,8 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_read_image(self._ctx, C.c_int(which), _ptr(buf), C.byref(w), C.byref(h)))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 
-    for fn in (flow_configure, flow_init, flow_begin, flow_arm, flow_release, flow_wait_lk, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
+    for fn in (flow_configure, flow_init, flow_begin, flow_arm, flow_release, flow_wait_lk, track_predict_async,
+               track_predict_wait, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
                flow_background,
                flow_lk, flow_estimate, flow_read_image):
         setattr(cls, fn.__name__, fn)

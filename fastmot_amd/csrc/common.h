@@ -94,6 +94,7 @@ struct fm_ctx {
     std::atomic<int> flow_phase{0};    // 0 idle, 1 armed (a KLT prediction of this step has not finished its LK launch), 2 LK done
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network
+    hipStream_t s_up = nullptr;     // H2D copy of the prefetched next frame (overlaps the running detector pass)
     hipStream_t s_ext = nullptr;    // ReID network
     hipStream_t s_ext_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // streams of the extra ReID instances
     hipEvent_t ev_ext_in = nullptr, ev_ext_x_done[FM_MAX_EXTRA_EXTRACTORS] = {};

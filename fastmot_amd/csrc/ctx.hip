@@ -83,6 +83,7 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     int rc_s;
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, prio_hi));
     if ((rc_s = make_stream(&ctx->s_det, "FASTMOT_CU_MASK_DET", prio_lo))) return rc_s;
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_up, hipStreamNonBlocking, prio_lo));
     if ((rc_s = make_stream(&ctx->s_ext, "FASTMOT_CU_MASK_EXT", prio_hi))) return rc_s;
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_in, hipEventDisableTiming));
     for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
@@ -121,7 +122,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     for (DevBuf* b : {&ctx->as_in, &ctx->as_pair, &ctx->as_stage_in, &ctx->as_cost, &ctx->as_work,
                       &ctx->as_out, &ctx->io0, &ctx->io1, &ctx->feat_in, &ctx->occ_in, &ctx->occ_out})
         b->release();
-    for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_ext, ctx->s_flow, ctx->s_flow2})
+    for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_up, ctx->s_ext, ctx->s_flow, ctx->s_flow2})
         if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr})
         if (e) (void)hipEventDestroy(e);
@@ -137,6 +138,7 @@ extern "C" int fm_ctx_synchronize(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx);
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_det));
+    FM_HIP(hipStreamSynchronize(ctx->s_up));
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
     for (hipStream_t x : ctx->s_ext_x) FM_HIP(hipStreamSynchronize(x));
     FM_HIP(hipStreamSynchronize(ctx->s_flow));

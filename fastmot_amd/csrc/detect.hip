@@ -569,12 +569,17 @@ extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
         memcpy(ctx->frame_pinned2, bgr, bytes);
         src = ctx->frame_pinned2;
     }
-    // (the previous readers of frame_own2 -- the stages of the step before the last promote -- were
-    // synchronised by fm_frame_promote_next; the detector stream orders the copy behind its own reads)
-    int rc_copy = enqueue_frame_copy(ctx->frame_own2, src, bytes, ctx->s_det);
+    // The previous readers of frame_own2 -- every stage of the step before the last promote, its detector pass
+    // included -- are done (fm_frame_promote_next synchronised the ReID / KLT streams, that pass was collected), so the
+    // copy runs on its own stream: it overlaps the tail of the detector pass that is still running on s_det instead
+    // of queueing behind it (the detector chain upload -> network -> NMS is the longest chain of a step once the
+    // tracker side is fast: 0.12 ms per frame); the pass on this frame waits for the event (detect_async_on).
+    static const bool own_stream = !(getenv("FASTMOT_UPLOAD_STREAM") && atoi(getenv("FASTMOT_UPLOAD_STREAM")) == 0);
+    hipStream_t cs = own_stream ? ctx->s_up : ctx->s_det;
+    int rc_copy = enqueue_frame_copy(ctx->frame_own2, src, bytes, cs);
     if (rc_copy) return rc_copy;
     if (!ctx->ev_next_upload) FM_HIP(hipEventCreateWithFlags(&ctx->ev_next_upload, hipEventDisableTiming));
-    FM_HIP(hipEventRecord(ctx->ev_next_upload, ctx->s_det));
+    FM_HIP(hipEventRecord(ctx->ev_next_upload, cs));
     ctx->frame_next = ctx->frame_own2;
     return 0;
 }
@@ -681,6 +686,7 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     NetState* net = ctx->det_net;
     const fm_yolo_cfg& c = d->cfg;
     hipStream_t s = ctx->s_det;
+    if (frame == ctx->frame_own2 && ctx->ev_next_upload) FM_HIP(hipStreamWaitEvent(s, ctx->ev_next_upload, 0));
     int rc = enqueue_preprocess(ctx, d, net, frame);
     if (rc) return rc;
     FM_HIP(hipEventRecord(d->ev0[d->wr], s));

@@ -805,6 +805,158 @@ extern "C" int fm_flow_estimate(fm_ctx* ctx, int n_pts, const float* prev_pts, c
 // ---------------------------------------------------------------------------------------------------
 extern double g_flow_sub[8];
 
+// ---- The KLT + Kalman chain of a step on a native worker thread (fm_track_predict_async / _wait).
+// fastmot_amd/mot.py used to hand Flow.predict + apply_kalman to a second PYTHON thread: its marshalling and result
+// scattering then shared the interpreter lock with the main thread's own Python (every return from a C call had to win
+// the lock back), which stretched both threads by 0.1-0.2 ms per step.  The worker below runs fm_flow_predict and the
+// Kalman launch (fm_trk_step, with the KLT boxes and multipliers MultiTracker.apply_kalman derives from the
+// prediction: tracker.py:164-183) without touching Python; the caller marshals before and scatters after, on its own
+// thread, while the GPU is busy anyway.  The worker spins (bounded, 2 ms) for the next job after finishing one and
+// sleeps on a condition variable otherwise.
+namespace {
+struct TrackPredictJob {
+    fm_ctx* ctx = nullptr;
+    int nT = 0, pts_cap = 0, nK = 0;
+    const double *inside = nullptr, *full = nullptr;
+    const float* kps = nullptr;
+    const int32_t* kp_off = nullptr;
+    fm_flow_predict_params prm{};
+    float *prev_out = nullptr, *cur_out = nullptr;
+    int32_t *trk_off_out = nullptr, *bg_range_out = nullptr, *result_out = nullptr, *n_matched_out = nullptr;
+    double *H_out = nullptr, *est_out = nullptr;
+    const int32_t *slots = nullptr, *ages = nullptr, *sorted_idx = nullptr;
+    double age_penalty = 1.;
+    double* tlbr_out = nullptr;
+    uint8_t* lost_out = nullptr;
+    int status = FM_FLOW_NO_BACKGROUND, kalman_done = 0, rc = 0;
+    char err[512] = {0};
+};
+
+struct PredictWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::atomic<uint64_t> submitted{0}, completed{0};
+    TrackPredictJob job;
+    bool quit = false;
+
+    PredictWorker() { th = std::thread([this] { loop(); }); }
+    ~PredictWorker() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    static void run(TrackPredictJob& j) {
+        fm_ctx* ctx = j.ctx;
+        j.rc = 0; j.kalman_done = 0; j.err[0] = 0;
+        j.status = FM_FLOW_NO_BACKGROUND;
+        if (hipSetDevice(ctx->device) != hipSuccess) { j.rc = FM_ERR_HIP; snprintf(j.err, sizeof(j.err), "hipSetDevice failed"); }
+        if (!j.rc)
+            j.rc = fm_flow_predict(ctx, j.nT, j.inside, j.full, j.kps, j.kp_off, &j.prm, j.pts_cap, j.prev_out, j.cur_out,
+                                   j.trk_off_out, j.bg_range_out, j.H_out, &j.status, j.result_out, j.est_out, j.n_matched_out);
+        ctx->flow_phase.store(2, std::memory_order_release);      // whatever happened: nobody waits for the LK kernel any more
+        if (!j.rc && j.status == FM_FLOW_OK && j.nK > 0) {
+            // MultiTracker.apply_kalman: a track whose KLT box was estimated gets it as a measurement, with a large
+            // uncertainty for occluded tracks (large age / low inlier ratio)
+            std::vector<double> klt(4 * (size_t)j.nK, 0.), mult(j.nK, 1.);
+            std::vector<uint8_t> has(j.nK, 0);
+            for (int i = 0; i < j.nK; ++i) {
+                const int k = j.sorted_idx[i];
+                if (k < 0 || j.result_out[k] == 0 || j.result_out[k] == 2) continue;
+                for (int e = 0; e < 4; ++e) klt[4 * i + e] = j.est_out[4 * k + e];
+                has[i] = 1;
+                const double inlier_ratio = (double)(j.trk_off_out[k + 1] - j.trk_off_out[k]) / (double)j.n_matched_out[k];
+                const double a = j.age_penalty * (double)j.ages[i];
+                mult[i] = (a > 1. ? a : 1.) / inlier_ratio;
+            }
+            j.rc = fm_trk_step(ctx, j.nK, j.slots, j.H_out, klt.data(), has.data(), mult.data(), j.tlbr_out, j.lost_out);
+            j.kalman_done = j.rc == 0;
+        }
+        if (j.rc) snprintf(j.err, sizeof(j.err), "%s", fm_last_error());
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            // bounded spin for the next job (a pipeline submits one per frame), then sleep
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            while (submitted.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < t_end) cpu_relax();
+            if (submitted.load(std::memory_order_acquire) == seen) {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || submitted.load() != seen; });
+                if (quit) return;
+            }
+            seen = submitted.load(std::memory_order_acquire);
+            run(job);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                completed.store(seen, std::memory_order_release);
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+PredictWorker& predict_worker() {
+    static PredictWorker w;
+    return w;
+}
+}  // namespace
+
+extern "C" int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr,
+                                      const float* kps, const int32_t* kp_off, const fm_flow_predict_params* prm,
+                                      int pts_cap, float* prev_out, float* cur_out, int32_t* trk_off_out,
+                                      int32_t* bg_range_out, double* H_out, int32_t* result_out, double* est_tlbr_out,
+                                      int32_t* n_matched_out, int nK, const int32_t* slots, const int32_t* ages,
+                                      const int32_t* sorted_idx, double age_penalty, double* tlbr_out,
+                                      uint8_t* lost_out) {
+    FM_CHECK_ARG(ctx && ctx->flow && nT >= 0 && nK >= 0 && prm && pts_cap > 0 && prev_out && cur_out && trk_off_out &&
+                 bg_range_out && H_out);
+    FM_CHECK_ARG(nT == 0 || (inside_tlbr && full_tlbr && kp_off && result_out && est_tlbr_out && n_matched_out));
+    FM_CHECK_ARG(nK == 0 || (slots && ages && sorted_idx && tlbr_out && lost_out));
+    PredictWorker& w = predict_worker();
+    if (w.completed.load(std::memory_order_acquire) != w.submitted.load(std::memory_order_acquire)) {
+        fm_set_error("a track prediction is already in flight (fm_track_predict_wait first)");
+        return FM_ERR_STATE;
+    }
+    TrackPredictJob& j = w.job;
+    j.ctx = ctx; j.nT = nT; j.inside = inside_tlbr; j.full = full_tlbr; j.kps = kps; j.kp_off = kp_off; j.prm = *prm;
+    j.pts_cap = pts_cap; j.prev_out = prev_out; j.cur_out = cur_out; j.trk_off_out = trk_off_out;
+    j.bg_range_out = bg_range_out; j.H_out = H_out; j.result_out = result_out; j.est_out = est_tlbr_out;
+    j.n_matched_out = n_matched_out; j.nK = nK; j.slots = slots; j.ages = ages; j.sorted_idx = sorted_idx;
+    j.age_penalty = age_penalty; j.tlbr_out = tlbr_out; j.lost_out = lost_out;
+    ctx->flow_phase.store(1, std::memory_order_release);          // = fm_flow_arm: the ReID launch waits for the LK kernel
+    {
+        std::lock_guard<std::mutex> lk(w.m);
+        w.submitted.fetch_add(1, std::memory_order_release);
+    }
+    w.cv.notify_all();
+    return 0;
+}
+
+// blocks until the job of fm_track_predict_async has finished; status_out: FM_FLOW_*; kalman_done_out: 1 when the
+// Kalman step ran (status OK and nK > 0) and tlbr_out / lost_out are valid
+extern "C" int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_done_out) {
+    FM_CHECK_ARG(ctx && status_out && kalman_done_out);
+    PredictWorker& w = predict_worker();
+    const uint64_t want = w.submitted.load(std::memory_order_acquire);
+    for (int spins = 0; spins < 20000 && w.completed.load(std::memory_order_acquire) != want; ++spins) cpu_relax();
+    if (w.completed.load(std::memory_order_acquire) != want) {
+        std::unique_lock<std::mutex> lk(w.m);
+        w.cv_done.wait(lk, [&] { return w.completed.load() == want; });
+    }
+    const TrackPredictJob& j = w.job;
+    *status_out = j.status;
+    *kalman_done_out = j.kalman_done;
+    if (j.rc) {
+        fm_set_error("%s", j.err);
+        return j.rc;
+    }
+    return 0;
+}
+
 // ---- LK / ReID exclusion (see the isolation note at the LK launch in flow.hip).  fm_flow_arm: the caller is about
 // to hand this step's fm_flow_predict to another thread; fm_flow_wait_lk: blocks until that prediction has finished
 // its LK launch (or was released / never armed); fm_flow_release: the prediction thread is done, however it ended.

@@ -112,10 +112,16 @@ class Flow:
         method only orders the tracks and scatters the results."""
         ctx = self.ctx
         bind_frame(ctx, frame, self.size)
-        empty = np.empty((0, 2), np.float32)
+        tracks, inside, tlbrs, kps, kp_off = self.marshal(tracks)
+        out = ctx.flow_predict(inside, tlbrs, kps, kp_off, self._params)
+        return self.scatter(tracks, *out)
 
-        # order tracks from closest to farthest: same order as `tracks.sort(reverse=True)` with Track.__lt__
-        # (track.py:160-162 compares exactly this tuple), without ~6 Python-level comparisons per track
+    def marshal(self, tracks):
+        """Orders `tracks` (in place) from closest to farthest and packs what fm_flow_predict reads:
+        -> (tracks, inside_tlbr f64[n,4], tlbr f64[n,4], keypoints f32[m,2], keypoint offsets i32[n+1])."""
+        empty = np.empty((0, 2), np.float32)
+        # same order as `tracks.sort(reverse=True)` with Track.__lt__ (track.py:160-162 compares exactly this tuple),
+        # without ~6 Python-level comparisons per track
         tracks.sort(key=lambda t: (t.tlbr[3], -t.age), reverse=True)
         n_trk = len(tracks)
         fr = self.frame_rect
@@ -130,9 +136,12 @@ class Flow:
         else:
             tlbrs, inside = np.zeros((0, 4)), np.zeros((0, 4))
             kp_off, kps = np.zeros(1, np.int32), empty
+        return tracks, inside, tlbrs, kps, kp_off
 
-        status, homography, result, est, n_matched, prev, cur, off, bg = ctx.flow_predict(
-            inside, tlbrs, kps, kp_off, self._params)
+    def scatter(self, tracks, status, homography, result, est, n_matched, prev, cur, off, bg):
+        """Writes the outputs of fm_flow_predict back to the (ordered) tracks; -> ({trk_id: tlbr}, homography)
+        or ({}, None) when the camera motion could not be estimated."""
+        empty = np.empty((0, 2), np.float32)
         if status != _lib.FLOW_OK:
             self.bg_keypoints = empty
             LOGGER.warning('Camera motion estimation failed')
@@ -142,7 +151,7 @@ class Flow:
 
         # estimate target bounding boxes: the per-track keypoint arrays are views cut in one call each
         next_bboxes = {}
-        if n_trk:
+        if len(tracks):
             cuts = off[1:-1]
             prev_parts, cur_parts = np.split(prev[:off[-1]], cuts), np.split(cur[:off[-1]], cuts)
             counts = (off[1:] - off[:-1]).tolist()

@@ -15,11 +15,31 @@ import numpy as np
 from .detector import SSDDetector, YOLODetector, PublicDetector, bind_frame
 from .feature_extractor import FeatureExtractor
 from .tracker import MultiTracker
+from .flow import Flow
 from .utils import Profiler
 from .utils.visualization import Visualizer
 
 LOGGER = logging.getLogger(__name__)
 _PREFETCH_FIRST = os.environ.get('FASTMOT_PREFETCH_FIRST', '0') != '0'
+_UPDATE_EARLY = os.environ.get('FASTMOT_UPDATE_EARLY', '1') != '0'
+_NATIVE_FLOW = os.environ.get('FASTMOT_NATIVE_FLOW', '1') != '0'
+
+
+class _NativeFlowJob:
+    """Future-like handle of MultiTracker.predict_async (same interface as the thread-pool future it replaces)."""
+
+    def __init__(self, tracker, frame):
+        self._tracker = tracker
+        self._job = tracker.predict_async(frame)
+
+    def done(self):
+        return self._job is None or self._tracker.ctx.flow_wait_lk(0)
+
+    def result(self):
+        job, self._job = self._job, None
+        if job is not None:
+            with Profiler('track'):
+                self._tracker.predict_finish(job)
 
 
 class DetectorType(Enum):
@@ -148,7 +168,8 @@ class MOT:
             # second host thread and its own HIP streams, so the critical path of a step is
             # detector -> ReID network -> association.  The stages are independent exactly as in the
             # reference, so the results are identical.
-            if self._lk_exclusion:
+            native = _NATIVE_FLOW and type(self.tracker.flow) is Flow      # (tests script the flow with a fake)
+            if self._lk_exclusion and not native:
                 ctx.flow_arm()
             # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
             # detector stream never idles; results are collected in order, detect.hip).  Two host threads launching
@@ -157,7 +178,12 @@ class MOT:
             # (FASTMOT_PREFETCH_FIRST=1 is the other order).
             if _PREFETCH_FIRST:
                 self._prefetch_next()
-            flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
+            if native:
+                # KLT + Kalman on the library's worker thread: marshalled here, scattered in predict_finish -- no second
+                # Python thread competing for the interpreter lock (fastmot_hip.h: fm_track_predict_async)
+                flow_done = _NativeFlowJob(self.tracker, frame)
+            else:
+                flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
             try:
                 self._prefetch_next()
                 with Profiler('detect'):
@@ -173,15 +199,23 @@ class MOT:
                 with Profiler('extract'):
                     if len(self.extractors) == 1:
                         self.extractors[0].extract_async(frame, detections.tlbr)
-                        self.tracker.prepare_detections(detections)
-                        embeddings = self.extractors[0].postprocess()
                     else:
                         # one extractor per class id (mot.py:147-157); _split_bboxes_by_cls keeps the
                         # reference's bisect_right, quirk included
                         cls_bboxes = self._split_bboxes_by_cls(detections.tlbr, detections.label, self.class_ids)
                         for extractor, bboxes in zip(self.extractors, cls_bboxes):
                             extractor.extract_async(frame, bboxes)
-                        self.tracker.prepare_detections(detections)
+                    self.tracker.prepare_detections(detections)
+                    # the embedding-independent part of the association (track grouping, cost-matrix row order,
+                    # packed launch arguments) runs while the ReID network is still busy: it only needs the Kalman
+                    # step, i.e. the KLT thread, to have finished
+                    pre = None
+                    if _UPDATE_EARLY:
+                        flow_done.result()
+                        pre = self.tracker.update_begin(detections)
+                    if len(self.extractors) == 1:
+                        embeddings = self.extractors[0].postprocess()
+                    else:
                         parts = [extractor.postprocess() for extractor in self.extractors]
                         filled = [p for p in parts if len(p)]
                         # (a single non-empty part is passed through as it is: the association kernels then
@@ -192,7 +226,7 @@ class MOT:
                 flow_done.result()
 
             with Profiler('assoc'):
-                self.tracker.update(self.frame_count, detections, embeddings)
+                self.tracker.update(self.frame_count, detections, embeddings, pre=pre)
         else:
             self._prefetch_next()
             with Profiler('track'):

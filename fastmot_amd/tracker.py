@@ -20,6 +20,7 @@ import numpy as np
 from . import _lib
 from .track import Track
 from .flow import Flow
+from .detector import bind_frame
 from .kalman_filter import KalmanFilter
 from .runtime import get_context
 
@@ -150,6 +151,44 @@ class MultiTracker:
             # clear tracks when camera motion cannot be estimated
             self._clear_tracks()
 
+    def predict_async(self, frame):
+        """compute_flow + apply_kalman of this frame on the library's worker thread (fm_track_predict_async): this
+        method marshals on the calling thread and returns a job for `predict_finish`.  Nothing may touch the tracks
+        in between.  Same results as compute_flow(frame); apply_kalman()."""
+        flow = self.flow
+        bind_frame(self.ctx, frame, flow.size)
+        items = list(self.tracks.items())
+        active, inside, tlbrs, kps, kp_off = flow.marshal([track for _, track in items if track.active])
+        pos = {id(track): k for k, track in enumerate(active)}
+        n = len(items)
+        slots = np.fromiter((track.slot for _, track in items), np.int32, n)
+        ages = np.fromiter((track.age for _, track in items), np.int32, n)
+        sorted_idx = np.fromiter((pos.get(id(track), -1) for _, track in items), np.int32, n)
+        job = self.ctx.track_predict_async(inside, tlbrs, kps, kp_off, flow._params, slots, ages, sorted_idx,
+                                           self.age_penalty)
+        job.items, job.active = items, active
+        return job
+
+    def predict_finish(self, job):
+        pred, next_tlbrs, lost = self.ctx.track_predict_wait(job)
+        self.klt_bboxes, self.homography = self.flow.scatter(job.active, *pred)
+        if self.homography is None:
+            # clear tracks when camera motion cannot be estimated
+            self._clear_tracks()
+            return
+        if next_tlbrs is not None:
+            self._after_kalman(job.items, next_tlbrs, lost)
+
+    def _after_kalman(self, items, next_tlbrs, lost):
+        for (trk_id, track), row in zip(items, list(next_tlbrs)):
+            track.bboxes.append(row)
+        if lost.any():
+            for i in np.flatnonzero(lost).tolist():
+                trk_id, track = items[i]
+                if track.confirmed:
+                    LOGGER.info(f"{'Out:':<14}{track}")
+                self._mark_lost(trk_id)
+
     def apply_kalman(self):
         """Kalman predict + KLT update of every track in one launch (tracker.py:164-183)."""
         items = list(self.tracks.items())
@@ -171,15 +210,7 @@ class MultiTracker:
                 # give large KLT uncertainty for occluded tracks (large age / low inlier ratio)
                 mult[idx] = [max(age_penalty * h[2].age, 1) / h[2].inlier_ratio for h in hit]
         next_tlbrs, lost = self.kf.step_slots(slots, self.homography, klt, has_klt, mult)
-        rows = list(next_tlbrs)
-        for (trk_id, track), row in zip(items, rows):
-            track.bboxes.append(row)
-        if lost.any():
-            for i in np.flatnonzero(lost).tolist():
-                trk_id, track = items[i]
-                if track.confirmed:
-                    LOGGER.info(f"{'Out:':<14}{track}")
-                self._mark_lost(trk_id)
+        self._after_kalman(items, next_tlbrs, lost)
 
     # ------------------------------------------------------------------ association
     def _solve(self, stage, solver, trk_ids, rows, det_ids, cols, **kw):
@@ -221,26 +252,49 @@ class MultiTracker:
         occluded = self.ctx.find_occluded(det_tlbr, self.occlusion_thresh)
         self._prepared = (detections, det_tlbr, det_label, det_conf, occluded)
 
-    def update(self, frame_id, detections, embeddings):
-        """Associates detections to tracklets based on motion and feature embeddings
-        (tracker.py:185-293).
-
-        detections : recarray[DET_DTYPE]; embeddings : (N, M) float32 (host) -- if it is the
-        array last returned by FeatureExtractor.postprocess the device copy is used directly."""
-        ctx = self.ctx
-        n_det = len(detections)
+    def update_begin(self, detections):
+        """The part of `update` that needs no embeddings: track grouping, the row order of the cost matrices and
+        the packed arguments of the pairwise-cost launch.  MOT.step calls it while the ReID network is still
+        running (after the Kalman step has finished) and hands the result to `update`; nothing may touch the
+        tracks in between."""
         if self._prepared is None or self._prepared[0] is not detections:
             self.prepare_detections(detections)
         _, det_tlbr, det_label, det_conf, occluded_det_mask = self._prepared
         self._prepared = None
-        confirmed_by_depth, unconfirmed = self._group_tracks_by_depth()
-
-        # ---- device: embeddings + every pairwise term of this frame in one launch
+        groups = self._group_tracks_by_depth()
         hist_ids = [trk_id for trk_id, track in self.hist_tracks.items()
                     if track.avg_feat.count >= 2]
         row_ids = list(self.tracks.keys()) + hist_ids
         row_of = {trk_id: i for i, trk_id in enumerate(row_ids)}
         foreign = self._exchange_gallery(hist_ids) if self.gallery_sync is not None else []
+        assoc_args = trk_feat_f32 = None
+        if len(detections) > 0 and (row_ids or foreign):
+            row_tracks = [self.tracks[t] if t in self.tracks else self.hist_tracks[t] for t in row_ids]
+            # foreign gallery entries (other streams) come after all local rows
+            assoc_args = ([t.slot for t in row_tracks] + self._foreign_slots[:len(foreign)],
+                          np.array([t.tlbr for t in row_tracks] + [np.zeros(4)] * len(foreign)),
+                          [t.label for t in row_tracks] + [e['label'] for e in foreign])
+            trk_feat_f32 = [t not in self.tracks for t in row_ids] + [True] * len(foreign)
+        return dict(detections=detections, det=(det_tlbr, det_label, det_conf, occluded_det_mask), groups=groups,
+                    hist_ids=hist_ids, row_ids=row_ids, row_of=row_of, foreign=foreign, assoc_args=assoc_args,
+                    trk_feat_f32=trk_feat_f32)
+
+    def update(self, frame_id, detections, embeddings, pre=None):
+        """Associates detections to tracklets based on motion and feature embeddings
+        (tracker.py:185-293).
+
+        detections : recarray[DET_DTYPE]; embeddings : (N, M) float32 (host) -- if it is the
+        array last returned by FeatureExtractor.postprocess the device copy is used directly.
+        pre : the result of `update_begin(detections)` when the caller has already run it."""
+        ctx = self.ctx
+        n_det = len(detections)
+        if pre is None or pre['detections'] is not detections:
+            pre = self.update_begin(detections)
+        det_tlbr, det_label, det_conf, occluded_det_mask = pre['det']
+        confirmed_by_depth, unconfirmed = pre['groups']
+        hist_ids, row_ids, row_of, foreign = pre['hist_ids'], pre['row_ids'], pre['row_of'], pre['foreign']
+
+        # ---- device: embeddings + every pairwise term of this frame in one launch
         if n_det > 0:
             if embeddings is ctx.device_emb_host and embeddings is not None:
                 ctx.emb_use_device(n_det)
@@ -248,13 +302,8 @@ class MultiTracker:
                 ctx.emb_upload(embeddings)
                 ctx.device_emb_host = None
             if row_ids or foreign:
-                row_tracks = [self.tracks[t] if t in self.tracks else self.hist_tracks[t] for t in row_ids]
-                # foreign gallery entries (other streams) come after all local rows
-                ctx.assoc_prepare(self._metric_id, [t.slot for t in row_tracks] + self._foreign_slots[:len(foreign)],
-                                  np.array([t.tlbr for t in row_tracks] + [np.zeros(4)] * len(foreign)),
-                                  [t.label for t in row_tracks] + [e['label'] for e in foreign],
-                                  det_tlbr, det_label, occluded_det_mask,
-                                  trk_feat_f32=[t not in self.tracks for t in row_ids] + [True] * len(foreign))
+                ctx.assoc_prepare(self._metric_id, *pre['assoc_args'], det_tlbr, det_label, occluded_det_mask,
+                                  trk_feat_f32=pre['trk_feat_f32'])
 
         # ---- 1st association: motion + embeddings, tracks with small age are prioritized
         fill_val = min(self.max_assoc_cost + 0.1, 1.)

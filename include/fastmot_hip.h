@@ -442,6 +442,19 @@ int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
                     const int32_t* kp_off, const fm_flow_predict_params* prm, int pts_cap, float* prev_out,
                     float* cur_out, int32_t* trk_off_out, int32_t* bg_range_out, double* H_out, int* status_out,
                     int32_t* result_out, double* est_tlbr_out, int32_t* n_matched_out);
+/* The KLT + Kalman chain of one step on the library's own worker thread: fm_flow_predict followed by fm_trk_step with
+ * the KLT measurements MultiTracker.apply_kalman derives from it (tracker.py:150-183).  nT tracks in prediction order
+ * (as fm_flow_predict), nK tracks in table order for the Kalman step: slots, ages and sorted_idx[i] = position of
+ * track i among the nT predicted ones or -1; multiplier = max(age_penalty * age, 1) / inlier_ratio.  All pointers
+ * must stay valid until fm_track_predict_wait returns; one job at a time.  The call also arms the LK / ReID ordering
+ * (fm_flow_arm); fm_track_predict_wait reports the prediction status (FM_FLOW_*) and whether the Kalman step ran. */
+int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr, const float* kps,
+                           const int32_t* kp_off, const fm_flow_predict_params* prm, int pts_cap, float* prev_out,
+                           float* cur_out, int32_t* trk_off_out, int32_t* bg_range_out, double* H_out,
+                           int32_t* result_out, double* est_tlbr_out, int32_t* n_matched_out, int nK,
+                           const int32_t* slots, const int32_t* ages, const int32_t* sorted_idx, double age_penalty,
+                           double* tlbr_out, uint8_t* lost_out);
+int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_done_out);
 /* LK / ReID exclusion for pipelines that run fm_flow_predict on a second host thread (fastmot_amd/mot.py; the
  * reference overlaps its optical flow with the asynchronous detector the same way, mot.py:138-145).  The LK
  * kernel must not share compute units with the ReID network's fused LightConv kernels;
