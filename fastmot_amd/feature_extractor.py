@@ -15,7 +15,7 @@ from .runtime import get_context
 
 class FeatureExtractor:
     def __init__(self, model='OSNet025', batch_size=16, weights=None, size=None, reuse_buffers=True,
-                 split_batches=int(os.environ.get('FASTMOT_EXT_SPLIT', '2')), resident=True):
+                 split_batches=int(os.environ.get('FASTMOT_EXT_SPLIT', '1')), resident=True):
         """model : name of a class that inherits `models.ReID`; batch_size : samples per network
         launch (fastmot/feature_extractor.py:12-25).  `size` (frame width, height) is only needed
         when the extractor is used without a detector having bound the frame first.  `resident=False`
