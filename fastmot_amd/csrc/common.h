@@ -102,6 +102,7 @@ struct fm_ctx {
     hipStream_t s_flow2 = nullptr;  // KLT: pyramid of the new frame (independent of the keypoint preparation on s_flow)
     hipEvent_t ev_pyr = nullptr;    // completion of that pyramid; s_flow waits on it before its first reader (LK)
     bool pyr_pending = false;
+    hipEvent_t ev_prep = nullptr, ev_bg = nullptr;   // fork / join of the background-keypoint branch of fm_flow_prepare
     hipEvent_t ev_feat = nullptr;   // last reader of ctx->emb on s_main (fm_feat_update); s_ext waits on it
 
     // ---- device-resident track table

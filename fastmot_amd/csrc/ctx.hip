@@ -94,6 +94,8 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     if ((rc_s = make_stream(&ctx->s_flow, "FASTMOT_CU_MASK_FLOW", fp && atoi(fp) == 0 ? prio_lo : prio_hi))) return rc_s;
     if ((rc_s = make_stream(&ctx->s_flow2, "FASTMOT_CU_MASK_FLOW", fp && atoi(fp) == 0 ? prio_lo : prio_hi))) return rc_s;
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_pyr, hipEventDisableTiming));
+    FM_HIP(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+    FM_HIP(hipEventCreateWithFlags(&ctx->ev_bg, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_feat, hipEventDisableTiming));
     int rc = fm_ensure_slots(ctx, 1024);
     if (rc) return rc;
@@ -124,7 +126,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
         b->release();
     for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_up, ctx->s_ext, ctx->s_flow, ctx->s_flow2})
         if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr})
+    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr, ctx->ev_prep, ctx->ev_bg})
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
         if (ctx->s_ext_x[i]) (void)hipStreamDestroy(ctx->s_ext_x[i]);

@@ -938,11 +938,13 @@ __global__ __launch_bounds__(1024) void fast_compact_kernel(const uint8_t* __res
     if (tid == 1023) {
         *n_out = s_cnt[1023];
         if (totals_host) {            // [0] = new keypoints (gftt_select_kernel, earlier on this stream), [1] = background
-            totals_host[0] = new_total[0];
+            if (new_total) totals_host[0] = new_total[0];
             totals_host[1] = s_cnt[1023];
         }
     }
 }
+
+__global__ void copy_total_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) { dst[0] = src[0]; }
 
 // dynamic LDS of gftt_select_kernel: the min-eigenvalue crop (up to GFTT_EIG_LDS floats next to ~65 KB of static
 // arrays; 160 KB per workgroup on gfx950).  Larger crops (4K frames) are read from global memory.
@@ -1464,6 +1466,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     // ONE upload; the kernels read rects / overlap lists / counters straight from it (no device-to-device
     // copies, no memset)
     FM_HIP(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, s));
+    FM_HIP(hipEventRecord(ctx->ev_prep, s));           // the background branch (side stream) needs the rects only
     f->v_rects = reinterpret_cast<const int32_t*>(db + o_rect);
     f->v_ov_off = reinterpret_cast<const int32_t*>(db + o_ovoff);
     f->v_ov_idx = reinterpret_cast<const int32_t*>(db + o_ovidx);
@@ -1493,22 +1496,34 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
                            reinterpret_cast<int32_t*>(dbo + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(dbo + q_off),
                            gftt_lds_bytes(max_area) / 4);
     }
-    // background keypoints under the final mask
+    // background keypoints under the final mask: four small dependent launches that share nothing with the per-track
+    // branch above except the uploaded rects -- they run on the side stream (behind the new frame's pyramid, which is
+    // shorter than the per-track branch) and join at the end of the call
+    static const bool bg_side = !(getenv("FASTMOT_BG_STREAM") && atoi(getenv("FASTMOT_BG_STREAM")) == 0);
+    hipStream_t sb = bg_side ? ctx->s_flow2 : s;
     const int bw = f->cfg.bg_w, bh = f->cfg.bg_h;
-    hipLaunchKernelGGL(resize_linear_kernel, dim3((bw + 255) / 256, bh), dim3(256), 0, s, f->gray[f->prev], f->W,
+    // (the fork event is recorded behind the upload only: the branch must not wait for the per-track kernels)
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((bw + 255) / 256, bh), dim3(256), 0, sb, f->gray[f->prev], f->W,
                        f->H, f->bg_img, bw, bh);
-    hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_img, bw, bh,
+    hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, sb, f->bg_img, bw, bh,
                        f->cfg.fast_thresh, f->bg_flags);
     uint8_t* d_flag = reinterpret_cast<uint8_t*>(f->bg_flags + (size_t)bw * bh + 8);
-    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->v_rects,
+    if (bg_side) FM_HIP(hipStreamWaitEvent(sb, ctx->ev_prep, 0));
+    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, sb, f->bg_flags, bw, bh, f->v_rects,
                        nT, f->W, f->H, d_flag);
-    // the last kernel of the call also puts both totals into the result block
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh,
-                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, tot, reinterpret_cast<int32_t*>(dbo + q_tot));
+    // the last kernels of the two branches put the totals into the result block
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, sb, d_flag, bw, bh,
+                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, bg_side ? nullptr : tot,
+                       reinterpret_cast<int32_t*>(dbo + q_tot));
+    if (bg_side) {
+        FM_HIP(hipEventRecord(ctx->ev_bg, sb));
+        hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(1), 0, s, tot, reinterpret_cast<int32_t*>(dbo + q_tot));
+    }
     FM_HIP(hipGetLastError());
     if (out_mode != 1) FM_HIP(hipMemcpyAsync(ho, dbo, q_pts, hipMemcpyDeviceToHost, s));
     g_flow_sub[2] += fm_now_ms() - tp0; tp0 = fm_now_ms();
     FM_HIP(hipStreamSynchronize(s));
+    if (bg_side) FM_HIP(hipEventSynchronize(ctx->ev_bg));
     g_flow_sub[3] += fm_now_ms() - tp0;
     if (nT) {
         memcpy(area_out, ho + q_area, 4 * (size_t)nT);

@@ -109,6 +109,33 @@ def test_next_frame_prefetch_changes_nothing(ctx, skip, resident):
     assert len(runs[0][-1]) >= 8
 
 
+def test_native_prediction_worker_equals_python_thread(ctx, monkeypatch):
+    """The KLT + Kalman chain on the library's worker thread (fm_track_predict_async: marshal on the main thread,
+    fm_flow_predict + fm_trk_step in C, scatter after the join) gives the same tracks as Flow.predict +
+    MultiTracker.apply_kalman on a second Python thread, frame by frame."""
+    import fastmot_amd.mot as mot_mod
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from fastmot_amd import Track
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=10, n_frames=16, seed=11)
+    runs = []
+    for native in (True, False):
+        monkeypatch.setattr(mot_mod, '_NATIVE_FLOW', native)
+        mot = build_mot(size, video, 2)                 # detector frames and tracker-only frames alternate
+        Track._count = 0
+        mot.reset(1 / 30.)
+        rows = []
+        for f in range(video.n_frames):
+            mot.detector._frame_idx = f
+            mot.step(video.frames[f])
+            rows.append([(t.trk_id, tuple(t.tlbr), t.confirmed, t.active, t.age, t.hits, len(t.keypoints),
+                          float(t.inlier_ratio)) for t in mot.tracker.tracks.values()])
+        runs.append(rows)
+        mot.tracker._clear_tracks()
+    assert runs[0] == runs[1]
+    assert len(runs[0][-1]) >= 8
+
+
 def test_pipeline_is_deterministic(ctx):
     """The two-thread, four-stream pipeline gives the same tracks (ids, boxes, keypoint counts) on every run
     of the same clip (scripts/stress_determinism.py is the long version of this check)."""
