@@ -632,6 +632,12 @@ __global__ FM_SGPR_CAP void eig_kernel(const uint8_t* __restrict__ img, int stri
 // The min-eigenvalue crop is staged in LDS first (one coalesced pass; the two scans below read every value
 // ten times): with the map in global memory the scans were a chain of dependent L2 round trips per
 // iteration and the kernel took 180-330 us on the benchmark crops.
+#ifdef FM_GFTT_TIMING
+__device__ long long g_gftt_stamps[64][8];
+#define GFTT_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 64) g_gftt_stamps[blockIdx.x][i] = __builtin_readcyclecounter();
+#else
+#define GFTT_STAMP(i)
+#endif
 constexpr int GFTT_MAX_CAND = 4096;      // sorted in LDS (32 KB)
 constexpr int GFTT_MAX_CELLS = 1536;     // x 4 slots x 4 B = 24 KB
 constexpr int GFTT_BLK = 1024;
@@ -656,6 +662,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float s_eig[];
+    GFTT_STAMP(0)
     const int npx = c.w * c.h;
     const bool staged = npx <= eig_lds_floats;
     const float* eg = eig + c.eig_off;
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
     __shared__ float red[GFTT_BLK];
     __shared__ int s_n;
     __shared__ unsigned long long keys[GFTT_MAX_CAND];
-    __shared__ int cells[GFTT_MAX_CELLS * 4];
+    __shared__ __attribute__((aligned(16))) int cells[GFTT_MAX_CELLS * 4];
     __syncthreads();
     auto covered = [&](int x, int y) {
         return ov_lds ? covered_lds(s_ov, lcnt, x, y) : covered_by(rects, list, lcnt, x, y);
@@ -694,6 +701,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
     }
     const float thr = red[0] * quality;
     __syncthreads();
+    GFTT_STAMP(1)
     // candidates: val > thr, val >= 8 neighbours (dilate inside the crop), mask set, 1-px border skipped.
     // key = (float bits of val << 32) | raster index : descending 64-bit order == (val desc, index desc),
     // the order of std::sort(..., greaterThanPtr) in featureselect.cpp
@@ -713,6 +721,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
         if (slot < GFTT_MAX_CAND) keys[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
     }
     __syncthreads();
+    GFTT_STAMP(2)
     const int n = min(s_n, GFTT_MAX_CAND);
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
@@ -730,6 +739,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
             }
             __syncthreads();
         }
+    GFTT_STAMP(3)
     // greedy min-distance selection by the first wavefront
     const int md = min_dist[needy ? c.k : t];
     const int gw = (c.w + md - 1) / md, gh = (c.h + md - 1) / md;
@@ -762,19 +772,30 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
                 y = fast_div(ri, c.w, inv_w);
                 x = ri - y * c.w;
                 if (use_grid) {
+                    // the 3 x 3 neighbourhood as nine independent 16-byte reads (clamped, masked afterwards): one LDS
+                    // round trip per batch instead of up to 36 dependent ones (this loop was 57 % of the kernel:
+                    // 15.7 k cycles per batch of 64 candidates, scripts/gftt_timing.py)
                     const int cx0 = fast_div(x, md, inv_md), cy0 = fast_div(y, md, inv_md);
-                    for (int cyn = max(cy0 - 1, 0); cyn <= min(cy0 + 1, gh - 1) && alive; ++cyn)
-                        for (int cxn = max(cx0 - 1, 0); cxn <= min(cx0 + 1, gw - 1) && alive; ++cxn) {
-                            const int* cell = cells + (cyn * gw + cxn) * 4;
+                    int4 cv[9];
 #pragma unroll
-                            for (int sidx = 0; sidx < 4; ++sidx) {
-                                const int p = cell[sidx];
-                                if (p >= 0) {
-                                    const int dx = x - (p & 0xffff), dy = y - (p >> 16);
-                                    if (dx * dx + dy * dy < md2) alive = false;
-                                }
+                    for (int j = 0; j < 9; ++j) {
+                        const int cyn = min(max(cy0 + j / 3 - 1, 0), gh - 1), cxn = min(max(cx0 + j % 3 - 1, 0), gw - 1);
+                        cv[j] = *reinterpret_cast<const int4*>(cells + (cyn * gw + cxn) * 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const int cyn = cy0 + j / 3 - 1, cxn = cx0 + j % 3 - 1;
+                        if (cyn < 0 || cyn >= gh || cxn < 0 || cxn >= gw) continue;
+                        const int pv[4] = {cv[j].x, cv[j].y, cv[j].z, cv[j].w};
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx) {
+                            const int p = pv[sidx];
+                            if (p >= 0) {
+                                const int dx = x - (p & 0xffff), dy = y - (p >> 16);
+                                if (dx * dx + dy * dy < md2) alive = false;
                             }
                         }
+                    }
                 } else {
                     for (int j = 0; j < nacc && alive; ++j) {
                         const int dx = x - acc_x[j], dy = y - acc_y[j];
@@ -782,19 +803,15 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
                     }
                 }
             }
+            // survivors are resolved in lane (= sorted) order with register traffic only; every accepted lane then
+            // files its own corner (list slot = its rank, grid slot by compare-and-swap) -- in parallel
             unsigned long long mask = __ballot(alive);
+            unsigned long long accepted = 0ull;
+            const int nacc0 = nacc;
             while (mask != 0ull && nacc < limit) {
                 const int first = __ffsll((long long)mask) - 1;
                 const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);
-                if (tid == 0) {
-                    acc_x[nacc] = (short)fx;
-                    acc_y[nacc] = (short)fy;
-                    if (use_grid) {
-                        int* cell = cells + (fast_div(fy, md, inv_md) * gw + fast_div(fx, md, inv_md)) * 4;
-                        for (int sidx = 0; sidx < 4; ++sidx)
-                            if (cell[sidx] < 0) { cell[sidx] = (fy << 16) | fx; break; }
-                    }
-                }
+                accepted |= 1ull << first;
                 ++nacc;
                 if (alive) {
                     const int dx = x - fx, dy = y - fy;
@@ -802,12 +819,27 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
                 }
                 mask = __ballot(alive);
             }
+            if ((accepted >> tid) & 1ull) {
+                const int slot = nacc0 + __popcll(accepted & ((1ull << tid) - 1ull));
+                acc_x[slot] = (short)x;
+                acc_y[slot] = (short)y;
+                if (use_grid) {
+                    int* cell = cells + (fast_div(y, md, inv_md) * gw + fast_div(x, md, inv_md)) * 4;
+                    const int pk = (y << 16) | x;
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        if (atomicCAS(&cell[sidx], -1, pk) == -1) break;
+                }
+            }
             __builtin_amdgcn_wave_barrier();
-            __threadfence_block();          // lane 0's grid / list writes are visible to the next batch
+            __threadfence_block();          // the grid / list writes are visible to the next batch
         }
         if (tid == 0) s_acc = nacc;
     }
     __syncthreads();
+    GFTT_STAMP(4)
+#ifdef FM_GFTT_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 64) { g_gftt_stamps[blockIdx.x][6] = n; g_gftt_stamps[blockIdx.x][7] = ((long long)npx << 20) | s_acc; }
+#endif
     // _ellipse_filter (flow.py:297-306): pts (f32) + offset (f32), then float64 ellipse test -- flags in
     // parallel, order-preserving compaction by ballot ranks
     const int nacc_all = s_acc;
@@ -853,6 +885,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
         }
         if (tid == 0) counts[t] = m;
     }
+    GFTT_STAMP(5)
 }
 
 // ---- FAST-9/16 (features2d/fast.cpp), score = max threshold keeping the pixel a corner
@@ -1543,6 +1576,14 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     *n_bg_out = n_bg;
     return 0;
 }
+
+#ifdef FM_GFTT_TIMING
+extern "C" int fm_debug_gftt_stamps(long long* out512) {
+    FM_HIP(hipDeviceSynchronize());
+    FM_HIP(hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_gftt_stamps), sizeof(long long) * 512));
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Diagnostic kernel (scripts/stress_spin.py): a long, fully deterministic computation on the flow stream,
