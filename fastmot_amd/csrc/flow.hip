@@ -485,10 +485,15 @@ __device__ __forceinline__ int fast_div(int i, int w, float inv_w) {
 
 constexpr int OV_LDS = 32;     // overlapping earlier rects of one track kept in LDS (more: global lists)
 
+// (one 16-byte broadcast read per rect and no early exit: the short-circuit version was four dependent LDS reads and
+// four branches per rect, in the per-pixel loops of the bookkeeping and GFTT kernels)
 __device__ __forceinline__ bool covered_lds(const int* s_ov, int cnt, int x, int y) {
-    for (int q = 0; q < cnt; ++q)
-        if (x >= s_ov[4 * q] && x <= s_ov[4 * q + 2] && y >= s_ov[4 * q + 1] && y <= s_ov[4 * q + 3]) return true;
-    return false;
+    bool c = false;
+    for (int q = 0; q < cnt; ++q) {
+        const int4 r = *reinterpret_cast<const int4*>(s_ov + 4 * q);
+        c |= (x >= r.x) & (x <= r.z) & (y >= r.y) & (y <= r.w);
+    }
+    return c;
 }
 
 __global__ __launch_bounds__(256) void target_area_kernel(const int32_t* __restrict__ rects, Overlaps ov,
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(PREP_BLK) FM_SGPR_CAP void prepare_kernel(const int
     const int w = r2 - r0 + 1, h = r3 - r1 + 1;
     const int32_t* list = ov.idx + ov.off[k];
     const int cnt = ov.off[k + 1] - ov.off[k];
-    __shared__ int s_ov[4 * OV_LDS];
+    __shared__ __attribute__((aligned(16))) int s_ov[4 * OV_LDS];
     const bool in_lds = cnt <= OV_LDS;
     if (in_lds && tid < 4 * cnt) s_ov[tid] = rects[4 * list[tid >> 2] + (tid & 3)];
     __syncthreads();
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
     const float* e = staged ? s_eig : eg;
     const int32_t* list = ov.idx + ov.off[c.k];
     const int lcnt = ov.off[c.k + 1] - ov.off[c.k];
-    __shared__ int s_ov[4 * OV_LDS];
+    __shared__ __attribute__((aligned(16))) int s_ov[4 * OV_LDS];
     const bool ov_lds = lcnt <= OV_LDS;
     if (ov_lds && tid < 4 * lcnt) s_ov[tid] = rects[4 * list[tid >> 2] + (tid & 3)];
     __shared__ float red[GFTT_BLK];
@@ -727,18 +732,37 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
     while (np2 < n) np2 <<= 1;
     for (int i = n + tid; i < np2; i += GFTT_BLK) keys[i] = 0ull;     // padding sorts last
     __syncthreads();
-    for (int k2 = 2; k2 <= np2; k2 <<= 1)
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += GFTT_BLK) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a0 = keys[i], a1 = keys[l];
-                    const bool desc = (i & k2) == 0;
-                    if (desc ? a0 < a1 : a0 > a1) { keys[i] = a1; keys[l] = a0; }
-                }
-            }
-            __syncthreads();
+    if (n <= GFTT_BLK) {
+        // rank sort: keys are unique (the raster index is part of them), so a key's position is the number of larger
+        // keys -- n broadcast LDS reads per thread, no dependent passes (the 55 passes of the bitonic network for
+        // ~550 candidates took 36 k cycles, each one an LDS round trip)
+        const unsigned long long mine = tid < n ? keys[tid] : 0ull;
+        int rank = 0, q = 0;
+        for (; q + 8 <= n; q += 8) {                  // eight reads in flight (a lone wavefront per SIMD has no other
+            unsigned long long k8[8];                 // way to hide the LDS latency)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k8[u] = keys[q + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += k8[u] > mine ? 1 : 0;
         }
+        for (; q < n; ++q) rank += keys[q] > mine ? 1 : 0;
+        __syncthreads();
+        if (tid < n) keys[rank] = mine;
+        __syncthreads();
+    } else {
+        for (int k2 = 2; k2 <= np2; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np2; i += GFTT_BLK) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a0 = keys[i], a1 = keys[l];
+                        const bool desc = (i & k2) == 0;
+                        if (desc ? a0 < a1 : a0 > a1) { keys[i] = a1; keys[l] = a0; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
     GFTT_STAMP(3)
     // greedy min-distance selection by the first wavefront
     const int md = min_dist[needy ? c.k : t];
