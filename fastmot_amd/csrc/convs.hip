@@ -18,6 +18,11 @@
 // 32x32x16 MFMA), so this path is L1-bandwidth bound (~64 B/clk/CU) and only used where the tiled kernel is
 // parallelism bound (graph.py picks it per layer).
 #include "net.h"
+#include <cstdlib>
+
+#ifndef FM_CONVS_PD2
+#define FM_CONVS_PD2 3      // (5 measured no better: 15.6 vs 15.2 us for the 38 x 38 layers)
+#endif
 
 namespace {
 
@@ -26,11 +31,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // stands in for the rows of out-of-image taps (zero padding); walked like a pixel row: Cin + 64 <= 4160
 __device__ __attribute__((aligned(128))) f16 g_zero_page[4160];
 
-template <int CT, int NW>
+// PT: 32-pixel tiles per workgroup.  PT = 2 (with 4 waves = one per SIMD, so that the 288 operand + 64 accumulator
+// registers fit) reuses every weight fragment for two pixel tiles: 1 KB instead of 1.5 KB of L1 traffic per MFMA, and the
+// 38 x 38 layers become ONE round of 184 workgroups instead of 1.44 rounds of 368.
+template <int CT, int NW, int PT>
 __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int npt, int ncg) {
-    constexpr int PD = CT == 1 ? 4 : 3;            // chunks in flight per wave: PD * (CT + 1) * 16 VGPRs
+    constexpr int PD = PT == 2 ? FM_CONVS_PD2 : (CT == 1 ? 4 : 3);   // chunks in flight per wave: PD * (CT + PT) * 16 VGPRs
     constexpr int BROW = 64 + 8;                    // halfs per pixel row of a staged chunk (+16 B: conflict-free)
-    constexpr int STAGE = NW * 32 * BROW * 2, RED = NW * CT * 4 * 64 * 16;
+    constexpr int NU = 4 * PT;                      // 8-pixel row groups of a staged chunk
+    constexpr int STAGE = NW * PT * 32 * BROW * 2, RED = NW * CT * 4 * 64 * 16;
     __shared__ __attribute__((aligned(16))) char smem[STAGE > RED ? STAGE : RED];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, half = lane >> 5;
@@ -47,19 +56,19 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     // pixels x 128 contiguous bytes (lane -> pixel lane / 8 + 8 u, 16 B segment lane % 8), and turns it into
     // fragment layout through a wave-private 4.5 KB LDS tile.
     const int seg = lane & 7;
-    const f16* img[4];
-    int iy0[4], ix0[4];
+    const f16* img[NU];
+    int iy0[NU], ix0[NU];
     const int hw = p.Ho * p.Wo;
     const float inv_hw = 1.f / (float)hw, inv_wo = 1.f / (float)p.Wo;           // P < 2^22 (checked at the launch)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int pix = min(tile_p * 32 + (lane >> 3) + 8 * u, p.P - 1);        // clamped; masked at the store
+    for (int u = 0; u < NU; ++u) {
+        const int pix = min(tile_p * 32 * PT + (lane >> 3) + 8 * u, p.P - 1);   // clamped; masked at the store
         const int n = idiv_small(pix, hw, inv_hw), rem = pix - n * hw, oy = idiv_small(rem, p.Wo, inv_wo), ox = rem - oy * p.Wo;
         iy0[u] = oy * p.stride - p.pad;
         ix0[u] = ox * p.stride - p.pad;
         img[u] = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_coff + seg * 8;
     }
-    f16* stage = reinterpret_cast<f16*>(smem) + wave * 32 * BROW;
+    f16* stage = reinterpret_cast<f16*>(smem) + wave * PT * 32 * BROW;
 
     const int nq = p.K >> 6;                        // chunks of 64 k (4 MFMA steps)
     const int q0 = wave * nq / NW, q1 = (wave + 1) * nq / NW, nloc = q1 - q0;
@@ -70,8 +79,8 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     // constant (per-chunk address arithmetic was the bottleneck of the first version: ~60 VALU instructions
     // against 8 MFMAs).  Pointers are rebuilt only when the walk enters the next (kh, kw) tap; out-of-image
     // taps read a zero page instead of being masked afterwards.
-    f16x8 fa[PD][CT][4], raw[PD][4];
-    const f16* bp[4];
+    f16x8 fa[PD][CT][4], raw[PD][NU];
+    const f16* bp[NU];
     // (kh, kw, c0) of the next chunk: divided out once, then walked -- the divisions inside load() were evaluated
     // for every chunk (if-converted: 46 scalar instructions per 8 MFMAs)
     int left = 0, kh, kw, c0;
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     auto load = [&](int slot) {
         if (left == 0) {                            // wave-uniform: the walk enters tap (kh, kw) at channel c0
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 const int iy = iy0[u] + kh, ix = ix0[u] + kw;
                 const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 bp[u] = (ok ? img[u] + ((size_t)iy * p.W + ix) * p.in_cs : g_zero_page + seg * 8) + c0;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
             if (++kw == p.KW) { kw = 0; ++kh; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             raw[slot][u] = *reinterpret_cast<const f16x8*>(bp[u]);
             bp[u] += 64;
         }
@@ -105,11 +114,13 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
         ap += 2048;
         --left;
     };
-    f32x16 acc[CT];
+    f32x16 acc[CT][PT];
 #pragma unroll
     for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < PD; ++r)
         if (r < nloc) load(r);
@@ -118,16 +129,21 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
         for (int r = 0; r < PD; ++r) {
             if (base + r < nloc) {                  // wave-uniform
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < NU; ++u)
                     *reinterpret_cast<f16x8*>(stage + ((lane >> 3) + 8 * u) * BROW + seg * 8) = raw[r][u];
-                f16x8 b[4];
+                f16x8 b[PT][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f16x8*>(stage + frow * BROW + (u * 2 + half) * 8);
+                for (int t = 0; t < PT; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        b[t][u] = *reinterpret_cast<const f16x8*>(stage + (t * 32 + frow) * BROW + (u * 2 + half) * 8);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int i = 0; i < CT; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[r][i][u], b[u], acc[i], 0, 0, 0);
+                    for (int t = 0; t < PT; ++t)
+#pragma unroll
+                        for (int i = 0; i < CT; ++i)
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[r][i][u], b[t][u], acc[i][t], 0, 0, 0);
                 if (base + r + PD < nloc) load(r);
             }
         }
@@ -135,57 +151,62 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     __syncthreads();                                // staging tiles are dead: the partial tiles reuse the space
     float4 (*red)[CT * 4][64] = reinterpret_cast<float4 (*)[CT * 4][64]>(smem);
 
-    // ---- partial tiles -> LDS, then every thread finishes 4 couts of one pixel
+    // ---- partial tiles -> LDS, then every thread finishes 4 couts of one pixel (one pixel tile at a time)
 #pragma unroll
-    for (int i = 0; i < CT; ++i)
+    for (int t = 0; t < PT; ++t) {
+        if (t) __syncthreads();                     // the previous tile's partial sums have been read
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            red[wave][i * 4 + g][lane] = make_float4(acc[i][g * 4], acc[i][g * 4 + 1], acc[i][g * 4 + 2], acc[i][g * 4 + 3]);
-    __syncthreads();
-    for (int e = tid; e < CT * 256; e += NW * 64) {
-        const int ig = e >> 6, ln = e & 63;
-        float4 a = red[0][ig][ln];
+        for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            const float4 t = red[w][ig][ln];
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-        }
-        const int co = (tile_c * CT + (ig >> 2)) * 32 + (ig & 3) * 8 + (ln >> 5) * 4;
-        const long opix = (long)tile_p * 32 + (ln & 31);
-        if (opix >= p.P || co >= p.cout_store) continue;
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
-        float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.res_mode != RES_NONE) {
-            const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)opix * p.res_cs + p.res_coff + co);
+            for (int g = 0; g < 4; ++g)
+                red[wave][i * 4 + g][lane] = make_float4(acc[i][t][g * 4], acc[i][t][g * 4 + 1], acc[i][t][g * 4 + 2],
+                                                         acc[i][t][g * 4 + 3]);
+        __syncthreads();
+        for (int e = tid; e < CT * 256; e += NW * 64) {
+            const int ig = e >> 6, ln = e & 63;
+            float4 a = red[0][ig][ln];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
-        }
-        if (p.res_mode == RES_BEFORE_ACT) {
+            for (int w = 1; w < NW; ++w) {
+                const float4 tt = red[w][ig][ln];
+                a.x += tt.x; a.y += tt.y; a.z += tt.z; a.w += tt.w;
+            }
+            const int co = (tile_c * CT + (ig >> 2)) * 32 + (ig & 3) * 8 + (ln >> 5) * 4;
+            const long opix = ((long)tile_p * PT + t) * 32 + (ln & 31);
+            if (opix >= p.P || co >= p.cout_store) continue;
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+            float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.res_mode != RES_NONE) {
+                const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)opix * p.res_cs + p.res_coff + co);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j];
-        }
-        apply_act_n<4>(v, p.act);
-        if (p.res_mode == RES_AFTER_ACT) {
+                for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
+            }
+            if (p.res_mode == RES_BEFORE_ACT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j];
-        }
-        if (p.out32) {
-            *reinterpret_cast<float4*>(p.out32 + (size_t)opix * p.out_cs + p.out_coff + co) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            f16x4 o;
+                for (int j = 0; j < 4; ++j) v[j] += r[j];
+            }
+            apply_act_n<4>(v, p.act);
+            if (p.res_mode == RES_AFTER_ACT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
-            store_out(p, opix, co, o);
+                for (int j = 0; j < 4; ++j) v[j] += r[j];
+            }
+            if (p.out32) {
+                *reinterpret_cast<float4*>(p.out32 + (size_t)opix * p.out_cs + p.out_coff + co) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                f16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+                store_out(p, opix, co, o);
+            }
         }
     }
 }
 
-template <int CT, int NW>
+template <int CT, int NW, int PT>
 int convs_launch(const ConvParams& p, int ntiles_c, hipStream_t s) {
-    const int npt = (p.P + 31) / 32, ncg = ntiles_c / CT;
+    const int npt = (p.P + 32 * PT - 1) / (32 * PT), ncg = ntiles_c / CT;
     const int total = npt * ncg;
-    hipLaunchKernelGGL((convs_kernel<CT, NW>), dim3(((total + 7) / 8) * 8), dim3(NW * 64), 0, s, p, npt, ncg);
+    hipLaunchKernelGGL((convs_kernel<CT, NW, PT>), dim3(((total + 7) / 8) * 8), dim3(NW * 64), 0, s, p, npt, ncg);
     FM_HIP(hipGetLastError());
     return 0;
 }
@@ -202,6 +223,10 @@ int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
     // two cout tiles per workgroup halve the pixel-fragment traffic; only when that still fills the chip
     const bool ct2 = ntiles_c % 2 == 0 && (ntiles_c / 2) * npt >= 192;
     const bool nw8 = nq >= 16;                      // >= 2 chunks per wave
-    if (ct2) return nw8 ? convs_launch<2, 8>(p, ntiles_c, s) : convs_launch<2, 4>(p, ntiles_c, s);
-    return nw8 ? convs_launch<1, 8>(p, ntiles_c, s) : convs_launch<1, 4>(p, ntiles_c, s);
+    // two pixel tiles as well when the single-tile grid would need a second, mostly empty round of workgroups
+    static const int pt2_mode = [] { const char* e = getenv("FASTMOT_CONVS_PT2"); return e ? atoi(e) : 1; }();
+    const int wgs1 = (ntiles_c / 2) * npt;
+    if (pt2_mode && ct2 && nq >= 16 && wgs1 > 256 && wgs1 <= 512) return convs_launch<2, 4, 2>(p, ntiles_c, s);
+    if (ct2) return nw8 ? convs_launch<2, 8, 1>(p, ntiles_c, s) : convs_launch<2, 4, 1>(p, ntiles_c, s);
+    return nw8 ? convs_launch<1, 8, 1>(p, ntiles_c, s) : convs_launch<1, 4, 1>(p, ntiles_c, s);
 }
