@@ -28,6 +28,18 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// profiling build only (-DFM_CONVS_TIMING, scripts/convs_timing.py): cycle stamps of workgroup 0, wave 0
+#ifdef FM_CONVS_TIMING
+__device__ long long g_convs_stamps[64];
+#ifndef FM_CONVS_TIMING_K
+#define FM_CONVS_TIMING_K 2304
+#define FM_CONVS_TIMING_P 1444
+#endif
+#define CONVS_STAMP(i) if ((blockIdx.x == 0 || blockIdx.x == 320) && threadIdx.x == 0 && p.K == FM_CONVS_TIMING_K && p.P == FM_CONVS_TIMING_P) g_convs_stamps[(blockIdx.x ? 32 : 0) + (i)] = __builtin_readcyclecounter();
+#else
+#define CONVS_STAMP(i)
+#endif
+
 // stands in for the rows of out-of-image taps (zero padding); walked like a pixel row: Cin + 64 <= 4160
 __device__ __attribute__((aligned(128))) f16 g_zero_page[4160];
 
@@ -43,6 +55,7 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     __shared__ __attribute__((aligned(16))) char smem[STAGE > RED ? STAGE : RED];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, half = lane >> 5;
+    CONVS_STAMP(0)
     // XCD-aware order (workgroup id % 8 = XCD): each XCD gets a contiguous run of the cout-group-major tile
     // order, so a cout group's weights are fetched into few L2s
     const int total = npt * ncg, per_xcd = (total + 7) >> 3;
@@ -121,10 +134,13 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
         for (int t = 0; t < PT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    CONVS_STAMP(1)
 #pragma unroll
     for (int r = 0; r < PD; ++r)
         if (r < nloc) load(r);
+    CONVS_STAMP(2)
     for (int base = 0; base < nloc; base += PD) {
+        if (base < 24) { CONVS_STAMP(8 + base) }
 #pragma unroll
         for (int r = 0; r < PD; ++r) {
             if (base + r < nloc) {                  // wave-uniform
@@ -148,7 +164,9 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
             }
         }
     }
+    CONVS_STAMP(3)
     __syncthreads();                                // staging tiles are dead: the partial tiles reuse the space
+    CONVS_STAMP(4)
     float4 (*red)[CT * 4][64] = reinterpret_cast<float4 (*)[CT * 4][64]>(smem);
 
     // ---- partial tiles -> LDS, then every thread finishes 4 couts of one pixel (one pixel tile at a time)
@@ -200,6 +218,185 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
             }
         }
     }
+    CONVS_STAMP(5)
+#ifdef FM_CONVS_TIMING
+    if ((blockIdx.x == 0 || blockIdx.x == 320) && threadIdx.x == 0 && p.K == FM_CONVS_TIMING_K && p.P == FM_CONVS_TIMING_P) { g_convs_stamps[(blockIdx.x ? 32 : 0) + 6] = nloc; g_convs_stamps[(blockIdx.x ? 32 : 0) + 7] = CT * 100 + NW * 10 + PT; }
+#endif
+}
+
+// ---- 3x3 / stride 1 / pad 1 layers: the input halo of the pixel tile goes to LDS ONCE.
+// convs_kernel above is bound by the CU's vector-L1 path (64 B/clk: profiles/r02_convs_phase_cycles.txt), and half of its
+// traffic is the pixel operand, of which every row is fetched nine times (once per tap).  Here a workgroup owns CT x 32
+// couts x an 8 x 8 output tile (two MFMA pixel tiles); the (8 + 2)^2 input positions x Cin channels are loaded once
+// (52 KB at Cin = 256, 104 KB at 512 of the 160 KB per CU), every wave reads its B fragments for any (tap, channel chunk)
+// straight from that tile in MFMA layout (row stride Cin + 8 halfs: conflict-free 16-byte reads), and only the weight
+// fragments still stream through L1: 340 KB instead of 590 KB per workgroup at K = 2304.  K is split over the NW waves
+// as above, same ring, same in-LDS reduction and epilogue.
+template <int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void convs_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int ncg) {
+    constexpr int PT = 2, PD = 3, TH = 8, TW = 8, HWT = TW + 2, NPOS = (TH + 2) * (TW + 2);
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+    f16* tile = reinterpret_cast<f16*>(hsm);
+    const int ROW = p.Cin + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    const int ntiles = tiles_x * tiles_y, total = ntiles * ncg, per_xcd = (total + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int tile_c = idiv_small(logical, ntiles, 1.f / (float)ntiles), tile_id = logical - tile_c * ntiles;
+    const int tyi = idiv_small(tile_id, tiles_x, 1.f / (float)tiles_x);
+    const int ty0 = tyi * TH, tx0 = (tile_id - tyi * tiles_x) * TW;
+
+    const int nq = p.K >> 6;
+    const int q0 = wave * nq / NW, q1 = (wave + 1) * nq / NW, nloc = q1 - q0;
+    const size_t wtile = (size_t)(p.K >> 4) * 512;
+    const f16* ap = p.w + ((size_t)tile_c * CT * (p.K >> 4) * 64 + lane) * 8 + (size_t)q0 * 2048;
+    f16x8 fa[PD][CT][4];
+    auto load_a = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fa[slot][i][u] = *reinterpret_cast<const f16x8*>(ap + i * wtile + u * 512);
+        ap += 2048;
+    };
+    // the weight ring starts before the halo is in place
+#pragma unroll
+    for (int r = 0; r < PD; ++r)
+        if (r < nloc) load_a(r);
+
+    {   // halo tile -> LDS (zero outside the image = the layer's padding)
+        const int segs = p.Cin >> 3;
+        const float inv_segs = 1.f / (float)segs;
+        const f16* src = p.in + p.in_coff;
+        for (int i = tid; i < NPOS * segs; i += NW * 64) {
+            const int pos = idiv_small(i, segs, inv_segs), sg = i - pos * segs;
+            const int py = pos / HWT, px = pos - py * HWT;
+            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = *reinterpret_cast<const uint4*>(src + ((size_t)iy * p.W + ix) * p.in_cs + sg * 8);
+            *reinterpret_cast<uint4*>(tile + pos * ROW + sg * 8) = v;
+        }
+    }
+    // B fragment base of this lane for the two pixel tiles (tile-local pixel = t * 32 + frow, 8 pixels per row)
+    int boff[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int pl = t * 32 + frow;
+        boff[t] = ((pl >> 3) * HWT + (pl & 7)) * ROW + half * 8;
+    }
+    int kh, kw, c0;
+    {
+        const int k0 = q0 << 6, tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        kh = tap / 3;
+        kw = tap - kh * 3;
+    }
+    f32x16 acc[CT][PT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    __syncthreads();
+    for (int base = 0; base < nloc; base += PD) {
+#pragma unroll
+        for (int r = 0; r < PD; ++r) {
+            if (base + r < nloc) {                  // wave-uniform
+                const int tapoff = (kh * HWT + kw) * ROW + c0;
+                f16x8 b[PT][4];
+#pragma unroll
+                for (int t = 0; t < PT; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        b[t][u] = *reinterpret_cast<const f16x8*>(tile + boff[t] + tapoff + u * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < PT; ++t)
+#pragma unroll
+                        for (int i = 0; i < CT; ++i)
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[r][i][u], b[t][u], acc[i][t], 0, 0, 0);
+                if (base + r + PD < nloc) load_a(r);
+                c0 += 64;
+                if (c0 == p.Cin) {
+                    c0 = 0;
+                    if (++kw == 3) { kw = 0; ++kh; }
+                }
+            }
+        }
+    }
+    __syncthreads();                                // the input tile is dead: the partial tiles reuse the space
+    float4 (*red)[CT * 4][64] = reinterpret_cast<float4 (*)[CT * 4][64]>(hsm);
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        if (t) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                red[wave][i * 4 + g][lane] = make_float4(acc[i][t][g * 4], acc[i][t][g * 4 + 1], acc[i][t][g * 4 + 2],
+                                                         acc[i][t][g * 4 + 3]);
+        __syncthreads();
+        for (int e = tid; e < CT * 256; e += NW * 64) {
+            const int ig = e >> 6, ln = e & 63;
+            float4 a = red[0][ig][ln];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float4 tt = red[w][ig][ln];
+                a.x += tt.x; a.y += tt.y; a.z += tt.z; a.w += tt.w;
+            }
+            const int co = (tile_c * CT + (ig >> 2)) * 32 + (ig & 3) * 8 + (ln >> 5) * 4;
+            const int pl = t * 32 + (ln & 31);
+            const int oy = ty0 + (pl >> 3), ox = tx0 + (pl & 7);
+            if (oy >= p.Ho || ox >= p.Wo || co >= p.cout_store) continue;
+            const long opix = (long)oy * p.Wo + ox;
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+            float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.res_mode != RES_NONE) {
+                const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)opix * p.res_cs + p.res_coff + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
+            }
+            if (p.res_mode == RES_BEFORE_ACT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += r[j];
+            }
+            apply_act_n<4>(v, p.act);
+            if (p.res_mode == RES_AFTER_ACT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += r[j];
+            }
+            if (p.out32) {
+                *reinterpret_cast<float4*>(p.out32 + (size_t)opix * p.out_cs + p.out_coff + co) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                f16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+                store_out(p, opix, co, o);
+            }
+        }
+    }
+}
+
+template <int CT, int NW>
+int convs_halo_launch(const ConvParams& p, int ntiles_c, hipStream_t s) {
+    const int tiles_x = (p.Wo + 7) / 8, tiles_y = (p.Ho + 7) / 8, ncg = ntiles_c / CT;
+    const int total = tiles_x * tiles_y * ncg;
+    const size_t tile_bytes = (size_t)100 * (p.Cin + 8) * 2, red_bytes = (size_t)NW * CT * 4 * 64 * 16;
+    const size_t shmem = tile_bytes > red_bytes ? tile_bytes : red_bytes;
+    static size_t configured = 0;
+    if (shmem > configured) {
+        FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convs_halo_kernel<CT, NW>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        configured = shmem;
+    }
+    hipLaunchKernelGGL((convs_halo_kernel<CT, NW>), dim3(((total + 7) / 8) * 8), dim3(NW * 64), shmem, s, p, tiles_x,
+                       tiles_y, ncg);
+    FM_HIP(hipGetLastError());
+    return 0;
 }
 
 template <int CT, int NW, int PT>
@@ -212,6 +409,14 @@ int convs_launch(const ConvParams& p, int ntiles_c, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef FM_CONVS_TIMING
+extern "C" int fm_debug_convs_stamps(long long* out64) {
+    FM_HIP(hipDeviceSynchronize());
+    FM_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_convs_stamps), sizeof(long long) * 64));
+    return 0;
+}
+#endif
 
 // p.w: fragment-order weights (see header); p.K = KH * KW * Cin with Cin % 64 == 0; p.Kpad unused
 int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
@@ -226,6 +431,18 @@ int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
     // two pixel tiles as well when the single-tile grid would need a second, mostly empty round of workgroups
     static const int pt2_mode = [] { const char* e = getenv("FASTMOT_CONVS_PT2"); return e ? atoi(e) : 1; }();
     const int wgs1 = (ntiles_c / 2) * npt;
+    // 3x3 / stride 1 / pad 1 on one image: input halo staged in LDS once (convs_halo_kernel)
+    static const int halo_mode = [] { const char* e = getenv("FASTMOT_CONVS_HALO"); return e ? atoi(e) : 1; }();
+    if (halo_mode && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.N == 1 && p.Ho == p.H && p.Wo == p.W &&
+        p.up != 2 && (size_t)100 * (p.Cin + 8) * 2 <= 150 * 1024 && nq >= 8) {
+        // only where the 8 x 8 tiles waste little (38 x 38: 90 % of the tile pixels exist, 15.2 -> 12.5 us per layer; at
+        // 19 x 19 = 3 x 3 tiles for 361 pixels, 63 %, it measured 12.5 -> 16.5 us)
+        const int tiles = ((p.Wo + 7) / 8) * ((p.Ho + 7) / 8);
+        if (halo_mode == 2 || p.Ho * p.Wo * 5 >= tiles * 64 * 4) {
+            if (ntiles_c % 2 == 0 && (ntiles_c / 2) * tiles >= 128) return convs_halo_launch<2, 8>(p, ntiles_c, s);
+            return convs_halo_launch<1, 8>(p, ntiles_c, s);
+        }
+    }
     if (pt2_mode && ct2 && nq >= 16 && wgs1 > 256 && wgs1 <= 512) return convs_launch<2, 4, 2>(p, ntiles_c, s);
     if (ct2) return nw8 ? convs_launch<2, 8, 1>(p, ntiles_c, s) : convs_launch<2, 4, 1>(p, ntiles_c, s);
     return nw8 ? convs_launch<1, 8, 1>(p, ntiles_c, s) : convs_launch<1, 4, 1>(p, ntiles_c, s);
