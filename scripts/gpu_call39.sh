@@ -1,7 +1,7 @@
 #!/bin/bash
 # consolidated round-2 evidence run: full GPU suite, smoke, bench (configs 1/2/4), timelines, per-layer roofline, kernel stats, PMC
 export TMPDIR=/tmp FASTMOT_RANDOM_WEIGHTS=1
-O=$GRAFT_REPO_ROOT/gpurun_out/c47; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/c59; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest.txt; tail -2 $O/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt

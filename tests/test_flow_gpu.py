@@ -284,6 +284,60 @@ def test_lk_deterministic_while_other_streams_are_busy(ctx, hammer):
     assert bad == 0
 
 
+def test_unisolated_lk_beside_the_detector(ctx):
+    """What the LK / ReID ordering of MOT.step relies on: with `lk_isolation` off (ordinary 4-point workgroups, no
+    whole-CU request) the LK kernel reproduces its idle result bit for bit while the DETECTOR network -- every conv
+    kernel variant YOLOv4@608 uses -- runs on another stream.  A conv kernel that disturbs it shows up here (one
+    did: the two-pixel-tile streamed conv of late round 2, which is therefore not used)."""
+    import threading
+    from fastmot_amd.detector import DeviceFrame
+    from fastmot_amd.engine import HipNet, NET_DETECTOR
+    from fastmot_amd.models import YOLO
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=6, n_frames=2, seed=4)
+    ctx.frame_configure(size[0], size[1], 2)
+    for i in range(2):
+        ctx.frame_ring_store(i, video.frames[i])
+    flow = Flow(size)
+    flow.init(DeviceFrame(0))
+    bind_frame(ctx, DeviceFrame(1), size)
+    ctx.flow_begin()
+    ctx.synchronize()
+    g, _ = YOLO.get_model('YOLOv4_608').build_graph()
+    net = HipNet(ctx, NET_DETECTOR, g, 1, reuse_buffers=True)
+    net.run(1)                                           # (graph capture happens here, not beside the copies below)
+    ctx.synchronize()
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(20, size[0] / 2 - 20, 600), rng.uniform(20, size[1] / 2 - 20, 600)], 1).astype(np.float32)
+    ctx.set_option('lk_isolation', 0)
+    stop = []
+
+    def hammer_loop():
+        ctx.bind_thread()
+        while not stop:
+            net.run(1)
+            ctx.synchronize()
+    try:
+        base = [ctx.flow_lk(pts), ctx.flow_lk(pts)]      # the second call tracks in the opposite direction
+        th = threading.Thread(target=hammer_loop)
+        th.start()
+        try:
+            bad = 0
+            for r in range(150):
+                for k in range(2):
+                    nxt, st, _ = ctx.flow_lk(pts)
+                    ok = np.array_equal(st, base[k][1]) and np.array_equal(nxt[st > 0], base[k][0][st > 0])
+                    bad += not ok
+        finally:
+            stop.append(1)
+            th.join()
+    finally:
+        ctx.set_option('lk_isolation', 1)
+        net.close()
+    assert bad == 0, f'{bad} of 300 LK calls differ beside the detector network'
+
+
 def test_lk_reid_ordering_protocol(ctx):
     """fm_flow_arm / fm_flow_wait_lk / fm_flow_release (the LK / ReID ordering MOT.step relies on): nothing armed ->
     done at once; armed -> the wait times out until the prediction has passed its LK launch or was released."""
