@@ -23,8 +23,13 @@ def sources():
     return sorted(CSRC.glob('*.hip'))
 
 
+FLAGS_STAMP = PKG / 'build' / 'flags.txt'      # the flags the in-tree library was built with (profiling builds differ)
+
+
 def needs_build():
     if not OUT.exists():
+        return True
+    if not FLAGS_STAMP.exists() or FLAGS_STAMP.read_text() != ' '.join(FLAGS):
         return True
     t = OUT.stat().st_mtime
     deps = list(CSRC.glob('*')) + [PKG.parent / 'include' / 'fastmot_hip.h']
@@ -34,6 +39,8 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
+    if FLAGS_STAMP.exists() and FLAGS_STAMP.read_text() != ' '.join(FLAGS):
+        force = True                                  # every object file must be rebuilt with the current flags
     objs = []
     procs = []
     bdir = PKG / 'build'
@@ -57,6 +64,7 @@ def build(force=False, verbose=True):
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if res.returncode != 0:
         raise RuntimeError(f'link failed:\n{res.stdout.decode()}')
+    FLAGS_STAMP.write_text(' '.join(FLAGS))
     if verbose:
         print(f'built {OUT}')
     return OUT
