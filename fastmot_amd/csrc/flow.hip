@@ -77,13 +77,15 @@ void fm_flow_free(FlowState* f) {
 
 namespace {
 
-// FM_SGPR_CAP: kernels of the KLT stream run beside the ReID network's kernels on the same CUs.  Measured on MI355X
-// (scripts/stress_lk4.py, stress_lk5.py): while grouped LightConv launches (liteconv_kernel) or the OSNet graph run on
-// another stream, 15-30 % of the calls of this kernel returned one or two of 600 points off by 1e-5 .. 0.2 px --
-// constant inputs, images intact afterwards, never when idle or beside conv / YOLOv4 launches, never when this kernel
-// had its CUs to itself (150 KB LDS request).  The effect follows the SCALAR register budget of the victim: 106 and 78
-// SGPRs per wave were hit (73 and 59 of 400 calls), 46 SGPRs never (0 of 400).  The cause inside the part was not
-// established; the budget of the KLT kernels is therefore capped (the compiler spills the rest to VGPR lanes).
+// FM_SGPR_CAP: kernels of the KLT stream run beside other streams' kernels on the same CUs.  Measured on MI355X
+// (scripts/stress_lk4.py .. stress_lk6.py, profiles/r02_lk_disturbance.txt): while fused LightConv launches (liteconv_kernel,
+// litechain_kernel) -- and, found later, two streamed-conv variants that are therefore switched off -- are resident on
+// the same CU, a fraction of the LK kernel's calls returns one or two of 600 points off by 1e-5 .. 6 px: constant inputs,
+// images intact afterwards, never when idle, never beside the shipped detector's kernels, never when this kernel has its
+// CUs to itself (150 KB LDS request).  With the readlane-based window sums the rate followed the SCALAR register budget
+// (106 / 78 SGPRs: 15-18 % of the calls, 46: 0-2.5 %), hence the cap; the cause inside the part is not established.
+// What protects the results: MOT.step never runs the ReID network while this kernel runs, stand-alone launches take
+// whole CUs.
 #define FM_SGPR_CAP __attribute__((amdgpu_num_sgpr(48)))
 
 __device__ __forceinline__ int reflect101(int i, int n) {

@@ -224,14 +224,15 @@ def test_lk_deterministic_while_other_streams_are_busy(ctx, hammer):
     with the ReID network's kernels.
 
     History: round 1 found single points changing in 50-80 % of the calls with two points per wavefront and blamed
-    the diverging halves.  Round 2 (scripts/stress_lk4.py .. stress_lk6.py) narrowed it down: only the two fused
-    LightConv kernels (liteconv_kernel, litechain_kernel -- the only kernels of the library with SGPR spill code,
-    v_writelane / v_readlane) disturb the LK kernel, only when their workgroups are resident on the same CU, and the
-    scalar register budget of the LK kernel matters (106 / 78 SGPRs: 15-18 % of the calls, 46: 2.5 % beside
-    litechain, 0 beside liteconv).  Conv / YOLOv4 / pool / gate / head launches never do, the images stay intact, the
-    networks themselves and the Kalman / cost kernels reproduce bit for bit under the same load
-    (scripts/stress_nets.py).  The LK launch therefore (a) caps its SGPR budget at 48 and (b) requests 150 KB of
-    LDS per 16-wavefront workgroup so that no LDS-using workgroup shares its CU: 0 of 600 calls differ."""
+    the diverging halves.  Round 2 (scripts/stress_lk4.py .. stress_lk6.py, profiles/r02_lk_disturbance.txt) narrowed
+    it down: among the ReID network's kernels only the two fused LightConv kernels (liteconv_kernel,
+    litechain_kernel) disturb the LK kernel, only when their workgroups are resident on the same CU; conv / pool /
+    gate / head launches never do, the images stay intact, the networks themselves and the Kalman / cost kernels
+    reproduce bit for bit under the same load (scripts/stress_nets.py).  The cause is not known (an early "SGPR spill
+    code" explanation did not survive: the OSNet-x0.25 instances of the chain kernel have none).  The stand-alone LK
+    launch tested here therefore requests 150 KB of LDS per 16-wavefront workgroup so that nothing shares its CU:
+    0 of 600 calls differ.  (MOT.step orders the ReID network behind the LK kernel instead:
+    test_unisolated_lk_beside_the_detector guards the other half of that arrangement.)"""
     import threading
     from fastmot_amd.detector import DeviceFrame
     from fastmot_amd.engine import HipNet, NET_EXTRACTOR
