@@ -271,6 +271,20 @@ struct LKArgs {
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
+// one image byte.  -DFM_LK_DWORD_LOADS: through an ALIGNED 32-bit load, the byte shifted out in registers -- experiment of
+// late round 2: what the disturbed LK kernel gets wrong looks like single window samples being off (err changes by one
+// or two quanta of 1/800, positions by 1e-4 .. 0.15 px: scripts/stress_lk7.py), which pointed at the scattered sub-dword
+// loads; but the disturbance is the same with dword loads (34 vs 42 differing results in 400 calls), so they are not it.
+__device__ __forceinline__ int lk_px(const uint8_t* __restrict__ row, int c) {
+#ifndef FM_LK_DWORD_LOADS
+    return row[c];
+#else
+    const uintptr_t a = reinterpret_cast<uintptr_t>(row) + (uintptr_t)c;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(a & ~uintptr_t(3));
+    return (int)((w >> ((a & 3) * 8)) & 0xffu);
+#endif
+}
+
 // float32 sum of lanes 0..N-1 in lane order, starting from 0.f like the scalar loops of lkpyramid.cpp.
 // Sequential inclusive scan over the lanes: every step adds the left neighbour's running value (DPP wave_shr:1,
 // lane 0 reads 0) to the lane's own term, a(s)[i] = a(s-1)[i-1] + v[i].  By induction lane i holds
@@ -370,7 +384,7 @@ __device__ __forceinline__ void lk_wave_body(const LKArgs& a, int n, const float
             const uint8_t* r0 = I + (size_t)reflect101(yy0, h) * w;
             const uint8_t* r1 = I + (size_t)reflect101(yy1, h) * w;
             const int c0 = reflect101(xx0, w), c1 = reflect101(xx1, w);
-            ival = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5);
+            ival = LK_DESCALE(lk_px(r0, c0) * iw00 + lk_px(r0, c1) * iw01 + lk_px(r1, c0) * iw10 + lk_px(r1, c1) * iw11, 14 - 5);
             // derivative image is zero outside (BORDER_CONSTANT), lkpyramid.cpp
             auto dv = [&](int xx, int yy) -> int2 {
                 if (xx < 0 || xx >= w || yy < 0 || yy >= h) return make_int2(0, 0);
@@ -408,7 +422,7 @@ __device__ __forceinline__ void lk_wave_body(const LKArgs& a, int n, const float
                 const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
                 const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
                 const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
-                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
+                diff = LK_DESCALE(lk_px(r0, c0) * iw00 + lk_px(r0, c1) * iw01 + lk_px(r1, c0) * iw10 + lk_px(r1, c1) * iw11, 14 - 5) - ival;
             }
             float b1, b2;
             seq_sum2<WINC * WINC>((float)(diff * ixval), (float)(diff * iyval), b1, b2);
@@ -434,7 +448,7 @@ __device__ __forceinline__ void lk_wave_body(const LKArgs& a, int n, const float
                 const uint8_t* r0 = J + (size_t)reflect101(iny + wy, h) * w;
                 const uint8_t* r1 = J + (size_t)reflect101(iny + wy + 1, h) * w;
                 const int c0 = reflect101(inx + wx, w), c1 = reflect101(inx + wx + 1, w);
-                diff = LK_DESCALE(r0[c0] * iw00 + r0[c1] * iw01 + r1[c0] * iw10 + r1[c1] * iw11, 14 - 5) - ival;
+                diff = LK_DESCALE(lk_px(r0, c0) * iw00 + lk_px(r0, c1) * iw01 + lk_px(r1, c0) * iw10 + lk_px(r1, c1) * iw11, 14 - 5) - ival;
             }
             er = seq_sum<WINC * WINC>(fabsf((float)diff)) * 1.f / (32 * win * win);
         }
