@@ -131,6 +131,25 @@ def compiled_baseline(cfg, video, budget_s=10.0):
     return c_baseline.time_clip(cfg, video, tracker_cfg(), budget_s)
 
 
+def usable_cpus():
+    """Host cores this process may use: the affinity mask, capped by a cgroup-v2 CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def flow_threads_for(local_world):
+    """FASTMOT_FLOW_THREADS for one of `local_world` ranks on this node: main thread + prediction worker + pool must
+    fit the rank's share of the cores; between 1 (no pool) and the library's own maximum of 7."""
+    share = usable_cpus() // max(local_world, 1)
+    return max(1, min(7, share - 2))
+
+
 def pmc_traffic():
     """HBM-side bytes per conv launch from the committed rocprofv3 PMC passes (profiles/*_pmc_conv.json,
     produced by scripts/collect_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of the detector network;
@@ -173,6 +192,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    if world > 1 and 'FASTMOT_FLOW_THREADS' not in os.environ:
+        # N processes share the node's host cores: size every rank's RANSAC worker pool to its share (the library's
+        # default assumes the whole machine; its workers and the prediction worker spin, bounded, while they wait)
+        os.environ['FASTMOT_FLOW_THREADS'] = str(flow_threads_for(int(os.environ.get('LOCAL_WORLD_SIZE', world))))
 
     from fastmot_amd import Track, models
     from fastmot_amd.detector import DeviceFrame
@@ -263,6 +287,8 @@ def main():
                                     'frames in pinned host memory, H2D per frame included'),
                        'next_frame_prefetch': bool(args.prefetch), 'streams_per_gpu': 1,
                        'parallelism': f'1 stream/GPU x {world}',
+                       'host_threads_per_rank': {'ransac_pool': os.environ.get('FASTMOT_FLOW_THREADS', 'library default'),
+                                                 'usable_cpus': usable_cpus()},
                        'gallery_allgather': None if sync is None else sync.stats(),
                        'visible_tracks': len(list(mot.visible_tracks())),
                        'yolo_candidates_nms_out': mot.detector.last_real_count,
