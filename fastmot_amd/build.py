@@ -19,6 +19,13 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp
          '-Wno-unused-result'] + os.environ.get('FASTMOT_EXTRA_HIPCC_FLAGS', '').split()   # profiling builds (-DFM_*_TIMING)
 
 
+# Per-file flags.  -fno-slp-vectorize: no packed-fp32 VALU arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 pairs
+# formed by the SLP vectoriser) in the KLT kernels -- round 3 traced the LK results that differed under load to such a
+# chain mis-executing in lanes 48..63 while VALU-heavy wavefronts of another kernel share the CU (DESIGN 5b,
+# csrc/diag.hip is the stand-alone reproducer and is built the same way so that only its hand-written chain is packed).
+FILE_FLAGS = {'diag.hip': ['-fno-slp-vectorize']}
+
+
 def sources():
     return sorted(CSRC.glob('*.hip'))
 
@@ -32,7 +39,7 @@ def needs_build():
     if not FLAGS_STAMP.exists() or FLAGS_STAMP.read_text() != ' '.join(FLAGS):
         return True
     t = OUT.stat().st_mtime
-    deps = list(CSRC.glob('*')) + [PKG.parent / 'include' / 'fastmot_hip.h']
+    deps = list(CSRC.glob('*')) + [PKG.parent / 'include' / 'fastmot_hip.h', Path(__file__)]
     return any(p.stat().st_mtime > t for p in deps)
 
 
@@ -52,7 +59,7 @@ def build(force=False, verbose=True):
                 src.stat().st_mtime, *(h.stat().st_mtime for h in CSRC.glob('*.h')),
                 (PKG.parent / 'include' / 'fastmot_hip.h').stat().st_mtime):
             continue
-        cmd = [HIPCC] + [f for f in FLAGS if f != '-shared'] + ['-c', str(src), '-o', str(obj)]
+        cmd = [HIPCC] + [f for f in FLAGS if f != '-shared'] + FILE_FLAGS.get(src.name, []) + ['-c', str(src), '-o', str(obj)]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()

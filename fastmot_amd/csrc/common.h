@@ -91,6 +91,7 @@ struct fm_ctx {
     int opt_use_graphs = 1;            // FASTMOT_GRAPHS: 0 = launch network layers one by one (no hipGraph)
     int opt_lk_isolation = 1;          // FASTMOT_LK_ISOLATION: the LK launch takes whole CUs (flow.hip); a pipeline that
                                        // never runs the ReID network beside it (fm_flow_arm / fm_flow_wait_lk) clears it
+    int opt_lk_variant = 0;            // "lk_variant": diagnostic variants of the LK kernel (flow.hip lk_diag_kernel)
     std::atomic<int> flow_phase{0};    // 0 idle, 1 armed (a KLT prediction of this step has not finished its LK launch), 2 LK done
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network

@@ -23,6 +23,7 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
     else if (!strcmp(key, "use_graphs")) ctx->opt_use_graphs = value;
     else if (!strcmp(key, "lk_isolation")) ctx->opt_lk_isolation = value;
+    else if (!strcmp(key, "lk_variant")) ctx->opt_lk_variant = value;
     else {
         fm_set_error("unknown option '%s'", key);
         return FM_ERR_ARG;

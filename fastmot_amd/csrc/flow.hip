@@ -56,6 +56,11 @@ struct FlowState {
     const int32_t* v_ov_idx = nullptr;
     const int32_t* v_ov_off = nullptr;
     int32_t* bg_flags = nullptr;                    // FAST score / flags
+    // diagnostic LK variants (ctx option "lk_variant"): counters, capture records + per-point header
+    int* lk_diag = nullptr;
+    int* lk_cap = nullptr;
+    int* lk_cap_hdr = nullptr;
+    int lk_cap_pts = 0;
 };
 
 void fm_flow_free(FlowState* f) {
@@ -68,7 +73,8 @@ void fm_flow_free(FlowState* f) {
     for (int st = 0; st < 2; ++st)
         for (int l = 0; l < MAX_LEVELS; ++l)
             if (f->deriv[st][l]) (void)hipFree(f->deriv[st][l]);
-    for (void* p : {(void*)f->bg_img, (void*)f->rects, (void*)f->eig, (void*)f->ov_idx, (void*)f->ov_off, (void*)f->bg_flags})
+    for (void* p : {(void*)f->bg_img, (void*)f->rects, (void*)f->eig, (void*)f->ov_idx, (void*)f->ov_off, (void*)f->bg_flags,
+                    (void*)f->lk_diag, (void*)f->lk_cap, (void*)f->lk_cap_hdr})
         if (p) (void)hipFree(p);
     for (DevBuf* b : {&f->tgt_in, &f->tgt_out, &f->det_in, &f->det_out, &f->lk_in, &f->lk_out, &f->bg_out})
         b->release();
@@ -299,30 +305,65 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 template <int N>
-__device__ __forceinline__ float seq_sum(float v) {
+__device__ __forceinline__ float seq_sum(float v, float* pfx = nullptr) {
     float acc = v;
 #pragma unroll
     for (int k = 1; k < N; ++k) acc = seq_step(acc, v);
+    if (pfx) *pfx = acc;
     return lane_value(acc, N - 1);
 }
 // two / three independent sums, their scans interleaved step by step (a DPP read of a VGPR written by the previous
-// VALU instruction costs wait states; the neighbouring chain fills them)
+// VALU instruction costs wait states; the neighbouring chain fills them).  `pfx` (diagnostic builds): the lanes' running
+// sums after the scan, lane i = v0 + .. + vi.
 template <int N>
-__device__ __forceinline__ void seq_sum2(float v0, float v1, float& s0, float& s1) {
+__device__ __forceinline__ void seq_sum2(float v0, float v1, float& s0, float& s1, float* pfx = nullptr) {
     float a0 = v0, a1 = v1;
 #pragma unroll
     for (int k = 1; k < N; ++k) { a0 = seq_step(a0, v0); a1 = seq_step(a1, v1); }
+    if (pfx) { pfx[0] = a0; pfx[1] = a1; }
     s0 = lane_value(a0, N - 1);
     s1 = lane_value(a1, N - 1);
 }
 template <int N>
-__device__ __forceinline__ void seq_sum3(float v0, float v1, float v2, float& s0, float& s1, float& s2) {
+__device__ __forceinline__ void seq_sum3(float v0, float v1, float v2, float& s0, float& s1, float& s2, float* pfx = nullptr) {
     float a0 = v0, a1 = v1, a2 = v2;
 #pragma unroll
     for (int k = 1; k < N; ++k) { a0 = seq_step(a0, v0); a1 = seq_step(a1, v1); a2 = seq_step(a2, v2); }
+    if (pfx) { pfx[0] = a0; pfx[1] = a1; pfx[2] = a2; }
     s0 = lane_value(a0, N - 1);
     s1 = lane_value(a1, N - 1);
     s2 = lane_value(a2, N - 1);
+}
+
+// The same sums WITHOUT any cross-lane VALU operation: every lane parks its term in the wavefront's LDS slab, then
+// every lane reads all N terms back (same address in all lanes: broadcast reads) and adds them in scalar order in its
+// own registers -- N - 1 dependent float32 adds per sum again, the result is in every lane by construction.
+// LDS operations of one wavefront execute in order; the fences keep the compiler from moving them.
+template <int N>
+__device__ __forceinline__ float lds_seq(const float* __restrict__ slab) {
+    const float4* q = reinterpret_cast<const float4*>(slab);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) {
+        const float4 t = q[k];
+        acc += t.x; acc += t.y; acc += t.z; acc += t.w;
+    }
+#pragma unroll
+    for (int k = N / 4 * 4; k < N; ++k) acc += slab[k];
+    return acc;
+}
+template <int N, int K>
+__device__ __forceinline__ void lds_sums(float* slab, int lane, const float (&v)[K], float (&s)[K]) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < 32) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) slab[32 * k + lane] = v[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = lds_seq<N>(slab + 32 * k);
+    __builtin_amdgcn_wave_barrier();
 }
 
 // One WAVEFRONT per point: lane g < win*win owns window pixel (g / win, g % win) -- the samples of a window are
@@ -467,6 +508,218 @@ __global__ __launch_bounds__(1024) FM_SGPR_CAP void lk_wave_kernel(LKArgs a, int
                                                       float* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                       float* __restrict__ err) {
     lk_wave_body<WINC>(a, n, prev_pts, next_pts, status, err);
+}
+
+// ---- diagnostic variants of the LK kernel (round 3: bisect of the results that differ under load).
+// MODE 0: window sums as DPP scans (the production arithmetic), 1: through LDS (no cross-lane VALU operation),
+// 2: both, compared, re-evaluated on a mismatch (counters say which of the two changed its mind).
+// CHK: every image sample is loaded twice (second time through a laundered pointer the compiler cannot merge) and
+//      the wave-uniform position update is compared across the lanes.
+// CAP: every (level, iteration) appends a record of 8 rows x 64 lanes to `cap`: the lanes' samples, the lanes'
+//      running sums after the scan, the broadcast sums, every lane's copy of the position; header = HW_ID / XCC_ID.
+// diag[]: 0 sum mismatches (MODE 2), 1 DPP value changed on re-evaluation, 2 LDS value changed, 3 still different
+//      after 3 retries, 4 duplicate-load mismatches, 5 lanes disagree on the position, 6 iterations evaluated.
+constexpr int LK_CAP_ROWS = 12, LK_CAP_REC = LK_CAP_ROWS * 64, LK_CAP_MAXREC = 80;
+
+__device__ __forceinline__ const uint8_t* launder(const uint8_t* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+template <int WINC, int MODE, bool CHK, bool CAP>
+__global__ __launch_bounds__(1024) FM_SGPR_CAP void lk_diag_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+                                                                   float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                                   float* __restrict__ err, int* __restrict__ diag,
+                                                                   int* __restrict__ cap, int* __restrict__ cap_hdr) {
+    __shared__ float slab_all[MODE == 0 ? 1 : 16 * 96];
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pt = gidx >> 6, g = gidx & 63;
+    if (pt >= n) return;
+    float* slab = slab_all + (MODE == 0 ? 0 : (threadIdx.x >> 6) * 96);
+    constexpr int win = WINC;
+    constexpr int NW = WINC * WINC;
+    const bool lane_on = g < NW;
+    const int wy = lane_on ? g / win : 0, wx = lane_on ? g % win : 0;
+    const float half = (win - 1) * 0.5f;
+    const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
+    float nx = 0.f, ny = 0.f;
+    bool st = true;
+    float er = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    int nrec = 0;
+    int* rec0 = CAP ? cap + (size_t)pt * LK_CAP_MAXREC * LK_CAP_REC : nullptr;
+    auto put = [&](int row, int v) { if (CAP && nrec < LK_CAP_MAXREC) rec0[(size_t)nrec * LK_CAP_REC + row * 64 + g] = v; };
+    auto putf = [&](int row, float v) { put(row, __builtin_bit_cast(int, v)); };
+    auto weights = [](float fa, float fb, int& iw00, int& iw01, int& iw10, int& iw11) {
+        iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
+        iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
+        iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
+        iw11 = (1 << 14) - iw00 - iw01 - iw10;
+    };
+    // bilinear sample of image `img` at window pixel (wy, wx) of the window whose corner is (bx, by)
+    auto sample = [&](const uint8_t* img, int w, int h, int bx, int by, int iw00, int iw01, int iw10, int iw11) -> int {
+        const uint8_t* r0 = img + (size_t)reflect101(by + wy, h) * w;
+        const uint8_t* r1 = img + (size_t)reflect101(by + wy + 1, h) * w;
+        const int c0 = reflect101(bx + wx, w), c1 = reflect101(bx + wx + 1, w);
+        const int v = LK_DESCALE(lk_px(r0, c0) * iw00 + lk_px(r0, c1) * iw01 + lk_px(r1, c0) * iw10 + lk_px(r1, c1) * iw11, 14 - 5);
+        if (CHK) {
+            const uint8_t* q0 = launder(r0);
+            const uint8_t* q1 = launder(r1);
+            const int v2 = LK_DESCALE(lk_px(q0, c0) * iw00 + lk_px(q0, c1) * iw01 + lk_px(q1, c0) * iw10 + lk_px(q1, c1) * iw11, 14 - 5);
+            if (v2 != v) atomicAdd(&diag[4], 1);
+        }
+        return v;
+    };
+    // K window sums in scalar order; pfx = the lanes' running sums of the DPP scan (capture)
+    auto sums2 = [&](float v0, float v1, float& s0, float& s1, float* pfx) {
+        if (MODE == 0) { seq_sum2<NW>(v0, v1, s0, s1, pfx); return; }
+        const float v[2] = {v0, v1};
+        float l[2];
+        lds_sums<NW, 2>(slab, g, v, l);
+        if (MODE == 1) { s0 = l[0]; s1 = l[1]; return; }
+        float d0, d1;
+        seq_sum2<NW>(v0, v1, d0, d1, pfx);
+        int tries = 0;
+        while ((__builtin_bit_cast(int, d0) != __builtin_bit_cast(int, l[0]) || __builtin_bit_cast(int, d1) != __builtin_bit_cast(int, l[1])) && tries < 3) {
+            if (g == 0 && tries == 0) atomicAdd(&diag[0], 1);
+            float e0, e1, m[2];
+            seq_sum2<NW>(v0, v1, e0, e1, nullptr);
+            lds_sums<NW, 2>(slab, g, v, m);
+            if (g == 0) {
+                if (__builtin_bit_cast(int, e0) != __builtin_bit_cast(int, d0) || __builtin_bit_cast(int, e1) != __builtin_bit_cast(int, d1)) atomicAdd(&diag[1], 1);
+                if (__builtin_bit_cast(int, m[0]) != __builtin_bit_cast(int, l[0]) || __builtin_bit_cast(int, m[1]) != __builtin_bit_cast(int, l[1])) atomicAdd(&diag[2], 1);
+            }
+            d0 = e0; d1 = e1; l[0] = m[0]; l[1] = m[1];
+            ++tries;
+        }
+        if (tries == 3 && g == 0) atomicAdd(&diag[3], 1);
+        s0 = l[0]; s1 = l[1];
+    };
+    for (int level = a.levels - 1; level >= 0; --level) {
+        const int w = a.w[level], h = a.h[level];
+        const uint8_t* I = a.I[level];
+        const uint8_t* J = a.J[level];
+        const int16_t* D = a.D[level];
+        const float sc = 1.f / (float)(1 << level);
+        float ppx = px0 * sc, ppy = py0 * sc;
+        if (level == a.levels - 1) { nx = ppx; ny = ppy; }
+        else { nx *= 2.f; ny *= 2.f; }
+        ppx -= half; ppy -= half;
+        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+        if (ipx < -win || ipx >= w || ipy < -win || ipy >= h) {
+            if (level == 0) { st = false; er = 0.f; }
+            continue;
+        }
+        int iw00, iw01, iw10, iw11;
+        weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
+        int ival = 0, ixval = 0, iyval = 0;
+        if (lane_on) {
+            const int xx0 = ipx + wx, xx1 = xx0 + 1, yy0 = ipy + wy, yy1 = yy0 + 1;
+            ival = sample(I, w, h, ipx, ipy, iw00, iw01, iw10, iw11);
+            auto dv = [&](int xx, int yy) -> int2 {
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return make_int2(0, 0);
+                const int v = *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
+                return make_int2((int)(short)(v & 0xffff), (int)(short)(v >> 16));
+            };
+            const int2 d00 = dv(xx0, yy0), d01 = dv(xx1, yy0), d10 = dv(xx0, yy1), d11 = dv(xx1, yy1);
+            ixval = LK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
+            iyval = LK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
+        }
+        float A11, A12, A22;
+        float pfx[3] = {0.f, 0.f, 0.f};
+        {
+            float s01, s02;
+            // (three sums = the two-sum helper twice in the LDS / checked modes; the DPP mode keeps the production shape)
+            if (MODE == 0) seq_sum3<NW>((float)(ixval * ixval), (float)(ixval * iyval), (float)(iyval * iyval), A11, A12, A22, CAP ? pfx : nullptr);
+            else {
+                sums2((float)(ixval * ixval), (float)(ixval * iyval), A11, A12, pfx);
+                sums2((float)(iyval * iyval), (float)(ixval * iyval), A22, s01, pfx + 1);
+                (void)s02;
+            }
+        }
+        put(0, ival); put(1, ixval); put(2, iyval); putf(3, pfx[0]); putf(4, pfx[1]); putf(5, pfx[2]);
+        putf(6, A11); put(7, (level << 8) | 1);
+        ++nrec;
+        A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+        float Dt = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
+        if (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f) {
+            if (level == 0) st = false;
+            continue;
+        }
+        Dt = 1.f / Dt;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        float outx = nx + half, outy = ny + half;
+        bool running = true;
+        for (int j = 0; j < a.max_count; ++j) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (running && (inx < -win || inx >= w || iny < -win || iny >= h)) {
+                if (level == 0) st = false;
+                running = false;
+            }
+            if (!running) break;
+            weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
+            int diff = 0;
+            if (lane_on) diff = sample(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            float b1, b2;
+            float pb[2] = {0.f, 0.f};
+            sums2((float)(diff * ixval), (float)(diff * iyval), b1, b2, CAP ? pb : nullptr);
+            put(0, diff); putf(1, pb[0]); putf(2, pb[1]); putf(5, b1); putf(6, b2); put(7, (level << 8) | (j << 16) | 2);
+            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+            putf(8, nx); putf(9, b1);
+            nx += dx; ny += dy;
+            putf(3, nx); putf(4, ny); putf(10, dx); putf(11, dy);
+            ++nrec;
+            if (CHK) {
+                if (g == 0) atomicAdd(&diag[6], 1);
+                const int fx = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nx));
+                const int fy = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ny));
+                if (__builtin_bit_cast(int, nx) != fx || __builtin_bit_cast(int, ny) != fy) {
+                    atomicAdd(&diag[5], 1);
+                    atomicAdd(&diag[8 + (g >> 4)], 1);          // which quarter of the wavefront
+                }
+            }
+            outx = nx + half; outy = ny + half;
+            if (dx * dx + dy * dy <= a.eps2) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        nx = outx; ny = outy;
+        if (st && level == 0) {
+            const float ex = nx - half, ey = ny - half;
+            const int inx = (int)floorf(ex), iny = (int)floorf(ey);
+            if (inx < -win || inx >= w || iny < -win || iny >= h) { st = false; continue; }
+            weights(ex - inx, ey - iny, iw00, iw01, iw10, iw11);
+            int diff = 0;
+            if (lane_on) diff = sample(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            float pe = 0.f;
+            if (MODE == 0) er = seq_sum<NW>(fabsf((float)diff), CAP ? &pe : nullptr) * 1.f / (32 * win * win);
+            else {
+                float e1, e2;
+                sums2(fabsf((float)diff), 0.f, e1, e2, nullptr);
+                er = e1 * 1.f / (32 * win * win);
+            }
+            put(0, diff); putf(1, pe); putf(5, er); put(7, 3);
+            ++nrec;
+        }
+    }
+    if (g == 0) {
+        next_pts[2 * pt] = nx;
+        next_pts[2 * pt + 1] = ny;
+        status[pt] = st ? 1 : 0;
+        err[pt] = er;
+        if (CAP) {
+            cap_hdr[4 * pt] = (int)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+            cap_hdr[4 * pt + 1] = (int)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+            cap_hdr[4 * pt + 2] = nrec;
+            cap_hdr[4 * pt + 3] = (int)blockIdx.x;
+        }
+    }
 }
 
 // ---- foreground-mask bookkeeping: rect k sees pixel p as foreground iff no rect j<k covers p.
@@ -1394,7 +1647,33 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
             }
             const int threads = lds_req > 0 ? 1024 : 256;
             const dim3 grid((unsigned)(((size_t)n * 64 + threads - 1) / threads));
-            if (a.win == 5)
+            if (ctx->opt_lk_variant > 0 && a.win == 5) {
+                const int v = ctx->opt_lk_variant;
+                if (!f->lk_diag) {
+                    FM_HIP(hipMalloc(&f->lk_diag, sizeof(int) * 16));
+                    FM_HIP(hipMemset(f->lk_diag, 0, sizeof(int) * 16));
+                }
+                if ((v & 32) && f->lk_cap_pts < n) {
+                    if (f->lk_cap) { (void)hipFree(f->lk_cap); (void)hipFree(f->lk_cap_hdr); }
+                    FM_HIP(hipMalloc(&f->lk_cap, sizeof(int) * (size_t)n * LK_CAP_MAXREC * LK_CAP_REC));
+                    FM_HIP(hipMalloc(&f->lk_cap_hdr, sizeof(int) * 4 * (size_t)n));
+                    f->lk_cap_pts = n;
+                }
+#define FM_LK_DIAG_LAUNCH(MODE, CHK, CAP) \
+    hipLaunchKernelGGL((lk_diag_kernel<5, MODE, CHK, CAP>), grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp, \
+                       f->lk_diag, f->lk_cap, f->lk_cap_hdr)
+                switch (v) {
+                case 1 | 64: FM_LK_DIAG_LAUNCH(0, false, false); break;      // DPP sums, diagnostic body (control)
+                case 1 | 32: FM_LK_DIAG_LAUNCH(0, false, true); break;       // DPP sums + capture
+                case 1 | 16: FM_LK_DIAG_LAUNCH(0, true, false); break;       // DPP sums + duplicate loads / lane agreement
+                case 2: FM_LK_DIAG_LAUNCH(1, false, false); break;           // LDS sums
+                case 2 | 16: FM_LK_DIAG_LAUNCH(1, true, false); break;
+                case 3: FM_LK_DIAG_LAUNCH(2, false, false); break;           // both, compared
+                case 3 | 16: FM_LK_DIAG_LAUNCH(2, true, false); break;
+                default: fm_set_error("unknown lk_variant %d", v); return FM_ERR_ARG;
+                }
+#undef FM_LK_DIAG_LAUNCH
+            } else if (a.win == 5)
                 hipLaunchKernelGGL(lk_wave_kernel<5>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
             else
                 hipLaunchKernelGGL(lk_wave_kernel<3>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
@@ -1412,6 +1691,23 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         FM_HIP(hipStreamSynchronize(s));
     }
     f->prev ^= 1;   // save preprocessed frame buffers for the next prediction (flow.py:212-213)
+    return 0;
+}
+
+// diagnostic read-out of the LK variants: 16 counters (reset afterwards), and for the capture variant the per-point
+// headers [n][4] and records [n][LK_CAP_MAXREC][8][64] of the last call
+extern "C" int fm_flow_lk_diag_read(fm_ctx* ctx, int32_t* counters, int n, int32_t* hdr, int32_t* records) {
+    FM_CHECK_ARG(ctx && ctx->flow && counters);
+    FlowState* f = ctx->flow;
+    FM_HIP(hipDeviceSynchronize());
+    if (!f->lk_diag) { memset(counters, 0, sizeof(int32_t) * 16); return 0; }
+    FM_HIP(hipMemcpy(counters, f->lk_diag, sizeof(int32_t) * 16, hipMemcpyDeviceToHost));
+    FM_HIP(hipMemset(f->lk_diag, 0, sizeof(int) * 16));
+    if (hdr && records) {
+        FM_CHECK_ARG(n > 0 && n <= f->lk_cap_pts);
+        FM_HIP(hipMemcpy(hdr, f->lk_cap_hdr, sizeof(int32_t) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+        FM_HIP(hipMemcpy(records, f->lk_cap, sizeof(int32_t) * (size_t)n * LK_CAP_MAXREC * LK_CAP_REC, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

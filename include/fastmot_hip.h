@@ -405,6 +405,18 @@ int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
 /* cv2.calcOpticalFlowPyrLK(prev_small, cur_small, pts) (flow.py:205-207): Scharr derivatives +
  * pyramidal LK for n points; then the frame buffers are swapped (flow.py:212-213). */
 int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next_pts, uint8_t* status, float* err);
+/* Diagnostics of the LK kernel (option "lk_variant" > 0 selects an instrumented variant of the kernel for
+ * fm_flow_lk; no counterpart in the reference): 16 event counters, reset by the call; with hdr / records non-null the
+ * capture of the last call, hdr [n][4] = HW_ID, XCC_ID, records written, workgroup; records [n][80][12][64]. */
+int fm_flow_lk_diag_read(fm_ctx* ctx, int32_t* counters, int n, int32_t* hdr, int32_t* records);
+/* Stand-alone reproducer of the packed-fp32 mis-execution that round 3's bisect found in the LK kernel (csrc/diag.hip,
+ * DESIGN 5b): `waves` wavefronts x `iters` evaluations of the LK position update on the KLT stream;
+ * out8[0..3] = lanes (per quarter of the wavefront) whose low result differed from lane 0's, out8[4..7] = high. */
+int fm_diag_pkhaz(fm_ctx* ctx, int variant, int waves, int iters, int32_t* out8);
+/* ... one packed instruction class (victim 0..5) checked per lane against unpacked arithmetic, `launches` launches on
+ * the KLT stream while a synthetic neighbour kernel of instruction class `aggressor` (0..6, -1 = none) occupies the
+ * ReID stream (csrc/diag.hip). */
+int fm_diag_pkhaz2(fm_ctx* ctx, int victim, int aggressor, int launches, int32_t* out8);
 /* swap without LK (failure paths of flow.py:191-196) */
 int fm_flow_swap(fm_ctx* ctx);
 /* second half of Flow.predict on the host side of the library (flow.py:215-263): camera motion by

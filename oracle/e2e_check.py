@@ -58,11 +58,14 @@ def hip_pass(mot, video, n_frames, skip, prefetch=False, frames=None):
     return recs, captured
 
 
-def oracle_pass(size, metric, tracker_kw, video, n_frames, skip, embeddings, budget_s=None, labels=None):
+def oracle_pass(size, metric, tracker_kw, video, n_frames, skip, embeddings, budget_s=None, labels=None, cv_impl=None):
     """The same clip through the CPU restatement (reference schedule mot.py:125-168: frame 0 = init, detector
-    frames = flow + kalman + update, other frames = track).  Returns (records, seconds, frames done)."""
+    frames = flow + kalman + update, other frames = track).  Returns (records, seconds, frames done).
+    cv_impl: None = cv_oracle (numpy), or the c_baseline module (the same routines compiled, pinned function by
+    function to cv_oracle by tests/test_c_baseline.py; ~12x faster, which is what makes the 4K / 300-object and the
+    KLT-heavy configurations fit a test budget)."""
     kw = {k: v for k, v in tracker_kw.items() if k != 'flow_cfg'}
-    trk = cpu_tracker.OracleTracker(size, metric, **kw)
+    trk = cpu_tracker.OracleTracker(size, metric, cv_impl=cv_impl, **kw)
     trk.reset(1 / 30.)
     recs = []
     t0 = time.perf_counter()
