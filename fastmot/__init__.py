@@ -5,6 +5,9 @@ The reference application (`/root/reference/app.py:10-12`: `import fastmot`, `im
 root is on `sys.path`: every public name and submodule of `fastmot` resolves to the object of the same name in
 `fastmot_amd` (one implementation, two import names -- nothing is re-implemented here)."""
 import importlib
+import importlib.abc
+import importlib.machinery
+import importlib.util
 import logging
 import sys
 
@@ -24,6 +27,30 @@ __all__ = list(fastmot_amd.__all__)
 
 # app.py:49 configures logging.getLogger(fastmot.__name__): make the implementation's loggers its children
 logging.getLogger('fastmot_amd').parent = logging.getLogger(__name__)
+
+
+class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """`import fastmot.mot` / `from fastmot.detector import YOLODetector`: the import system does not consult the
+    module-level __getattr__ for submodule imports, so any `fastmot.<x>` that is not in sys.modules yet resolves here
+    to the module object of `fastmot_amd.<x>` (imported at that moment: the lazy modules load the device library)."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if not fullname.startswith(__name__ + '.'):
+            return None
+        try:
+            found = importlib.util.find_spec('fastmot_amd.' + fullname[len(__name__) + 1:])
+        except (ImportError, ValueError):
+            return None
+        return None if found is None else importlib.machinery.ModuleSpec(fullname, self)
+
+    def create_module(self, spec):
+        return importlib.import_module('fastmot_amd.' + spec.name[len(__name__) + 1:])
+
+    def exec_module(self, module):
+        pass
+
+
+sys.meta_path.insert(0, _AliasFinder())
 
 
 def __getattr__(name):

@@ -459,6 +459,11 @@ def _bind_device_io(cls):
         check(self.lib.fm_filter_dets(self._ctx, _ptr(r), C.c_int(len(r)), _ptr(out), C.c_int(cap), C.byref(n)))
         return out[:n.value].view(np.recarray)
 
+    def detect_last_counts(self):
+        nc, nd = C.c_int(0), C.c_int(0)
+        check(self.lib.fm_detect_last_counts(self._ctx, C.byref(nc), C.byref(nd)))
+        return nc.value, nd.value
+
     def detect_raw_candidates(self, cap=65536):
         rows = np.empty((cap, 8), np.float32)
         n = C.c_int(0)
@@ -486,7 +491,7 @@ def _bind_device_io(cls):
     for fn in (frame_configure, frame_upload, pinned_frames, frame_ring_store, frame_ring_select, frame_read, frame_upload_next,
                frame_ring_select_next, frame_promote_next, detect_async_next,
                detect_configure, detect_async, detect_net_ms, detect_preprocess_only, detect_sync, filter_dets,
-               detect_raw_candidates, extract_configure, extract_async, extract_sync, extract_read_input):
+               detect_raw_candidates, detect_last_counts, extract_configure, extract_async, extract_sync, extract_read_input):
         setattr(cls, fn.__name__, fn)
 
 
@@ -520,19 +525,6 @@ def _bind_flow(cls):
 
     def flow_begin(self):
         check(self.lib.fm_flow_begin(self._ctx))
-
-    def flow_arm(self):
-        """This step's fm_flow_predict is about to run on another thread (LK / ReID exclusion, fastmot_hip.h)."""
-        check(self.lib.fm_flow_arm(self._ctx))
-
-    def flow_release(self):
-        check(self.lib.fm_flow_release(self._ctx))
-
-    def flow_wait_lk(self, timeout_us=200):
-        """True once the armed prediction has finished its LK launch (or nothing is armed)."""
-        done = C.c_int(0)
-        check(self.lib.fm_flow_wait_lk(self._ctx, C.c_int(int(timeout_us)), C.byref(done)))
-        return bool(done.value)
 
     def flow_swap(self):
         check(self.lib.fm_flow_swap(self._ctx))
@@ -712,7 +704,7 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_read_image(self._ctx, C.c_int(which), _ptr(buf), C.byref(w), C.byref(h)))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 
-    for fn in (flow_configure, flow_init, flow_begin, flow_arm, flow_release, flow_wait_lk, track_predict_async,
+    for fn in (flow_configure, flow_init, flow_begin, track_predict_async,
                track_predict_wait, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
                flow_background,
                flow_lk, flow_lk_diag, diag_pkhaz, diag_pkhaz2, flow_estimate, flow_read_image):

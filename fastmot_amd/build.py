@@ -23,7 +23,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp
 # formed by the SLP vectoriser) in the KLT kernels -- round 3 traced the LK results that differed under load to such a
 # chain mis-executing in lanes 48..63 while VALU-heavy wavefronts of another kernel share the CU (DESIGN 5b,
 # csrc/diag.hip is the stand-alone reproducer and is built the same way so that only its hand-written chain is packed).
-FILE_FLAGS = {'diag.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'flow.hip': ['-fno-slp-vectorize'], 'diag.hip': ['-fno-slp-vectorize']}
 
 
 def sources():

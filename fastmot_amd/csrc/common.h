@@ -89,10 +89,8 @@ struct fm_ctx {
     int opt_host_lap_elems = 262144;   // FASTMOT_HOST_LAP: cost matrices up to this size use lap_host.hip (measured: the
                                        // host solver is ~5x faster at every size up to 400 x 400, profiles/r02_lap_crossover.txt)
     int opt_use_graphs = 1;            // FASTMOT_GRAPHS: 0 = launch network layers one by one (no hipGraph)
-    int opt_lk_isolation = 1;          // FASTMOT_LK_ISOLATION: the LK launch takes whole CUs (flow.hip); a pipeline that
-                                       // never runs the ReID network beside it (fm_flow_arm / fm_flow_wait_lk) clears it
     int opt_lk_variant = 0;            // "lk_variant": diagnostic variants of the LK kernel (flow.hip lk_diag_kernel)
-    std::atomic<int> flow_phase{0};    // 0 idle, 1 armed (a KLT prediction of this step has not finished its LK launch), 2 LK done
+    void* predict_worker = nullptr;    // native KLT + Kalman worker thread of this context (flow_estimate.hip)
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network
     hipStream_t s_up = nullptr;     // H2D copy of the prefetched next frame (overlaps the running detector pass)
@@ -156,3 +154,4 @@ struct fm_ctx {
 };
 
 int fm_ensure_slots(fm_ctx* ctx, int max_slot_plus_1);
+void fm_predict_worker_free(fm_ctx* ctx);

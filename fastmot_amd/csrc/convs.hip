@@ -434,10 +434,10 @@ int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
     // stream stops reproducing its results while they run on the detector stream (tests/test_flow_gpu.py::
     // test_unisolated_lk_beside_the_detector fails with either of them, passes with the kernels above) --
     // and the pipeline relies on the detector being harmless to that kernel.
-    static const int pt2_mode = [] { const char* e = getenv("FASTMOT_CONVS_PT2"); return e ? atoi(e) : 0; }();
+    static const int pt2_mode = [] { const char* e = getenv("FASTMOT_CONVS_PT2"); return e ? atoi(e) : 1; }();
     const int wgs1 = (ntiles_c / 2) * npt;
     // 3x3 / stride 1 / pad 1 on one image: input halo staged in LDS once (convs_halo_kernel)
-    static const int halo_mode = [] { const char* e = getenv("FASTMOT_CONVS_HALO"); return e ? atoi(e) : 0; }();
+    static const int halo_mode = [] { const char* e = getenv("FASTMOT_CONVS_HALO"); return e ? atoi(e) : 1; }();
     if (halo_mode && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.N == 1 && p.Ho == p.H && p.Wo == p.W &&
         p.up != 2 && (size_t)100 * (p.Cin + 8) * 2 <= 150 * 1024 && nq >= 8) {
         // only where the 8 x 8 tiles waste little (38 x 38: 90 % of the tile pixels exist, 15.2 -> 12.5 us per layer; at

@@ -22,7 +22,6 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "zero_copy_tracks")) ctx->opt_zero_copy_tracks = value;
     else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
     else if (!strcmp(key, "use_graphs")) ctx->opt_use_graphs = value;
-    else if (!strcmp(key, "lk_isolation")) ctx->opt_lk_isolation = value;
     else if (!strcmp(key, "lk_variant")) ctx->opt_lk_variant = value;
     else {
         fm_set_error("unknown option '%s'", key);
@@ -62,7 +61,6 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     if (const char* e = getenv("FASTMOT_ZERO_COPY")) ctx->opt_zero_copy_tracks = atoi(e);
     if (const char* e = getenv("FASTMOT_HOST_LAP")) ctx->opt_host_lap_elems = atoi(e);
     if (const char* e = getenv("FASTMOT_GRAPHS")) ctx->opt_use_graphs = atoi(e);
-    if (const char* e = getenv("FASTMOT_LK_ISOLATION")) ctx->opt_lk_isolation = atoi(e);
     // the detector network is the long, throughput-oriented stream; tracker / KLT / ReID launches are
     // short and latency critical (the host waits on them), so they get the higher priority
     int prio_lo = 0, prio_hi = 0;
@@ -107,6 +105,7 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
 extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
+    fm_predict_worker_free(ctx);
     (void)hipDeviceSynchronize();
     if (ctx->det) fm_det_free(ctx->det);
     if (ctx->ext) fm_ext_free(ctx->ext);

@@ -742,6 +742,20 @@ extern "C" int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* o
     return collect(ctx, d, s, out, cap, n_out);
 }
 
+// candidates that passed the confidence threshold / detections that survived NMS and the box filters in the pass that
+// fm_detect_sync collected last (what the sort + NMS kernels of that pass worked on)
+extern "C" int fm_detect_last_counts(fm_ctx* ctx, int* n_candidates, int* n_detections) {
+    FM_CHECK_ARG(ctx && ctx->det && n_candidates && n_detections);
+    const DetState* d = ctx->det;
+    if (d->last < 0) {
+        *n_candidates = *n_detections = 0;
+        return 0;
+    }
+    *n_candidates = d->counters_host[d->last][0];
+    *n_detections = d->counters_host[d->last][2];
+    return 0;
+}
+
 extern "C" int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* n) {
     FM_CHECK_ARG(ctx && ctx->det && rows && n);
     DetState* d = ctx->det;

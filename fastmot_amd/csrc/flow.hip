@@ -83,15 +83,9 @@ void fm_flow_free(FlowState* f) {
 
 namespace {
 
-// FM_SGPR_CAP: kernels of the KLT stream run beside other streams' kernels on the same CUs.  Measured on MI355X
-// (scripts/stress_lk4.py .. stress_lk6.py, profiles/r02_lk_disturbance.txt): while fused LightConv launches (liteconv_kernel,
-// litechain_kernel) -- and, found later, two streamed-conv variants that are therefore switched off -- are resident on
-// the same CU, a fraction of the LK kernel's calls returns one or two of 600 points off by 1e-5 .. 6 px: constant inputs,
-// images intact afterwards, never when idle, never beside the shipped detector's kernels, never when this kernel has its
-// CUs to itself (150 KB LDS request).  With the readlane-based window sums the rate followed the SCALAR register budget
-// (106 / 78 SGPRs: 15-18 % of the calls, 46: 0-2.5 %), hence the cap; the cause inside the part is not established.
-// What protects the results: MOT.step never runs the ReID network while this kernel runs, stand-alone launches take
-// whole CUs.
+// FM_SGPR_CAP: scalar register budget of the KLT kernels.  A round-2 measure against the LK results that differed under
+// load (their rate followed the budget); round 3 found the cause elsewhere (packed-fp32 arithmetic, see lk_wave_body
+// and build.py FILE_FLAGS) -- the cap stays because the kernels were tuned with it (occupancy 8 either way).
 #define FM_SGPR_CAP __attribute__((amdgpu_num_sgpr(48)))
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -366,20 +360,29 @@ __device__ __forceinline__ void lds_sums(float* slab, int lane, const float (&v)
     __builtin_amdgcn_wave_barrier();
 }
 
-// One WAVEFRONT per point: lane g < win*win owns window pixel (g / win, g % win) -- the samples of a window are
-// taken in parallel, and every window sum (A11, A12, A22, b1, b2, the error) is then accumulated by all lanes in
-// the sequential (y, x) order of LKTrackerInvoker's scalar loops through v_readlane: 25 dependent float32 adds,
-// bit-identical to oracle/cv_oracle.calc_optical_flow_pyr_lk.  (Round 1 reduced with a butterfly: as fast, but it
-// agrees with the scalar order to ~1e-4 px only -- enough to flip an inlier decision now and then and let the
-// keypoint sets of the two implementations drift apart over a clip, tests/test_e2e_parity_gpu.py.  A variant with
-// one LANE per point -- no cross-lane operations, 64x fewer wavefronts -- was also bit-identical when idle but
-// 2 of 120 calls differed while another stream kept the CUs busy, the same symptom as the two-points-per-wavefront
-// kernel of round 1, and it was slower (latency of scattered byte loads with one wave per SIMD): removed.)  The control flow (pyramid levels skipped, iteration counts) depends on the point, so
-// it must be WAVE-uniform: with two points per wavefront (32 lanes each, the first version) the two halves
-// diverged, and the results of single points then varied from run to run whenever other streams kept the
-// CUs' LDS pipelines busy (reproduced in isolation: scripts/stress_lk2.py; constant images, constant
-// arguments, no such effect with one point per wavefront or with equal trip counts).  39 idle lanes are
-// the price; the kernel is latency bound anyway.
+// One WAVEFRONT per point: lane g < win*win owns window pixel (g / win, g % win) -- the samples of a window are taken
+// in parallel, and every window sum (A11, A12, A22, b1, b2, the error) is accumulated in the sequential (y, x) order of
+// LKTrackerInvoker's scalar loops (seq_sum*: 24 dependent float32 adds): bit-identical to
+// oracle/cv_oracle.calc_optical_flow_pyr_lk.  (A butterfly reduction agrees with the scalar order to ~1e-4 px only --
+// enough to flip an inlier decision now and then and let the keypoint sets of the two implementations drift apart over
+// a clip, tests/test_e2e_parity_gpu.py.)  Everything after the sums is wave-uniform arithmetic that every lane
+// repeats; the control flow (levels skipped, iteration counts) is therefore uniform and compiled as scalar branches on
+// "any lane" conditions -- which is why ONE wrong lane changes the result of the point.
+//
+// The wrong lane (rounds 1-2: "LK results differ from call to call while the ReID network runs").  Round 3
+// captured every iteration of disturbed calls (lk_diag_kernel below, scripts/lk_bisect.py, profiles/r03_lk_bisect.txt):
+// samples, running sums and broadcast sums were always right; what was wrong was dx of the position update
+//     dx = (A12 * b2 - A22 * b1) * Dt,   dy = (A12 * b1 - A11 * b2) * Dt
+// in lanes 48..63 only.  The SLP vectoriser had packed the two expressions into v_pk_mul_f32 / v_pk_add_f32, the cross
+// terms through `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (low result from the HIGH register of a source pair);
+// on MI355X that instruction form returns a wrong low half in the last 16 lanes of the wavefront now and then while
+// wavefronts of the fused LightConv kernels (or of two streamed-conv variants) are resident on the same CU -- never
+// when idle, never with unpacked v_mul_f32 / v_sub_f32 (csrc/diag.hip reproduces it stand alone: 0 of 72 M evaluations
+// idle, ~25 k wrong lanes beside litechain_kernel, all in lanes 48..63, all in the low half).  A wrong dx in lanes
+// 48..63 then ends (or prolongs) the iteration through the any-lane branch: positions off by 1e-4 .. 6 px.
+// Consequence: this file is compiled with -fno-slp-vectorize (build.py FILE_FLAGS: no packed fp32 in the KLT kernels; 0
+// disagreeing lanes in 5.1 M iterations under the same load), tests/test_isa_lint.py refuses the instruction form in
+// every kernel of the library, and the launch needs neither whole CUs nor an ordering against the ReID network.
 template <int WINC>
 __device__ __forceinline__ void lk_wave_body(const LKArgs& a, int n, const float* __restrict__ prev_pts,
                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
@@ -1597,16 +1600,12 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const size_t o_st = sizeof(float) * 2 * n, o_err = (o_st + n + 15) & ~size_t(15);
         const size_t out_bytes = o_err + sizeof(float) * n;
         if ((rc = f->lk_out.reserve(out_bytes))) return rc;
-        static const int io_mode = getenv("FASTMOT_LK_IO") ? atoi(getenv("FASTMOT_LK_IO")) : 2;
         double tl0 = fm_now_ms();
         FM_HIP(hipStreamSynchronize(s));
         g_flow_sub[4] += fm_now_ms() - tl0; tl0 = fm_now_ms();
-        // io_mode 2 (default): points in and results out through device-mapped pinned host memory (each wavefront
-        // reads 8 bytes and writes 13: no blit copies around the kernel; measured 0.127 ms per call against 0.147 ms
-        // with H2D + D2H copies, mode 0).  Mode 1 (zero-copy in, D2H copy out) stalls the following stream
-        // synchronisations by ~0.4 ms on this runtime and is kept only as a record of that measurement.
+        // points in and results out through device-mapped pinned host memory (each wavefront reads 8 bytes and writes
+        // 13: no blit copies around the kernel; measured 0.127 ms per call against 0.147 ms with H2D + D2H copies)
         memcpy(f->lk_in.h, prev_pts, sizeof(float) * 2 * n);
-        if (io_mode == 0) FM_HIP(hipMemcpyAsync(f->lk_in.d, f->lk_in.h, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
         const int p = f->prev, c = p ^ 1;
         LKArgs a{};
         for (int l = 0; l < f->levels; ++l) {
@@ -1622,30 +1621,15 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
         const double eps = std::min(std::max(f->cfg.epsilon, 0.), 10.);
         a.eps2 = (float)(eps * eps);
         a.min_eig_thresh = 1e-4f;
-        char* o = io_mode == 2 ? f->lk_out.host<char>() : f->lk_out.dev<char>();
+        char* o = f->lk_out.host<char>();
         {
             float* o_pts = reinterpret_cast<float*>(o);
             uint8_t* o_stat = reinterpret_cast<uint8_t*>(o + o_st);
             float* o_errp = reinterpret_cast<float*>(o + o_err);
-            const float* in_pts = io_mode == 0 ? f->lk_in.dev<float>() : f->lk_in.host<float>();
-            // CU isolation: the launch requests (and never touches) 150 KB of dynamic LDS per 16-wavefront workgroup, so
-            // exactly one of its workgroups fits a CU and no LDS-using workgroup of another stream (the ReID network's
-            // fused LightConv kernels: the ones that disturb this kernel, see FM_SGPR_CAP) can be resident beside it.
-            // It is expensive inside a busy pipeline -- a workgroup waits until a CU has drained completely while
-            // the other streams keep filling the gaps (LK stage 0.17 ms alone, 0.5 ms beside the detector + ReID) --
-            // so a caller that keeps the ReID network off the GPU while this kernel runs (fastmot_amd/mot.py:
-            // fm_flow_arm / fm_flow_wait_lk) clears the "lk_isolation" option and gets ordinary 4-point workgroups.
-            static const int lds_env = getenv("FASTMOT_LK_LDS") ? atoi(getenv("FASTMOT_LK_LDS")) : 150000;
-            const int lds_req = ctx->opt_lk_isolation ? lds_env : 0;
-            static bool lds_set = false;
-            if (lds_req > 65536 && !lds_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lk_wave_kernel<5>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lk_wave_kernel<3>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
-                lds_set = true;
-            }
-            const int threads = lds_req > 0 ? 1024 : 256;
+            const float* in_pts = f->lk_in.host<float>();
+            // ordinary 4-point workgroups beside whatever the other streams run (rounds 1-2 gave this launch whole CUs
+            // or ordered the ReID network behind it; see the note at lk_wave_body for what was actually wrong)
+            const int threads = 256, lds_req = 0;
             const dim3 grid((unsigned)(((size_t)n * 64 + threads - 1) / threads));
             if (ctx->opt_lk_variant > 0 && a.win == 5) {
                 const int v = ctx->opt_lk_variant;
@@ -1679,7 +1663,6 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
                 hipLaunchKernelGGL(lk_wave_kernel<3>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
         }
         FM_HIP(hipGetLastError());
-        if (io_mode != 2) FM_HIP(hipMemcpyAsync(f->lk_out.h, f->lk_out.d, out_bytes, hipMemcpyDeviceToHost, s));
         g_flow_sub[5] += fm_now_ms() - tl0; tl0 = fm_now_ms();
         FM_HIP(hipStreamSynchronize(s));
         g_flow_sub[6] += fm_now_ms() - tl0;

@@ -857,7 +857,6 @@ struct PredictWorker {
         if (!j.rc)
             j.rc = fm_flow_predict(ctx, j.nT, j.inside, j.full, j.kps, j.kp_off, &j.prm, j.pts_cap, j.prev_out, j.cur_out,
                                    j.trk_off_out, j.bg_range_out, j.H_out, &j.status, j.result_out, j.est_out, j.n_matched_out);
-        ctx->flow_phase.store(2, std::memory_order_release);      // whatever happened: nobody waits for the LK kernel any more
         if (!j.rc && j.status == FM_FLOW_OK && j.nK > 0) {
             // MultiTracker.apply_kalman: a track whose KLT box was estimated gets it as a measurement, with a large
             // uncertainty for occluded tracks (large age / low inlier ratio)
@@ -899,11 +898,17 @@ struct PredictWorker {
     }
 };
 
-PredictWorker& predict_worker() {
-    static PredictWorker w;
-    return w;
+// one worker per context (a second fm_ctx, or a second pipeline thread on another context, has its own job slot)
+PredictWorker& predict_worker(fm_ctx* ctx) {
+    if (!ctx->predict_worker) ctx->predict_worker = new PredictWorker();
+    return *static_cast<PredictWorker*>(ctx->predict_worker);
 }
 }  // namespace
+
+void fm_predict_worker_free(fm_ctx* ctx) {
+    delete static_cast<PredictWorker*>(ctx->predict_worker);
+    ctx->predict_worker = nullptr;
+}
 
 extern "C" int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr,
                                       const float* kps, const int32_t* kp_off, const fm_flow_predict_params* prm,
@@ -916,7 +921,7 @@ extern "C" int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_
                  bg_range_out && H_out);
     FM_CHECK_ARG(nT == 0 || (inside_tlbr && full_tlbr && kp_off && result_out && est_tlbr_out && n_matched_out));
     FM_CHECK_ARG(nK == 0 || (slots && ages && sorted_idx && tlbr_out && lost_out));
-    PredictWorker& w = predict_worker();
+    PredictWorker& w = predict_worker(ctx);
     if (w.completed.load(std::memory_order_acquire) != w.submitted.load(std::memory_order_acquire)) {
         fm_set_error("a track prediction is already in flight (fm_track_predict_wait first)");
         return FM_ERR_STATE;
@@ -927,7 +932,6 @@ extern "C" int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_
     j.bg_range_out = bg_range_out; j.H_out = H_out; j.result_out = result_out; j.est_out = est_tlbr_out;
     j.n_matched_out = n_matched_out; j.nK = nK; j.slots = slots; j.ages = ages; j.sorted_idx = sorted_idx;
     j.age_penalty = age_penalty; j.tlbr_out = tlbr_out; j.lost_out = lost_out;
-    ctx->flow_phase.store(1, std::memory_order_release);          // = fm_flow_arm: the ReID launch waits for the LK kernel
     {
         std::lock_guard<std::mutex> lk(w.m);
         w.submitted.fetch_add(1, std::memory_order_release);
@@ -940,7 +944,7 @@ extern "C" int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_
 // Kalman step ran (status OK and nK > 0) and tlbr_out / lost_out are valid
 extern "C" int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_done_out) {
     FM_CHECK_ARG(ctx && status_out && kalman_done_out);
-    PredictWorker& w = predict_worker();
+    PredictWorker& w = predict_worker(ctx);
     const uint64_t want = w.submitted.load(std::memory_order_acquire);
     for (int spins = 0; spins < 20000 && w.completed.load(std::memory_order_acquire) != want; ++spins) cpu_relax();
     if (w.completed.load(std::memory_order_acquire) != want) {
@@ -954,36 +958,6 @@ extern "C" int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_d
         fm_set_error("%s", j.err);
         return j.rc;
     }
-    return 0;
-}
-
-// ---- LK / ReID exclusion (see the isolation note at the LK launch in flow.hip).  fm_flow_arm: the caller is about
-// to hand this step's fm_flow_predict to another thread; fm_flow_wait_lk: blocks until that prediction has finished
-// its LK launch (or was released / never armed); fm_flow_release: the prediction thread is done, however it ended.
-extern "C" int fm_flow_arm(fm_ctx* ctx) {
-    FM_CHECK_ARG(ctx);
-    ctx->flow_phase.store(1, std::memory_order_release);
-    return 0;
-}
-extern "C" int fm_flow_release(fm_ctx* ctx) {
-    FM_CHECK_ARG(ctx);
-    ctx->flow_phase.store(0, std::memory_order_release);
-    return 0;
-}
-extern "C" int fm_flow_wait_lk(fm_ctx* ctx, int timeout_us, int* done) {
-    FM_CHECK_ARG(ctx && done && timeout_us >= 0);
-    const auto t0 = std::chrono::steady_clock::now();
-    int spins = 0;
-    while (ctx->flow_phase.load(std::memory_order_acquire) == 1) {
-        if (++spins < 2000) { cpu_relax(); continue; }
-        spins = 0;
-        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_us) {
-            *done = 0;
-            return 0;
-        }
-        std::this_thread::yield();
-    }
-    *done = 1;
     return 0;
 }
 
@@ -1079,7 +1053,6 @@ extern "C" int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     }
     pool().prewake();          // the RANSAC workers wake up while this thread waits for the LK kernel
     rc = fm_flow_lk(ctx, n_pts, scaled.data(), cur.data(), status.data(), err.data());
-    ctx->flow_phase.store(2, std::memory_order_release);      // (fm_flow_lk returns after the kernel has finished)
     if (rc) return rc;
     lap(2);
     const float iox = 1.0f / prm->opt_scale[0], ioy = 1.0f / prm->opt_scale[1];

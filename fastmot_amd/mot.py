@@ -4,7 +4,6 @@ Same stage schedule as the reference's MOT.step (mot.py:125-168) -- detector enq
 extractor enqueue || Kalman, then association -- but every stage is a set of kernels on its own HIP
 stream of one shared device context, and the frame is uploaded once per step (or is already
 resident: pass a detector.DeviceFrame)."""
-import os
 from types import SimpleNamespace
 from enum import Enum
 import logging
@@ -20,9 +19,7 @@ from .utils import Profiler
 from .utils.visualization import Visualizer
 
 LOGGER = logging.getLogger(__name__)
-_PREFETCH_FIRST = os.environ.get('FASTMOT_PREFETCH_FIRST', '0') != '0'
-_UPDATE_EARLY = os.environ.get('FASTMOT_UPDATE_EARLY', '1') != '0'
-_NATIVE_FLOW = os.environ.get('FASTMOT_NATIVE_FLOW', '1') != '0'
+_NATIVE_FLOW = True      # tests flip this to compare the native prediction worker with the Python-thread path
 
 
 class _NativeFlowJob:
@@ -31,9 +28,6 @@ class _NativeFlowJob:
     def __init__(self, tracker, frame):
         self._tracker = tracker
         self._job = tracker.predict_async(frame)
-
-    def done(self):
-        return self._job is None or self._tracker.ctx.flow_wait_lk(0)
 
     def result(self):
         job, self._job = self._job, None
@@ -101,10 +95,6 @@ class MOT:
         self.tracker = MultiTracker(self.size, self.extractors[0].metric, **vars(tracker_cfg))
         self.frame_count = 0
         self._next_frame = None
-        # LK / ReID exclusion (fastmot_hip.h: fm_flow_arm): inside step() the ReID network is launched only after the
-        # KLT thread's LK kernel has finished, so the LK launch need not take whole CUs.  FASTMOT_LK_EXCLUSION=0 keeps
-        # the isolated launch instead (needed when ANOTHER process runs a ReID network on the same GPU).
-        self._lk_exclusion = os.environ.get('FASTMOT_LK_EXCLUSION', '1') != '0'
         # KLT + Kalman run on a second host thread while this one drives detector -> ReID network (the
         # C-ABI calls release the GIL; the stages use separate HIP streams and share no state)
         self._flow_thread = ThreadPoolExecutor(max_workers=1, thread_name_prefix='fastmot-flow',
@@ -132,15 +122,11 @@ class MOT:
         bind_frame(ctx, frame, self.size, begin_step=True)
         ctx.in_step = True
         self._next_frame = next_frame
-        if self._lk_exclusion:
-            ctx.set_option('lk_isolation', 0)       # only while this pipeline orders LK and ReID itself
         try:
             self._step(frame)
         finally:
             ctx.in_step = False
             self._next_frame = None
-            if self._lk_exclusion:
-                ctx.set_option('lk_isolation', 1)
         if self.draw:
             self._draw(frame, self._last_detections)
         self.frame_count += 1
@@ -152,7 +138,6 @@ class MOT:
             self.detector.prefetch(nxt)
 
     def _step(self, frame):
-        ctx = self.tracker.ctx
         self._last_detections = []          # what _draw shows: this frame's detections, none on skipped frames
         if self.frame_count == 0:
             detections = self._last_detections = self.detector(frame)
@@ -169,15 +154,6 @@ class MOT:
             # detector -> ReID network -> association.  The stages are independent exactly as in the
             # reference, so the results are identical.
             native = _NATIVE_FLOW and type(self.tracker.flow) is Flow      # (tests script the flow with a fake)
-            if self._lk_exclusion and not native:
-                ctx.flow_arm()
-            # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
-            # detector stream never idles; results are collected in order, detect.hip).  Two host threads launching
-            # at once serialise inside the HIP runtime (the upload call takes 0.15 ms beside the KLT thread's burst of
-            # ~15 launches, 0.01 ms before it), but starting the KLT thread later costs as much: measured neutral
-            # (FASTMOT_PREFETCH_FIRST=1 is the other order).
-            if _PREFETCH_FIRST:
-                self._prefetch_next()
             if native:
                 # KLT + Kalman on the library's worker thread: marshalled here, scattered in predict_finish -- no second
                 # Python thread competing for the interpreter lock (fastmot_hip.h: fm_track_predict_async)
@@ -185,16 +161,11 @@ class MOT:
             else:
                 flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
             try:
+                # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
+                # detector stream never idles; results are collected in order, detect.hip)
                 self._prefetch_next()
                 with Profiler('detect'):
                     detections = self._last_detections = self.detector.postprocess()
-
-                # LK / ReID exclusion: the ReID network starts once the KLT thread's LK kernel has finished (the two
-                # must not share compute units; ordering them is far cheaper than giving the LK launch
-                # whole CUs inside the busy pipeline).  The ReID launch still overlaps the host RANSAC + Kalman step.
-                if self._lk_exclusion:
-                    while not ctx.flow_wait_lk(200) and not flow_done.done():
-                        pass
 
                 with Profiler('extract'):
                     if len(self.extractors) == 1:
@@ -209,10 +180,8 @@ class MOT:
                     # the embedding-independent part of the association (track grouping, cost-matrix row order,
                     # packed launch arguments) runs while the ReID network is still busy: it only needs the Kalman
                     # step, i.e. the KLT thread, to have finished
-                    pre = None
-                    if _UPDATE_EARLY:
-                        flow_done.result()
-                        pre = self.tracker.update_begin(detections)
+                    flow_done.result()
+                    pre = self.tracker.update_begin(detections)
                     if len(self.extractors) == 1:
                         embeddings = self.extractors[0].postprocess()
                     else:
@@ -269,13 +238,9 @@ class MOT:
                                caption=f'visible: {len(visible)}')
 
     def _flow_and_kalman(self, frame):
-        try:
-            with Profiler('track'):
-                self.tracker.compute_flow(frame)
-                self.tracker.apply_kalman()
-        finally:
-            if self._lk_exclusion:
-                self.tracker.ctx.flow_release()
+        with Profiler('track'):
+            self.tracker.compute_flow(frame)
+            self.tracker.apply_kalman()
 
     @staticmethod
     def print_timing_info():

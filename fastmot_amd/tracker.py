@@ -440,7 +440,9 @@ class MultiTracker:
         cache = self._gallery_cache
         for tid in [t for t in cache if t not in self.hist_tracks]:
             del cache[tid]
-        fresh = [t for t in hist_ids if t not in cache]
+        # (a history track that was re-identified and lost again between two exchanges keeps its id but has a new
+        # feature: the cached copy is valid only for the count it was read with)
+        fresh = [t for t in hist_ids if t not in cache or cache[t][0] != self.hist_tracks[t].avg_feat.count]
         if fresh:
             avg, cnt = ctx.feat_read([self.hist_tracks[t].slot for t in fresh])
             for tid, a, c in zip(fresh, avg, cnt):

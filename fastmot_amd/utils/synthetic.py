@@ -6,6 +6,7 @@ while the detector network, decode and NMS still execute on the GPU."""
 import numpy as np
 
 from ..detector import YOLODetector, DET_DTYPE
+from ..models.graph import RandomWeights
 
 
 class SyntheticVideo:
@@ -78,7 +79,7 @@ class InjectedYOLODetector(YOLODetector):
         if labels is not None and len(labels) == 1:
             self._label = labels[0]
         self._frame_idx = 0
-        self.last_real_count = 0
+        self.last_real_count = self.last_candidates = 0
         self.net_ms = []          # HIP-event time of the detector's layer sequence, one entry per postprocess()
 
     def detect_async(self, frame):
@@ -87,7 +88,62 @@ class InjectedYOLODetector(YOLODetector):
     def postprocess(self):
         real = super().postprocess()
         self.last_real_count = len(real)
+        self.last_candidates = self.ctx.detect_last_counts()[0]
         self.net_ms.append(self.ctx.detect_net_ms())      # the events of THIS frame's network are complete here
         dets = self._video.detections(self._frame_idx, self._label, self._labels)
         self._frame_idx += 1
         return dets
+
+
+class ScriptedHeadWeights(RandomWeights):
+    """The seeded random parameters of `RandomWeights(seed)` (same random stream: every other layer is unchanged) with
+    the biases of the YOLO head convolutions set so that a chosen share of the candidate boxes passes the detector's
+    confidence threshold with class `label`: with purely random heads nothing passes `conf_thresh` and the DIoU-NMS
+    stage of a benchmark would run on an empty list.  obj_bias[h] = objectness bias of head h (in build order)."""
+
+    def __init__(self, seed, num_classes, label, obj_bias):
+        super().__init__(seed)
+        self.num_classes, self.label, self.obj_bias = num_classes, label, list(obj_bias)
+        self._head = 0
+
+    def conv(self, name, cout, cin, k, bn=True, gain=1.0, groups=1):
+        p = super().conv(name, cout, cin, k, bn=bn, gain=gain, groups=groups)
+        rec = 5 + self.num_classes
+        if not bn and cout % rec == 0:
+            b = p['bias'].reshape(-1, rec)
+            b[:, 4] = self.obj_bias[self._head]
+            b[:, 5:] = -4.0
+            b[:, 5 + self.label] = 4.0
+            self._head += 1
+        return p
+
+
+def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.25, seed=0):
+    """ScriptedHeadWeights for `model` whose heads let about `target` candidates per frame through `conf_thresh` on
+    frames like `frame`: one calibration pass with zero objectness bias, then the bias of every head is set to the
+    quantile of its objectness logits that leaves its share of the target above the threshold."""
+    from .. import models
+    m = models.YOLO.get_model(model)
+    n_heads = len(m.LAYER_FACTORS)
+    det = YOLODetector(size, (label,), model=model, conf_thresh=conf_thresh,
+                       weights=ScriptedHeadWeights(seed, m.NUM_CLASSES, label, [0.0] * n_heads))
+    try:
+        det.detect_async(frame)
+        det.postprocess()
+        rec = 5 + m.NUM_CLASSES
+        logits = []
+        for head in det.heads:
+            t = det.backend.read(head, 1)[0]                       # (h, w, anchors * rec)
+            logits.append(t.reshape(t.shape[0], t.shape[1], -1, rec)[..., 4].ravel())
+    finally:
+        det.backend.close()
+    total = sum(len(v) for v in logits)
+    # class probability ~ sigmoid(4) = 0.982: box_conf * cls_prob >= thr  <=>  objectness logit >= logit(thr / 0.982)
+    need = conf_thresh / (1.0 / (1.0 + np.exp(-4.0)))
+    cut = float(np.log(need / (1.0 - need)))
+    bias = []
+    for v in logits:
+        share = min(0.5, target / total)                          # the same share of every head's cells
+        q = float(np.quantile(v, 1.0 - share))
+        bias.append(cut - q)
+    return ScriptedHeadWeights(seed, m.NUM_CLASSES, label, bias)

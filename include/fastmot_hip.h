@@ -47,9 +47,9 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
  * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
  * "host_lap_elems" (default 262144; LAP cost matrices up to this many elements are solved by the host
  * solver of the library, larger ones by the device kernels; 0 = always device), "use_graphs" (default 1;
- * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_isolation" (default 1, see
- * fm_flow_arm).  Initial values can be set with the environment variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP /
- * FASTMOT_GRAPHS / FASTMOT_LK_ISOLATION. */
+ * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (default 0; > 0 selects an
+ * instrumented variant of the LK kernel, see fm_flow_lk_diag_read).  Initial values can be set with the environment
+ * variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP / FASTMOT_GRAPHS. */
 int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value);
 /* writes "name:gcnArch:CUs:clockMHz:hbmBytes" of the ctx device */
 int fm_device_info(fm_ctx* ctx, char* buf, int buflen);
@@ -336,6 +336,8 @@ int fm_detect_async(fm_ctx* ctx);
 /* YOLODetector.postprocess (detector.py:275-287): waits for the stream, returns detections sorted
  * by class id.  Returns FM_ERR_STATE if the candidate list overflowed. */
 int fm_detect_sync(fm_ctx* ctx, fm_det48* out, int cap, int* n);
+/* candidates over conf_thresh / detections after NMS + box filters of the pass fm_detect_sync collected last */
+int fm_detect_last_counts(fm_ctx* ctx, int* n_candidates, int* n_detections);
 /* test hooks: run only the preprocessing / only the filter+NMS stage on host-provided YOLO
  * candidate rows [n][7] = x, y, w, h, box_conf, class_id, class_prob (yolo_layer.h:34-39) */
 int fm_detect_preprocess_only(fm_ctx* ctx);
@@ -458,8 +460,8 @@ int fm_flow_predict(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
  * the KLT measurements MultiTracker.apply_kalman derives from it (tracker.py:150-183).  nT tracks in prediction order
  * (as fm_flow_predict), nK tracks in table order for the Kalman step: slots, ages and sorted_idx[i] = position of
  * track i among the nT predicted ones or -1; multiplier = max(age_penalty * age, 1) / inlier_ratio.  All pointers
- * must stay valid until fm_track_predict_wait returns; one job at a time.  The call also arms the LK / ReID ordering
- * (fm_flow_arm); fm_track_predict_wait reports the prediction status (FM_FLOW_*) and whether the Kalman step ran. */
+ * must stay valid until fm_track_predict_wait returns; one job at a time PER CONTEXT (every fm_ctx owns its worker).
+ * fm_track_predict_wait reports the prediction status (FM_FLOW_*) and whether the Kalman step ran. */
 int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const double* full_tlbr, const float* kps,
                            const int32_t* kp_off, const fm_flow_predict_params* prm, int pts_cap, float* prev_out,
                            float* cur_out, int32_t* trk_off_out, int32_t* bg_range_out, double* H_out,
@@ -467,16 +469,6 @@ int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const
                            const int32_t* slots, const int32_t* ages, const int32_t* sorted_idx, double age_penalty,
                            double* tlbr_out, uint8_t* lost_out);
 int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_done_out);
-/* LK / ReID exclusion for pipelines that run fm_flow_predict on a second host thread (fastmot_amd/mot.py; the
- * reference overlaps its optical flow with the asynchronous detector the same way, mot.py:138-145).  The LK
- * kernel must not share compute units with the ReID network's fused LightConv kernels;
- * by default its launch therefore takes whole CUs (option "lk_isolation" = 1), which is slow beside busy streams.
- * A pipeline that orders the two instead -- fm_flow_arm before handing the prediction to its thread,
- * fm_flow_wait_lk (done = 1: the prediction has finished its LK launch or is not armed; 0: timeout) before
- * fm_extract_async, fm_flow_release when the prediction thread is through -- may set "lk_isolation" to 0. */
-int fm_flow_arm(fm_ctx* ctx);
-int fm_flow_wait_lk(fm_ctx* ctx, int timeout_us, int* done);
-int fm_flow_release(fm_ctx* ctx);
 /* diagnostic: a long deterministic kernel on the flow stream (mode bit 0: 32-lane butterflies, bit 1: byte
  * loads from the previous gray image); out_host: 256 * blocks words.  See scripts/stress_spin.py. */
 int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsigned* out_host);

@@ -40,7 +40,6 @@ ctx.flow_begin()
 ctx.synchronize()
 rng = np.random.default_rng(0)
 pts = np.stack([rng.uniform(20, size[0] / 2 - 20, NPTS), rng.uniform(20, size[1] / 2 - 20, NPTS)], 1).astype(np.float32)
-ctx.set_option('lk_isolation', 0)
 ctx.set_option('lk_variant', 0)
 base = [ctx.flow_lk(pts), ctx.flow_lk(pts)]      # consecutive calls track in opposite directions (the call swaps the image sets)
 
@@ -220,7 +219,7 @@ try:
 finally:
     stop.append(1)
     th.join()
-    ctx.set_option('lk_isolation', 1)
+    pass
 # where do waves of an idle call land?  (reference distribution for the disturbed-wave list)
 hdr = cap_idle[0][0]
 xcc = hdr[:, 1] & 15

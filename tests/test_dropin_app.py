@@ -130,3 +130,21 @@ def test_alias_package_is_the_same_implementation():
             "assert logging.getLogger('fastmot_amd.tracker').getEffectiveLevel() == logging.ERROR\n" % str(ROOT))
     res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_alias_submodule_imports_before_attribute_access():
+    """`import fastmot.mot` / `from fastmot.detector import ...` as the FIRST thing a user does (the import system
+    does not consult a module-level __getattr__ for submodules: a meta-path finder maps them)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from fastmot.mot import MOT\n"
+            "import fastmot.detector, fastmot.feature_extractor, fastmot.utils\n"
+            "import fastmot_amd.mot, fastmot_amd.detector\n"
+            "assert MOT is fastmot_amd.mot.MOT and fastmot.detector is fastmot_amd.detector\n"
+            "assert sys.modules['fastmot.mot'] is fastmot_amd.mot\n"
+            "try:\n"
+            "    import fastmot.no_such_module\n"
+            "    raise SystemExit('imported a module that does not exist')\n"
+            "except ModuleNotFoundError:\n"
+            "    pass\n" % str(ROOT))
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]

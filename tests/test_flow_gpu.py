@@ -221,18 +221,13 @@ def test_prepare_matches_staged_calls(ctx):
 @pytest.mark.parametrize('hammer', ['liteconv', 'osnet'])
 def test_lk_deterministic_while_other_streams_are_busy(ctx, hammer):
     """LK on constant inputs must reproduce its idle result bit for bit while another host thread keeps the CUs busy
-    with the ReID network's kernels.
+    with the ReID network's kernels -- an ORDINARY launch (4-point workgroups, no whole-CU request, no ordering).
 
-    History: round 1 found single points changing in 50-80 % of the calls with two points per wavefront and blamed
-    the diverging halves.  Round 2 (scripts/stress_lk4.py .. stress_lk6.py, profiles/r02_lk_disturbance.txt) narrowed
-    it down: among the ReID network's kernels only the two fused LightConv kernels (liteconv_kernel,
-    litechain_kernel) disturb the LK kernel, only when their workgroups are resident on the same CU; conv / pool /
-    gate / head launches never do, the images stay intact, the networks themselves and the Kalman / cost kernels
-    reproduce bit for bit under the same load (scripts/stress_nets.py).  The cause is not known (an early "SGPR spill
-    code" explanation did not survive: the OSNet-x0.25 instances of the chain kernel have none).  The stand-alone LK
-    launch tested here therefore requests 150 KB of LDS per 16-wavefront workgroup so that nothing shares its CU:
-    0 of 600 calls differ.  (MOT.step orders the ReID network behind the LK kernel instead:
-    test_unisolated_lk_beside_the_detector guards the other half of that arrangement.)"""
+    History: rounds 1-2 saw single points change by 1e-5 .. 6 px in up to 70 % of such calls, traced it to the two
+    fused LightConv kernels being resident on the same CU, and shipped isolation / ordering around an unknown cause.
+    Round 3 captured disturbed calls (scripts/lk_bisect.py): the packed-fp32 form the compiler had chosen for the
+    position update returned a wrong low half in lanes 48..63 (csrc/flow.hip lk_wave_body, csrc/diag.hip); without
+    packed fp32 in the KLT kernels 0 of 5.1 M iterations disagree under the same load."""
     import threading
     from fastmot_amd.detector import DeviceFrame
     from fastmot_amd.engine import HipNet, NET_EXTRACTOR
@@ -285,11 +280,10 @@ def test_lk_deterministic_while_other_streams_are_busy(ctx, hammer):
     assert bad == 0
 
 
-def test_unisolated_lk_beside_the_detector(ctx):
-    """What the LK / ReID ordering of MOT.step relies on: with `lk_isolation` off (ordinary 4-point workgroups, no
-    whole-CU request) the LK kernel reproduces its idle result bit for bit while the DETECTOR network -- every conv
-    kernel variant YOLOv4@608 uses -- runs on another stream.  A conv kernel that disturbs it shows up here (one
-    did: the two-pixel-tile streamed conv of late round 2, which is therefore not used)."""
+def test_lk_beside_the_detector(ctx):
+    """... and while the DETECTOR network -- every conv kernel variant YOLOv4@608 uses, the LDS-halo and two-pixel-tile
+    streamed convs of late round 2 included (they were switched off then because this test failed with them) -- runs on
+    another stream."""
     import threading
     from fastmot_amd.detector import DeviceFrame
     from fastmot_amd.engine import HipNet, NET_DETECTOR
@@ -311,7 +305,6 @@ def test_unisolated_lk_beside_the_detector(ctx):
     ctx.synchronize()
     rng = np.random.default_rng(0)
     pts = np.stack([rng.uniform(20, size[0] / 2 - 20, 600), rng.uniform(20, size[1] / 2 - 20, 600)], 1).astype(np.float32)
-    ctx.set_option('lk_isolation', 0)
     stop = []
 
     def hammer_loop():
@@ -334,29 +327,5 @@ def test_unisolated_lk_beside_the_detector(ctx):
             stop.append(1)
             th.join()
     finally:
-        ctx.set_option('lk_isolation', 1)
         net.close()
     assert bad == 0, f'{bad} of 300 LK calls differ beside the detector network'
-
-
-def test_lk_reid_ordering_protocol(ctx):
-    """fm_flow_arm / fm_flow_wait_lk / fm_flow_release (the LK / ReID ordering MOT.step relies on): nothing armed ->
-    done at once; armed -> the wait times out until the prediction has passed its LK launch or was released."""
-    assert ctx.flow_wait_lk(0)
-    ctx.flow_arm()
-    try:
-        assert not ctx.flow_wait_lk(300)
-    finally:
-        ctx.flow_release()
-    assert ctx.flow_wait_lk(0)
-    # an armed prediction that runs to its LK kernel flips the flag itself
-    size = (640, 360)
-    flow = make_flow(size)
-    flow.init(textured_frame(*size, 11))
-    ctx.flow_arm()
-    try:
-        boxes, H = flow.predict(textured_frame(*size, 11, shift=(6, -4)), [FakeTrack(1, [100, 100, 170, 300])])
-        assert H is not None
-        assert ctx.flow_wait_lk(0)
-    finally:
-        ctx.flow_release()

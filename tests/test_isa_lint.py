@@ -1,0 +1,60 @@
+"""Build-time guard over the gfx950 code of every kernel in the library.
+
+Round 3 traced the LK results that differed under load to ONE instruction form: packed-fp32 VALU
+arithmetic whose LOW result reads the HIGH register of a source pair (`v_pk_mul_f32 ... op_sel:[0,1]`; the SLP
+vectoriser emits it for cross terms like a*d - b*c).  On MI355X it returns a wrong low half in lanes 48..63 now and
+then while wavefronts of the fused LightConv kernels share the CU (csrc/diag.hip reproduces it stand alone).  The
+half-straight forms (`op_sel_hi` broadcasts, no `op_sel` bit) occur in every conv epilogue and were never seen wrong
+(networks bit-reproducible under the same load, 5.1 M LK iterations with 0 disagreeing lanes after the change).
+This test compiles every source to assembly with the flags of the build and refuses the form anywhere but in the
+reproducer's hand-written chain."""
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+from fastmot_amd import build as fm_build
+
+PACKED = re.compile(r'^\s*(v_pk_(?:mul|add|fma)_f32)\b(.*)$')
+OPSEL = re.compile(r'op_sel:\[([01,]+)\]')
+
+
+def _asm(src, tmp):
+    out = tmp / (src.stem + '.s')
+    cmd = [fm_build.HIPCC] + [f for f in fm_build.FLAGS if f not in ('-shared', '-fPIC')] + \
+        fm_build.FILE_FLAGS.get(src.name, []) + ['-S', '--cuda-device-only', '-o', str(out), str(src)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return src.name, out.read_text()
+
+
+def test_no_cross_half_packed_fp32(tmp_path):
+    with ThreadPoolExecutor(8) as ex:
+        listings = list(ex.map(lambda s: _asm(s, tmp_path), fm_build.sources()))
+    offenders = []
+    n_packed = 0
+    for name, text in listings:
+        for line in text.splitlines():
+            m = PACKED.match(line)
+            if not m:
+                continue
+            n_packed += 1
+            sel = OPSEL.search(m.group(2))
+            if sel and '1' in sel.group(1) and name != 'diag.hip':        # (diag.hip: the reproducer's hand-written chain)
+                offenders.append(f'{name}: {line.strip()}')
+    assert n_packed > 500          # (the conv epilogues: the listing really is the device code)
+    assert not offenders, 'packed fp32 with a cross-half op_sel:\n' + '\n'.join(offenders[:20])
+
+
+def test_klt_kernels_have_no_modified_packed_fp32(tmp_path):
+    """flow.hip is built without the SLP vectoriser: what packed fp32 remains (loop-vectorised adds of the corner
+    selection) is the straight form, and the LK kernels contain none at all."""
+    _, text = _asm(fm_build.CSRC / 'flow.hip', tmp_path)
+    in_lk = False
+    for line in text.splitlines():
+        if line.startswith('_Z'):
+            in_lk = 'lk_wave_kernel' in line or 'lk_diag_kernel' in line
+        m = PACKED.match(line)
+        if m:
+            assert not in_lk, line
+            assert 'op_sel' not in m.group(2), line
