@@ -17,6 +17,7 @@ import numpy as np
 from . import _lib, models
 from .engine import HipNet, NET_DETECTOR
 from .runtime import get_context
+from .utils.setorder import IntSet
 
 DET_DTYPE = _lib.DET_DTYPE
 
@@ -203,7 +204,7 @@ class SSDDetector(Detector):
         links to every detection of the same class in ANOTHER tile whose intersection-over-minimum is >= thresh
         and exceeds every earlier candidate of that tile (scan in index order: running maxima are all kept);
         connected groups collapse into their first member (enclosing box, maximum confidence); the survivors
-        are returned in index order, then argsorted by class."""
+        are returned in the iteration order of the reference's (Numba) set, then argsorted by class."""
         n = len(dets)
         if n == 0:
             return dets
@@ -225,7 +226,7 @@ class SSDDetector(Detector):
                     mine.append(int(j))
             links.append(mine)
         seen = np.zeros(n, bool)
-        keep = np.ones(n, bool)
+        keep = IntSet(n)            # `keep = set(range(len(dets)))` inside @njit: Numba's set, its iteration order
         out = dets.copy().view(np.recarray)
         for i in range(n):
             if not links[i] or seen[i]:
@@ -242,8 +243,8 @@ class SSDDetector(Detector):
                 out.tlbr[i] = np.concatenate([np.minimum(out.tlbr[i, :2], out.tlbr[k, :2]),
                                               np.maximum(out.tlbr[i, 2:], out.tlbr[k, 2:])])
                 out.conf[i] = max(out.conf[i], out.conf[k])
-                keep[k] = False
-        out = out[np.flatnonzero(keep)]
+                keep.discard(k)
+        out = out[np.array(list(keep), np.int64)]
         return out[np.argsort(out.label)].view(np.recarray)
 
 

@@ -23,6 +23,7 @@ from .flow import Flow
 from .detector import bind_frame
 from .kalman_filter import KalmanFilter
 from .runtime import get_context
+from .utils.setorder import unmatched_order
 
 LOGGER = logging.getLogger(__name__)
 
@@ -223,9 +224,10 @@ class MultiTracker:
 
     @staticmethod
     def _assignment_matches(nr, nc, row_ids, col_ids, m_rows, m_cols, gated):
-        """utils/matching.py:58-70 -- same expressions, hence the same CPython set order."""
-        unmatched_rows = list(set(range(nr)) - set(m_rows))
-        unmatched_cols = list(set(range(nc)) - set(m_cols))
+        """utils/matching.py:58-70.  The two set differences run inside @njit in the reference: their iteration order
+        is that of Numba's hash set, not CPython's (utils/setorder.py)."""
+        unmatched_rows = unmatched_order(nr, m_rows)
+        unmatched_cols = unmatched_order(nc, m_cols)
         unmatched_row_ids = [row_ids[row] for row in unmatched_rows]
         unmatched_col_ids = [col_ids[col] for col in unmatched_cols]
         matches = []

@@ -18,6 +18,8 @@ Third-party arithmetic the reference delegates to:
 import numpy as np
 from scipy.optimize import linear_sum_assignment
 
+import numba_set
+
 INF_COST = 1e5            # utils/matching.py:7
 CHI_SQ_INV_95 = 9.4877    # utils/matching.py:6
 
@@ -308,12 +310,12 @@ def lsa(cost):
 
 def assignment_matches(cost, m_rows, m_cols):
     """utils/matching.py:58-70 on local indices: matches, unmatched rows, unmatched cols.
-    The unmatched lists are `list(set(range(n)) - set(matched))`: CPython hash-table order, which
-    is NOT always ascending (e.g. {6, 8} iterates 8, 6) -- reproduced with the same expression
-    because it decides the order in which new track IDs are handed out."""
+    The unmatched lists are `list(set(range(n)) - set(matched))` evaluated INSIDE @njit: the iteration order of
+    Numba's hash set (numba_set.py), which is neither ascending nor CPython's in general -- reproduced because it
+    decides the order in which new track IDs are handed out."""
     nr, nc = cost.shape
-    u_rows = list(set(range(nr)) - set(int(r) for r in m_rows))
-    u_cols = list(set(range(nc)) - set(int(c) for c in m_cols))
+    u_rows = numba_set.difference_order(nr, [int(r) for r in m_rows])
+    u_cols = numba_set.difference_order(nc, [int(c) for c in m_cols])
     matches = []
     for r, c in zip(m_rows, m_cols):
         if cost[r, c] < INF_COST:

@@ -12,7 +12,10 @@ section 8c).  Recipe (proven during the survey):
   * synthetic package objects for fastmot, fastmot.utils, fastmot.models with
     __path__ set, so the real __init__.py files are never executed.
 Caveat: numba `fastmath`/`parallel` reassociation is NOT reproduced; the shim
-yields the IEEE sequential answer of the reference source.
+yields the IEEE sequential answer of the reference source.  One Numba semantic
+IS reproduced because it is observable in the track IDs: inside @njit functions
+the builtin `set` is Numba's hash set (restated in oracle/numba_set.py), whose
+iteration order differs from CPython's (matching.py:59-60, detector.py:196).
 
 /root/reference only exists in the build container; nothing on the GPU box may
 call load_reference().
@@ -30,13 +33,30 @@ def reference_available():
     return (REF_ROOT / 'fastmot' / 'tracker.py').exists()
 
 
+def _numba_semantics(fn):
+    """What the jitted body would see where CPython differs observably: the builtin `set` inside @njit code is Numba's
+    own hash set, whose iteration order is not CPython's (oracle/numba_set.py).  The function object is rebuilt over a
+    copy of its module globals in which `set` is that container; the reference's source stays untouched.  Only
+    functions that mention `set` are rebuilt (closures and everything else pass through)."""
+    if not isinstance(fn, types.FunctionType) or 'set' not in fn.__code__.co_names or fn.__closure__:
+        return fn
+    import numba_set
+    g = dict(fn.__globals__)
+    g['set'] = numba_set.NumbaIntSet
+    out = types.FunctionType(fn.__code__, g, fn.__name__, fn.__defaults__, None)
+    out.__kwdefaults__ = fn.__kwdefaults__
+    out.__dict__.update(fn.__dict__)
+    out.__doc__ = fn.__doc__
+    return out
+
+
 def _fake_numba():
     nb = types.ModuleType('numba')
 
     def _decorator(*args, **kwargs):
         if len(args) == 1 and callable(args[0]) and not kwargs:
-            return args[0]
-        return lambda fn: fn
+            return _numba_semantics(args[0])
+        return _numba_semantics
 
     nb.njit = _decorator
     nb.jit = _decorator
