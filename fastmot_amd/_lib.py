@@ -666,6 +666,28 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_lk_diag_read(self._ctx, _ptr(counters), C.c_int(n_capture), _ptr(hdr), _ptr(rec)))
         return counters, hdr, rec
 
+    def gallery_unique_id(self):
+        buf = C.create_string_buffer(128)
+        check(self.lib.fm_gallery_unique_id(buf))
+        return buf.raw
+
+    def gallery_init(self, world, rank, unique_id, row_bytes):
+        assert len(unique_id) == 128
+        check(self.lib.fm_gallery_init(self._ctx, C.c_int(world), C.c_int(rank), C.c_char_p(unique_id), C.c_size_t(row_bytes)))
+
+    def gallery_allgather_async(self, row):
+        row = np.ascontiguousarray(row, np.uint8)
+        check(self.lib.fm_gallery_allgather_async(self._ctx, _ptr(row)))
+
+    def gallery_allgather_wait(self, world, row_bytes):
+        out = np.empty(world * row_bytes, np.uint8)
+        ms = C.c_float(0)
+        check(self.lib.fm_gallery_allgather_wait(self._ctx, _ptr(out), C.byref(ms)))
+        return out, float(ms.value)
+
+    def gallery_destroy(self):
+        check(self.lib.fm_gallery_destroy(self._ctx))
+
     def diag_pkhaz(self, variant, waves=600, iters=2000):
         out = np.zeros(8, np.int32)
         check(self.lib.fm_diag_pkhaz(self._ctx, C.c_int(variant), C.c_int(waves), C.c_int(iters), _ptr(out)))
@@ -707,7 +729,8 @@ def _bind_flow(cls):
     for fn in (flow_configure, flow_init, flow_begin, track_predict_async,
                track_predict_wait, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
                flow_background,
-               flow_lk, flow_lk_diag, diag_pkhaz, diag_pkhaz2, flow_estimate, flow_read_image):
+               flow_lk, flow_lk_diag, diag_pkhaz, diag_pkhaz2, gallery_unique_id, gallery_init,
+               gallery_allgather_async, gallery_allgather_wait, gallery_destroy, flow_estimate, flow_read_image):
         setattr(cls, fn.__name__, fn)
 
 

@@ -81,6 +81,7 @@ struct NetState;     // conv engine (net.hip)
 struct DetState;     // detector pre/post (detect.hip)
 struct ExtState;     // extractor pre (extract.hip)
 struct FlowState;    // KLT (flow.hip)
+struct GalleryState; // cross-stream ReID-gallery all-gather over RCCL (gallery.hip)
 
 struct fm_ctx {
     int device = 0;
@@ -151,7 +152,9 @@ struct fm_ctx {
     NetState* ext_net = nullptr;
     NetState* ext_net_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // FM_NET_EXTRACTOR_B + i: further parts of a split batch
     FlowState* flow = nullptr;
+    GalleryState* gallery = nullptr;
 };
 
 int fm_ensure_slots(fm_ctx* ctx, int max_slot_plus_1);
 void fm_predict_worker_free(fm_ctx* ctx);
+void fm_gallery_free(fm_ctx* ctx);

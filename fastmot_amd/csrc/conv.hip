@@ -399,7 +399,7 @@ int launch_cfg_tap(const ConvParams& p, int S, float* ws, hipStream_t s) {
     q.grid_z = S;
     // operand bytes: weights vs. (im2col-free) input; the heavier one gets the XCD-private slice
     q.weight_major = (size_t)cout_pad * p.Kpad > (size_t)p.N * p.H * p.W * p.Cin ? 1 : 0;
-    static const int force = [] { const char* e = getenv("FASTMOT_CONV_ORDER"); return e ? atoi(e) : -1; }();
+    constexpr int force = -1;
     if (force >= 0) q.weight_major = force;
     const int total = q.grid_p * q.grid_c * q.grid_z;
     dim3 grid(((total + 7) / 8) * 8);
@@ -439,9 +439,9 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
     auto tiles = [&](int bmc, int bnp) { return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc); };
     const int nk = p.Kpad / BK;
     // a split costs a second (reduce) launch, ~5 us: only worth it when it removes >= ~12 K-steps
-    static const int split_min_nk = [] { const char* e = getenv("FASTMOT_SPLIT_MIN_NK"); return e ? atoi(e) : 16; }();
-    static const int split_target = [] { const char* e = getenv("FASTMOT_SPLIT_TARGET"); return e ? atoi(e) : 384; }();
-    static const int split_min_steps = [] { const char* e = getenv("FASTMOT_SPLIT_MIN_STEPS"); return e ? atoi(e) : 4; }();
+    constexpr int split_min_nk = 16;
+    constexpr int split_target = 384;
+    constexpr int split_min_steps = 4;
     auto split_for = [&](long t) {
         int S = 1;
         if (t < 256 && nk >= split_min_nk) {
@@ -455,7 +455,7 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
         }
         return S;
     };
-    static const int minb = [] { const char* e = getenv("FASTMOT_CONV_MINB"); return e ? atoi(e) : 2; }();
+    constexpr int minb = 2;
     if (cout_pad <= 32) return launch_cfg<1, 4, 1, 1, 2>(p, 1, ws, s);                   //  32c x 128p
     const long t = tiles(64, 64);
     // many short workgroups (early, memory-bound layers): 128 VGPRs -> 4 workgroups per CU

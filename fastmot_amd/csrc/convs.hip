@@ -429,15 +429,12 @@ int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
     const bool ct2 = ntiles_c % 2 == 0 && (ntiles_c / 2) * npt >= 192;
     const bool nw8 = nq >= 16;                      // >= 2 chunks per wave
     // two pixel tiles as well when the single-tile grid would need a second, mostly empty round of workgroups
-    // NOT USED by default (FASTMOT_CONVS_PT2=1 / FASTMOT_CONVS_HALO=1 enable them): both variants below are faster
-    // (38 x 38 3x3 layers 16.3 -> 15.2 / 12.5 us) and numerically identical, but the un-isolated LK kernel of the KLT
-    // stream stops reproducing its results while they run on the detector stream (tests/test_flow_gpu.py::
-    // test_unisolated_lk_beside_the_detector fails with either of them, passes with the kernels above) --
-    // and the pipeline relies on the detector being harmless to that kernel.
-    static const int pt2_mode = [] { const char* e = getenv("FASTMOT_CONVS_PT2"); return e ? atoi(e) : 1; }();
+    // (both variants below were switched off at the end of round 2 because the LK kernel of the KLT stream stopped
+    // reproducing its results while they ran; round 3 found the cause in the LK kernel's own packed-fp32 code, flow.hip)
+    constexpr int pt2_mode = 1;
     const int wgs1 = (ntiles_c / 2) * npt;
     // 3x3 / stride 1 / pad 1 on one image: input halo staged in LDS once (convs_halo_kernel)
-    static const int halo_mode = [] { const char* e = getenv("FASTMOT_CONVS_HALO"); return e ? atoi(e) : 1; }();
+    constexpr int halo_mode = 1;
     if (halo_mode && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.N == 1 && p.Ho == p.H && p.Wo == p.W &&
         p.up != 2 && (size_t)100 * (p.Cin + 8) * 2 <= 150 * 1024 && nq >= 8) {
         // only where the 8 x 8 tiles waste little (38 x 38: 90 % of the tile pixels exist, 15.2 -> 12.5 us per layer; at

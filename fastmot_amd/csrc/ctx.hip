@@ -65,33 +65,17 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     // short and latency critical (the host waits on them), so they get the higher priority
     int prio_lo = 0, prio_hi = 0;
     FM_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least, hi = greatest priority
-    // Experiment knob (spatial instead of temporal sharing): FASTMOT_CU_MASK_<DET|EXT|FLOW>="lo-hi" pins that
-    // stream to the compute units [lo, hi) of the queue CU mask; a masked stream has no priority.
-    auto make_stream = [&](hipStream_t* st, const char* knob, int prio) -> int {
-        const char* e = getenv(knob);
-        int lo = 0, hi = 0;
-        if (e && sscanf(e, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi > lo && hi <= 1024) {
-            uint32_t mask[32] = {};
-            for (int b = lo; b < hi; ++b) mask[b >> 5] |= 1u << (b & 31);
-            FM_HIP(hipExtStreamCreateWithCUMask(st, (uint32_t)((hi + 31) / 32), mask));
-            return 0;
-        }
-        FM_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio));
-        return 0;
-    };
-    int rc_s;
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, prio_hi));
-    if ((rc_s = make_stream(&ctx->s_det, "FASTMOT_CU_MASK_DET", prio_lo))) return rc_s;
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_lo));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_up, hipStreamNonBlocking, prio_lo));
-    if ((rc_s = make_stream(&ctx->s_ext, "FASTMOT_CU_MASK_EXT", prio_hi))) return rc_s;
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext, hipStreamNonBlocking, prio_hi));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_in, hipEventDisableTiming));
     for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
-        if ((rc_s = make_stream(&ctx->s_ext_x[i], "FASTMOT_CU_MASK_EXT", prio_hi))) return rc_s;
+        FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext_x[i], hipStreamNonBlocking, prio_hi));
         FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_x_done[i], hipEventDisableTiming));
     }
-    const char* fp = getenv("FASTMOT_FLOW_PRIO");   // experiment knob: 0 = flow stream at the detector's (low) priority
-    if ((rc_s = make_stream(&ctx->s_flow, "FASTMOT_CU_MASK_FLOW", fp && atoi(fp) == 0 ? prio_lo : prio_hi))) return rc_s;
-    if ((rc_s = make_stream(&ctx->s_flow2, "FASTMOT_CU_MASK_FLOW", fp && atoi(fp) == 0 ? prio_lo : prio_hi))) return rc_s;
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_flow, hipStreamNonBlocking, prio_hi));
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_flow2, hipStreamNonBlocking, prio_hi));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_pyr, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_bg, hipEventDisableTiming));
@@ -106,6 +90,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     fm_predict_worker_free(ctx);
+    fm_gallery_free(ctx);
     (void)hipDeviceSynchronize();
     if (ctx->det) fm_det_free(ctx->det);
     if (ctx->ext) fm_ext_free(ctx->ext);

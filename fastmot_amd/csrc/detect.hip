@@ -510,28 +510,8 @@ extern "C" int fm_host_free(void* p) {
     return 0;
 }
 
-// H2D frame copy as a kernel reading the page-locked (device-mapped) source (FASTMOT_UPLOAD_KERNEL=1; experiment: the
-// 0.09-0.15 ms the hipMemcpyAsync call takes in front of the prefetched detector pass turned out to be runtime lock
-// contention with the KLT thread's launches -- a kernel launch waits just as long -- so the copy engine stays the default).
-__global__ __launch_bounds__(256) void frame_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
-                                                         const uint8_t* __restrict__ src8, uint8_t* __restrict__ dst8,
-                                                         size_t bytes) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    if (i < n16) reinterpret_cast<u32x4*>(dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + i);
-    if (i == 0)
-        for (size_t b = n16 * 16; b < bytes; ++b) dst8[b] = src8[b];
-}
-
+// H2D copy of a frame from page-locked memory (the copy engine; a copy KERNEL measured no faster in round 2)
 static int enqueue_frame_copy(uint8_t* dst, const uint8_t* src_pinned, size_t bytes, hipStream_t s) {
-    static const int use_kernel = [] { const char* e = getenv("FASTMOT_UPLOAD_KERNEL"); return e ? atoi(e) : 0; }();
-    if (use_kernel && ((uintptr_t)src_pinned & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
-        const size_t n16 = bytes / 16;
-        hipLaunchKernelGGL(frame_copy_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<const uint4*>(src_pinned), reinterpret_cast<uint4*>(dst), n16, src_pinned, dst, bytes);
-        FM_HIP(hipGetLastError());
-        return 0;
-    }
     FM_HIP(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, s));
     return 0;
 }
@@ -574,8 +554,7 @@ extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
     // copy runs on its own stream: it overlaps the tail of the detector pass that is still running on s_det instead
     // of queueing behind it (the detector chain upload -> network -> NMS is the longest chain of a step once the
     // tracker side is fast: 0.12 ms per frame); the pass on this frame waits for the event (detect_async_on).
-    static const bool own_stream = !(getenv("FASTMOT_UPLOAD_STREAM") && atoi(getenv("FASTMOT_UPLOAD_STREAM")) == 0);
-    hipStream_t cs = own_stream ? ctx->s_up : ctx->s_det;
+    hipStream_t cs = ctx->s_up;
     int rc_copy = enqueue_frame_copy(ctx->frame_own2, src, bytes, cs);
     if (rc_copy) return rc_copy;
     if (!ctx->ev_next_upload) FM_HIP(hipEventCreateWithFlags(&ctx->ev_next_upload, hipEventDisableTiming));

@@ -1303,8 +1303,7 @@ int flow_stream(fm_ctx* ctx, hipStream_t* out) {
 
 int build_pyramid(fm_ctx* ctx, FlowState* f, int set, hipStream_t s) {
     const int n = ctx->frame_w * ctx->frame_h;
-    static const bool fused = !(getenv("FASTMOT_PYR_FUSED") && atoi(getenv("FASTMOT_PYR_FUSED")) == 0);
-    if (fused && f->W == 2 * f->lw[0] && f->H == 2 * f->lh[0] && (f->W & 1) == 0) {
+    if (f->W == 2 * f->lw[0] && f->H == 2 * f->lh[0] && (f->W & 1) == 0) {
         // gray + half-resolution image in one pass over the frame; levels 0-2 as one launch each
         // (derivatives + next level); everything from level 3 on in one workgroup
         hipLaunchKernelGGL(gray_half_kernel, dim3((f->lw[0] + 255) / 256, f->lh[0]), dim3(256), 0, s, ctx->frame_cur,
@@ -1395,8 +1394,6 @@ extern "C" int fm_flow_init(fm_ctx* ctx) {
 
 extern "C" int fm_flow_begin(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx && ctx->flow && ctx->frame_cur);
-    static const bool side = !(getenv("FASTMOT_PYR_STREAM") && atoi(getenv("FASTMOT_PYR_STREAM")) == 0);
-    if (!side) return build_pyramid(ctx, ctx->flow, ctx->flow->prev ^ 1, ctx->s_flow);
     hipStream_t s;
     int rc = flow_stream(ctx, &s);          // (a pyramid nobody read: order this one behind it)
     if (rc) return rc;
@@ -1734,7 +1731,6 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     f->nT = nT;
     const int nk = nT ? kp_off[nT] : 0;
     double tp0 = fm_now_ms();
-    static const int out_mode = getenv("FASTMOT_PREP_OUT") ? atoi(getenv("FASTMOT_PREP_OUT")) : 1;
     // ---- host side: integer rects, overlap lists, crop table
     std::vector<int32_t> irect(4 * (size_t)nT), ov_off(nT + 1, 0), ov_idx;
     std::vector<CropArgs> crops(nT);
@@ -1822,11 +1818,10 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     f->v_rects = reinterpret_cast<const int32_t*>(db + o_rect);
     f->v_ov_off = reinterpret_cast<const int32_t*>(db + o_ovoff);
     f->v_ov_idx = reinterpret_cast<const int32_t*>(db + o_ovidx);
-    // results: written by the kernels straight into the pinned, device-mapped block (out_mode 1, default); out_mode 0
-    // keeps the small per-track / per-keypoint arrays in device memory and fetches them with one D2H copy (same
-    // speed, measured; the consumers of needy / min-distance read the device copy either way)
+    // results: written by the kernels straight into the pinned, device-mapped block (a device block + one D2H copy
+    // measured the same; the consumers of needy / min-distance read device copies either way)
     char* ho = f->tgt_out.host<char>();      // pinned, device accessible
-    char* dbo = out_mode == 1 ? ho : f->tgt_out.dev<char>();     // (1: zero-copy stores, A/B experiments)
+    char* dbo = ho;
     int32_t* tot_host = reinterpret_cast<int32_t*>(ho + q_tot);
     int32_t* tot = reinterpret_cast<int32_t*>(db + o_tot);             // device counters: [0] new pts, [1] bg pts
     if (nT) {
@@ -1851,8 +1846,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     // background keypoints under the final mask: four small dependent launches that share nothing with the per-track
     // branch above except the uploaded rects -- they run on the side stream (behind the new frame's pyramid, which is
     // shorter than the per-track branch) and join at the end of the call
-    static const bool bg_side = !(getenv("FASTMOT_BG_STREAM") && atoi(getenv("FASTMOT_BG_STREAM")) == 0);
-    hipStream_t sb = bg_side ? ctx->s_flow2 : s;
+    hipStream_t sb = ctx->s_flow2;
     const int bw = f->cfg.bg_w, bh = f->cfg.bg_h;
     // (the fork event is recorded behind the upload only: the branch must not wait for the per-track kernels)
     hipLaunchKernelGGL(resize_linear_kernel, dim3((bw + 255) / 256, bh), dim3(256), 0, sb, f->gray[f->prev], f->W,
@@ -1860,22 +1854,19 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, sb, f->bg_img, bw, bh,
                        f->cfg.fast_thresh, f->bg_flags);
     uint8_t* d_flag = reinterpret_cast<uint8_t*>(f->bg_flags + (size_t)bw * bh + 8);
-    if (bg_side) FM_HIP(hipStreamWaitEvent(sb, ctx->ev_prep, 0));
+    FM_HIP(hipStreamWaitEvent(sb, ctx->ev_prep, 0));
     hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, sb, f->bg_flags, bw, bh, f->v_rects,
                        nT, f->W, f->H, d_flag);
     // the last kernels of the two branches put the totals into the result block
     hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, sb, d_flag, bw, bh,
-                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, bg_side ? nullptr : tot,
+                       reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, nullptr,
                        reinterpret_cast<int32_t*>(dbo + q_tot));
-    if (bg_side) {
-        FM_HIP(hipEventRecord(ctx->ev_bg, sb));
-        hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(1), 0, s, tot, reinterpret_cast<int32_t*>(dbo + q_tot));
-    }
+    FM_HIP(hipEventRecord(ctx->ev_bg, sb));
+    hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(1), 0, s, tot, reinterpret_cast<int32_t*>(dbo + q_tot));
     FM_HIP(hipGetLastError());
-    if (out_mode != 1) FM_HIP(hipMemcpyAsync(ho, dbo, q_pts, hipMemcpyDeviceToHost, s));
     g_flow_sub[2] += fm_now_ms() - tp0; tp0 = fm_now_ms();
     FM_HIP(hipStreamSynchronize(s));
-    if (bg_side) FM_HIP(hipEventSynchronize(ctx->ev_bg));
+    FM_HIP(hipEventSynchronize(ctx->ev_bg));
     g_flow_sub[3] += fm_now_ms() - tp0;
     if (nT) {
         memcpy(area_out, ho + q_area, 4 * (size_t)nT);

@@ -1,0 +1,170 @@
+// Cross-stream ReID-gallery all-gather behind the C ABI (fm_gallery_allgather).  NOT in the reference
+// (single process, single stream): with one video stream per GPU the only exchange between the ranks is every rank's
+// lost-track gallery -- one fixed-size row per rank (header + {id, label, count} + average features, ~104 KB), see
+// fastmot_amd/gallery.py for the wire format and the protocol.
+//
+// RCCL is bound at run time (dlopen librccl.so on the first fm_gallery_* call): a single-GPU deployment never loads
+// it, and the library has no link-time dependency on it.  The collective runs on its own stream: H2D of the local row
+// from pinned staging, ncclAllGather over xGMI, D2H of all rows, completion event -- fm_gallery_allgather_async returns
+// after the enqueue, fm_gallery_allgather_wait publishes the rows (normally long finished: the tracker asks for them
+// one detector frame later).  The payload is latency bound (<= 832 KB for 8 ranks): one collective per exchange.
+#include "common.h"
+#include <dlfcn.h>
+#include <cstring>
+
+namespace {
+
+constexpr int kUniqueIdBytes = 128;                 // NCCL_UNIQUE_ID_BYTES (rccl.h)
+struct UniqueId { char internal[kUniqueIdBytes]; };
+typedef void* Comm;
+
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, Comm, hipStream_t) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (r.handle) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+        }
+    }
+    if (!r.handle || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) {
+        fm_set_error("librccl.so could not be loaded: %s", r.handle ? "missing symbols" : dlerror());
+        return nullptr;
+    }
+    return &r;
+}
+
+#define FM_RCCL(call)                                                                                   \
+    do {                                                                                                \
+        const int rc_ = (call);                                                                         \
+        if (rc_ != 0) {                                                                                 \
+            fm_set_error("%s:%d RCCL error %d: %s", __FILE__, __LINE__, rc_,                            \
+                         r->GetErrorString ? r->GetErrorString(rc_) : "?");                             \
+            return FM_ERR_HIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+}  // namespace
+
+struct GalleryState {
+    Comm comm = nullptr;
+    int world = 0, rank = 0;
+    size_t row_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *send_host = nullptr, *recv_host = nullptr;      // pinned
+    void *send_dev = nullptr, *recv_dev = nullptr;
+    bool pending = false;
+};
+
+void fm_gallery_free(fm_ctx* ctx) {
+    GalleryState* g = ctx->gallery;
+    if (!g) return;
+    if (g->pending) (void)hipEventSynchronize(g->ev1);
+    if (g->comm) {
+        Rccl* r = rccl();
+        if (r) (void)r->CommDestroy(g->comm);
+    }
+    for (void* p : {g->send_dev, g->recv_dev})
+        if (p) (void)hipFree(p);
+    for (void* p : {g->send_host, g->recv_host})
+        if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : {g->ev0, g->ev1})
+        if (e) (void)hipEventDestroy(e);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    ctx->gallery = nullptr;
+}
+
+// rank 0 creates the communicator id; the application hands the 128 bytes to the other ranks (any channel)
+extern "C" int fm_gallery_unique_id(char* out128) {
+    FM_CHECK_ARG(out128);
+    Rccl* r = rccl();
+    if (!r) return FM_ERR_STATE;
+    UniqueId id;
+    FM_RCCL(r->GetUniqueId(&id));
+    memcpy(out128, id.internal, kUniqueIdBytes);
+    return 0;
+}
+
+// collective over all ranks: joins the communicator `id128` as rank `rank` of `world` on the context's device
+extern "C" int fm_gallery_init(fm_ctx* ctx, int world, int rank, const char* id128, size_t row_bytes) {
+    FM_CHECK_ARG(ctx && id128 && world >= 1 && rank >= 0 && rank < world && row_bytes > 0 && row_bytes % 8 == 0);
+    if (ctx->gallery) fm_gallery_free(ctx);
+    Rccl* r = rccl();
+    if (!r) return FM_ERR_STATE;
+    FM_HIP(hipSetDevice(ctx->device));
+    GalleryState* g = new GalleryState();
+    ctx->gallery = g;
+    g->world = world; g->rank = rank; g->row_bytes = row_bytes;
+    FM_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    FM_HIP(hipEventCreate(&g->ev0));
+    FM_HIP(hipEventCreate(&g->ev1));
+    FM_HIP(hipHostMalloc(&g->send_host, row_bytes, hipHostMallocDefault));
+    FM_HIP(hipHostMalloc(&g->recv_host, row_bytes * world, hipHostMallocDefault));
+    FM_HIP(hipMalloc(&g->send_dev, row_bytes));
+    FM_HIP(hipMalloc(&g->recv_dev, row_bytes * world));
+    UniqueId id;
+    memcpy(id.internal, id128, kUniqueIdBytes);
+    FM_RCCL(r->CommInitRank(&g->comm, world, id, rank));
+    return 0;
+}
+
+// enqueues one all-gather of this rank's row (row_bytes, copied before the call returns); collective
+extern "C" int fm_gallery_allgather_async(fm_ctx* ctx, const void* send_row) {
+    FM_CHECK_ARG(ctx && ctx->gallery && send_row);
+    GalleryState* g = ctx->gallery;
+    if (g->pending) {
+        fm_set_error("an all-gather is already in flight (fm_gallery_allgather_wait first)");
+        return FM_ERR_STATE;
+    }
+    Rccl* r = rccl();
+    if (!r) return FM_ERR_STATE;
+    memcpy(g->send_host, send_row, g->row_bytes);
+    FM_HIP(hipEventRecord(g->ev0, g->stream));
+    FM_HIP(hipMemcpyAsync(g->send_dev, g->send_host, g->row_bytes, hipMemcpyHostToDevice, g->stream));
+    FM_RCCL(r->AllGather(g->send_dev, g->recv_dev, g->row_bytes, 1 /* ncclUint8 */, g->comm, g->stream));
+    FM_HIP(hipMemcpyAsync(g->recv_host, g->recv_dev, g->row_bytes * g->world, hipMemcpyDeviceToHost, g->stream));
+    FM_HIP(hipEventRecord(g->ev1, g->stream));
+    g->pending = true;
+    return 0;
+}
+
+// waits for the in-flight all-gather and copies the world * row_bytes rows (rank-major) out; stream_ms_out (optional):
+// time the exchange occupied its stream
+extern "C" int fm_gallery_allgather_wait(fm_ctx* ctx, void* recv_rows, float* stream_ms_out) {
+    FM_CHECK_ARG(ctx && ctx->gallery && recv_rows);
+    GalleryState* g = ctx->gallery;
+    if (!g->pending) {
+        fm_set_error("no all-gather in flight");
+        return FM_ERR_STATE;
+    }
+    FM_HIP(hipEventSynchronize(g->ev1));
+    g->pending = false;
+    memcpy(recv_rows, g->recv_host, g->row_bytes * g->world);
+    if (stream_ms_out) FM_HIP(hipEventElapsedTime(stream_ms_out, g->ev0, g->ev1));
+    return 0;
+}
+
+extern "C" int fm_gallery_destroy(fm_ctx* ctx) {
+    FM_CHECK_ARG(ctx);
+    fm_gallery_free(ctx);
+    return 0;
+}

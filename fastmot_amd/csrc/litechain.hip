@@ -283,9 +283,8 @@ int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     for (int i = 0; i < 4; ++i) gaps.p[i] = gap ? gap[i] : nullptr;
     const long wgs = (long)N * tiles_x * tiles_y * 4;
     const dim3 grid((unsigned)(wgs / 4), 4);
-    // few workgroups: wider ones (see the kernel); FASTMOT_LCH_THREADS forces a width (A/B runs, tests)
-    static const int forced = [] { const char* e = getenv("FASTMOT_LCH_THREADS"); return e ? atoi(e) : 0; }();
-    const int nthr = forced ? forced : wgs <= 384 ? 512 : 256;
+    // few workgroups: wider ones (see the kernel)
+    const int nthr = wgs <= 384 ? 512 : 256;
 #define LCH_LAUNCH_T(NT_, KS_, NTHR_)                                                                             \
     hipLaunchKernelGGL((litechain_kernel<NT_, KS_, NTHR_>), grid, dim3(NTHR_), shmem, s, in, in_cs, in_coff, out, \
                        out_cs, out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act, gaps, S,   \

@@ -3,7 +3,6 @@
 extract_async crops / resizes / normalises on the GPU straight from the resident frame and runs
 OSNet for all boxes (batches of `batch_size`); postprocess returns the L2-normalised embeddings as a
 host array and leaves a copy on the device for MultiTracker.update (no re-upload)."""
-import os
 
 import numpy as np
 
@@ -15,7 +14,7 @@ from .runtime import get_context
 
 class FeatureExtractor:
     def __init__(self, model='OSNet025', batch_size=16, weights=None, size=None, reuse_buffers=True,
-                 split_batches=int(os.environ.get('FASTMOT_EXT_SPLIT', '1')), resident=True):
+                 split_batches=1, resident=True):
         """model : name of a class that inherits `models.ReID`; batch_size : samples per network
         launch (fastmot/feature_extractor.py:12-25).  `size` (frame width, height) is only needed
         when the extractor is used without a detector having bound the frame first.  `resident=False`
@@ -30,7 +29,7 @@ class FeatureExtractor:
         self.ctx.feat_configure(self.feature_dim)
         self.graph, _ = self.model.build_graph(weights)
         self._reuse_buffers = reuse_buffers
-        self._split_batches = max(1, min(int(split_batches), 4))
+        self._split_batches = max(1, min(int(split_batches), 4))     # (default 1: more parts measured slower)
         self.backend = None
         self.extra_backends = []
         self.last_num_features = 0

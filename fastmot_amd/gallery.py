@@ -4,8 +4,8 @@ NOT in the reference (which is single process, single stream).  Streams shard na
 with no data-path collective; the only optional exchange is an all-gather of every rank's lost-track
 gallery (MultiTracker.hist_tracks: <= history_size entries of {track id, label, feature count,
 512-d average feature}, ~104 KB per rank) so that an identity that left camera A can be re-identified
-on camera B.  It runs through torch.distributed: backend "nccl" is RCCL on ROCm (xGMI), "gloo" is
-used by the CPU tests.  The payload is latency bound (<= 832 KB for 8 ranks): ONE fixed-size all_gather
+on camera B.  It runs through the library's C ABI (fm_gallery_*: RCCL's ncclAllGather over xGMI, bound in
+csrc/gallery.hip, no torch at run time); the multi-process CPU tests inject a torch.distributed "gloo" communicator.  The payload is latency bound (<= 832 KB for 8 ranks): ONE fixed-size all_gather
 per exchange, strictly opt-in -- with it disabled every stream's results are bit-identical to a
 single-GPU run.
 
@@ -27,23 +27,118 @@ Foreign entries are appended AFTER the local history rows of the ReID cost matri
 tie-breaks (greedy first-minimum order, tracker.py:229-241) are unchanged; an entry that has been
 matched is consumed (`consume`) and never offered again.
 """
+import os
+import socket
 import time
 
 import numpy as np
 
 
-class GallerySync:
-    def __init__(self, history_size=50, feat_dim=512, period=1, group=None, asynchronous=True):
+class RcclComm:
+    """The collective through the library's C ABI (fm_gallery_*: csrc/gallery.hip binds librccl.so, ncclAllGather on a
+    side stream with pinned staging) -- no torch at run time.  Bootstrap: rank 0 creates the 128-byte communicator id
+    and serves it to the other ranks over one TCP connection each (MASTER_ADDR : MASTER_PORT + 29, the rendezvous
+    variables torchrun / any launcher already exports); world 1 needs no channel."""
+    name = 'rccl'
+    on_gpu = True
+
+    def __init__(self, ctx, row_bytes, rank=None, world=None, addr=None, port=None, unique_id=None, timeout=120.):
+        self.ctx = ctx
+        self.rank = int(os.environ.get('RANK', 0)) if rank is None else rank
+        self.world = int(os.environ.get('WORLD_SIZE', 1)) if world is None else world
+        self.row_bytes = row_bytes
+        if unique_id is None:
+            addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+            port = int(os.environ.get('MASTER_PORT', 29500)) + 29 if port is None else port
+            unique_id = self._bootstrap(addr, port, timeout)
+        ctx.gallery_init(self.world, self.rank, unique_id, row_bytes)
+
+    def _bootstrap(self, addr, port, timeout):
+        if self.rank == 0:
+            uid = self.ctx.gallery_unique_id()
+            if self.world > 1:
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, port))
+                    srv.listen(self.world)
+                    srv.settimeout(timeout)
+                    for _ in range(self.world - 1):
+                        conn, _ = srv.accept()
+                        with conn:
+                            conn.sendall(uid)
+            return uid
+        deadline = time.time() + timeout
+        while True:
+            try:
+                with socket.create_connection((addr, port), timeout=5) as c:
+                    buf = b''
+                    while len(buf) < 128:
+                        chunk = c.recv(128 - len(buf))
+                        if not chunk:
+                            raise ConnectionError('rank 0 closed the bootstrap connection')
+                        buf += chunk
+                    return buf
+            except (ConnectionError, OSError):
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.05)
+
+    def issue(self, row):
+        self.ctx.gallery_allgather_async(row)
+
+    def complete(self):
+        """-> (uint8[world * row_bytes], milliseconds the exchange occupied its stream)"""
+        return self.ctx.gallery_allgather_wait(self.world, self.row_bytes)
+
+    def close(self):
+        self.ctx.gallery_destroy()
+
+
+class TorchComm:
+    """The same exchange through torch.distributed (backend gloo): what the multi-process CPU tests run on."""
+    on_gpu = False
+
+    def __init__(self, row_bytes, group=None):
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
-            raise RuntimeError('torch.distributed must be initialised (backend nccl on GPUs, gloo on CPU)')
+            raise RuntimeError('torch.distributed must be initialised for TorchComm')
         self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.name = dist.get_backend(group)
+        self._send = torch.zeros(row_bytes, dtype=torch.uint8)
+        self._recv = torch.zeros(self.world * row_bytes, dtype=torch.uint8)
+        self._work = None
+
+    def issue(self, row):
+        self._send.numpy()[:] = row
+        self._work = self.dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=True)
+
+    def complete(self):
+        self._work.wait()
+        self._work = None
+        return self._recv.numpy(), None
+
+    def close(self):
+        pass
+
+
+class GallerySync:
+    def __init__(self, history_size=50, feat_dim=512, period=1, group=None, asynchronous=True, comm=None):
+        """comm: the communicator (RcclComm / TorchComm / anything with rank, world, issue(row), complete()).  Default:
+        TorchComm when a gloo process group is initialised (CPU tests), else RcclComm on this process's context with
+        the launcher's RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
         self.history_size, self.feat_dim, self.period = history_size, feat_dim, max(int(period), 1)
-        self.backend = dist.get_backend(group)
-        self.on_gpu = self.backend == 'nccl'
-        self.device = torch.device('cuda', torch.cuda.current_device()) if self.on_gpu else torch.device('cpu')
+        H, D = history_size, feat_dim
+        self._hdr = 32
+        self._meta_bytes = H * 3 * 8
+        self.row_bytes = self._hdr + self._meta_bytes + H * D * 4
+        if comm is None:
+            comm = self._default_comm(group)
+        self.comm = comm
+        self.rank, self.world = comm.rank, comm.world
+        self.backend = comm.name
+        self.on_gpu = comm.on_gpu
         self.asynchronous = asynchronous
         self._calls = 0
         self._consumed = set()     # (rank, trk_id) of foreign entries that were re-identified here
@@ -53,22 +148,17 @@ class GallerySync:
         self._wait_s = 0.
         self._enqueue_s = 0.
         self._gpu_ms = []
+        self._pending = False      # an exchange is in flight
 
-        H, D = history_size, feat_dim
-        self._hdr = 32
-        self._meta_bytes = H * 3 * 8
-        self.row_bytes = self._hdr + self._meta_bytes + H * D * 4
-        # staging: page-locked host mirrors on the GPU path so that both copies are asynchronous
-        pin = self.on_gpu
-        self._send_host = torch.zeros(self.row_bytes, dtype=torch.uint8, pin_memory=pin)
-        self._recv_host = torch.zeros(self.world * self.row_bytes, dtype=torch.uint8, pin_memory=pin)
-        if self.on_gpu:
-            self._send_dev = torch.zeros(self.row_bytes, dtype=torch.uint8, device=self.device)
-            self._recv_dev = torch.zeros(self.world * self.row_bytes, dtype=torch.uint8, device=self.device)
-            self._stream = torch.cuda.Stream(device=self.device)
-            self._ev0 = torch.cuda.Event(enable_timing=True)
-            self._ev1 = torch.cuda.Event(enable_timing=True)
-        self._pending = None       # in-flight exchange: torch Work (cpu) or CUDA event (gpu)
+    def _default_comm(self, group):
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'gloo':
+                return TorchComm(self.row_bytes, group)
+        except ImportError:
+            pass
+        from .runtime import get_context
+        return RcclComm(get_context(), self.row_bytes)
 
     # ------------------------------------------------------------------ wire format
     def pack(self, entries, done=False):
@@ -110,36 +200,22 @@ class GallerySync:
     # ------------------------------------------------------------------ collective
     def _issue(self, entries, done=False):
         t0 = time.perf_counter()
-        torch, dist = self.torch, self.dist
-        self._send_host.numpy()[:] = self.pack(entries, done)
-        if self.on_gpu:
-            # side stream: H2D of the local row, RCCL all-gather, D2H of all rows, completion event
-            with torch.cuda.stream(self._stream):
-                self._ev0.record(self._stream)
-                self._send_dev.copy_(self._send_host, non_blocking=True)
-                dist.all_gather_into_tensor(self._recv_dev, self._send_dev, group=self.group)
-                self._recv_host.copy_(self._recv_dev, non_blocking=True)
-                self._ev1.record(self._stream)
-            self._pending = self._ev1
-        else:
-            self._pending = dist.all_gather_into_tensor(self._recv_host, self._send_host, group=self.group,
-                                                        async_op=True)
+        self.comm.issue(self.pack(entries, done))
+        self._pending = True
         self.n_collectives += 1
         self._enqueue_s += time.perf_counter() - t0
 
     def _complete(self):
         """Waits for the in-flight exchange (normally long finished) and publishes its entries."""
-        if self._pending is None:
+        if not self._pending:
             return
         t0 = time.perf_counter()
-        if self.on_gpu:
-            self._pending.synchronize()
-            self._gpu_ms.append(self._ev0.elapsed_time(self._ev1))
-        else:
-            self._pending.wait()
-        self._pending = None
+        rows, stream_ms = self.comm.complete()
+        self._pending = False
+        if stream_ms is not None:
+            self._gpu_ms.append(stream_ms)
         self._wait_s += time.perf_counter() - t0
-        self.foreign, self._done_seen = self.unpack(self._recv_host.numpy())
+        self.foreign, self._done_seen = self.unpack(rows)
 
     def exchange(self, entries, force=False):
         """Called once per detector frame with the local gallery.  Every `period` calls: publishes the result of
@@ -170,6 +246,7 @@ class GallerySync:
             self._issue([], done=True)
             self._complete()
             rounds += 1
+        self.comm.close()
         return rounds
 
     def stats(self):

@@ -484,6 +484,19 @@ int fm_flow_timing(double* out5, int reset);
  * (2+l) and cur (10+l), 20 bg image) */
 int fm_flow_read_image(fm_ctx* ctx, int which, uint8_t* out, int* w, int* h);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Cross-stream ReID-gallery all-gather (multi-GPU: one process and one fm_ctx per GPU / video stream).  NOT in the
+ * reference, which tracks one stream in one process; the exchanged rows extend the history side of _reid_cost
+ * (tracker.py:355-366).  RCCL (librccl.so) is loaded on the first call.  fm_gallery_unique_id: rank 0 creates the
+ * 128-byte communicator id and the application distributes it; fm_gallery_init (collective) joins it;
+ * fm_gallery_allgather_async (collective) enqueues H2D + ncclAllGather + D2H of one fixed-size row per rank on a
+ * side stream and returns; fm_gallery_allgather_wait copies out the world * row_bytes gathered rows, rank-major. */
+int fm_gallery_unique_id(char* out128);
+int fm_gallery_init(fm_ctx* ctx, int world, int rank, const char* id128, size_t row_bytes);
+int fm_gallery_allgather_async(fm_ctx* ctx, const void* send_row);
+int fm_gallery_allgather_wait(fm_ctx* ctx, void* recv_rows, float* stream_ms_out);
+int fm_gallery_destroy(fm_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

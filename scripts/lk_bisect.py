@@ -83,7 +83,6 @@ ctx.set_option('lk_variant', 0)
 
 def make_hammer():
     if HAMMER == 'yolo':
-        _os.environ['FASTMOT_CONVS_HALO'] = '1'
         g, _ = YOLO.get_model('YOLOv4_608').build_graph()
         net = HipNet(ctx, NET_DETECTOR, g, 1, reuse_buffers=True)
         batch = 1

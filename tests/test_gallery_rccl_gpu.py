@@ -1,7 +1,8 @@
-"""The ReID-gallery exchange on the real backend: one rank, backend "nccl" (= RCCL), in a subprocess (a process group
-must not leak into the rest of the suite).  With a single rank there are no foreign entries, so the tracks must be
-identical to a run without the exchange; what is exercised is the side-stream path itself (pinned staging, H2D,
-all_gather_into_tensor on the RCCL communicator, D2H, completion event, end-of-stream protocol) and its statistics."""
+"""The ReID-gallery exchange on the real backend: one rank on RCCL through the library's C ABI (fm_gallery_*:
+csrc/gallery.hip, librccl.so bound at run time -- NO torch in the process), in a subprocess.  With a single rank
+there are no foreign entries, so the tracks must be identical to a run without the exchange; what is exercised is the
+side-stream path itself (pinned staging, H2D, ncclAllGather on the communicator, D2H, completion event, end-of-stream
+protocol) and its statistics."""
 import json
 import os
 import subprocess
@@ -17,10 +18,6 @@ import json, os, sys
 sys.path[:0] = [%(root)r, %(root)r + '/tests']
 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%(port)r, HSA_ENABLE_IPC_MODE_LEGACY='0', FASTMOT_RANDOM_WEIGHTS='1')
 import numpy as np
-import torch
-import torch.distributed as dist
-torch.cuda.set_device(0)
-dist.init_process_group('nccl', rank=0, world_size=1)
 from types import SimpleNamespace
 import scenes
 import fastmot_amd.mot as mot_mod
@@ -71,7 +68,7 @@ sync = GallerySync(history_size=50, feat_dim=512)
 with_sync, hist = run(sync)
 rounds = sync.close()
 stats = sync.stats()
-dist.destroy_process_group()
+assert 'torch' not in sys.modules, 'the RCCL path must not need torch'
 print('RESULT ' + json.dumps(dict(identical=plain == with_sync, stats=stats, rounds=rounds, foreign=len(sync.foreign),
                                   frames=len(plain), max_hist=hist)))
 '''
