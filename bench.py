@@ -183,24 +183,18 @@ def main():
     ap.add_argument('--no-prefetch', dest='prefetch', action='store_false',
                     help='strictly sequential steps: do not start the detector on frame t+1 during frame t')
     ap.add_argument('--resident', action='store_true', help='frames resident in HBM (no H2D in the timed region)')
+    ap.add_argument('--nms-candidates', type=int, default=1500,
+                    help='candidate boxes per frame the scripted YOLO heads let through conf_thresh (0: purely random heads, none)')
     ap.add_argument('--no-gallery-sync', dest='gallery', action='store_false',
                     help='N > 1: disable the cross-stream ReID-gallery all-gather (RCCL)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
-    import torch
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus}')
-    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if world > 1 and 'FASTMOT_FLOW_THREADS' not in os.environ:
         # N processes share the node's host cores: size every rank's RANSAC worker pool to its share (the library's
         # default assumes the whole machine; its workers and the prediction worker spin, bounded, while they wait)
@@ -211,10 +205,24 @@ def main():
     models.allow_random_weights()          # no weight files offline: seeded random parameters (stated in `data`)
     from fastmot_amd.runtime import get_context
     from fastmot_amd.utils.synthetic import SyntheticVideo
+    ctx = get_context()                    # device = LOCAL_RANK (torchrun convention)
+
+    # Collectives of the harness itself (barrier around the timed region, max over ranks).  Default: the library's own
+    # RCCL binding (fm_gallery_*, control channel) -- the process never imports torch, and the gallery exchange inside
+    # the timed region runs on the same binding.  FASTMOT_BENCH_TORCH=1: torch.distributed "nccl" for both instead.
+    ctl = dist = torch = None
+    if world > 1:
+        if os.environ.get('FASTMOT_BENCH_TORCH', '0') == '1':
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
+            dist.init_process_group('nccl', rank=rank, world_size=world)
+        else:
+            from fastmot_amd.gallery import RcclComm
+            ctl = RcclComm(ctx, 64, channel=1)
 
     size = cfg['size']
     video = SyntheticVideo(size, n_ids=cfg['n_dets'], n_frames=RING, seed=100 + rank)
-    ctx = get_context()
     ctx.frame_configure(size[0], size[1], RING)
     host_frames = ctx.pinned_frames(RING)                 # page-locked host memory = the capture queue
     for i, fr in enumerate(video.frames):
@@ -227,7 +235,7 @@ def main():
     if world > 1 and args.gallery:
         from fastmot_amd.gallery import GallerySync
         sync = GallerySync(history_size=tracker_cfg().history_size, feat_dim=512)
-    mot = build_mot(cfg, video, gallery_sync=sync)
+    mot = build_mot(cfg, video, gallery_sync=sync, nms_candidates=args.nms_candidates)
     Track._count = 0
     mot.reset(1 / 30.)
 
@@ -241,9 +249,11 @@ def main():
         return list(mot.detector.net_ms)
 
     def fence():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
+        ctx.synchronize()                  # hipDeviceSynchronize on this rank's GPU (all streams of the pipeline)
+        if ctl is not None:
+            ctl.barrier()
+        elif dist is not None:
+            torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -279,7 +289,9 @@ def main():
     run(args.warmup, pos, frames, args.prefetch)
     pos += args.warmup
     elapsed, net_ms = timed(args.steps, pos, frames, args.prefetch)
-    if dist is not None:
+    if ctl is not None:
+        elapsed = float(ctl.allgather_small([elapsed]).max())
+    elif dist is not None:
         t = torch.tensor([elapsed], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -321,6 +333,8 @@ def main():
                                     'frames in pinned host memory, H2D per frame included'),
                        'next_frame_prefetch': bool(args.prefetch), 'streams_per_gpu': 1,
                        'parallelism': f'1 stream/GPU x {world}',
+                       'harness_collectives': None if world == 1 else ('torch.distributed nccl' if dist is not None else
+                                                                         'fm_gallery_* control channel (RCCL via the C ABI, no torch in the process)'),
                        'host_threads_per_rank': {'ransac_pool': os.environ.get('FASTMOT_FLOW_THREADS', 'library default'),
                                                  'usable_cpus': usable_cpus()},
                        'gallery_allgather': None if sync is None else sync.stats(),
@@ -353,6 +367,9 @@ def main():
         print(json.dumps(out), flush=True)
     if sync is not None:
         sync.close()
+    if ctl is not None:
+        ctl.barrier()
+        ctl.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

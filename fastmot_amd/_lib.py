@@ -671,22 +671,23 @@ def _bind_flow(cls):
         check(self.lib.fm_gallery_unique_id(buf))
         return buf.raw
 
-    def gallery_init(self, world, rank, unique_id, row_bytes):
+    def gallery_init(self, channel, world, rank, unique_id, row_bytes):
         assert len(unique_id) == 128
-        check(self.lib.fm_gallery_init(self._ctx, C.c_int(world), C.c_int(rank), C.c_char_p(unique_id), C.c_size_t(row_bytes)))
+        check(self.lib.fm_gallery_init(self._ctx, C.c_int(channel), C.c_int(world), C.c_int(rank), C.c_char_p(unique_id),
+                                       C.c_size_t(row_bytes)))
 
-    def gallery_allgather_async(self, row):
+    def gallery_allgather_async(self, channel, row):
         row = np.ascontiguousarray(row, np.uint8)
-        check(self.lib.fm_gallery_allgather_async(self._ctx, _ptr(row)))
+        check(self.lib.fm_gallery_allgather_async(self._ctx, C.c_int(channel), _ptr(row)))
 
-    def gallery_allgather_wait(self, world, row_bytes):
+    def gallery_allgather_wait(self, channel, world, row_bytes):
         out = np.empty(world * row_bytes, np.uint8)
         ms = C.c_float(0)
-        check(self.lib.fm_gallery_allgather_wait(self._ctx, _ptr(out), C.byref(ms)))
+        check(self.lib.fm_gallery_allgather_wait(self._ctx, C.c_int(channel), _ptr(out), C.byref(ms)))
         return out, float(ms.value)
 
-    def gallery_destroy(self):
-        check(self.lib.fm_gallery_destroy(self._ctx))
+    def gallery_destroy(self, channel=0):
+        check(self.lib.fm_gallery_destroy(self._ctx, C.c_int(channel)))
 
     def diag_pkhaz(self, variant, waves=600, iters=2000):
         out = np.zeros(8, np.int32)

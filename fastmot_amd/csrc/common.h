@@ -82,6 +82,7 @@ struct DetState;     // detector pre/post (detect.hip)
 struct ExtState;     // extractor pre (extract.hip)
 struct FlowState;    // KLT (flow.hip)
 struct GalleryState; // cross-stream ReID-gallery all-gather over RCCL (gallery.hip)
+constexpr int FM_GALLERY_CHANNELS = 2;
 
 struct fm_ctx {
     int device = 0;
@@ -152,7 +153,7 @@ struct fm_ctx {
     NetState* ext_net = nullptr;
     NetState* ext_net_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // FM_NET_EXTRACTOR_B + i: further parts of a split batch
     FlowState* flow = nullptr;
-    GalleryState* gallery = nullptr;
+    GalleryState* gallery[2] = {nullptr, nullptr};   // [FM_GALLERY_CHANNELS]
 };
 
 int fm_ensure_slots(fm_ctx* ctx, int max_slot_plus_1);

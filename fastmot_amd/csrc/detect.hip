@@ -210,26 +210,41 @@ __global__ void rows_filter_kernel(const float* __restrict__ rows, int n, Filter
 }
 
 // ------------------------------------------------------------------------------------ sort
-// rank sort by (class asc, box_conf desc, original index asc); K is read from the device counter
-__global__ void rank_sort_kernel(const float* __restrict__ cand, float* __restrict__ sorted,
-                                 const int32_t* __restrict__ counters, int cap) {
+// rank sort by (class asc, box_conf desc, original index asc); K is read from the device counter.  Every workgroup
+// ranks 256 candidates against all K: the sort keys of 256 candidates at a time are staged in LDS as ONE 64-bit integer
+// each -- class (14 bits) | ~bits(box_conf) (32 bits; confidences are non-negative floats, whose bit patterns order
+// like their values) | original index (18 bits) -- and read by all lanes at the same address (broadcast): K^2 integer
+// comparisons from LDS instead of K^2 dependent global reads (K = 1500: 1.24 ms -> ~10 us).
+__device__ __forceinline__ uint64_t sort_key(const float* r) {
+    const uint64_t cls = (uint64_t)(uint32_t)(int)r[5] & 0x3fffull;
+    const uint64_t inv_score = (uint32_t)~__float_as_uint(r[4]);
+    const uint64_t ord = (uint64_t)(uint32_t)__float_as_int(r[7]) & 0x3ffffull;
+    return (cls << 50) | (inv_score << 18) | ord;
+}
+
+__global__ __launch_bounds__(256) void rank_sort_kernel(const float* __restrict__ cand, float* __restrict__ sorted,
+                                                        const int32_t* __restrict__ counters, int cap) {
     const int K = min(counters[0], cap);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K) return;
-    const float* ri = cand + (size_t)i * 8;
-    const float ci = ri[5], si = ri[4];
-    const int oi = __float_as_int(ri[7]);
+    if ((int)blockIdx.x * 256 >= K) return;
+    __shared__ uint64_t keys[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < K;
+    const float* ri = cand + (size_t)(live ? i : 0) * 8;
+    const uint64_t ki = sort_key(ri);
     int rank = 0;
-    for (int j = 0; j < K; ++j) {
-        const float* rj = cand + (size_t)j * 8;
-        const float cj = rj[5], sj = rj[4];
-        const int oj = __float_as_int(rj[7]);
-        const bool before = (cj < ci) || (cj == ci && (sj > si || (sj == si && oj < oi)));
-        rank += before ? 1 : 0;
+    for (int j0 = 0; j0 < K; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        keys[threadIdx.x] = j < K ? sort_key(cand + (size_t)j * 8) : ~0ull;      // (padding keys rank after everything)
+        __syncthreads();
+#pragma unroll 8
+        for (int t = 0; t < 256; ++t) rank += keys[t] < ki ? 1 : 0;
+        __syncthreads();
     }
+    if (!live) return;
     float* o = sorted + (size_t)rank * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = ri[e];
+    const float4 r0 = *reinterpret_cast<const float4*>(ri), r1 = *reinterpret_cast<const float4*>(ri + 4);
+    *reinterpret_cast<float4*>(o) = r0;
+    *reinterpret_cast<float4*>(o + 4) = r1;
 }
 
 // ------------------------------------------------------------------------------------ NMS
@@ -246,6 +261,10 @@ __device__ __forceinline__ bool diou_suppresses(const float* a, const float* b, 
     const double inter = iw * ih;
     const double uni = (double)(area_a + area_b) - inter;
     const double iou = inter / uni;
+    // (d / c)^0.6 >= 0, so DIoU <= IoU: a pair whose IoU does not exceed the threshold is never suppressed -- the
+    // float64 pow (hundreds of instructions) is only evaluated for the few pairs that overlap that much.  A NaN IoU
+    // (degenerate boxes) fails this test and takes the full path, like the reference's arithmetic.
+    if (iou <= thresh) return false;
     const double exmin = fminf(a[0], b[0]), eymin = fminf(a[1], b[1]);
     const double exmax = fmax(abr_x, bbr_x), eymax = fmax(abr_y, bbr_y);
     const double ew = exmax - exmin + 1, eh = eymax - eymin + 1;
@@ -255,88 +274,194 @@ __device__ __forceinline__ bool diou_suppresses(const float* a, const float* b, 
     return !(diou <= thresh);
 }
 
-// mask[i][w] bit b = candidate j = 64*w + b (j > i, same class) is suppressed by i
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sorted,
-                                                      const int32_t* __restrict__ counters, int cap,
-                                                      double thresh, uint64_t* __restrict__ mask) {
+// mask[w][i] bit b = candidate j = 64*w + b (j > i, same class) is suppressed by i.  One workgroup per block of 64
+// rows (lane = row) and 4 column words (one per wavefront), the 64 column boxes of a word staged in LDS.  Workgroups
+// beyond K exit at once (the grid is sized for the capacity, K is only known on the device).
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ sorted,
+                                                       const int32_t* __restrict__ counters, int cap,
+                                                       double thresh, uint64_t* __restrict__ mask) {
     const int K = min(counters[0], cap);
-    const int words = cap / 64;
-    const int i = blockIdx.y * 64 + threadIdx.x;     // row handled by this lane
-    const int w = blockIdx.x;                        // column word
-    if (blockIdx.y * 64 >= K || w * 64 >= K) return;
-    if (w < (int)blockIdx.y) {                       // columns entirely before the rows: nothing
-        if (i < K) mask[(size_t)i * words + w] = 0;
-        return;
-    }
-    __shared__ float cols[64][8];
-    const int j0 = w * 64;
-    {
-        const int j = j0 + threadIdx.x;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cols[threadIdx.x][e] = j < K ? sorted[(size_t)j * 8 + e] : 0.f;
-    }
-    __syncthreads();
-    if (i >= K) return;
+    const int rb = blockIdx.x;
+    const int kw = (K + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = rb + blockIdx.y * 4 + wave;           // this wavefront's column word
+    if (rb * 64 >= K || w >= kw) return;
+    const int i = rb * 64 + lane;
+    __shared__ float cols[4][64][8];
     float a[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = sorted[(size_t)i * 8 + e];
-    uint64_t bits = 0;
-    for (int b = 0; b < 64; ++b) {
-        const int j = j0 + b;
-        if (j <= i || j >= K) continue;
-        if (cols[b][5] != a[5]) continue;
-        if (diou_suppresses(a, cols[b], thresh)) bits |= (1ull << b);
+    {
+        const int ii = min(i, K - 1);
+        const float4 r0 = *reinterpret_cast<const float4*>(sorted + (size_t)ii * 8);
+        const float4 r1 = *reinterpret_cast<const float4*>(sorted + (size_t)ii * 8 + 4);
+        a[0] = r0.x; a[1] = r0.y; a[2] = r0.z; a[3] = r0.w; a[4] = r1.x; a[5] = r1.y; a[6] = r1.z; a[7] = r1.w;
     }
-    mask[(size_t)i * words + w] = bits;
+    {
+        const int j = w * 64 + lane;
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+        if (j < K) {
+            c0 = *reinterpret_cast<const float4*>(sorted + (size_t)j * 8);
+            c1 = *reinterpret_cast<const float4*>(sorted + (size_t)j * 8 + 4);
+        }
+        *reinterpret_cast<float4*>(&cols[wave][lane][0]) = c0;
+        *reinterpret_cast<float4*>(&cols[wave][lane][4]) = c1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (i >= K) return;
+    uint64_t bits = 0;
+    const int nb = min(64, K - w * 64);
+    const float a_x1 = a[0] + a[2], a_y1 = a[1] + a[3], a_area = a[2] * a[3];
+    const float cut = (float)thresh - 1e-3f;            // slack far above the float32 error of the estimate below
+    for (int b = 0; b < nb; ++b) {
+        if (w * 64 + b <= i) continue;
+        const float* cb = cols[wave][b];
+        if (cb[5] != a[5]) continue;
+        // float32 estimate of the IoU (the +1 pixel convention of rect.py included): DIoU <= IoU, so a pair whose
+        // estimate stays clearly below the threshold cannot be suppressed; only the rest pays for the exact float64
+        // arithmetic (and its pow) of the reference
+        const float iw = fminf(a_x1, cb[0] + cb[2]) - fmaxf(a[0], cb[0]);
+        const float ih = fminf(a_y1, cb[1] + cb[3]) - fmaxf(a[1], cb[1]);
+        if (iw <= 0.f || ih <= 0.f) continue;
+        const float inter = iw * ih;
+        if (inter <= cut * (a_area + cb[2] * cb[3] - inter)) continue;
+        if (diou_suppresses(a, cb, thresh)) bits |= (1ull << b);
+    }
+    mask[(size_t)w * cap + i] = bits;                   // word-major: the scan reads a word of many rows at once
 }
 
-// greedy scan in sorted order (one wavefront) + final box filter (detector.py:356-364)
-__global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ sorted,
-                                                      int32_t* __restrict__ counters, int cap,
-                                                      const uint64_t* __restrict__ mask, double max_area,
-                                                      double min_ar, fm_det48* __restrict__ dets) {
-    extern __shared__ uint64_t removed[];    // [cap/64]
-    const int lane = threadIdx.x;
+// greedy scan in sorted order + final box filter (detector.py:356-364), one workgroup.  Chunk by chunk of 64
+// candidates: the bits "removed by an earlier survivor" of chunk c are the OR of mask word c over all SURVIVING rows
+// before the chunk -- a gather over the word-major mask that all 256 lanes issue one chunk AHEAD (for the rows whose
+// fate is known) so that its latency hides behind the serial part: wavefront 0 resolves the chunk's own 64 x 64 block
+// in registers (lane b holds row b's word, 64 uniform steps).  Per chunk: two barriers, one wave reduction, 64 scalar
+// steps -- no dependent memory round trip (K = 1500: 5.1 ms -> ~20 us).  The survivors are then filtered and written
+// in order (prefix counts over the keep bits).
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict__ sorted,
+                                                       int32_t* __restrict__ counters, int cap,
+                                                       const uint64_t* __restrict__ mask, double max_area,
+                                                       double min_ar, fm_det48* __restrict__ dets) {
+    extern __shared__ uint64_t keep[];       // [cap/64] survivors
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = min(counters[0], cap);
-    const int words = cap / 64;
     const int kw = (K + 63) / 64;
-    for (int w = lane; w < words; w += 64) removed[w] = 0;
+    // OR of mask word w over the surviving rows i < lim (keep bits of those rows are final): the share of one of the
+    // 960 lanes of wavefronts 1..15 (wavefront 0 keeps its memory queue short, see below): the gather is bound by the
+    // bytes ONE workgroup can keep in flight, hence the wide workgroup
+    auto gather = [&](int w, int lim) {
+        uint64_t acc = 0;
+        const uint64_t* col = mask + (size_t)w * cap;
+        const int g = tid - 64;
+        for (int i0 = 0; i0 < lim; i0 += 960 * 8) {
+            uint64_t t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 960 + g;
+                t[u] = (i < lim && ((keep[i >> 6] >> (i & 63)) & 1ull)) ? col[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc |= t[u];
+        }
+        return acc;
+    };
+    // barrier that waits for this wave's LDS traffic only: __syncthreads() would also drain the global loads in flight
+    // (its fence waits for vmcnt(0)) and expose their latency in every chunk
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // Roles: wavefronts 1..15 gather (many loads, consumed one chunk later), wavefront 0 resolves (two loads per chunk:
+    // the compiler can count them and wait for exactly the older ones; mixed with the gather it waited for everything).
+    // Two chunks of lead.  removed(c) = OR of mask word c over the surviving rows before chunk c =
+    //     P[c]  (rows before chunk c-2, gathered by wavefronts 1..15 during iteration c-2, consumed two barriers later)
+    //   | tailA[c] masked by the survivors of chunk c-2 | tailB[c] masked by the survivors of chunk c-1 (wavefront 0,
+    //     one word per lane each, loaded during iteration c-2 like the chunk's own diagonal block diag[c]).
+    __shared__ unsigned long long rem_word[2];             // removed bits of the chunk being resolved (double buffered)
+    if (tid < 2) rem_word[tid] = 0;
+    auto word_at = [&](int w, int i) -> uint64_t { return (w < kw && i < K) ? mask[(size_t)w * cap + i] : 0ull; };
+    uint64_t p_cur = 0, p_nxt = 0;                         // P[c], P[c+1]   (wavefronts 1..15)
+    uint64_t ta_cur = 0, tb_cur = 0, dg_cur = 0;           // tailA / tailB / diag of chunk c     (wavefront 0)
+    uint64_t ta_nxt = 0, tb_nxt = 0, dg_nxt = 0;           // ... of chunk c + 1
+    uint64_t kept_1 = 0, kept_2 = 0;                       // survivors of chunks c-1, c-2
+    if (wave == 0) {
+        dg_cur = word_at(0, lane);
+        tb_nxt = word_at(1, lane);                         // chunk 1: rows of chunk 0
+        dg_nxt = word_at(1, 64 + lane);
+    }
     __syncthreads();
-    int n_det = 0;
-    for (int i = 0; i < K; ++i) {
-        const bool rem = (removed[i >> 6] >> (i & 63)) & 1ull;   // uniform read
-        if (rem) continue;
-        for (int w = lane + (i >> 6); w < kw; w += 64) removed[w] |= mask[(size_t)i * words + w];
-        if (lane == 0) {
-            const float* r = sorted + (size_t)i * 8;
+    for (int c = 0; c < kw; ++c) {
+        uint64_t p_new = 0, ta_new = 0, tb_new = 0, dg_new = 0;
+        if (wave > 0) {
+            if (p_cur) atomicOr(&rem_word[c & 1], (unsigned long long)p_cur);
+            if (c + 2 < kw) p_new = gather(c + 2, c * 64);
+        } else {
+            if (c + 2 < kw) {
+                ta_new = word_at(c + 2, c * 64 + lane);
+                tb_new = word_at(c + 2, (c + 1) * 64 + lane);
+                dg_new = word_at(c + 2, (c + 2) * 64 + lane);
+            }
+            const uint64_t t = (((kept_2 >> lane) & 1ull) ? ta_cur : 0ull) | (((kept_1 >> lane) & 1ull) ? tb_cur : 0ull);
+            if (t) atomicOr(&rem_word[c & 1], (unsigned long long)t);
+        }
+        lds_barrier();
+        if (wave == 0) {
+            const uint64_t rem_v = rem_word[c & 1];
+            // (scalar registers from here on: wave-uniform bookkeeping)
+            uint64_t rem = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem_v) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rem_v >> 32)) << 32);
+            if (c == kw - 1 && (K & 63)) rem |= ~0ull << (K & 63);         // rows beyond K do not exist
+            // the lowest candidate not removed yet survives and removes its row's bits; repeat until none is left
+            uint64_t kept = 0;
+            uint64_t avail = ~rem;
+            while (avail) {
+                const int b = __builtin_ctzll(avail);
+                const uint64_t row = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dg_cur, b) |
+                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dg_cur >> 32), b) << 32);
+                kept |= 1ull << b;
+                avail &= ~row & (~1ull << b);                                  // rows only carry bits above b
+            }
+            if (lane == 0) { keep[c] = kept; rem_word[c & 1] = 0; }
+            kept_2 = kept_1; kept_1 = kept;
+        }
+        p_cur = p_nxt; p_nxt = p_new;
+        ta_cur = ta_nxt; tb_cur = tb_nxt; dg_cur = dg_nxt;
+        ta_nxt = ta_new; tb_nxt = tb_new; dg_nxt = dg_new;
+        lds_barrier();
+    }
+    // final filter of the survivors, in order
+    __shared__ int base;
+    __shared__ int wave_cnt[16];
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < K; i0 += 1024) {
+        const int i = i0 + tid;
+        bool ok = false;
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        const float* r = sorted + (size_t)min(i, K - 1) * 8;
+        if (i < K && ((keep[i >> 6] >> (i & 63)) & 1ull)) {
             // to_tlbr (utils/rect.py:49-57) on float64 copies of the float32 row
             const double xmin = r[0], ymin = r[1];
-            const double t0 = rint(xmin), t1 = rint(ymin);
-            const double t2 = rint(xmin + (double)r[2] - 1.), t3 = rint(ymin + (double)r[3] - 1.);
+            t0 = rint(xmin); t1 = rint(ymin);
+            t2 = rint(xmin + (double)r[2] - 1.); t3 = rint(ymin + (double)r[3] - 1.);
             const double bw = t2 - t0 + 1, bh = t3 - t1 + 1;
             const double area = (bw <= 0 || bh <= 0) ? 0. : bw * bh;
             const double ar = bw > 0 ? bh / bw : 0.;
-            if (area > 0 && area <= max_area && ar >= min_ar) {
-                fm_det48& d = dets[n_det];
-                d.tlbr[0] = t0; d.tlbr[1] = t1; d.tlbr[2] = t2; d.tlbr[3] = t3;
-                d.label = (int64_t)r[5];
-                d.conf = (double)(r[4] * r[6]);     // float32 product (detector.py:362)
-            }
-            // n_det is tracked in lane 0 only; broadcast below
+            ok = area > 0 && area <= max_area && ar >= min_ar;
         }
-        {
-            const float* r = sorted + (size_t)i * 8;
-            const double xmin = r[0], ymin = r[1];
-            const double t0 = rint(xmin), t1 = rint(ymin);
-            const double t2 = rint(xmin + (double)r[2] - 1.), t3 = rint(ymin + (double)r[3] - 1.);
-            const double bw = t2 - t0 + 1, bh = t3 - t1 + 1;
-            const double area = (bw <= 0 || bh <= 0) ? 0. : bw * bh;
-            const double ar = bw > 0 ? bh / bw : 0.;
-            if (area > 0 && area <= max_area && ar >= min_ar) ++n_det;   // uniform
+        const uint64_t bal = __ballot(ok);
+        if (lane == 0) wave_cnt[tid >> 6] = __builtin_popcountll(bal);
+        __syncthreads();
+        int off = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        for (int wv = 0; wv < (tid >> 6); ++wv) off += wave_cnt[wv];
+        if (ok) {
+            fm_det48& d = dets[off];
+            d.tlbr[0] = t0; d.tlbr[1] = t1; d.tlbr[2] = t2; d.tlbr[3] = t3;
+            d.label = (int64_t)r[5];
+            d.conf = (double)(r[4] * r[6]);     // float32 product (detector.py:362)
         }
         __syncthreads();
+        if (tid == 0)
+            for (int wv = 0; wv < 16; ++wv) base += wave_cnt[wv];
+        __syncthreads();
     }
-    if (lane == 0) counters[2] = n_det;
+    if (tid == 0) counters[2] = base;
 }
 
 int ensure_det(fm_ctx* ctx) {
@@ -394,9 +519,9 @@ FilterArgs filter_args(DetState* d) {
 int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
     const int cap = d->cap;
     hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, s, d->cand, d->sorted, d->counters, cap);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64), dim3(64), 0, s, d->sorted, d->counters, cap,
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, s, d->sorted, d->counters, cap,
                        d->cfg.nms_thresh, d->mask);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), sizeof(uint64_t) * (cap / 64), s, d->sorted,
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), s, d->sorted,
                        d->counters, cap, d->mask, d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets);
     FM_HIP(hipGetLastError());
     if (d->pending >= DetState::NSLOT) {      // never collected (a caller that only ever enqueues): drop the oldest

@@ -74,8 +74,8 @@ struct GalleryState {
     bool pending = false;
 };
 
-void fm_gallery_free(fm_ctx* ctx) {
-    GalleryState* g = ctx->gallery;
+static void gallery_free_channel(fm_ctx* ctx, int channel) {
+    GalleryState* g = ctx->gallery[channel];
     if (!g) return;
     if (g->pending) (void)hipEventSynchronize(g->ev1);
     if (g->comm) {
@@ -90,7 +90,11 @@ void fm_gallery_free(fm_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
-    ctx->gallery = nullptr;
+    ctx->gallery[channel] = nullptr;
+}
+
+void fm_gallery_free(fm_ctx* ctx) {
+    for (int c = 0; c < FM_GALLERY_CHANNELS; ++c) gallery_free_channel(ctx, c);
 }
 
 // rank 0 creates the communicator id; the application hands the 128 bytes to the other ranks (any channel)
@@ -104,15 +108,18 @@ extern "C" int fm_gallery_unique_id(char* out128) {
     return 0;
 }
 
-// collective over all ranks: joins the communicator `id128` as rank `rank` of `world` on the context's device
-extern "C" int fm_gallery_init(fm_ctx* ctx, int world, int rank, const char* id128, size_t row_bytes) {
+// collective over all ranks: joins the communicator `id128` as rank `rank` of `world` on the context's device.
+// channel: a context owns FM_GALLERY_CHANNELS independent communicators (0 = the ReID gallery; 1 = small control
+// messages of the application, e.g. the barrier and the max-over-ranks of a benchmark) -- one exchange in flight each
+extern "C" int fm_gallery_init(fm_ctx* ctx, int channel, int world, int rank, const char* id128, size_t row_bytes) {
     FM_CHECK_ARG(ctx && id128 && world >= 1 && rank >= 0 && rank < world && row_bytes > 0 && row_bytes % 8 == 0);
-    if (ctx->gallery) fm_gallery_free(ctx);
+    FM_CHECK_ARG(channel >= 0 && channel < FM_GALLERY_CHANNELS);
+    if (ctx->gallery[channel]) gallery_free_channel(ctx, channel);
     Rccl* r = rccl();
     if (!r) return FM_ERR_STATE;
     FM_HIP(hipSetDevice(ctx->device));
     GalleryState* g = new GalleryState();
-    ctx->gallery = g;
+    ctx->gallery[channel] = g;
     g->world = world; g->rank = rank; g->row_bytes = row_bytes;
     FM_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     FM_HIP(hipEventCreate(&g->ev0));
@@ -128,9 +135,9 @@ extern "C" int fm_gallery_init(fm_ctx* ctx, int world, int rank, const char* id1
 }
 
 // enqueues one all-gather of this rank's row (row_bytes, copied before the call returns); collective
-extern "C" int fm_gallery_allgather_async(fm_ctx* ctx, const void* send_row) {
-    FM_CHECK_ARG(ctx && ctx->gallery && send_row);
-    GalleryState* g = ctx->gallery;
+extern "C" int fm_gallery_allgather_async(fm_ctx* ctx, int channel, const void* send_row) {
+    FM_CHECK_ARG(ctx && channel >= 0 && channel < FM_GALLERY_CHANNELS && ctx->gallery[channel] && send_row);
+    GalleryState* g = ctx->gallery[channel];
     if (g->pending) {
         fm_set_error("an all-gather is already in flight (fm_gallery_allgather_wait first)");
         return FM_ERR_STATE;
@@ -149,9 +156,9 @@ extern "C" int fm_gallery_allgather_async(fm_ctx* ctx, const void* send_row) {
 
 // waits for the in-flight all-gather and copies the world * row_bytes rows (rank-major) out; stream_ms_out (optional):
 // time the exchange occupied its stream
-extern "C" int fm_gallery_allgather_wait(fm_ctx* ctx, void* recv_rows, float* stream_ms_out) {
-    FM_CHECK_ARG(ctx && ctx->gallery && recv_rows);
-    GalleryState* g = ctx->gallery;
+extern "C" int fm_gallery_allgather_wait(fm_ctx* ctx, int channel, void* recv_rows, float* stream_ms_out) {
+    FM_CHECK_ARG(ctx && channel >= 0 && channel < FM_GALLERY_CHANNELS && ctx->gallery[channel] && recv_rows);
+    GalleryState* g = ctx->gallery[channel];
     if (!g->pending) {
         fm_set_error("no all-gather in flight");
         return FM_ERR_STATE;
@@ -163,8 +170,8 @@ extern "C" int fm_gallery_allgather_wait(fm_ctx* ctx, void* recv_rows, float* st
     return 0;
 }
 
-extern "C" int fm_gallery_destroy(fm_ctx* ctx) {
-    FM_CHECK_ARG(ctx);
-    fm_gallery_free(ctx);
+extern "C" int fm_gallery_destroy(fm_ctx* ctx, int channel) {
+    FM_CHECK_ARG(ctx && channel >= 0 && channel < FM_GALLERY_CHANNELS);
+    gallery_free_channel(ctx, channel);
     return 0;
 }

@@ -29,6 +29,7 @@ matched is consumed (`consume`) and never offered again.
 """
 import os
 import socket
+import sys
 import time
 
 import numpy as np
@@ -36,22 +37,27 @@ import numpy as np
 
 class RcclComm:
     """The collective through the library's C ABI (fm_gallery_*: csrc/gallery.hip binds librccl.so, ncclAllGather on a
-    side stream with pinned staging) -- no torch at run time.  Bootstrap: rank 0 creates the 128-byte communicator id
-    and serves it to the other ranks over one TCP connection each (MASTER_ADDR : MASTER_PORT + 29, the rendezvous
-    variables torchrun / any launcher already exports); world 1 needs no channel."""
+    side stream with pinned staging) -- no torch in the process.  Bootstrap: rank 0 creates the 128-byte communicator
+    id and serves it to the other ranks over one TCP connection each (MASTER_ADDR : MASTER_PORT + 29 + channel, the
+    rendezvous variables torchrun / any launcher already exports); world 1 needs no channel.
+    channel 0 = the gallery, 1 = control messages (`barrier`, `allgather_small`)."""
     name = 'rccl'
     on_gpu = True
 
-    def __init__(self, ctx, row_bytes, rank=None, world=None, addr=None, port=None, unique_id=None, timeout=120.):
-        self.ctx = ctx
+    def __init__(self, ctx, row_bytes, rank=None, world=None, addr=None, port=None, unique_id=None, timeout=120.,
+                 channel=0):
+        if 'torch' in sys.modules:
+            raise RuntimeError('RcclComm needs a process without torch: RCCL binds the HSA runtime by bare library '
+                               'name and would pick the copy torch ships (use TorchComm there)')
+        self.ctx, self.channel = ctx, channel
         self.rank = int(os.environ.get('RANK', 0)) if rank is None else rank
         self.world = int(os.environ.get('WORLD_SIZE', 1)) if world is None else world
         self.row_bytes = row_bytes
         if unique_id is None:
             addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
-            port = int(os.environ.get('MASTER_PORT', 29500)) + 29 if port is None else port
+            port = int(os.environ.get('MASTER_PORT', 29500)) + 29 + channel if port is None else port
             unique_id = self._bootstrap(addr, port, timeout)
-        ctx.gallery_init(self.world, self.rank, unique_id, row_bytes)
+        ctx.gallery_init(channel, self.world, self.rank, unique_id, row_bytes)
 
     def _bootstrap(self, addr, port, timeout):
         if self.rank == 0:
@@ -84,19 +90,31 @@ class RcclComm:
                 time.sleep(0.05)
 
     def issue(self, row):
-        self.ctx.gallery_allgather_async(row)
+        self.ctx.gallery_allgather_async(self.channel, row)
 
     def complete(self):
         """-> (uint8[world * row_bytes], milliseconds the exchange occupied its stream)"""
-        return self.ctx.gallery_allgather_wait(self.world, self.row_bytes)
+        return self.ctx.gallery_allgather_wait(self.channel, self.world, self.row_bytes)
+
+    def allgather_small(self, values):
+        """float64 values (row_bytes / 8 of them at most) of every rank -> array [world, n]; also a barrier."""
+        row = np.zeros(self.row_bytes // 8, np.float64)
+        v = np.atleast_1d(np.asarray(values, np.float64))
+        row[:len(v)] = v
+        self.issue(row.view(np.uint8))
+        rows, _ = self.complete()
+        return rows.view(np.float64).reshape(self.world, -1)[:, :len(v)]
+
+    def barrier(self):
+        self.allgather_small([0.0])
 
     def close(self):
-        self.ctx.gallery_destroy()
+        self.ctx.gallery_destroy(self.channel)
 
 
 class TorchComm:
-    """The same exchange through torch.distributed (backend gloo): what the multi-process CPU tests run on."""
-    on_gpu = False
+    """The same exchange through torch.distributed, for processes that run torch anyway: backend gloo (the
+    multi-process CPU tests) or nccl (= RCCL of the ROCm copy torch ships: side stream, pinned staging)."""
 
     def __init__(self, row_bytes, group=None):
         import torch
@@ -105,19 +123,43 @@ class TorchComm:
             raise RuntimeError('torch.distributed must be initialised for TorchComm')
         self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.name = dist.get_backend(group)
-        self._send = torch.zeros(row_bytes, dtype=torch.uint8)
-        self._recv = torch.zeros(self.world * row_bytes, dtype=torch.uint8)
+        backend = dist.get_backend(group)
+        self.on_gpu = backend == 'nccl'
+        self.name = 'rccl (torch.distributed)' if self.on_gpu else backend
+        self._send = torch.zeros(row_bytes, dtype=torch.uint8, pin_memory=self.on_gpu)
+        self._recv = torch.zeros(self.world * row_bytes, dtype=torch.uint8, pin_memory=self.on_gpu)
+        if self.on_gpu:
+            dev = torch.device('cuda', torch.cuda.current_device())
+            self._send_dev = torch.zeros(row_bytes, dtype=torch.uint8, device=dev)
+            self._recv_dev = torch.zeros(self.world * row_bytes, dtype=torch.uint8, device=dev)
+            self._stream = torch.cuda.Stream(device=dev)
+            self._ev0 = torch.cuda.Event(enable_timing=True)
+            self._ev1 = torch.cuda.Event(enable_timing=True)
         self._work = None
 
     def issue(self, row):
+        torch = self.torch
         self._send.numpy()[:] = row
-        self._work = self.dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=True)
+        if self.on_gpu:
+            with torch.cuda.stream(self._stream):
+                self._ev0.record(self._stream)
+                self._send_dev.copy_(self._send, non_blocking=True)
+                self.dist.all_gather_into_tensor(self._recv_dev, self._send_dev, group=self.group)
+                self._recv.copy_(self._recv_dev, non_blocking=True)
+                self._ev1.record(self._stream)
+            self._work = self._ev1
+        else:
+            self._work = self.dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=True)
 
     def complete(self):
-        self._work.wait()
+        ms = None
+        if self.on_gpu:
+            self._work.synchronize()
+            ms = self._ev0.elapsed_time(self._ev1)
+        else:
+            self._work.wait()
         self._work = None
-        return self._recv.numpy(), None
+        return self._recv.numpy(), ms
 
     def close(self):
         pass
@@ -126,8 +168,8 @@ class TorchComm:
 class GallerySync:
     def __init__(self, history_size=50, feat_dim=512, period=1, group=None, asynchronous=True, comm=None):
         """comm: the communicator (RcclComm / TorchComm / anything with rank, world, issue(row), complete()).  Default:
-        TorchComm when a gloo process group is initialised (CPU tests), else RcclComm on this process's context with
-        the launcher's RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+        RcclComm on this process's context with the launcher's RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; TorchComm
+        when the process has initialised torch.distributed (gloo: the CPU tests)."""
         self.history_size, self.feat_dim, self.period = history_size, feat_dim, max(int(period), 1)
         H, D = history_size, feat_dim
         self._hdr = 32
@@ -151,12 +193,11 @@ class GallerySync:
         self._pending = False      # an exchange is in flight
 
     def _default_comm(self, group):
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'gloo':
-                return TorchComm(self.row_bytes, group)
-        except ImportError:
-            pass
+        """No torch in the process: the C-ABI communicator.  A process that already runs torch.distributed (it has
+        loaded torch's own ROCm copy, see RcclComm) keeps its collectives there."""
+        torch = sys.modules.get('torch')
+        if torch is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            return TorchComm(self.row_bytes, group)
         from .runtime import get_context
         return RcclComm(get_context(), self.row_bytes)
 

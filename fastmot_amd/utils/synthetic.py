@@ -97,13 +97,15 @@ class InjectedYOLODetector(YOLODetector):
 
 class ScriptedHeadWeights(RandomWeights):
     """The seeded random parameters of `RandomWeights(seed)` (same random stream: every other layer is unchanged) with
-    the biases of the YOLO head convolutions set so that a chosen share of the candidate boxes passes the detector's
-    confidence threshold with class `label`: with purely random heads nothing passes `conf_thresh` and the DIoU-NMS
-    stage of a benchmark would run on an empty list.  obj_bias[h] = objectness bias of head h (in build order)."""
+    the YOLO head convolutions scripted so that a chosen share of the candidate boxes passes the detector's confidence
+    threshold with class `label`: with purely random heads nothing passes `conf_thresh` and the DIoU-NMS stage of a
+    benchmark would run on an empty list.  The class logits get biases of +-4; the objectness rows of the weight are
+    amplified by `obj_gain` (the random head's logits are all but constant over the image) and get the per-anchor
+    biases obj_bias[head][anchor] (heads in build order)."""
 
-    def __init__(self, seed, num_classes, label, obj_bias):
+    def __init__(self, seed, num_classes, label, obj_bias, obj_gain=1.0):
         super().__init__(seed)
-        self.num_classes, self.label, self.obj_bias = num_classes, label, list(obj_bias)
+        self.num_classes, self.label, self.obj_bias, self.obj_gain = num_classes, label, obj_bias, obj_gain
         self._head = 0
 
     def conv(self, name, cout, cin, k, bn=True, gain=1.0, groups=1):
@@ -111,22 +113,26 @@ class ScriptedHeadWeights(RandomWeights):
         rec = 5 + self.num_classes
         if not bn and cout % rec == 0:
             b = p['bias'].reshape(-1, rec)
-            b[:, 4] = self.obj_bias[self._head]
+            b[:, 4] = np.asarray(self.obj_bias[self._head], np.float32)
             b[:, 5:] = -4.0
             b[:, 5 + self.label] = 4.0
+            p['w'].reshape(-1, rec, *p['w'].shape[1:])[:, 4] *= self.obj_gain
             self._head += 1
         return p
 
 
-def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.25, seed=0):
+def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.25, seed=0, obj_gain=40.0):
     """ScriptedHeadWeights for `model` whose heads let about `target` candidates per frame through `conf_thresh` on
-    frames like `frame`: one calibration pass with zero objectness bias, then the bias of every head is set to the
-    quantile of its objectness logits that leaves its share of the target above the threshold."""
+    frames like `frame`: one calibration pass with an objectness bias that lets nothing through, then the bias of every
+    (head, anchor) is set to the quantile of its objectness logits that leaves its share of the target above the
+    threshold."""
     from .. import models
     m = models.YOLO.get_model(model)
     n_heads = len(m.LAYER_FACTORS)
+    n_anchors = [len(a) // 2 for a in m.ANCHORS]
+    CAL = -12.0
     det = YOLODetector(size, (label,), model=model, conf_thresh=conf_thresh,
-                       weights=ScriptedHeadWeights(seed, m.NUM_CLASSES, label, [0.0] * n_heads))
+                       weights=ScriptedHeadWeights(seed, m.NUM_CLASSES, label, [[CAL] * n for n in n_anchors], obj_gain))
     try:
         det.detect_async(frame)
         det.postprocess()
@@ -134,16 +140,13 @@ def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.
         logits = []
         for head in det.heads:
             t = det.backend.read(head, 1)[0]                       # (h, w, anchors * rec)
-            logits.append(t.reshape(t.shape[0], t.shape[1], -1, rec)[..., 4].ravel())
+            logits.append(t.reshape(t.shape[0] * t.shape[1], -1, rec)[..., 4].astype(np.float64) - CAL)   # [cells, anchors]
     finally:
         det.backend.close()
-    total = sum(len(v) for v in logits)
+    total = sum(v.size for v in logits)
     # class probability ~ sigmoid(4) = 0.982: box_conf * cls_prob >= thr  <=>  objectness logit >= logit(thr / 0.982)
     need = conf_thresh / (1.0 / (1.0 + np.exp(-4.0)))
     cut = float(np.log(need / (1.0 - need)))
-    bias = []
-    for v in logits:
-        share = min(0.5, target / total)                          # the same share of every head's cells
-        q = float(np.quantile(v, 1.0 - share))
-        bias.append(cut - q)
-    return ScriptedHeadWeights(seed, m.NUM_CLASSES, label, bias)
+    share = min(0.5, target / total)                              # the same share of every (head, anchor)'s cells
+    bias = [[cut - float(np.quantile(v[:, a], 1.0 - share)) for a in range(v.shape[1])] for v in logits]
+    return ScriptedHeadWeights(seed, m.NUM_CLASSES, label, bias, obj_gain)

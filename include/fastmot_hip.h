@@ -490,12 +490,16 @@ int fm_flow_read_image(fm_ctx* ctx, int which, uint8_t* out, int* w, int* h);
  * (tracker.py:355-366).  RCCL (librccl.so) is loaded on the first call.  fm_gallery_unique_id: rank 0 creates the
  * 128-byte communicator id and the application distributes it; fm_gallery_init (collective) joins it;
  * fm_gallery_allgather_async (collective) enqueues H2D + ncclAllGather + D2H of one fixed-size row per rank on a
- * side stream and returns; fm_gallery_allgather_wait copies out the world * row_bytes gathered rows, rank-major. */
+ * side stream and returns; fm_gallery_allgather_wait copies out the world * row_bytes gathered rows, rank-major.
+ * channel: a context owns two independent communicators, 0 = the gallery, 1 = small control messages of the
+ * application (barrier / max-over-ranks of a benchmark); one exchange in flight per channel.
+ * In-process constraint: RCCL resolves the HSA runtime by its bare library name; a process that has ALSO loaded
+ * another ROCm copy (import torch) must run its collectives through that copy's RCCL (gallery.py: TorchComm). */
 int fm_gallery_unique_id(char* out128);
-int fm_gallery_init(fm_ctx* ctx, int world, int rank, const char* id128, size_t row_bytes);
-int fm_gallery_allgather_async(fm_ctx* ctx, const void* send_row);
-int fm_gallery_allgather_wait(fm_ctx* ctx, void* recv_rows, float* stream_ms_out);
-int fm_gallery_destroy(fm_ctx* ctx);
+int fm_gallery_init(fm_ctx* ctx, int channel, int world, int rank, const char* id128, size_t row_bytes);
+int fm_gallery_allgather_async(fm_ctx* ctx, int channel, const void* send_row);
+int fm_gallery_allgather_wait(fm_ctx* ctx, int channel, void* recv_rows, float* stream_ms_out);
+int fm_gallery_destroy(fm_ctx* ctx, int channel);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ for one round on the GPU box (run through gpurun from the repo root):
+#   bash scripts/collect_profiles.sh r03 [quick]
+# -> gpurun_out/<tag>/: GPU test summary, bench lines (default command line, the driver's --steps 20 --warmup 5, configs 2
+#    and 4), rocprofv3 kernel stats of the bench command, per-layer roofline table of the detector, OSNet dispatch list,
+#    PMC traffic passes (separate rocprofv3 --pmc runs, MI355X_MICROARCH.md).  Copy what is to be judged into profiles/.
+TAG=${1:-r03}; QUICK=${2:-}
+export TMPDIR=/tmp FASTMOT_RANDOM_WEIGHTS=1
+R=$GRAFT_REPO_ROOT; [ -n "$R" ] || R=$(pwd)
+O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.txt; tail -3 $O/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-180 $O/bench_n1.json
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_cmdline.json 2> $O/bench_driver.err; cut -c1-180 $O/bench_driver_cmdline.json
+if [ -z "$QUICK" ]; then
+    timeout 900 python bench.py --config 2 > $O/bench_config2.json 2> $O/bench_config2.err; cut -c1-230 $O/bench_config2.json
+    timeout 900 python bench.py --config 4 --steps 60 --warmup 10 > $O/bench_config4.json 2> $O/bench_config4.err; cut -c1-230 $O/bench_config4.json
+fi
+# kernel stats of the bench command itself (the durations roofline.achieved must agree with)
+cd /tmp && rm -rf /tmp/kt_$TAG && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o b -- python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-variants > $O/bench_under_rocprof.json 2> /dev/null
+cd $R && python scripts/rocpd_summary.py "$(find /tmp/kt_$TAG -name '*.db' | head -1)" > $O/bench_kernel_stats.txt 2>&1; head -30 $O/bench_kernel_stats.txt | cut -c1-160
+# stand-alone replays: per-layer roofline of the detector, dispatch list of the ReID network
+cd /tmp && rm -rf /tmp/tr_$TAG && rocprofv3 --kernel-trace -d /tmp/tr_$TAG -o t -- python $R/scripts/trace_net.py 0 > /dev/null 2>&1
+cd $R && python scripts/layer_roofline.py /tmp/tr_$TAG > $O/yolo_layer_roofline.txt 2>&1; tail -3 $O/yolo_layer_roofline.txt
+cd /tmp && rm -rf /tmp/tro_$TAG && rocprofv3 --kernel-trace -d /tmp/tro_$TAG -o t -- python $R/scripts/trace_net.py 1 50 > /dev/null 2>&1
+cd $R && python scripts/rocpd_dispatches.py "$(find /tmp/tro_$TAG -name '*.db' | head -1)" 40 > $O/osnet_b50_dispatches.txt 2>&1; tail -3 $O/osnet_b50_dispatches.txt
+if [ -z "$QUICK" ]; then
+    bash scripts/collect_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/r02_pmc_conv.json $O/pmc_conv.json 2>/dev/null; tail -1 $O/pmc.log | cut -c1-400
+fi

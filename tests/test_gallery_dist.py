@@ -78,3 +78,47 @@ def test_gallery_allgather_gloo(tmp_path):
     # both ranks issued the same number of collectives and left close() together
     assert int(r0['collectives']) == int(r1['collectives'])
     assert int(r0['rounds']) >= 2 and int(r1['rounds']) >= 1
+
+
+def test_rccl_comm_bootstrap_distributes_the_unique_id():
+    """RcclComm's TCP bootstrap (rank 0 serves the 128-byte communicator id to the other ranks) with the device
+    calls replaced by a recorder: every rank must join with rank 0's id, its own rank and the common row size."""
+    import socket
+    import threading
+    from fastmot_amd.gallery import RcclComm
+
+    class FakeCtx:
+        def __init__(self):
+            self.joined = None
+
+        def gallery_unique_id(self):
+            return bytes(range(128))
+
+        def gallery_init(self, channel, world, rank, uid, row_bytes):
+            self.joined = (channel, world, rank, uid, row_bytes)
+
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctxs = [FakeCtx() for _ in range(3)]
+    errs = []
+
+    def join(r):
+        try:
+            RcclComm(ctxs[r], 64, rank=r, world=3, addr='127.0.0.1', port=port, channel=1, timeout=30)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    import sys
+    saved = sys.modules.pop('torch', None)          # (RcclComm refuses processes that have loaded torch's ROCm copy)
+    try:
+        th = [threading.Thread(target=join, args=(r,)) for r in (2, 1, 0)]       # clients first: they retry
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+    finally:
+        if saved is not None:
+            sys.modules['torch'] = saved
+    assert not errs, errs
+    assert [c.joined for c in ctxs] == [(1, 3, r, bytes(range(128)), 64) for r in range(3)]
