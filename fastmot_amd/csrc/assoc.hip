@@ -41,21 +41,34 @@ __device__ inline double iou_dist_pair(const double* a, double area_a, const dou
     return 1.;
 }
 
-__global__ void occluded_kernel(int n, const double* __restrict__ tlbr, double thresh,
-                                uint8_t* __restrict__ out) {
+// (the boxes arrive through device-mapped HOST memory for small n: every lane walking all boxes there cost one PCIe
+// read per box and lane, 29 us for 50 boxes; they are staged in LDS 256 at a time by one coalesced read instead)
+__global__ __launch_bounds__(64) void occluded_kernel(int n, const double* __restrict__ tlbr, double thresh,
+                                                      uint8_t* __restrict__ out) {
+    __shared__ double box[256][4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double* a = tlbr + (size_t)i * 4;
+    const bool live = i < n;
+    double a[4] = {0, 0, 0, 0};
+    if (live) {
+        const double4 v = *reinterpret_cast<const double4*>(tlbr + (size_t)i * 4);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    }
     const double area_self = box_area(a);
     uint8_t occ = 0;
-    for (int j = 0; j < n && !occ; ++j) {
-        if (j == i) continue;
-        const double* b = tlbr + (size_t)j * 4;
-        const double iw = fmin(a[2], b[2]) - fmax(a[0], b[0]) + 1;
-        const double ih = fmin(a[3], b[3]) - fmax(a[1], b[1]) + 1;
-        if (iw > 0 && ih > 0 && iw * ih / area_self >= thresh) occ = 1;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int m = min(256, n - j0);
+        for (int e = threadIdx.x; e < m * 4; e += 64) (&box[0][0])[e] = tlbr[(size_t)j0 * 4 + e];
+        __syncthreads();
+        for (int t = 0; t < m && !occ; ++t) {
+            if (j0 + t == i) continue;
+            const double* b = box[t];
+            const double iw = fmin(a[2], b[2]) - fmax(a[0], b[0]) + 1;
+            const double ih = fmin(a[3], b[3]) - fmax(a[1], b[1]) + 1;
+            if (iw > 0 && ih > 0 && iw * ih / area_self >= thresh) occ = 1;
+        }
+        __syncthreads();
     }
-    out[i] = occ;
+    if (live) out[i] = occ;
 }
 
 __global__ void iou_dist_kernel(int na, const double* __restrict__ a, int nb,

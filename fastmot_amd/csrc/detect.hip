@@ -27,15 +27,16 @@ struct DetState {
     fm_yolo_cfg cfg{};
     bool configured = false;
     int cap = 8192;
-    float* cand = nullptr;        // [cap][8] : x y w h box_conf class cls_prob orig_idx(as float bits)
-    float* sorted = nullptr;      // [cap][8]
-    int32_t* counters = nullptr;  // [0]=n_cand [1]=overflow [2]=n_det
-    uint64_t* mask = nullptr;     // [cap][cap/64]
-    fm_det48* dets = nullptr;     // [cap]
-    // Results are double buffered on the host side and completed by events, so that the pass on the NEXT frame
-    // can already be queued behind this one (MOT.step with next_frame: the detector stream never idles) while the
-    // host still has to collect this frame's detections: passes are collected in the order they were enqueued.
+    // Results and the post-processing buffers are double buffered and completed by events: the pass on the NEXT frame
+    // can be queued behind this one (MOT.step with next_frame: the detector stream never idles) while the host still
+    // has to collect this frame's detections.  Passes are collected in enqueue order.
     static constexpr int NSLOT = 2;
+    float* cand[NSLOT] = {nullptr, nullptr};        // [cap][8] : x y w h box_conf class cls_prob orig_idx(as float bits)
+    float* sorted[NSLOT] = {nullptr, nullptr};      // [cap][8]
+    int32_t* counters[NSLOT] = {nullptr, nullptr};  // [0]=n_cand [1]=overflow [2]=n_det
+    uint64_t* mask[NSLOT] = {nullptr, nullptr};     // [cap/64][cap]
+    fm_det48* dets[NSLOT] = {nullptr, nullptr};     // [cap]
+    bool used[NSLOT] = {false, false};
     static constexpr int PREFIX = 2048;        // detections copied back with the pass (more: synchronous fallback)
     fm_det48* dets_host[NSLOT] = {nullptr, nullptr};
     int32_t* counters_host[NSLOT] = {nullptr, nullptr};
@@ -49,8 +50,11 @@ struct DetState {
 
 void fm_det_free(DetState* d) {
     if (!d) return;
-    for (void* p : {(void*)d->cand, (void*)d->sorted, (void*)d->counters, (void*)d->mask, (void*)d->dets,
-                    (void*)d->label_mask, (void*)d->rows_in})
+    for (int i = 0; i < DetState::NSLOT; ++i) {
+        for (void* q : {(void*)d->cand[i], (void*)d->sorted[i], (void*)d->counters[i], (void*)d->mask[i], (void*)d->dets[i]})
+            if (q) (void)hipFree(q);
+    }
+    for (void* p : {(void*)d->label_mask, (void*)d->rows_in})
         if (p) (void)hipFree(p);
     for (int i = 0; i < DetState::NSLOT; ++i) {
         if (d->dets_host[i]) (void)hipHostFree(d->dets_host[i]);
@@ -472,26 +476,28 @@ int ensure_det(fm_ctx* ctx) {
 
 int alloc_post(DetState* d, int cap) {
     cap = (cap + 63) & ~63;
-    if (d->cand && cap == d->cap) return 0;
-    for (void* p : {(void*)d->cand, (void*)d->sorted, (void*)d->mask, (void*)d->dets})
-        if (p) (void)hipFree(p);
+    if (d->cand[0] && cap == d->cap) return 0;
     for (int i = 0; i < DetState::NSLOT; ++i) {
+        for (void* p : {(void*)d->cand[i], (void*)d->sorted[i], (void*)d->mask[i], (void*)d->dets[i]})
+            if (p) (void)hipFree(p);
         if (d->dets_host[i]) (void)hipHostFree(d->dets_host[i]);
         d->dets_host[i] = nullptr;
+        d->cand[i] = d->sorted[i] = nullptr; d->mask[i] = nullptr; d->dets[i] = nullptr;
+        d->used[i] = false;
     }
-    d->cand = d->sorted = nullptr; d->mask = nullptr; d->dets = nullptr;
     d->cap = cap;
     d->wr = d->rd = d->pending = 0;
     d->last = -1;
-    FM_HIP(hipMalloc(&d->cand, sizeof(float) * 8 * cap));
-    FM_HIP(hipMalloc(&d->sorted, sizeof(float) * 8 * cap));
-    FM_HIP(hipMalloc(&d->mask, sizeof(uint64_t) * (size_t)cap * (cap / 64)));
-    FM_HIP(hipMalloc(&d->dets, sizeof(fm_det48) * cap));
-    for (int i = 0; i < DetState::NSLOT; ++i)
+    for (int i = 0; i < DetState::NSLOT; ++i) {
+        FM_HIP(hipMalloc(&d->cand[i], sizeof(float) * 8 * cap));
+        FM_HIP(hipMalloc(&d->sorted[i], sizeof(float) * 8 * cap));
+        FM_HIP(hipMalloc(&d->mask[i], sizeof(uint64_t) * (size_t)cap * (cap / 64)));
+        FM_HIP(hipMalloc(&d->dets[i], sizeof(fm_det48) * cap));
         FM_HIP(hipHostMalloc(&d->dets_host[i], sizeof(fm_det48) * cap, hipHostMallocDefault));
-    if (!d->counters) {
-        FM_HIP(hipMalloc(&d->counters, sizeof(int32_t) * 4));
+    }
+    if (!d->counters[0]) {
         for (int i = 0; i < DetState::NSLOT; ++i) {
+            FM_HIP(hipMalloc(&d->counters[i], sizeof(int32_t) * 4));
             FM_HIP(hipHostMalloc(&d->counters_host[i], sizeof(int32_t) * 4, hipHostMallocDefault));
             FM_HIP(hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming));
             FM_HIP(hipEventCreate(&d->ev0[i]));
@@ -502,40 +508,55 @@ int alloc_post(DetState* d, int cap) {
     return 0;
 }
 
-FilterArgs filter_args(DetState* d) {
+FilterArgs filter_args(DetState* d, int slot) {
     FilterArgs fa{};
     fa.label_mask = d->label_mask;
     fa.num_classes = d->cfg.num_classes;
     fa.conf_thresh = (float)d->cfg.conf_thresh;
     fa.size[0] = d->cfg.size[0]; fa.size[1] = d->cfg.size[1];
     fa.offset[0] = d->cfg.offset[0]; fa.offset[1] = d->cfg.offset[1];
-    fa.cand = d->cand;
-    fa.counters = d->counters;
+    fa.cand = d->cand[slot];
+    fa.counters = d->counters[slot];
     fa.cap = d->cap;
     return fa;
 }
 
-// sort + NMS + final filter + async D2H of the result (shared by the real path and the test hook)
+// sort + NMS + final filter + async D2H of the result (shared by the real path and the test hook), on the stream `s`
+// that produced the candidates of slot d->wr.
 int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
     const int cap = d->cap;
-    hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, s, d->cand, d->sorted, d->counters, cap);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, s, d->sorted, d->counters, cap,
-                       d->cfg.nms_thresh, d->mask);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), s, d->sorted,
-                       d->counters, cap, d->mask, d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets);
-    FM_HIP(hipGetLastError());
     if (d->pending >= DetState::NSLOT) {      // never collected (a caller that only ever enqueues): drop the oldest
         d->rd = (d->rd + 1) % DetState::NSLOT;
         --d->pending;
     }
     const int slot = d->wr;
-    FM_HIP(hipMemcpyAsync(d->counters_host[slot], d->counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, s));
+    // (Round 3 tried the post-processing on a stream of its own, so that the next frame's network would start while
+    // the one-workgroup NMS scan of this frame runs: 612 -> 430 frames/s in alternating runs on one box.  The context
+    // already drives more HIP streams than the runtime has hardware queues; one more made the KLT and ReID streams
+    // share a queue with long work.  It stays on the stream that produced the candidates.)
+    hipStream_t sp = s;
+    hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, sp, d->cand[slot], d->sorted[slot],
+                       d->counters[slot], cap);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, sp, d->sorted[slot],
+                       d->counters[slot], cap, d->cfg.nms_thresh, d->mask[slot]);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), sp, d->sorted[slot],
+                       d->counters[slot], cap, d->mask[slot], d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets[slot]);
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipMemcpyAsync(d->counters_host[slot], d->counters[slot], sizeof(int32_t) * 4, hipMemcpyDeviceToHost, sp));
     // detections are few: copy a bounded prefix with the pass, the rest (rare) at collection time
-    FM_HIP(hipMemcpyAsync(d->dets_host[slot], d->dets, sizeof(fm_det48) * (cap < DetState::PREFIX ? cap : DetState::PREFIX),
-                          hipMemcpyDeviceToHost, s));
-    FM_HIP(hipEventRecord(d->ev_done[slot], s));
+    FM_HIP(hipMemcpyAsync(d->dets_host[slot], d->dets[slot],
+                          sizeof(fm_det48) * (cap < DetState::PREFIX ? cap : DetState::PREFIX), hipMemcpyDeviceToHost, sp));
+    FM_HIP(hipEventRecord(d->ev_done[slot], sp));
+    d->used[slot] = true;
     d->wr = (slot + 1) % DetState::NSLOT;
     ++d->pending;
+    return 0;
+}
+
+// a pass is about to write the candidate buffers of slot d->wr on stream `s`: the post-processing of the pass that
+// used the slot before (two passes ago) must be through with them
+static int acquire_slot(DetState* d, hipStream_t s) {
+    if (d->used[d->wr]) FM_HIP(hipStreamWaitEvent(s, d->ev_done[d->wr], 0));
     return 0;
 }
 
@@ -555,12 +576,8 @@ int collect(fm_ctx* ctx, DetState* d, hipStream_t s, fm_det48* out, int cap_out,
     }
     const int nd = d->counters_host[slot][2];
     if (nd > DetState::PREFIX) {
-        if (d->pending) {       // the device list already belongs to the next pass
-            fm_set_error("%d detections exceed the %d copied back with the pass while another pass is in flight",
-                         nd, DetState::PREFIX);
-            return FM_ERR_STATE;
-        }
-        FM_HIP(hipMemcpy(d->dets_host[slot], d->dets, sizeof(fm_det48) * nd, hipMemcpyDeviceToHost));
+        // (the slot's device list is not reused before the pass after next is enqueued, i.e. not before this returns)
+        FM_HIP(hipMemcpy(d->dets_host[slot], d->dets[slot], sizeof(fm_det48) * nd, hipMemcpyDeviceToHost));
     }
     if (nd > cap_out) {
         fm_set_error("output capacity %d < %d detections", cap_out, nd);
@@ -761,7 +778,7 @@ static int enqueue_preprocess(fm_ctx* ctx, DetState* d, NetState* net, const uin
     FM_CHECK_ARG(t.h == c.in_h && t.w == c.in_w && !t.f32);
     hipLaunchKernelGGL(preprocess_kernel, dim3((c.in_w + 255) / 256, c.in_h), dim3(256), 0, ctx->s_det,
                        frame, ctx->frame_w, ctx->frame_h, (f16*)net->bufs[c.input_tensor], c.in_w,
-                       c.in_h, t.c, c.roi_x, c.roi_y, c.roi_w, c.roi_h, filter_args(d).counters);
+                       c.in_h, t.c, c.roi_x, c.roi_y, c.roi_w, c.roi_h, filter_args(d, d->wr).counters);
     FM_HIP(hipGetLastError());
     return 0;
 }
@@ -791,12 +808,13 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     const fm_yolo_cfg& c = d->cfg;
     hipStream_t s = ctx->s_det;
     if (frame == ctx->frame_own2 && ctx->ev_next_upload) FM_HIP(hipStreamWaitEvent(s, ctx->ev_next_upload, 0));
-    int rc = enqueue_preprocess(ctx, d, net, frame);
+    int rc = acquire_slot(d, s);
     if (rc) return rc;
+    if ((rc = enqueue_preprocess(ctx, d, net, frame))) return rc;
     FM_HIP(hipEventRecord(d->ev0[d->wr], s));
     if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
     FM_HIP(hipEventRecord(d->ev1[d->wr], s));
-    FilterArgs fa = filter_args(d);      // (counters were zeroed by this frame's preprocess kernel)
+    FilterArgs fa = filter_args(d, d->wr);      // (counters were zeroed by this frame's preprocess kernel)
     HeadSet hs{};
     int base = 0, blocks = 0;
     for (int i = 0; i < FM_MAX_HEADS + 1; ++i) hs.first_block[i] = 0x7fffffff;
@@ -839,8 +857,8 @@ extern "C" int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* o
         d->rows_cap = n;
     }
     if (n) FM_HIP(hipMemcpyAsync(d->rows_in, rows, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice, s));
-    FM_HIP(hipMemsetAsync(d->counters, 0, sizeof(int32_t) * 4, s));
-    if (n) hipLaunchKernelGGL(rows_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d->rows_in, n, filter_args(d));
+    FM_HIP(hipMemsetAsync(d->counters[d->wr], 0, sizeof(int32_t) * 4, s));
+    if (n) hipLaunchKernelGGL(rows_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d->rows_in, n, filter_args(d, d->wr));
     int rc = enqueue_post(ctx, d, s);
     if (rc) return rc;
     return collect(ctx, d, s, out, cap, n_out);
@@ -864,11 +882,12 @@ extern "C" int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* 
     FM_CHECK_ARG(ctx && ctx->det && rows && n);
     DetState* d = ctx->det;
     FM_HIP(hipStreamSynchronize(ctx->s_det));
+    const int slot = (d->wr + DetState::NSLOT - 1) % DetState::NSLOT;       // the pass enqueued last
     int32_t cnt[4];
-    FM_HIP(hipMemcpy(cnt, d->counters, sizeof(cnt), hipMemcpyDeviceToHost));
+    FM_HIP(hipMemcpy(cnt, d->counters[slot], sizeof(cnt), hipMemcpyDeviceToHost));
     const int k = cnt[0] < d->cap ? cnt[0] : d->cap;
     FM_CHECK_ARG(k <= cap);
-    FM_HIP(hipMemcpy(rows, d->sorted, sizeof(float) * 8 * k, hipMemcpyDeviceToHost));
+    FM_HIP(hipMemcpy(rows, d->sorted[slot], sizeof(float) * 8 * k, hipMemcpyDeviceToHost));
     *n = k;
     return 0;
 }
