@@ -37,6 +37,8 @@ struct DetState {
     uint64_t* mask[NSLOT] = {nullptr, nullptr};     // [cap/64][cap]
     fm_det48* dets[NSLOT] = {nullptr, nullptr};     // [cap]
     bool used[NSLOT] = {false, false};
+    hipEvent_t ev_dec[NSLOT] = {nullptr, nullptr};  // candidates of the pass complete (stream that produced them)
+    int post_pending = -1;                          // slot whose sort + NMS has not been enqueued yet (flush_post)
     static constexpr int PREFIX = 2048;        // detections copied back with the pass (more: synchronous fallback)
     fm_det48* dets_host[NSLOT] = {nullptr, nullptr};
     int32_t* counters_host[NSLOT] = {nullptr, nullptr};
@@ -59,7 +61,7 @@ void fm_det_free(DetState* d) {
     for (int i = 0; i < DetState::NSLOT; ++i) {
         if (d->dets_host[i]) (void)hipHostFree(d->dets_host[i]);
         if (d->counters_host[i]) (void)hipHostFree(d->counters_host[i]);
-        for (hipEvent_t e : {d->ev_done[i], d->ev0[i], d->ev1[i]})
+        for (hipEvent_t e : {d->ev_done[i], d->ev_dec[i], d->ev0[i], d->ev1[i]})
             if (e) (void)hipEventDestroy(e);
     }
     delete d;
@@ -488,6 +490,7 @@ int alloc_post(DetState* d, int cap) {
     d->cap = cap;
     d->wr = d->rd = d->pending = 0;
     d->last = -1;
+    d->post_pending = -1;
     for (int i = 0; i < DetState::NSLOT; ++i) {
         FM_HIP(hipMalloc(&d->cand[i], sizeof(float) * 8 * cap));
         FM_HIP(hipMalloc(&d->sorted[i], sizeof(float) * 8 * cap));
@@ -500,6 +503,7 @@ int alloc_post(DetState* d, int cap) {
             FM_HIP(hipMalloc(&d->counters[i], sizeof(int32_t) * 4));
             FM_HIP(hipHostMalloc(&d->counters_host[i], sizeof(int32_t) * 4, hipHostMallocDefault));
             FM_HIP(hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming));
+            FM_HIP(hipEventCreateWithFlags(&d->ev_dec[i], hipEventDisableTiming));
             FM_HIP(hipEventCreate(&d->ev0[i]));
             FM_HIP(hipEventCreate(&d->ev1[i]));
         }
@@ -521,20 +525,22 @@ FilterArgs filter_args(DetState* d, int slot) {
     return fa;
 }
 
-// sort + NMS + final filter + async D2H of the result (shared by the real path and the test hook), on the stream `s`
-// that produced the candidates of slot d->wr.
-int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
+// sort + NMS + final filter + async D2H of the result of the pass in `slot`, on the UPLOAD stream behind the event that
+// marks the pass's candidates complete.  The NMS scan is one workgroup for tens of microseconds: on the detector stream
+// it kept the next frame's network waiting (1500 candidates per frame: 603 -> 667 frames/s in alternating runs with the
+// post-processing moved here).  The upload stream is the one stream of the context that is idle at that time -- a
+// stream of its own for this measured far worse (612 -> 430: the context drives more HIP streams than the runtime has
+// hardware queues, one more changed which of them share a queue).  Order on the upload stream matters: a pass's
+// post-processing waits for its network, so it must be enqueued BEHIND the next frame's H2D copy, not in front of it
+// -- hence flush_post() is called after that copy has been enqueued (fm_frame_upload_next), before the next pass is
+// enqueued, and at collection time at the latest.
+static int flush_post(fm_ctx* ctx, DetState* d) {
+    const int slot = d->post_pending;
+    if (slot < 0) return 0;
+    d->post_pending = -1;
     const int cap = d->cap;
-    if (d->pending >= DetState::NSLOT) {      // never collected (a caller that only ever enqueues): drop the oldest
-        d->rd = (d->rd + 1) % DetState::NSLOT;
-        --d->pending;
-    }
-    const int slot = d->wr;
-    // (Round 3 tried the post-processing on a stream of its own, so that the next frame's network would start while
-    // the one-workgroup NMS scan of this frame runs: 612 -> 430 frames/s in alternating runs on one box.  The context
-    // already drives more HIP streams than the runtime has hardware queues; one more made the KLT and ReID streams
-    // share a queue with long work.  It stays on the stream that produced the candidates.)
-    hipStream_t sp = s;
+    hipStream_t sp = ctx->s_up;
+    FM_HIP(hipStreamWaitEvent(sp, d->ev_dec[slot], 0));
     hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, sp, d->cand[slot], d->sorted[slot],
                        d->counters[slot], cap);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, sp, d->sorted[slot],
@@ -547,6 +553,21 @@ int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
     FM_HIP(hipMemcpyAsync(d->dets_host[slot], d->dets[slot],
                           sizeof(fm_det48) * (cap < DetState::PREFIX ? cap : DetState::PREFIX), hipMemcpyDeviceToHost, sp));
     FM_HIP(hipEventRecord(d->ev_done[slot], sp));
+    return 0;
+}
+
+// the candidates of slot d->wr are complete on stream `s` (real path: decode on the detector stream; test hook: the
+// row filter): book the pass and leave its post-processing pending
+int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
+    int rc = flush_post(ctx, d);              // (a pass whose post-processing nobody flushed yet: keep the order)
+    if (rc) return rc;
+    if (d->pending >= DetState::NSLOT) {      // never collected (a caller that only ever enqueues): drop the oldest
+        d->rd = (d->rd + 1) % DetState::NSLOT;
+        --d->pending;
+    }
+    const int slot = d->wr;
+    FM_HIP(hipEventRecord(d->ev_dec[slot], s));
+    d->post_pending = slot;
     d->used[slot] = true;
     d->wr = (slot + 1) % DetState::NSLOT;
     ++d->pending;
@@ -566,6 +587,8 @@ int collect(fm_ctx* ctx, DetState* d, hipStream_t s, fm_det48* out, int cap_out,
         return FM_ERR_STATE;
     }
     const int slot = d->rd;
+    int rc_f = flush_post(ctx, d);
+    if (rc_f) return rc_f;
     FM_HIP(hipEventSynchronize(d->ev_done[slot]));
     d->rd = (slot + 1) % DetState::NSLOT;
     --d->pending;
@@ -699,6 +722,7 @@ extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
     hipStream_t cs = ctx->s_up;
     int rc_copy = enqueue_frame_copy(ctx->frame_own2, src, bytes, cs);
     if (rc_copy) return rc_copy;
+    if (ctx->det && (rc_copy = flush_post(ctx, ctx->det))) return rc_copy;   // behind the copy, see flush_post
     if (!ctx->ev_next_upload) FM_HIP(hipEventCreateWithFlags(&ctx->ev_next_upload, hipEventDisableTiming));
     FM_HIP(hipEventRecord(ctx->ev_next_upload, cs));
     ctx->frame_next = ctx->frame_own2;
@@ -761,6 +785,8 @@ extern "C" int fm_detect_configure(fm_ctx* ctx, const fm_yolo_cfg* cfg) {
     if (rc) return rc;
     DetState* d = ctx->det;
     FM_HIP(hipStreamSynchronize(ctx->s_det));
+    FM_HIP(hipStreamSynchronize(ctx->s_up));
+    d->post_pending = -1;
     d->rd = d->wr;            // a new detector: nothing of the previous one is collected any more
     d->pending = 0;
     d->cfg = *cfg;
@@ -848,7 +874,9 @@ extern "C" int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* o
     DetState* d = ctx->det;
     hipStream_t s = ctx->s_det;
     FM_HIP(hipStreamSynchronize(s));
-    d->rd = d->wr;            // (test hook: passes nobody collected are dropped; the stream is idle here)
+    FM_HIP(hipStreamSynchronize(ctx->s_up));
+    d->post_pending = -1;
+    d->rd = d->wr;            // (test hook: passes nobody collected are dropped; the streams are idle here)
     d->pending = 0;
     if (n > d->rows_cap) {
         if (d->rows_in) FM_HIP(hipFree(d->rows_in));
@@ -881,7 +909,10 @@ extern "C" int fm_detect_last_counts(fm_ctx* ctx, int* n_candidates, int* n_dete
 extern "C" int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* n) {
     FM_CHECK_ARG(ctx && ctx->det && rows && n);
     DetState* d = ctx->det;
+    int rc_f = flush_post(ctx, d);
+    if (rc_f) return rc_f;
     FM_HIP(hipStreamSynchronize(ctx->s_det));
+    FM_HIP(hipStreamSynchronize(ctx->s_up));
     const int slot = (d->wr + DetState::NSLOT - 1) % DetState::NSLOT;       // the pass enqueued last
     int32_t cnt[4];
     FM_HIP(hipMemcpy(cnt, d->counters[slot], sizeof(cnt), hipMemcpyDeviceToHost));
