@@ -513,6 +513,146 @@ __global__ __launch_bounds__(1024) FM_SGPR_CAP void lk_wave_kernel(LKArgs a, int
     lk_wave_body<WINC>(a, n, prev_pts, next_pts, status, err);
 }
 
+// ---- two points per wavefront.  Lanes 0..24 carry the window of point 2 w, lanes 32..56 the window of point 2 w + 1;
+// the seven lanes behind each window LEAVE the kernel at once.  That is what lets the DPP scans of the two windows run
+// in the same instructions: a lane whose left neighbour is masked off reads 0 (bound_ctrl), exactly like lane 0 whose
+// neighbour does not exist, so the scan restarts at lane 32 by itself.  The broadcast of a sum comes from lane 24 of
+// the own half (ds_bpermute instead of v_readlane), the arithmetic behind it is per lane as before, and the control
+// flow -- levels skipped, iteration counts -- is now divergent between the halves (the compiler masks; nothing is
+// wave-uniform any more except the level loop).  Same operations in the same order per point: bit-identical to the
+// one-point kernel (tests/test_flow_gpu.py).  Half the wavefronts hold the registers half as long per point: the
+// kernel's footprint beside the other streams' kernels is what the pipeline pays for.
+__device__ __forceinline__ float half_value(float v, int lane_in_half, int half_base) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((half_base + lane_in_half) << 2, __builtin_bit_cast(int, v)));
+}
+
+template <int WINC>
+__global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+                                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                                  float* __restrict__ err) {
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = gidx & 63, g = l & 31, hb = l & 32;
+    const int pt = (gidx >> 6) * 2 + (l >> 5);
+    constexpr int win = WINC, NW = WINC * WINC;
+    if (pt >= n || g >= NW) return;
+    const int wy = g / win, wx = g % win;
+    const float half = (win - 1) * 0.5f;
+    const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
+    float nx = 0.f, ny = 0.f;
+    bool st = true;
+    float er = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    auto weights = [](float fa, float fb, int& iw00, int& iw01, int& iw10, int& iw11) {
+        iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
+        iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
+        iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
+        iw11 = (1 << 14) - iw00 - iw01 - iw10;
+    };
+    auto sample = [&](const uint8_t* img, int w, int h, int bx, int by, int iw00, int iw01, int iw10, int iw11) -> int {
+        const uint8_t* r0 = img + (size_t)reflect101(by + wy, h) * w;
+        const uint8_t* r1 = img + (size_t)reflect101(by + wy + 1, h) * w;
+        const int c0 = reflect101(bx + wx, w), c1 = reflect101(bx + wx + 1, w);
+        return LK_DESCALE(lk_px(r0, c0) * iw00 + lk_px(r0, c1) * iw01 + lk_px(r1, c0) * iw10 + lk_px(r1, c1) * iw11, 14 - 5);
+    };
+    for (int level = a.levels - 1; level >= 0; --level) {
+        const int w = a.w[level], h = a.h[level];
+        const uint8_t* I = a.I[level];
+        const uint8_t* J = a.J[level];
+        const int16_t* D = a.D[level];
+        const float sc = 1.f / (float)(1 << level);
+        float ppx = px0 * sc, ppy = py0 * sc;
+        if (level == a.levels - 1) { nx = ppx; ny = ppy; }
+        else { nx *= 2.f; ny *= 2.f; }
+        ppx -= half; ppy -= half;
+        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+        if (ipx < -win || ipx >= w || ipy < -win || ipy >= h) {
+            if (level == 0) { st = false; er = 0.f; }
+            continue;
+        }
+        int iw00, iw01, iw10, iw11;
+        weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
+        const int ival = sample(I, w, h, ipx, ipy, iw00, iw01, iw10, iw11);
+        int ixval, iyval;
+        {
+            const int xx0 = ipx + wx, xx1 = xx0 + 1, yy0 = ipy + wy, yy1 = yy0 + 1;
+            // derivative image is zero outside (BORDER_CONSTANT), lkpyramid.cpp
+            auto dv = [&](int xx, int yy) -> int2 {
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return make_int2(0, 0);
+                const int v = *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
+                return make_int2((int)(short)(v & 0xffff), (int)(short)(v >> 16));
+            };
+            const int2 d00 = dv(xx0, yy0), d01 = dv(xx1, yy0), d10 = dv(xx0, yy1), d11 = dv(xx1, yy1);
+            ixval = LK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
+            iyval = LK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
+        }
+        float A11, A12, A22;
+        {
+            const float v0 = (float)(ixval * ixval), v1 = (float)(ixval * iyval), v2 = (float)(iyval * iyval);
+            float a0 = v0, a1 = v1, a2 = v2;
+#pragma unroll
+            for (int k = 1; k < NW; ++k) { a0 = seq_step(a0, v0); a1 = seq_step(a1, v1); a2 = seq_step(a2, v2); }
+            A11 = half_value(a0, NW - 1, hb); A12 = half_value(a1, NW - 1, hb); A22 = half_value(a2, NW - 1, hb);
+        }
+        A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+        float Dt = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
+        if (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f) {
+            if (level == 0) st = false;
+            continue;
+        }
+        Dt = 1.f / Dt;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        float outx = nx + half, outy = ny + half;
+        for (int j = 0; j < a.max_count; ++j) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -win || inx >= w || iny < -win || iny >= h) {
+                if (level == 0) st = false;
+                break;
+            }
+            weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
+            const int diff = sample(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            float b1, b2;
+            {
+                const float v0 = (float)(diff * ixval), v1 = (float)(diff * iyval);
+                float a0 = v0, a1 = v1;
+#pragma unroll
+                for (int k = 1; k < NW; ++k) { a0 = seq_step(a0, v0); a1 = seq_step(a1, v1); }
+                b1 = half_value(a0, NW - 1, hb); b2 = half_value(a1, NW - 1, hb);
+            }
+            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+            nx += dx; ny += dy;
+            outx = nx + half; outy = ny + half;
+            if (dx * dx + dy * dy <= a.eps2) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        nx = outx; ny = outy;
+        if (st && level == 0) {
+            const float ex = nx - half, ey = ny - half;
+            const int inx = (int)floorf(ex), iny = (int)floorf(ey);
+            if (inx < -win || inx >= w || iny < -win || iny >= h) { st = false; continue; }
+            weights(ex - inx, ey - iny, iw00, iw01, iw10, iw11);
+            const int diff = sample(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            const float v0 = fabsf((float)diff);
+            float a0 = v0;
+#pragma unroll
+            for (int k = 1; k < NW; ++k) a0 = seq_step(a0, v0);
+            er = half_value(a0, NW - 1, hb) * 1.f / (32 * win * win);
+        }
+    }
+    if (g == 0) {
+        next_pts[2 * pt] = nx;
+        next_pts[2 * pt + 1] = ny;
+        status[pt] = st ? 1 : 0;
+        err[pt] = er;
+    }
+}
+
 // ---- diagnostic variants of the LK kernel (round 3: bisect of the results that differ under load).
 // MODE 0: window sums as DPP scans (the production arithmetic), 1: through LDS (no cross-lane VALU operation),
 // 2: both, compared, re-evaluated on a mismatch (counters say which of the two changed its mind).
@@ -1643,6 +1783,9 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
 #define FM_LK_DIAG_LAUNCH(MODE, CHK, CAP) \
     hipLaunchKernelGGL((lk_diag_kernel<5, MODE, CHK, CAP>), grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp, \
                        f->lk_diag, f->lk_cap, f->lk_cap_hdr)
+                if (v == 128) {                                              // one point per wavefront (the round-2 kernel)
+                    hipLaunchKernelGGL(lk_wave_kernel<5>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                } else
                 switch (v) {
                 case 1 | 64: FM_LK_DIAG_LAUNCH(0, false, false); break;      // DPP sums, diagnostic body (control)
                 case 1 | 32: FM_LK_DIAG_LAUNCH(0, false, true); break;       // DPP sums + capture
@@ -1654,10 +1797,13 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
                 default: fm_set_error("unknown lk_variant %d", v); return FM_ERR_ARG;
                 }
 #undef FM_LK_DIAG_LAUNCH
-            } else if (a.win == 5)
-                hipLaunchKernelGGL(lk_wave_kernel<5>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
-            else
-                hipLaunchKernelGGL(lk_wave_kernel<3>, grid, dim3(threads), lds_req, s, a, n, in_pts, o_pts, o_stat, o_errp);
+            } else {
+                const dim3 grid2((unsigned)((((size_t)n + 1) / 2 * 64 + threads - 1) / threads));     // two points per wavefront
+                if (a.win == 5)
+                    hipLaunchKernelGGL(lk_pair_kernel<5>, grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                else
+                    hipLaunchKernelGGL(lk_pair_kernel<3>, grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+            }
         }
         FM_HIP(hipGetLastError());
         g_flow_sub[5] += fm_now_ms() - tl0; tl0 = fm_now_ms();

@@ -28,5 +28,5 @@ cd $R && python scripts/layer_roofline.py /tmp/tr_$TAG > $O/yolo_layer_roofline.
 cd /tmp && rm -rf /tmp/tro_$TAG && rocprofv3 --kernel-trace -d /tmp/tro_$TAG -o t -- python $R/scripts/trace_net.py 1 50 > /dev/null 2>&1
 cd $R && python scripts/rocpd_dispatches.py "$(find /tmp/tro_$TAG -name '*.db' | head -1)" 40 > $O/osnet_b50_dispatches.txt 2>&1; tail -3 $O/osnet_b50_dispatches.txt
 if [ -z "$QUICK" ]; then
-    bash scripts/collect_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/r02_pmc_conv.json $O/pmc_conv.json 2>/dev/null; tail -1 $O/pmc.log | cut -c1-400
+    bash scripts/collect_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_conv.json gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt gpurun_out/pmc_sq_yolo.txt $O/ 2>/dev/null; tail -3 $O/pmc.log | cut -c1-400
 fi
