@@ -533,7 +533,9 @@ FilterArgs filter_args(DetState* d, int slot) {
 // hardware queues, one more changed which of them share a queue).  Order on the upload stream matters: a pass's
 // post-processing waits for its network, so it must be enqueued BEHIND the next frame's H2D copy, not in front of it
 // -- hence flush_post() is called after that copy has been enqueued (fm_frame_upload_next), before the next pass is
-// enqueued, and at collection time at the latest.
+// enqueued, and at collection time at the latest.  (Also measured: the unused streams of the extra ReID instances as
+// the post-processing stream -- 400 / 215 / 215 frames/s, the detector network 3.7x slower on two of them: which HIP
+// streams share a hardware queue decides everything here, and only the upload stream is known to be harmless.)
 static int flush_post(fm_ctx* ctx, DetState* d) {
     const int slot = d->post_pending;
     if (slot < 0) return 0;
