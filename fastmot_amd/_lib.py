@@ -111,6 +111,22 @@ class HipContext:
         """Tunables of the context: 'zero_copy_tracks', 'host_lap_elems' (include/fastmot_hip.h)."""
         check(self.lib.fm_ctx_set_option(self._ctx, key.encode(), C.c_int(int(value))))
 
+    def trace_start(self, cap=20000):
+        """Arms the library's stage-boundary event trace; -> host CLOCK_MONOTONIC ns of the trace's zero."""
+        t0 = C.c_int64(0)
+        check(self.lib.fm_trace_start(self._ctx, C.c_int(cap), C.byref(t0)))
+        self._trace_cap = cap
+        return t0.value
+
+    def trace_read(self):
+        """-> (tags int32[n], ms float32[n]): GPU time of every recorded stage boundary since the trace's zero."""
+        cap = self._trace_cap
+        tags = np.zeros(cap, np.int32)
+        ms = np.zeros(cap, np.float32)
+        n = C.c_int(0)
+        check(self.lib.fm_trace_read(self._ctx, C.c_int(cap), _ptr(tags), _ptr(ms), C.byref(n)))
+        return tags[:n.value], ms[:n.value]
+
     def bind_thread(self):
         """Called once by every additional host thread that drives this context."""
         check(self.lib.fm_ctx_bind_thread(self._ctx))

@@ -95,7 +95,7 @@ struct fm_ctx {
     void* predict_worker = nullptr;    // native KLT + Kalman worker thread of this context (flow_estimate.hip)
     hipStream_t s_main = nullptr;   // tracker kernels
     hipStream_t s_det = nullptr;    // detector network
-    hipStream_t s_up = nullptr;     // H2D copy of the prefetched next frame (overlaps the running detector pass)
+    hipStream_t s_up = nullptr;     // detector post-processing (sort, NMS, D2H), off the detector stream (detect.hip flush_post)
     hipStream_t s_ext = nullptr;    // ReID network
     hipStream_t s_ext_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // streams of the extra ReID instances
     hipEvent_t ev_ext_in = nullptr, ev_ext_x_done[FM_MAX_EXTRA_EXTRACTORS] = {};
@@ -143,7 +143,7 @@ struct fm_ctx {
     uint8_t* frame_own2 = nullptr;         // second upload slot (prefetched next frame); the two swap roles
     uint8_t* frame_next = nullptr;         // frame the detector was prefetched on (fm_frame_*_next)
     uint8_t* frame_pinned2 = nullptr;
-    hipEvent_t ev_next_upload = nullptr;   // completion of the prefetched frame's H2D copy (detector stream)
+    hipEvent_t ev_next_upload = nullptr;   // completion of the prefetched frame's H2D copy (enqueued on the ReID stream)
     uint8_t* frame_ring = nullptr;
     uint8_t* frame_pinned = nullptr;
 
@@ -154,7 +154,22 @@ struct fm_ctx {
     NetState* ext_net_x[FM_MAX_EXTRA_EXTRACTORS] = {};   // FM_NET_EXTRACTOR_B + i: further parts of a split batch
     FlowState* flow = nullptr;
     GalleryState* gallery[2] = {nullptr, nullptr};   // [FM_GALLERY_CHANNELS]
+
+    // ---- event trace of the pipeline (fm_trace_start / fm_trace_read, scripts/trace_pipeline.py); empty = off
+    std::vector<hipEvent_t> trace_ev;
+    std::vector<int> trace_tag;
+    std::atomic<int> trace_n{0};
+    hipEvent_t trace_base = nullptr;
 };
+
+// one timed event on stream `s` (no-op unless a trace is running; both host threads of a context may call it)
+inline void fm_trace_mark(fm_ctx* ctx, hipStream_t s, int tag) {
+    if (ctx->trace_ev.empty()) return;
+    const int i = ctx->trace_n.fetch_add(1);
+    if (i >= (int)ctx->trace_ev.size()) return;
+    ctx->trace_tag[i] = tag;
+    (void)hipEventRecord(ctx->trace_ev[i], s);
+}
 
 int fm_ensure_slots(fm_ctx* ctx, int max_slot_plus_1);
 void fm_predict_worker_free(fm_ctx* ctx);

@@ -30,6 +30,44 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     return 0;
 }
 
+// ---- event trace: where on the GPU's clock the stages of a pipelined step begin and end (hipGraph replays included,
+// which rocprofv3 cannot follow in this pipeline).  Tags: 10 detector stream reaches a pass, 11 its inputs are there
+// and preprocessed, 12 network done, 13 decode done; 20 / 21 post-processing begins / ends; 30 / 31 next frame's H2D
+// copy; 32 / 33 ReID crop + network; 40 / 41 LK launch.
+extern "C" int fm_trace_start(fm_ctx* ctx, int cap, int64_t* host_ns) {
+    FM_CHECK_ARG(ctx && cap > 0 && host_ns && ctx->trace_ev.empty());
+    FM_HIP(hipDeviceSynchronize());
+    std::vector<hipEvent_t> evs(cap);
+    for (auto& e : evs) FM_HIP(hipEventCreate(&e));
+    if (!ctx->trace_base) FM_HIP(hipEventCreate(&ctx->trace_base));
+    FM_HIP(hipEventRecord(ctx->trace_base, ctx->s_main));
+    FM_HIP(hipEventSynchronize(ctx->trace_base));
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    *host_ns = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+    ctx->trace_tag.assign(cap, 0);
+    ctx->trace_n = 0;
+    ctx->trace_ev = std::move(evs);
+    return 0;
+}
+
+extern "C" int fm_trace_read(fm_ctx* ctx, int cap, int32_t* tags, float* ms, int* n) {
+    FM_CHECK_ARG(ctx && tags && ms && n);
+    FM_HIP(hipDeviceSynchronize());
+    std::vector<hipEvent_t> evs = std::move(ctx->trace_ev);
+    ctx->trace_ev.clear();
+    int k = ctx->trace_n.load();
+    if (k > (int)evs.size()) k = (int)evs.size();
+    if (k > cap) k = cap;
+    for (int i = 0; i < k; ++i) {
+        tags[i] = ctx->trace_tag[i];
+        FM_HIP(hipEventElapsedTime(&ms[i], ctx->trace_base, evs[i]));
+    }
+    *n = k;
+    for (auto& e : evs) (void)hipEventDestroy(e);
+    return 0;
+}
+
 extern "C" int fm_ctx_bind_thread(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx);
     FM_HIP(hipSetDevice(ctx->device));

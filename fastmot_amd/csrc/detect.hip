@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
 __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict__ sorted,
                                                        int32_t* __restrict__ counters, int cap,
                                                        const uint64_t* __restrict__ mask, double max_area,
-                                                       double min_ar, fm_det48* __restrict__ dets) {
+                                                       double min_ar, fm_det48* __restrict__ dets,
+                                                       fm_det48* __restrict__ dets_host, int prefix,
+                                                       int32_t* __restrict__ counters_host) {
     extern __shared__ uint64_t keep[];       // [cap/64] survivors
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = min(counters[0], cap);
@@ -461,13 +463,17 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
             d.tlbr[0] = t0; d.tlbr[1] = t1; d.tlbr[2] = t2; d.tlbr[3] = t3;
             d.label = (int64_t)r[5];
             d.conf = (double)(r[4] * r[6]);     // float32 product (detector.py:362)
+            if (off < prefix) dets_host[off] = d;
         }
         __syncthreads();
         if (tid == 0)
             for (int wv = 0; wv < 16; ++wv) base += wave_cnt[wv];
         __syncthreads();
     }
-    if (tid == 0) counters[2] = base;
+    if (tid == 0) {
+        counters[2] = base;
+        counters_host[0] = counters[0]; counters_host[1] = counters[1]; counters_host[2] = base; counters_host[3] = counters[3];
+    }
 }
 
 int ensure_det(fm_ctx* ctx) {
@@ -525,17 +531,16 @@ FilterArgs filter_args(DetState* d, int slot) {
     return fa;
 }
 
-// sort + NMS + final filter + async D2H of the result of the pass in `slot`, on the UPLOAD stream behind the event that
-// marks the pass's candidates complete.  The NMS scan is one workgroup for tens of microseconds: on the detector stream
-// it kept the next frame's network waiting (1500 candidates per frame: 603 -> 667 frames/s in alternating runs with the
-// post-processing moved here).  The upload stream is the one stream of the context that is idle at that time -- a
-// stream of its own for this measured far worse (612 -> 430: the context drives more HIP streams than the runtime has
-// hardware queues, one more changed which of them share a queue).  Order on the upload stream matters: a pass's
-// post-processing waits for its network, so it must be enqueued BEHIND the next frame's H2D copy, not in front of it
-// -- hence flush_post() is called after that copy has been enqueued (fm_frame_upload_next), before the next pass is
-// enqueued, and at collection time at the latest.  (Also measured: the unused streams of the extra ReID instances as
-// the post-processing stream -- 400 / 215 / 215 frames/s, the detector network 3.7x slower on two of them: which HIP
-// streams share a hardware queue decides everything here, and only the upload stream is known to be harmless.)
+// sort + NMS + final filter + read-back of the result of the pass in `slot`, on a low-priority stream of their own
+// (s_up) behind the event that marks the pass's candidates complete.  The NMS scan is one workgroup for tens of
+// microseconds: on the detector stream it kept the next frame's network waiting (1500 candidates per frame: 603 -> 667
+// frames/s in alternating runs with the post-processing moved off it).  The post-processing is enqueued by whichever
+// comes first of: fm_frame_upload_next (behind the next frame's copy), the next pass, a collection -- in a pipelined
+// run that is the collection of the PREVIOUS pass, so it sits in its stream waiting for its network (enqueueing it
+// with the pass itself: 837 against 863 frames/s and a wider spread).  Which HIP streams share a hardware queue decides a lot here (the
+// context drives more streams than the runtime has queues): one more stream for this work measured 612 -> 430, the
+// idle streams of the extra ReID instances 400 / 215 / 215, the ReID stream itself 480, s_up at high priority 450
+// (profiles/r03_pipeline_order_ab.txt).
 static int flush_post(fm_ctx* ctx, DetState* d) {
     const int slot = d->post_pending;
     if (slot < 0) return 0;
@@ -543,18 +548,24 @@ static int flush_post(fm_ctx* ctx, DetState* d) {
     const int cap = d->cap;
     hipStream_t sp = ctx->s_up;
     FM_HIP(hipStreamWaitEvent(sp, d->ev_dec[slot], 0));
+    fm_trace_mark(ctx, sp, 20);
     hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, sp, d->cand[slot], d->sorted[slot],
                        d->counters[slot], cap);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, sp, d->sorted[slot],
                        d->counters[slot], cap, d->cfg.nms_thresh, d->mask[slot]);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), sp, d->sorted[slot],
-                       d->counters[slot], cap, d->mask[slot], d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets[slot]);
+                       d->counters[slot], cap, d->mask[slot], d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets[slot],
+                       d->dets_host[slot], cap < DetState::PREFIX ? cap : DetState::PREFIX, d->counters_host[slot]);
     FM_HIP(hipGetLastError());
-    FM_HIP(hipMemcpyAsync(d->counters_host[slot], d->counters[slot], sizeof(int32_t) * 4, hipMemcpyDeviceToHost, sp));
-    // detections are few: copy a bounded prefix with the pass, the rest (rare) at collection time
-    FM_HIP(hipMemcpyAsync(d->dets_host[slot], d->dets[slot],
-                          sizeof(fm_det48) * (cap < DetState::PREFIX ? cap : DetState::PREFIX), hipMemcpyDeviceToHost, sp));
+    // (The counters and a bounded prefix of the detections -- they are few; the rest, rare, is fetched at collection
+    // time -- are written to page-locked host memory by the scan kernel itself.  As two hipMemcpyAsync they were handed
+    // to a copy engine as soon as they were enqueued, i.e. while the pass they wait for still had a millisecond to run,
+    // and every later device-to-host copy that landed on that engine -- the embeddings of the frame being tracked, the
+    // KLT results -- waited behind them: scripts/trace_pipeline.py showed the main thread receiving its embeddings
+    // 0.6 ms after the ReID network had finished, exactly when the NEXT pass's post-processing ended.  Whether it
+    // happened depended on the engine the runtime picked: runs of the same binary fell into 650 or 860 frames/s.)
     FM_HIP(hipEventRecord(d->ev_done[slot], sp));
+    fm_trace_mark(ctx, sp, 21);
     return 0;
 }
 
@@ -717,16 +728,23 @@ extern "C" int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr) {
         src = ctx->frame_pinned2;
     }
     // The previous readers of frame_own2 -- every stage of the step before the last promote, its detector pass
-    // included -- are done (fm_frame_promote_next synchronised the ReID / KLT streams, that pass was collected), so the
-    // copy runs on its own stream: it overlaps the tail of the detector pass that is still running on s_det instead
-    // of queueing behind it (the detector chain upload -> network -> NMS is the longest chain of a step once the
-    // tracker side is fast: 0.12 ms per frame); the pass on this frame waits for the event (detect_async_on).
-    hipStream_t cs = ctx->s_up;
+    // included -- are done (fm_frame_promote_next synchronised the ReID / KLT streams, that pass was collected).  The
+    // copy goes to the ReID stream: that stream is idle at this point of a step (its network starts once this frame's
+    // detections have been collected, long after a 6 MB copy), it is a high-priority stream, and the pass on the new
+    // frame waits for the copy's event only.  On the low-priority stream that carries the post-processing the copy was
+    // held back while the KLT / ReID kernels of the running step kept the high-priority queues busy, and the detector
+    // -- the longest chain of a step -- started late every frame: 662 -> 780 frames/s for this move alone, 872 together
+    // with MOT.step enqueueing the prefetch before it starts the KLT job (config[1]; config[4] 100 -> 158;
+    // profiles/r03_pipeline_order_ab.txt holds the whole matrix, the tracker stream and a high-priority upload stream
+    // included: 550-600 and 450).
+    hipStream_t cs = ctx->s_ext;
+    fm_trace_mark(ctx, cs, 30);
     int rc_copy = enqueue_frame_copy(ctx->frame_own2, src, bytes, cs);
     if (rc_copy) return rc_copy;
-    if (ctx->det && (rc_copy = flush_post(ctx, ctx->det))) return rc_copy;   // behind the copy, see flush_post
+    fm_trace_mark(ctx, cs, 31);
     if (!ctx->ev_next_upload) FM_HIP(hipEventCreateWithFlags(&ctx->ev_next_upload, hipEventDisableTiming));
     FM_HIP(hipEventRecord(ctx->ev_next_upload, cs));
+    if (ctx->det && (rc_copy = flush_post(ctx, ctx->det))) return rc_copy;   // see flush_post
     ctx->frame_next = ctx->frame_own2;
     return 0;
 }
@@ -835,13 +853,16 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     NetState* net = ctx->det_net;
     const fm_yolo_cfg& c = d->cfg;
     hipStream_t s = ctx->s_det;
+    fm_trace_mark(ctx, s, 10);
     if (frame == ctx->frame_own2 && ctx->ev_next_upload) FM_HIP(hipStreamWaitEvent(s, ctx->ev_next_upload, 0));
     int rc = acquire_slot(d, s);
     if (rc) return rc;
     if ((rc = enqueue_preprocess(ctx, d, net, frame))) return rc;
     FM_HIP(hipEventRecord(d->ev0[d->wr], s));
+    fm_trace_mark(ctx, s, 11);
     if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
     FM_HIP(hipEventRecord(d->ev1[d->wr], s));
+    fm_trace_mark(ctx, s, 12);
     FilterArgs fa = filter_args(d, d->wr);      // (counters were zeroed by this frame's preprocess kernel)
     HeadSet hs{};
     int base = 0, blocks = 0;
@@ -863,6 +884,7 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     }
     if (blocks) hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), 0, s, hs, fa, c.in_w, c.in_h, c.new_coords);
     FM_HIP(hipGetLastError());
+    fm_trace_mark(ctx, s, 13);
     return enqueue_post(ctx, d, s);
 }
 

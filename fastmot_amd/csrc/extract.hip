@@ -21,6 +21,7 @@ struct ExtState {
     double* boxes_host = nullptr;  // pinned
     int cap = 0;
     DevBuf emb_out;                // pinned read-back buffer of fm_extract_sync
+    int exported_n = -1;           // rows of ctx->emb that export_kernel wrote to emb_out.h behind the last network pass
 };
 
 void fm_ext_free(ExtState* e) {
@@ -32,6 +33,13 @@ void fm_ext_free(ExtState* e) {
 }
 
 namespace {
+
+// embeddings -> page-locked host memory, by a kernel behind the network instead of a device-to-host copy at collection
+// time: no copy engine involved (see detect.hip flush_post for what a queued engine copy did to this pipeline), and
+// the rows are on the host when the stream is
+__global__ __launch_bounds__(256) void export_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n4) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) dst[i] = src[i];
+}
 
 struct Coef { int s; short a0, a1; };
 
@@ -110,9 +118,27 @@ extern "C" int fm_extract_configure(fm_ctx* ctx, int input_tensor, int in_w, int
 
 int fm_emb_reserve(fm_ctx* ctx, int n);
 
+static int export_embeddings(fm_ctx* ctx, ExtState* e, int n, hipStream_t s) {
+    const size_t bytes = sizeof(float) * (size_t)n * ctx->feat_dim;
+    e->exported_n = -1;
+    if (bytes > e->emb_out.cap) {             // (growing frees the old buffers: nothing may be in flight on them)
+        FM_HIP(hipStreamSynchronize(s));
+        int rc = e->emb_out.reserve(bytes);
+        if (rc) return rc;
+    }
+    const int n4 = (int)(bytes / 16);
+    hipLaunchKernelGGL(export_kernel, dim3((n4 + 255) / 256 < 64 ? (n4 + 255) / 256 : 64), dim3(256), 0, s,
+                       (const float4*)ctx->emb, (float4*)e->emb_out.h, n4);
+    FM_HIP(hipGetLastError());
+    e->exported_n = n;
+    return 0;
+}
+
 extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
     FM_CHECK_ARG(ctx && ctx->ext && ctx->ext_net && n >= 0 && ctx->frame_cur);
     ctx->emb_n = 0;
+    int rc_exp = 0;
+    if (ctx->ext) ctx->ext->exported_n = -1;
     if (n == 0) return 0;
     FM_CHECK_ARG(tlbr);
     ExtState* e = ctx->ext;
@@ -141,6 +167,7 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
     FM_HIP(hipStreamSynchronize(s));   // boxes_host reuse
     memcpy(e->boxes_host, tlbr, sizeof(double) * 4 * n);
     FM_HIP(hipMemcpyAsync(e->boxes, e->boxes_host, sizeof(double) * 4 * n, hipMemcpyHostToDevice, s));
+    fm_trace_mark(ctx, s, 32);
     const fm_tensor& t = net->tensors[e->input_tensor];
     // Several instances of the network (FM_NET_EXTRACTOR_B + i): the batch is cut into parts that run
     // concurrently on their own streams.  The ~30 dependent launches of OSNet are latency bound, so part-size
@@ -171,6 +198,8 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
             }
             off += b;
         }
+        if ((rc_exp = export_embeddings(ctx, e, n, s))) return rc_exp;
+        fm_trace_mark(ctx, s, 33);
         ctx->emb_n = n;
         return 0;
     }
@@ -185,6 +214,8 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
         net->emb_offset = 0;
         if (rc) return rc;
     }
+    if ((rc_exp = export_embeddings(ctx, e, n, s))) return rc_exp;
+    fm_trace_mark(ctx, s, 33);
     ctx->emb_n = n;
     return 0;
 }
@@ -199,9 +230,11 @@ extern "C" int fm_extract_sync(fm_ctx* ctx, int n, float* emb) {
     // read back on the extractor's own stream through a pinned buffer: a synchronous hipMemcpy runs on the
     // legacy NULL stream, which must not be mixed with the other host thread's asynchronous work
     const size_t bytes = sizeof(float) * (size_t)n * ctx->feat_dim;
-    int rc = ctx->ext->emb_out.reserve(bytes);
-    if (rc) return rc;
-    FM_HIP(hipMemcpyAsync(ctx->ext->emb_out.h, ctx->emb, bytes, hipMemcpyDeviceToHost, ctx->s_ext));
+    if (ctx->ext->exported_n != n) {          // (rows that did not come from fm_extract_async: plain copy)
+        int rc = ctx->ext->emb_out.reserve(bytes);
+        if (rc) return rc;
+        FM_HIP(hipMemcpyAsync(ctx->ext->emb_out.h, ctx->emb, bytes, hipMemcpyDeviceToHost, ctx->s_ext));
+    }
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
     memcpy(emb, ctx->ext->emb_out.h, bytes);
     return 0;

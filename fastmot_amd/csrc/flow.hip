@@ -1799,10 +1799,12 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
 #undef FM_LK_DIAG_LAUNCH
             } else {
                 const dim3 grid2((unsigned)((((size_t)n + 1) / 2 * 64 + threads - 1) / threads));     // two points per wavefront
+                fm_trace_mark(ctx, s, 40);
                 if (a.win == 5)
                     hipLaunchKernelGGL(lk_pair_kernel<5>, grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
                 else
                     hipLaunchKernelGGL(lk_pair_kernel<3>, grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                fm_trace_mark(ctx, s, 41);
             }
         }
         FM_HIP(hipGetLastError());

@@ -134,6 +134,13 @@ extern "C" int fm_gallery_init(fm_ctx* ctx, int channel, int world, int rank, co
     return 0;
 }
 
+__global__ __launch_bounds__(256) void rows_to_host_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes) {
+    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (size_t i = n16 * 16 + (size_t)blockIdx.x * 256 + threadIdx.x; i < bytes; i += stride) dst[i] = src[i];
+}
+
 // enqueues one all-gather of this rank's row (row_bytes, copied before the call returns); collective
 extern "C" int fm_gallery_allgather_async(fm_ctx* ctx, int channel, const void* send_row) {
     FM_CHECK_ARG(ctx && channel >= 0 && channel < FM_GALLERY_CHANNELS && ctx->gallery[channel] && send_row);
@@ -148,7 +155,15 @@ extern "C" int fm_gallery_allgather_async(fm_ctx* ctx, int channel, const void* 
     FM_HIP(hipEventRecord(g->ev0, g->stream));
     FM_HIP(hipMemcpyAsync(g->send_dev, g->send_host, g->row_bytes, hipMemcpyHostToDevice, g->stream));
     FM_RCCL(r->AllGather(g->send_dev, g->recv_dev, g->row_bytes, 1 /* ncclUint8 */, g->comm, g->stream));
-    FM_HIP(hipMemcpyAsync(g->recv_host, g->recv_dev, g->row_bytes * g->world, hipMemcpyDeviceToHost, g->stream));
+    // the gathered rows go to page-locked host memory by a kernel, not by a copy-engine transfer: a device-to-host copy
+    // queued here would occupy its engine until the collective -- i.e. the slowest rank -- is through, and hold up the
+    // tracker's own read-backs that land on the same engine (detect.hip flush_post has the measurement)
+    {
+        const size_t bytes = g->row_bytes * (size_t)g->world;
+        hipLaunchKernelGGL(rows_to_host_kernel, dim3(bytes / 16 / 256 + 1 < 64 ? bytes / 16 / 256 + 1 : 64), dim3(256), 0,
+                           g->stream, (const uint8_t*)g->recv_dev, (uint8_t*)g->recv_host, bytes);
+        FM_HIP(hipGetLastError());
+    }
     FM_HIP(hipEventRecord(g->ev1, g->stream));
     g->pending = true;
     return 0;

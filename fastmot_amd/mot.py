@@ -153,6 +153,11 @@ class MOT:
             # second host thread and its own HIP streams, so the critical path of a step is
             # detector -> ReID network -> association.  The stages are independent exactly as in the
             # reference, so the results are identical.
+            # next_frame known: its upload and detector pass are queued right behind this frame's pass (the detector
+            # stream never idles; results are collected in order, detect.hip) -- and BEFORE the KLT job is started: the
+            # detector chain is the longest of a step, and with the worker thread's launches in front of it the copy
+            # and the pass reached the GPU late and at varying times (779 +- 70 -> 872 +- 25 frames/s over 8 runs each)
+            self._prefetch_next()
             native = _NATIVE_FLOW and type(self.tracker.flow) is Flow      # (tests script the flow with a fake)
             if native:
                 # KLT + Kalman on the library's worker thread: marshalled here, scattered in predict_finish -- no second
@@ -161,9 +166,6 @@ class MOT:
             else:
                 flow_done = self._flow_thread.submit(self._flow_and_kalman, frame)
             try:
-                # next_frame known: its upload and detector pass are queued right behind this frame's pass (the
-                # detector stream never idles; results are collected in order, detect.hip)
-                self._prefetch_next()
                 with Profiler('detect'):
                     detections = self._last_detections = self.detector.postprocess()
 

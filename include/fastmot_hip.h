@@ -51,6 +51,13 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
  * instrumented variant of the LK kernel, see fm_flow_lk_diag_read).  Initial values can be set with the environment
  * variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP / FASTMOT_GRAPHS. */
 int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value);
+/* Event trace of a pipelined run (diagnostics; scripts/trace_pipeline.py).  fm_trace_start arms `cap` timed events and
+ * returns the host's CLOCK_MONOTONIC time (ns) that corresponds to the trace's zero; from then on the library records
+ * one event per stage boundary on the stage's own stream (tags: 10-13 detector pass reached / inputs ready / network done
+ * / decode done, 20-21 post-processing, 30-31 next frame's H2D copy, 32-33 ReID network, 40-41 LK launch).
+ * fm_trace_read synchronises the device, returns tags[i] / ms[i] (GPU time since the trace's zero) and disarms. */
+int fm_trace_start(fm_ctx* ctx, int cap, int64_t* host_ns);
+int fm_trace_read(fm_ctx* ctx, int cap, int32_t* tags, float* ms, int* n);
 /* writes "name:gcnArch:CUs:clockMHz:hbmBytes" of the ctx device */
 int fm_device_info(fm_ctx* ctx, char* buf, int buflen);
 
