@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ for one round on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r03 [quick]
+#   bash scripts/collect_profiles.sh r03 [quick]      (quick: no stand-alone network replays, no PMC passes, CPU baseline on config[1] only)
 # -> gpurun_out/<tag>/: GPU test summary, bench lines (default command line, the driver's --steps 20 --warmup 5, configs 2
 #    and 4), rocprofv3 kernel stats of the bench command, per-layer roofline table of the detector, OSNet dispatch list,
 #    PMC traffic passes (separate rocprofv3 --pmc runs, MI355X_MICROARCH.md).  Copy what is to be judged into profiles/.
@@ -13,20 +13,23 @@ timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-180 $O/bench_n1.json
 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_cmdline.json 2> $O/bench_driver.err; cut -c1-180 $O/bench_driver_cmdline.json
-if [ -z "$QUICK" ]; then
-    timeout 900 python bench.py --config 2 > $O/bench_config2.json 2> $O/bench_config2.err; cut -c1-230 $O/bench_config2.json
-    timeout 900 python bench.py --config 4 --steps 60 --warmup 10 > $O/bench_config4.json 2> $O/bench_config4.err; cut -c1-230 $O/bench_config4.json
-fi
+NOCPU=; [ -z "$QUICK" ] || NOCPU=--no-cpu-baseline
+timeout 900 python bench.py --config 2 $NOCPU > $O/bench_config2.json 2> $O/bench_config2.err; cut -c1-230 $O/bench_config2.json
+timeout 900 python bench.py --config 4 --steps 60 --warmup 10 $NOCPU > $O/bench_config4.json 2> $O/bench_config4.err; cut -c1-230 $O/bench_config4.json
+# stage boundaries of the pipelined step on the GPU's clock, hipGraph replays included (fm_trace_*)
+timeout 300 python scripts/trace_pipeline.py --show 3 > $O/pipeline_trace.txt 2> /dev/null; head -1 $O/pipeline_trace.txt
 # kernel stats of the bench command itself (the durations roofline.achieved must agree with).  FASTMOT_GRAPHS=0: the layers
 # are launched one by one -- rocprofv3's tool crashes inside hipGraphLaunch of this pipeline (ROCm 7.2), and per-kernel
 # durations are what is wanted here anyway
 cd /tmp && rm -rf /tmp/kt_$TAG && FASTMOT_GRAPHS=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o b -- python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-variants > $O/bench_under_rocprof.json 2> /dev/null
 cd $R && python scripts/rocpd_summary.py "$(find /tmp/kt_$TAG -name '*.db' | head -1)" > $O/bench_kernel_stats.txt 2>&1; head -30 $O/bench_kernel_stats.txt | cut -c1-160
+if [ -z "$QUICK" ]; then
 # stand-alone replays: per-layer roofline of the detector, dispatch list of the ReID network
 cd /tmp && rm -rf /tmp/tr_$TAG && rocprofv3 --kernel-trace -d /tmp/tr_$TAG -o t -- python $R/scripts/trace_net.py 0 > /dev/null 2>&1
 cd $R && python scripts/layer_roofline.py /tmp/tr_$TAG > $O/yolo_layer_roofline.txt 2>&1; tail -3 $O/yolo_layer_roofline.txt
 cd /tmp && rm -rf /tmp/tro_$TAG && rocprofv3 --kernel-trace -d /tmp/tro_$TAG -o t -- python $R/scripts/trace_net.py 1 50 > /dev/null 2>&1
 cd $R && python scripts/rocpd_dispatches.py "$(find /tmp/tro_$TAG -name '*.db' | head -1)" 40 > $O/osnet_b50_dispatches.txt 2>&1; tail -3 $O/osnet_b50_dispatches.txt
+fi
 if [ -z "$QUICK" ]; then
     bash scripts/collect_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_conv.json gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt gpurun_out/pmc_sq_yolo.txt $O/ 2>/dev/null; tail -3 $O/pmc.log | cut -c1-400
 fi
