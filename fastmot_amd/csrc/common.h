@@ -172,5 +172,6 @@ inline void fm_trace_mark(fm_ctx* ctx, hipStream_t s, int tag) {
 }
 
 int fm_ensure_slots(fm_ctx* ctx, int max_slot_plus_1);
+void fm_ext_invalidate_export(fm_ctx* ctx);
 void fm_predict_worker_free(fm_ctx* ctx);
 void fm_gallery_free(fm_ctx* ctx);

@@ -330,6 +330,7 @@ extern "C" int fm_emb_upload(fm_ctx* ctx, int n, const float* emb) {
         return 0;
     }
     FM_HIP(hipStreamSynchronize(ctx->s_main));
+    fm_ext_invalidate_export(ctx);
     int rc = fm_emb_reserve(ctx, n);
     if (rc) return rc;
     if (n)

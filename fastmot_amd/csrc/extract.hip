@@ -24,6 +24,11 @@ struct ExtState {
     int exported_n = -1;           // rows of ctx->emb that export_kernel wrote to emb_out.h behind the last network pass
 };
 
+// ctx->emb was written by something other than the extractor (fm_emb_upload): the exported copy is stale
+void fm_ext_invalidate_export(fm_ctx* ctx) {
+    if (ctx->ext) ctx->ext->exported_n = -1;
+}
+
 void fm_ext_free(ExtState* e) {
     if (!e) return;
     e->emb_out.release();

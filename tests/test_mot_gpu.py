@@ -202,3 +202,44 @@ def test_draw_overlays_do_not_change_tracking(ctx):
                 mot.step(DeviceFrame(0))
         mot.tracker._clear_tracks()
     assert runs[0] == runs[1]
+
+
+def test_stage_trace_orders_a_pipelined_step(ctx):
+    """fm_trace_start / fm_trace_read (include/fastmot_hip.h): one timed event per stage boundary on the stage's own
+    stream.  In a pipelined run every detector pass shows inputs-ready <= network-done <= decode-done, its
+    post-processing begins after the decode, the ReID network of a frame begins after that frame's detections left the
+    post-processing, and reading the trace disarms it (tracks are unaffected: same ids as an untraced run)."""
+    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from fastmot_amd import Track
+    size = (960, 540)
+    video = SyntheticVideo(size, n_ids=10, n_frames=16, seed=11)
+    ids = []
+    for traced in (False, True):
+        mot = build_mot(size, video, 1)
+        Track._count = 0
+        mot.reset(1 / 30.)
+        if traced:
+            zero_ns = ctx.trace_start(4096)
+            assert zero_ns > 0
+        for f in range(video.n_frames):
+            mot.detector._frame_idx = f
+            nxt = video.frames[f + 1] if f + 1 < video.n_frames else None
+            mot.step(video.frames[f], next_frame=nxt)
+        ids.append(sorted(t.trk_id for t in mot.tracker.tracks.values()))
+        if traced:
+            tags, ms = ctx.trace_read()
+            by = {t: ms[tags == t] for t in np.unique(tags)}
+            n = video.n_frames
+            assert all(len(by[t]) == n for t in (11, 12, 13)), {t: len(v) for t, v in by.items()}
+            assert len(by[30]) == len(by[31]) == n - 1                  # one copy per prefetched frame
+            assert len(by[20]) == len(by[21]) == n                      # every pass post-processed exactly once
+            assert np.all(by[11] <= by[12]) and np.all(by[12] <= by[13])
+            assert np.all(np.diff(by[11]) > 0)                           # passes run in order on their stream
+            assert np.all(by[20] >= by[13]) and np.all(by[21] >= by[20])
+            assert len(by[32]) == len(by[33]) and np.all(by[33] >= by[32])
+            m = min(len(by[32]), n - 1)                                  # (frame 0 initialises the tracker: no ReID)
+            assert m == n - 1 and np.all(by[32][-m:] >= by[21][-m:])
+            tags2, _ = ctx.trace_read()                                  # disarmed: nothing recorded any more
+            assert len(tags2) == 0
+        mot.tracker._clear_tracks()
+    assert ids[0] == ids[1] and len(ids[0]) >= 8
