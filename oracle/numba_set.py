@@ -10,8 +10,14 @@ size 8 vs 16, growth x4 at 3/5 load vs to >= 2 x used, no shrinking vs `downsize
 reference (oracle/ref_shim.py: decorators stubbed) can order these lists differently from the reference as it really
 runs.  ref_shim therefore hands `_get_assignment_matches` THIS set type in place of the builtin.
 
-PARITY UNPINNED: Numba is not installable in this image, so the restatement cannot be checked against a real Numba
-run; it follows the published source:
+PINNED against a real Numba (round 3): the image's /opt/conda Python 3.9 carries Numba 0.54.1, which imports once its
+NumPy-version gate is satisfied in-process (oracle/real_numba.py).  oracle/pin_with_numba.py compares this container
+with `list(set(range(n)) - set(removed))` and with one-by-one `discard()` inside @njit functions over 996 (n, removed)
+cases (n = 0..69 and sizes around every table-growth boundary up to 700): 0 mismatches; the cases and the real answers
+are committed as tests/golden/numba_set_order.npz and checked on every machine (tests/test_setorder.py), for this
+container and for the product's fastmot_amd/utils/setorder.py.  The reference pins Numba 0.48 (`requirements.txt:3`),
+which is not available here; 0.54.1's numba/cpython/setobj.py is the same algorithm as far as it is restated below.
+The restatement follows the published source:
   * open addressing; entry = (hash, key); EMPTY = -1, DELETED = -2; MINSIZE = 16; LINEAR_PROBES = 3
   * hash(int64 i) = i for 0 <= i < 2**61 - 1 (numba/targets/hashing.py; -1 -> -2, not reachable here)
   * probe sequence of `_lookup`: index = h & mask; three linear probes (index, index + 1, index + 2, wrapping), then

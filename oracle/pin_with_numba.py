@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE ONLY -- build container only.  Pins the oracle's goldens with a REAL Numba.
+
+The committed goldens (tests/golden/*.npz) come from the unmodified reference with Numba's decorators replaced by the
+identity (oracle/ref_shim.py) plus a restatement of Numba's typed set where its iteration order shows in the track IDs
+(oracle/numba_set.py).  That left open what the jit-compiled reference really computes: fastmath reassociation, typed
+containers, integer / float typing of the njit'ed bodies.  This script closes it as far as this image allows:
+
+    /opt/conda/bin/python3.9 oracle/pin_with_numba.py          (Numba 0.54.1; the reference pins 0.48, requirements.txt:3)
+
+1. re-runs every golden generator (make_golden.py, make_golden_mot.py, make_golden_ssd.py) with the reference's
+   @nb.njit functions compiled by the real Numba (ref_shim.load_reference(real_numba=True)) into a scratch directory
+   and compares array by array with the committed files: integer / bool arrays must be equal, float arrays are
+   reported with their largest absolute difference;
+2. compares oracle/numba_set.difference_order with `list(set(range(n)) - set(removed))` inside an @njit function over
+   ~1000 (n, removed) cases and writes them, with the real answers, to tests/golden/numba_set_order.npz -- the fixture
+   tests/test_setorder.py checks the restatement AND the product's utils/setorder.py against on every machine;
+3. writes tests/golden/REAL_NUMBA_PIN.json (versions, per-file verdicts) and tests/golden/real_numba_floats.npz: the
+   float arrays of the real-Numba run that differ from the committed ones ("<file>:<array>"), so that the restatement
+   can be held against what the jit-compiled reference computes, not only against its de-jitted source.
+
+Nothing under /root/reference is written (NUMBA_CACHE_DIR and byte-code writing are redirected, oracle/real_numba.py).
+"""
+import json
+import runpy
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / 'oracle'))
+sys.path.insert(0, str(ROOT / 'tests'))
+sys.dont_write_bytecode = True
+
+import real_numba  # noqa: E402
+
+numba, NUMPY_VERSION = real_numba.import_numba()
+import numpy as np  # noqa: E402
+import ref_shim  # noqa: E402
+import numba_set  # noqa: E402
+
+GOLDEN = ROOT / 'tests' / 'golden'
+
+
+def regenerate(tmp):
+    """Runs the three generators with the real Numba, their np.savez_compressed calls redirected to `tmp`."""
+    real_load = ref_shim.load_reference
+    real_save = np.savez_compressed
+
+    def load(prefix='fastmot', real_numba=True):
+        return real_load(prefix, real_numba=True)
+
+    def save(path, **arrays):
+        real_save(Path(tmp) / Path(path).name, **arrays)
+    ref_shim.load_reference = load
+    np.savez_compressed = save
+    try:
+        for script in ('make_golden.py', 'make_golden_mot.py', 'make_golden_ssd.py'):
+            for key in [k for k in sys.modules if k == 'fastmot' or k.startswith('fastmot.')]:
+                del sys.modules[key]
+            runpy.run_path(str(ROOT / 'oracle' / script), run_name='__main__')
+    finally:
+        ref_shim.load_reference = real_load
+        np.savez_compressed = real_save
+
+
+def compare(tmp):
+    verdicts = {}
+    real_floats = {}          # float arrays of the real-Numba run that differ from the committed (de-jitted) ones
+    for new in sorted(Path(tmp).glob('*.npz')):
+        old = GOLDEN / new.name
+        if not old.exists():
+            verdicts[new.name] = {'status': 'no committed file'}
+            continue
+        a, b = np.load(old, allow_pickle=False), np.load(new, allow_pickle=False)
+        rec = {'arrays': len(a.files), 'equal': 0, 'float_close': {}, 'different': []}
+        if sorted(a.files) != sorted(b.files):
+            rec['different'].append('key sets differ')
+        for k in a.files:
+            if k not in b.files:
+                continue
+            x, y = a[k], b[k]
+            if x.shape != y.shape or x.dtype != y.dtype:
+                rec['different'].append(f'{k}: {x.dtype}{x.shape} vs {y.dtype}{y.shape}')
+            elif np.array_equal(x, y, equal_nan=x.dtype.kind == 'f'):
+                rec['equal'] += 1
+            elif x.dtype.kind == 'f':
+                rec['float_close'][k] = float(np.nanmax(np.abs(x - y)))
+                real_floats[f'{new.stem}:{k}'] = y
+            else:
+                rec['different'].append(f'{k}: {int((x != y).sum())} of {x.size} elements')
+        rec['status'] = ('identical' if rec['equal'] == rec['arrays'] else
+                         'float differences only' if not rec['different'] else 'DIFFERENT')
+        verdicts[new.name] = rec
+    np.savez_compressed(GOLDEN / 'real_numba_floats.npz', **real_floats)
+    return verdicts
+
+
+def pin_set_order():
+    @numba.njit
+    def real(n, removed):
+        return list(set(range(n)) - set(removed))
+
+    @numba.njit
+    def real_discard(n, removed):
+        keep = set(range(n))
+        for k in removed:
+            keep.discard(k)
+        return list(keep)
+    rng = np.random.default_rng(0)
+    ns, offs, rem, out_d, out_k, out_off = [], [0], [], [], [], [0]
+    bad = 0
+    for n in list(range(0, 70)) + [100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 700]:
+        for trial in range(12):
+            k = 0 if trial == 0 else n if trial == 1 else int(rng.integers(0, n + 1))
+            r = rng.permutation(n)[:k].astype(np.int64)
+            d = np.array(real(n, r), np.int64)
+            kd = np.array(real_discard(n, r), np.int64)          # detector.py:196-211: set(range(n)), discard() one by one
+            mine = numba_set.difference_order(n, [int(x) for x in r])
+            s = numba_set.NumbaIntSet(range(n))
+            for x in r:
+                s.discard(int(x))
+            bad += list(d) != mine or list(kd) != list(s)
+            ns.append(n); rem.append(r); offs.append(offs[-1] + k)
+            out_d.append(d); out_k.append(kd); out_off.append(out_off[-1] + len(d))
+            assert len(d) == len(kd) == n - k
+    np.savez_compressed(GOLDEN / 'numba_set_order.npz', n=np.array(ns, np.int64), removed=np.concatenate(rem),
+                        removed_off=np.array(offs, np.int64), difference=np.concatenate(out_d),
+                        discarded=np.concatenate(out_k), out_off=np.array(out_off, np.int64))
+    return len(ns), bad
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        regenerate(tmp)
+        verdicts = compare(tmp)
+    cases, bad = pin_set_order()
+    rec = {'numba': numba.__version__, 'numpy': NUMPY_VERSION, 'python': sys.version.split()[0],
+           'reference_pins': 'numba==0.48 (requirements.txt:3)', 'goldens': verdicts,
+           'set_order': {'cases': cases, 'restatement_mismatches': bad, 'fixture': 'tests/golden/numba_set_order.npz'}}
+    (GOLDEN / 'REAL_NUMBA_PIN.json').write_text(json.dumps(rec, indent=1) + '\n')
+    for name, v in verdicts.items():
+        print(f'{name:42s} {v["status"]}' + (f'  max |diff| {max(v["float_close"].values()):.3g} in {len(v["float_close"])} arrays'
+                                             if v.get('float_close') else '') + (f'  {v["different"][:3]}' if v.get('different') else ''))
+    print(f'set order: {cases} cases, {bad} mismatches of the restatement')
+
+
+if __name__ == '__main__':
+    main()

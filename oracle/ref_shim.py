@@ -16,6 +16,12 @@ yields the IEEE sequential answer of the reference source.  One Numba semantic
 IS reproduced because it is observable in the track IDs: inside @njit functions
 the builtin `set` is Numba's hash set (restated in oracle/numba_set.py), whose
 iteration order differs from CPython's (matching.py:59-60, detector.py:196).
+What the de-jitting leaves open was measured with a real Numba 0.54.1
+(load_reference(real_numba=True), oracle/pin_with_numba.py, record in
+tests/golden/REAL_NUMBA_PIN.json): every integer / boolean array of every golden
+file (track ids, rounded boxes, life-cycle flags, history order, NMS keep lists,
+SSD merge) is identical; float arrays (Kalman states, distances) differ by at
+most 1.3e-10 (float64) / 4.3e-8 (float32 cosine terms) -- fastmath.
 
 /root/reference only exists in the build container; nothing on the GPU box may
 call load_reference().
@@ -71,9 +77,13 @@ def _stub(name, **attrs):
     return mod
 
 
-def load_reference(prefix='fastmot'):
+def load_reference(prefix='fastmot', real_numba=False):
     """Returns a namespace with the reference modules:
     rect, distance, matching, numba_utils, kalman_filter, track, tracker, flow, label
+
+    real_numba: the reference's @nb.njit functions are compiled by a real Numba (oracle/real_numba.py; only where one
+    is importable: the /opt/conda Python 3.9 of the build container) instead of being de-jitted -- fastmath, typed
+    containers and all.  oracle/pin_with_numba.py uses this to check the committed goldens.
     """
     if not reference_available():
         raise RuntimeError('/root/reference is not present (GPU box?)')
@@ -81,7 +91,11 @@ def load_reference(prefix='fastmot'):
 
     saved = {k: sys.modules.get(k) for k in
              ('numba', 'cv2', 'cupy', 'cupyx', 'cupyx.scipy', 'cupyx.scipy.ndimage', 'tensorrt')}
-    sys.modules['numba'] = _fake_numba()
+    if real_numba:
+        import real_numba as _rn
+        sys.modules['numba'] = _rn.import_numba()[0]
+    else:
+        sys.modules['numba'] = _fake_numba()
 
     class _Fast:
         def detect(self, *a, **k):

@@ -76,3 +76,29 @@ def test_tracker_scenes(golden_dir, name):
     np.testing.assert_array_equal(out['tracks'], g['tracks'])
     np.testing.assert_array_equal(out['hist'], g['hist'])
     np.testing.assert_allclose(out['final_mean'], g['final_mean'], rtol=1e-9, atol=1e-7)
+
+
+def test_restatement_against_the_jit_compiled_reference(golden_dir):
+    """tests/golden/real_numba_floats.npz (oracle/pin_with_numba.py): the float arrays the reference produces when its
+    @njit functions are compiled by a REAL Numba (0.54.1), where they differ from the de-jitted goldens.  The oracle's
+    cosine distance follows Numba's typing (float64 accumulation of the float32 terms), not the shim's NumPy-2 weak-scalar
+    artifact: it equals the real thing to the last bit or two, and the gated cost built on it exactly; everything Kalman
+    is within the reassociation noise of fastmath (1e-10 absolute on states of order 1e3)."""
+    rf = np.load(golden_dir / 'real_numba_floats.npz')
+    g = np.load(golden_dir / 'assoc_kat.npz')
+    for tag in 'abcd':
+        XA, XB, mask = g[f'{tag}_XA'].astype(np.float64), g[f'{tag}_XB'], g[f'{tag}_mask']
+        np.testing.assert_allclose(o.cdist(XA, XB, 'cosine', mask, 0.9), rf[f'assoc_kat:{tag}_cos'], rtol=0, atol=2e-15)
+        np.testing.assert_allclose(o.cdist(XA, XB, 'euclidean', mask, 0.9), rf[f'assoc_kat:{tag}_euc'], rtol=0, atol=1e-12)
+        cost = o.matching_cost(rf[f'assoc_kat:{tag}_cos'], g[f'{tag}_maha'], g[f'{tag}_tlab'], g[f'{tag}_dlab'], 0.2, 0.8)
+        np.testing.assert_array_equal(cost, rf[f'assoc_kat:{tag}_cost'])
+    for name in rf.files:
+        stem, key = name.split(':')
+        if stem == 'assoc_kat':
+            continue
+        committed = np.load(golden_dir / f'{stem}.npz')[key]
+        np.testing.assert_allclose(committed, rf[name], rtol=1e-9, atol=1e-9)
+    rec = __import__('json').loads((golden_dir / 'REAL_NUMBA_PIN.json').read_text())
+    assert rec['set_order']['restatement_mismatches'] == 0
+    assert all(v['status'] in ('identical', 'float differences only') for v in rec['goldens'].values())
+    assert sum(v['status'] == 'identical' for v in rec['goldens'].values()) >= 3

@@ -59,3 +59,37 @@ def test_discard_sequences_equal_restated_container():
             a.discard(k)
             b.discard(k)
         assert list(a) == list(b)
+
+
+def _real_numba_cases():
+    """tests/golden/numba_set_order.npz: answers of a REAL Numba (0.54.1, oracle/pin_with_numba.py) for
+    list(set(range(n)) - set(removed)) and for set(range(n)) with the same elements discard()ed one by one."""
+    from pathlib import Path
+    z = np.load(Path(__file__).parent / 'golden' / 'numba_set_order.npz')
+    for i, n in enumerate(z['n'].tolist()):
+        removed = z['removed'][z['removed_off'][i]:z['removed_off'][i + 1]].tolist()
+        lo, hi = z['out_off'][i], z['out_off'][i + 1]
+        yield n, removed, z['difference'][lo:hi].tolist(), z['discarded'][lo:hi].tolist()
+
+
+def test_restatement_equals_real_numba():
+    """the oracle's container against the jit-compiled thing itself (matching.py:59-60, detector.py:196-211)"""
+    cases = 0
+    for n, removed, difference, discarded in _real_numba_cases():
+        assert numba_set.difference_order(n, removed) == difference, (n, removed)
+        s = numba_set.NumbaIntSet(range(n))
+        for k in removed:
+            s.discard(k)
+        assert list(s) == discarded, (n, removed)
+        cases += 1
+    assert cases > 900
+
+
+def test_product_order_equals_real_numba():
+    """what the tracker / the SSD merge of the product use (fastmot_amd/utils/setorder.py), against the same answers"""
+    for n, removed, difference, discarded in _real_numba_cases():
+        assert unmatched_order(n, removed) == difference, (n, removed)
+        s = IntSet(n)
+        for k in removed:
+            s.discard(k)
+        assert list(s) == discarded, (n, removed)
