@@ -57,6 +57,46 @@ class OTrack:
             self.f_sum, self.f_avg = o.average_feature(self.f_sum, other.f_sum, self.f_count)
 
 
+# ---- the @njit glue of Flow.predict (flow.py:266-364), as OracleFlow.predict uses it; pinned against the jit-compiled
+# reference by tests/test_flow_helpers_kat.py (fixture from oracle/pin_with_numba.py)
+def rect_filter(kp, ins, fg):
+    """flow.py:283-295: keypoints whose rounded position lies inside the rectangle and on foreground"""
+    if len(kp) == 0:
+        return np.empty((0, 2), np.float32)
+    p2 = np.rint(kp).astype(np.int32)
+    ok = (p2[:, 0] >= ins[0]) & (p2[:, 0] <= ins[2]) & (p2[:, 1] >= ins[1]) & (p2[:, 1] <= ins[3])
+    kp, p2 = kp[ok], p2[ok]
+    return kp[fg[p2[:, 1], p2[:, 0]] == 255] if len(kp) else kp
+
+
+def feature_dist(area, factor):
+    """flow.py:268-271"""
+    return max(round(np.sqrt(area) * factor), 1)
+
+
+def ellipse_filter(kp_local, tlbr, offset):
+    """flow.py:298-307: crop-local corners -> frame coordinates (float32), those inside the box's inscribed ellipse"""
+    kp = kp_local.reshape(-1, 2) + np.asarray(offset, np.float32)
+    c = (tlbr[:2] + tlbr[2:]) / 2
+    ax = (tlbr[2:] - tlbr[:2] + 1) * 0.5
+    return kp[(((kp - c) / ax) ** 2).sum(1) <= 1.]
+
+
+def lk_status(st, err, max_error):
+    """flow.py:348-350"""
+    return st.ravel().astype(bool) & (err.ravel() < max_error)
+
+
+def unscale_pts(pts, scale, mask=None):
+    """flow.py:335-345 (float32 throughout: 1 / float32 array stays float32 under Numba as under NumPy)"""
+    un = 1 / np.array(scale, np.float32)
+    pts = pts.reshape(-1, 2)
+    if mask is None:
+        return pts * un
+    pts[mask] = pts[mask] * un
+    return pts
+
+
 class OracleFlow:
     """Flow.init / Flow.predict on real frames with cv_oracle (flow.py:121-264)."""
 
@@ -89,20 +129,12 @@ class OracleFlow:
             ins = np.concatenate([np.maximum(t.tlbr[:2], fr[:2]), np.minimum(t.tlbr[2:], fr[2:])]).astype(int)
             tm = fg[ins[1]:ins[3] + 1, ins[0]:ins[2] + 1]
             area = int((tm != 0).sum())
-            kp = t.keypoints
-            if len(kp):
-                p2 = np.rint(kp).astype(np.int32)
-                ok = (p2[:, 0] >= ins[0]) & (p2[:, 0] <= ins[2]) & (p2[:, 1] >= ins[1]) & (p2[:, 1] <= ins[3])
-                kp, p2 = kp[ok], p2[ok]
-                kp = kp[fg[p2[:, 1], p2[:, 0]] == 255] if len(kp) else kp
+            kp = rect_filter(t.keypoints, ins, fg) if len(t.keypoints) else t.keypoints
             if len(kp) < self.feat_density * area:
-                md = max(round(np.sqrt(area) * self.feat_dist_factor), 1)
+                md = feature_dist(area, self.feat_dist_factor)
                 kp = self.cv.good_features_to_track(self.prev_gray[ins[1]:ins[3] + 1, ins[0]:ins[2] + 1], tm, 1000, 0.06, md)
                 if len(kp):
-                    kp = kp + ins[:2].astype(np.float32)
-                    c = (t.tlbr[:2] + t.tlbr[2:]) / 2
-                    ax = (t.tlbr[2:] - t.tlbr[:2] + 1) * 0.5
-                    kp = kp[(((kp - c) / ax) ** 2).sum(1) <= 1.]
+                    kp = ellipse_filter(kp, t.tlbr, ins[:2])
             all_prev.append(kp.astype(np.float32).reshape(-1, 2))
             tm[:] = 0
         ends = np.cumsum([len(p) for p in all_prev]).astype(np.int32) if tracks else np.zeros(0, np.int32)
@@ -115,14 +147,14 @@ class OracleFlow:
             self.bg_keypoints = empty
             self.prev_gray, self.prev_small = gray, small
             return {}, None
-        kp = kp * (1 / np.array(self.bg_scale, np.float32))
+        kp = unscale_pts(kp, self.bg_scale)
         bg_begin = int(ends[-1]) if tracks else 0
         all_prev.append(kp)
         P = np.concatenate(all_prev).astype(np.float32)
         sp = P * np.array(self.opt_scale, np.float32)
         C, st, err = self.cv.calc_optical_flow_pyr_lk(self.prev_small, small, sp)
-        st = st.astype(bool) & (err < self.max_error)
-        C[st] = C[st] * (1 / np.array(self.opt_scale, np.float32))
+        st = lk_status(st, err, self.max_error)
+        C = unscale_pts(C, self.opt_scale, st)
         self.prev_gray, self.prev_small = gray, small
         tl = np.array([t.tlbr for t in tracks], float).reshape(-1, 4)
         H, res, est, nm, inl = self.cv.flow_estimate(P, C, st, begins, ends, bg_begin, max(len(P) - 1, bg_begin), tl,

@@ -592,6 +592,31 @@ def lm_refine(cb, a, b, M, max_iters=10):
     return cb.from_params(x)
 
 
+def fg_keep(pt, boxes, size):
+    """flow.py:310-324 (_fg_filter) for one matched point: its rounded position is inside the frame and on none of the
+    boxes estimated for the closer tracks so far (the reference zeroes those in fg_mask, flow.py:261-263)"""
+    x, y = int(np.rint(pt[0])), int(np.rint(pt[1]))
+    if x < 0 or y < 0 or x >= size[0] or y >= size[1]:
+        return False
+    return not any(b[0] <= x <= b[2] and b[1] <= y <= b[3] for b in boxes)
+
+
+def crop_box(e):
+    """the pixel rectangle rect.crop() addresses for a box (rect.py:83-89)"""
+    return [max(int(e[0]), 0), max(int(e[1]), 0), max(int(e[2]), 0), max(int(e[3]), 0)]
+
+
+def estimate_bbox(tb, M):
+    """flow.py:274-280 (_estimate_bbox) with M = the six coefficients of the 2x3 partial-affine matrix, row-major"""
+    tlx = tb[0] * M[0] + tb[1] * M[1] + M[2]
+    tly = tb[0] * M[3] + tb[1] * M[4] + M[5]
+    scale = np.sqrt(M[0] * M[0] + M[3] * M[3])
+    if scale < 0.9 or scale > 1.1:
+        scale = 1.
+    w, h = tb[2] - tb[0] + 1, tb[3] - tb[1] + 1
+    return np.rint([tlx, tly, tlx + w * scale - 1., tly + h * scale - 1.])
+
+
 def flow_estimate(prev_pts, cur_pts, status, begins, ends, bg_begin, bg_end, track_tlbr, size,
                   ransac_max_iter, ransac_conf, inlier_thresh):
     """Second half of Flow.predict (flow.py:215-263) with cv2.findHomography /
@@ -622,14 +647,8 @@ def flow_estimate(prev_pts, cur_pts, status, begins, ends, bg_begin, bg_end, tra
     for k in range(nT):
         idx = []
         for i in range(begins[k], ends[k]):
-            if not st[i]:
-                continue
-            x, y = int(np.rint(Cc[i, 0])), int(np.rint(Cc[i, 1]))
-            if x < 0 or y < 0 or x >= size[0] or y >= size[1]:
-                continue
-            if any(b[0] <= x <= b[2] and b[1] <= y <= b[3] for b in boxes):
-                continue
-            idx.append(i)
+            if st[i] and fg_keep(Cc[i], boxes, size):
+                idx.append(i)
         n = len(idx)
         n_matched[k] = n
         if n < 3:
@@ -640,14 +659,7 @@ def flow_estimate(prev_pts, cur_pts, status, begins, ends, bg_begin, bg_end, tra
             continue
         if n > 2 and mask.any():
             M = lm_refine(acb, P[idx][mask], Cc[idx][mask], M, 10)
-        tb = track_tlbr[k]
-        tlx = tb[0] * M[0] + tb[1] * M[1] + M[2]
-        tly = tb[0] * M[3] + tb[1] * M[4] + M[5]
-        scale = np.sqrt(M[0] * M[0] + M[3] * M[3])
-        if scale < 0.9 or scale > 1.1:
-            scale = 1.
-        w, h = tb[2] - tb[0] + 1, tb[3] - tb[1] + 1
-        e = np.rint([tlx, tly, tlx + w * scale - 1., tly + h * scale - 1.])
+        e = estimate_bbox(track_tlbr[k], M)
         inl[idx[mask]] = True
         est[k] = e
         outside = min(e[2], size[0] - 1) < max(e[0], 0) or min(e[3], size[1] - 1) < max(e[1], 0)
@@ -655,5 +667,5 @@ def flow_estimate(prev_pts, cur_pts, status, begins, ends, bg_begin, bg_end, tra
             result[k] = 2
             continue
         result[k] = 1
-        boxes.append([max(int(e[0]), 0), max(int(e[1]), 0), max(int(e[2]), 0), max(int(e[3]), 0)])
+        boxes.append(crop_box(e))
     return H.reshape(3, 3), result, est, n_matched, inl

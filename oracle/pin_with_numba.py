@@ -14,7 +14,9 @@ containers, integer / float typing of the njit'ed bodies.  This script closes it
 2. compares oracle/numba_set.difference_order with `list(set(range(n)) - set(removed))` inside an @njit function over
    ~1000 (n, removed) cases and writes them, with the real answers, to tests/golden/numba_set_order.npz -- the fixture
    tests/test_setorder.py checks the restatement AND the product's utils/setorder.py against on every machine;
-3. writes tests/golden/REAL_NUMBA_PIN.json (versions, per-file verdicts) and tests/golden/real_numba_floats.npz: the
+3. writes tests/golden/flow_helpers_kat.npz: the @njit glue of Flow.predict that needs no OpenCV, run jit-compiled on
+   seeded inputs (the oracle's own restatement of that glue is tested against it, tests/test_flow_helpers_kat.py);
+4. writes tests/golden/REAL_NUMBA_PIN.json (versions, per-file verdicts) and tests/golden/real_numba_floats.npz: the
    float arrays of the real-Numba run that differ from the committed ones ("<file>:<array>"), so that the restatement
    can be held against what the jit-compiled reference computes, not only against its de-jitted source.
 
@@ -95,6 +97,80 @@ def compare(tmp):
     return verdicts
 
 
+def golden_flow_helpers(ns):
+    """The @njit glue of Flow.predict that needs no OpenCV (flow.py:266-364: _estimate_feature_dist, _estimate_bbox,
+    _rect_filter, _ellipse_filter, _fg_filter, _scale_pts, _unscale_pts, _get_status, _get_good_match, _get_inliers) and
+    the rect.py helpers it is built on (intersection, crop), on seeded inputs -- generated with the REAL Numba only: the
+    de-jitted bodies do not even run on empty inputs (`np.array([])` of an empty list comprehension is float64 in NumPy
+    and cannot index; Numba types it int64)."""
+    F = ns.flow.Flow
+    rect = ns.rect
+    rng = np.random.default_rng(23)
+    out = {}
+    areas = np.concatenate([np.arange(0, 400), rng.integers(400, 200000, 300), [1736, 1737, 6944, 6945, 15625, 27777, 27778]])
+    out['fd_area'] = areas.astype(np.int64)
+    out['fd_dist'] = np.array([F._estimate_feature_dist(int(a), 0.06) for a in areas], np.int64)
+    W, H = 160, 120
+    frame_rect = np.array([0., 0., W - 1., H - 1.])
+    n_cases = 24
+    for c in range(n_cases):
+        fg = np.full((H, W), 255, np.uint8)
+        holes = []
+        for _ in range(int(rng.integers(0, 4))):                       # earlier (closer) tracks already zeroed
+            b = np.sort(rng.integers(-10, W + 10, 2)).tolist() + np.sort(rng.integers(-10, H + 10, 2)).tolist()
+            hole = np.array([b[0], b[2], b[1], b[3]], float)            # (flow.py:261-263 crops the estimated box itself)
+            rect.crop(fg, hole)[:] = 0
+            holes.append(hole)
+        out[f'c{c}_holes'] = np.array(holes, float).reshape(-1, 4)
+        tl = rng.uniform(-20, [W - 20, H - 20])
+        tlbr = np.rint(np.concatenate([tl, tl + rng.uniform(8, 90, 2)]))
+        ins = rect.intersection(tlbr, frame_rect)
+        if ins is None:
+            tlbr = np.array([10., 12., 70., 90.])
+            ins = rect.intersection(tlbr, frame_rect)
+        n = 0 if c == 0 else int(rng.integers(1, 60))
+        pts = (rng.uniform(-6, 6, (n, 2)) + rng.uniform(ins[:2] - 4, ins[2:] + 4, (n, 2))).astype(np.float32)
+        if n > 4:
+            pts[0] = ins[:2] - 0.5                                      # rint half cases on the rectangle's edge
+            pts[1] = ins[2:] + 0.5
+            pts[2] = ins[:2] + np.float32(0.5)
+        out[f'c{c}_fg'] = fg.copy()
+        out[f'c{c}_tlbr'] = tlbr
+        out[f'c{c}_ins'] = ins
+        out[f'c{c}_pts'] = pts
+        out[f'c{c}_rect'] = F._rect_filter(pts, ins, fg)
+        local = rng.uniform(-2, [ins[2] - ins[0] + 3, ins[3] - ins[1] + 3], (max(n, 3), 2)).astype(np.float32).reshape(-1, 1, 2)
+        out[f'c{c}_gftt'] = local
+        out[f'c{c}_ellipse'] = F._ellipse_filter(local, tlbr, ins[:2])
+        # LK outputs -> status, unscale (masked, in place on a copy), good matches, fg filter, inliers
+        m = max(n, 5)
+        prev = rng.uniform(0, [W, H], (m, 2)).astype(np.float32)
+        cur = (prev * np.float32(0.5) + rng.normal(0, 1.5, (m, 2)).astype(np.float32)).reshape(-1, 1, 2)
+        st = (rng.random((m, 1)) < 0.8).astype(np.uint8)
+        err = rng.uniform(0, 160, (m, 1)).astype(np.float32)
+        status = F._get_status(st, err, 100)
+        cur_un = F._unscale_pts(cur.copy(), (0.5, 0.5), status)
+        out.update({f'c{c}_prev': prev, f'c{c}_cur': cur, f'c{c}_st': st, f'c{c}_err': err, f'c{c}_status': status,
+                    f'c{c}_cur_un': cur_un, f'c{c}_scaled': F._scale_pts(prev, (0.5, 0.5)),
+                    f'c{c}_bg_un': F._unscale_pts(prev.copy(), (0.1, 0.1))})
+        b, e = int(rng.integers(0, m // 2)), int(rng.integers(m // 2, m + 1))
+        gp, gc = F._get_good_match(prev, cur_un, status, b, e)
+        fp, fc = F._fg_filter(gp, gc, fg, (W, H))
+        inl = (rng.random((len(fc), 1)) < 0.7).astype(np.uint8)
+        ip, ic = F._get_inliers(fp, fc, inl)
+        out.update({f'c{c}_range': np.array([b, e]), f'c{c}_good_prev': gp, f'c{c}_good_cur': gc, f'c{c}_fgf_prev': fp,
+                    f'c{c}_fgf_cur': fc, f'c{c}_inl': inl, f'c{c}_inl_prev': ip, f'c{c}_inl_cur': ic})
+        ang, sc = rng.normal(0, 0.05), rng.choice([0.85, 0.9, 0.95, 1.0, 1.04, 1.1, 1.12]) * (1 + rng.normal(0, 1e-3))
+        A = np.array([[sc * np.cos(ang), -sc * np.sin(ang), rng.normal(0, 6)],
+                      [sc * np.sin(ang), sc * np.cos(ang), rng.normal(0, 6)]])
+        out[f'c{c}_affine'] = A
+        out[f'c{c}_est'] = F._estimate_bbox(tlbr, A)
+    out['n_cases'] = np.array(n_cases)
+    np.savez_compressed(GOLDEN / 'flow_helpers_kat.npz', **out)
+    print('flow_helpers_kat: ok', len(out), 'arrays')
+
+
+
 def pin_set_order():
     @numba.njit
     def real(n, removed):
@@ -134,6 +210,9 @@ def main():
         regenerate(tmp)
         verdicts = compare(tmp)
     cases, bad = pin_set_order()
+    for key in [k for k in sys.modules if k == 'fastmot' or k.startswith('fastmot.')]:
+        del sys.modules[key]
+    golden_flow_helpers(ref_shim.load_reference(real_numba=True))
     rec = {'numba': numba.__version__, 'numpy': NUMPY_VERSION, 'python': sys.version.split()[0],
            'reference_pins': 'numba==0.48 (requirements.txt:3)', 'goldens': verdicts,
            'set_order': {'cases': cases, 'restatement_mismatches': bad, 'fixture': 'tests/golden/numba_set_order.npz'}}
