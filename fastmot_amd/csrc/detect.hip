@@ -758,8 +758,8 @@ extern "C" int fm_frame_ring_select_next(fm_ctx* ctx, int index) {
 extern "C" int fm_frame_promote_next(fm_ctx* ctx) {
     FM_CHECK_ARG(ctx && ctx->frame_next);
     if (ctx->frame_next == ctx->frame_own2) {
-        // the upload of the prefetched frame was enqueued on s_det; the other streams read the frame from
-        // now on and must wait for that copy (they never waited for the detector stream otherwise)
+        // the upload of the prefetched frame was enqueued on the ReID stream (fm_frame_upload_next); every stream that
+        // reads the frame from now on waits for that copy's event
         FM_HIP(hipStreamSynchronize(ctx->s_ext));
         FM_HIP(hipStreamSynchronize(ctx->s_flow));
         FM_HIP(hipStreamSynchronize(ctx->s_flow2));
