@@ -205,7 +205,64 @@ def pin_set_order():
     return len(ns), bad
 
 
+def quick_check():
+    """--quick-check: a subset that fits a unit test (tests/test_real_numba_pin.py runs it where this interpreter and
+    /root/reference exist): the Kalman / association / NMS known-answer files and two tracker scenes regenerated with the
+    jit-compiled reference and compared with the committed goldens, the set-order restatement on every tenth case.
+    Writes nothing under tests/golden; exit code 1 on any integer difference or a float difference above 1e-9."""
+    import importlib
+    with tempfile.TemporaryDirectory() as tmp:
+        real_save = np.savez_compressed
+        np.savez_compressed = lambda path, **arrays: real_save(Path(tmp) / Path(path).name, **arrays)
+        try:
+            mg = importlib.import_module('make_golden')
+            ns = ref_shim.load_reference(real_numba=True)
+            mg.golden_kalman(ns)
+            mg.golden_assoc(ns)
+            mg.golden_nms(ns)
+            all_scenes = mg.scenes.SCENES
+            mg.scenes.SCENES = {k: all_scenes[k] for k in ('s8_flowfail', 's16_blackout_confirm3')}
+            try:
+                mg.golden_tracker(ns)
+            finally:
+                mg.scenes.SCENES = all_scenes
+        finally:
+            np.savez_compressed = real_save
+        keep = globals()['GOLDEN']
+        verdicts = {}
+        for new in sorted(Path(tmp).glob('*.npz')):
+            a, b = np.load(keep / new.name), np.load(new)
+            worst, bad = 0.0, []
+            for k in a.files:
+                x, y = a[k], b[k]
+                if x.shape != y.shape or x.dtype != y.dtype:
+                    bad.append(k)
+                elif x.dtype.kind == 'f':
+                    if x.size:
+                        worst = max(worst, float(np.nanmax(np.abs(x - y))))
+                elif not np.array_equal(x, y):
+                    bad.append(k)
+            verdicts[new.name] = (bad, worst)
+            print(f'{new.name:40s} integer arrays {"identical" if not bad else "DIFFERENT " + str(bad)}, floats within {worst:.3g}')
+    @numba.njit
+    def real(n, removed):
+        return list(set(range(n)) - set(removed))
+    z = np.load(GOLDEN / 'numba_set_order.npz')
+    mism = 0
+    for i in range(0, len(z['n']), 10):
+        n = int(z['n'][i])
+        r = z['removed'][z['removed_off'][i]:z['removed_off'][i + 1]]
+        mism += list(real(n, r)) != numba_set.difference_order(n, r.tolist())
+    print(f'set order: {len(range(0, len(z["n"]), 10))} cases, {mism} mismatches')
+    ok = mism == 0 and all(not bad and worst <= 1e-9 or (not bad and name.startswith('assoc') and worst <= 1e-7)
+                           for name, (bad, worst) in verdicts.items())
+    print('numba', numba.__version__, 'numpy', NUMPY_VERSION, 'OK' if ok else 'FAILED')
+    return 0 if ok else 1
+
+
 def main():
+    if '--quick-check' in sys.argv:
+        sys.exit(quick_check())
     with tempfile.TemporaryDirectory() as tmp:
         regenerate(tmp)
         verdicts = compare(tmp)
