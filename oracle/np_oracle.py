@@ -366,10 +366,22 @@ def yolo_preprocess(frame, in_hw, roi=None):
     interpolation in float64, edge clamp ('nearest'), result cast to uint8 by rint.  Then BGR->RGB,
     HWC->CHW, * 1/255 into float32.  Returns float32 [3, in_h, in_w]; outside `roi`
     (x, y, w, h) the letterbox value is 0.5."""
-    fh, fw = frame.shape[:2]
     in_h, in_w = in_hw
     rx, ry, rw, rh = (0, 0, in_w, in_h) if roi is None else roi
     out = np.full((3, in_h, in_w), 0.5, np.float32)
+    val = np.clip(np.rint(zoom_linear_opencv(frame, rh, rw)), 0, 255)
+    rgb = val[..., ::-1].transpose(2, 0, 1)
+    out[:, ry:ry + rh, rx:rx + rw] = (rgb * (1 / 255.)).astype(np.float32)
+    return out
+
+
+def zoom_linear_opencv(frame, rh, rw):
+    """The interpolated values of cupyx.scipy.ndimage.zoom(frame, ..., order=1, mode='opencv') before the cast to the
+    integer output type, float64 [rh, rw, C]: CuPy turns mode='opencv' into affine_transform(zoom = in / out,
+    offset = (zoom - 1) / 2, mode='nearest').  tests/test_preprocess_scipy_pin.py holds this against SciPy's
+    affine_transform with the same arguments (the CPU sibling of the CuPy routine): identical but for exact .5 ties,
+    which SciPy's integer cast rounds up and CuPy's rint() rounds to even."""
+    fh, fw = frame.shape[:2]
     zy, zx = fh / rh, fw / rw
     sy = np.arange(rh) * zy + (zy - 1.) / 2.
     sx = np.arange(rw) * zx + (zx - 1.) / 2.
@@ -380,10 +392,7 @@ def yolo_preprocess(frame, in_hw, roi=None):
     f = frame.astype(np.float64)
     top = (1. - wx)[None, :, None] * f[y0i][:, x0i] + wx[None, :, None] * f[y0i][:, x1i]
     bot = (1. - wx)[None, :, None] * f[y1i][:, x0i] + wx[None, :, None] * f[y1i][:, x1i]
-    val = np.clip(np.rint((1. - wy)[:, None, None] * top + wy[:, None, None] * bot), 0, 255)
-    rgb = val[..., ::-1].transpose(2, 0, 1)
-    out[:, ry:ry + rh, rx:rx + rw] = (rgb * (1 / 255.)).astype(np.float32)
-    return out
+    return (1. - wy)[:, None, None] * top + wy[:, None, None] * bot
 
 
 def yolo_decode(head, anchors, num_classes, in_wh, scale_xy, new_coords=False):

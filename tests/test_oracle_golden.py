@@ -102,3 +102,19 @@ def test_restatement_against_the_jit_compiled_reference(golden_dir):
     assert rec['set_order']['restatement_mismatches'] == 0
     assert all(v['status'] in ('identical', 'float differences only') for v in rec['goldens'].values())
     assert sum(v['status'] == 'identical' for v in rec['goldens'].values()) >= 3
+
+
+def test_yolo_decode_against_reference_kernel_outputs(golden_dir):
+    """tests/golden/yolo_decode_ref.npz: outputs of the reference's CalDetection / CalDetection_NewCoords compiled for the
+    host from plugins/yolo_layer.cu (oracle/yolo_layer_ref.py --golden; __expf -> expf): same rows in the same order,
+    class ids identical, NEW_COORDS bit for bit, the sigmoid / exp variant to the last bits of exp()."""
+    g = np.load(golden_dir / 'yolo_decode_ref.npz')
+    for k in range(int(g['n'])):
+        nc, new, iw, ih, sxy = g[f'k{k}_params']
+        got = o.yolo_decode(g[f'k{k}_head'], g[f'k{k}_anchors'], int(nc), (int(iw), int(ih)), float(sxy), bool(new))
+        ref = g[f'k{k}_rows']
+        np.testing.assert_array_equal(got[:, 5], ref[:, 5])
+        if new:
+            np.testing.assert_array_equal(got, ref)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=2e-6)

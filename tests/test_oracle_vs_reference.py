@@ -70,3 +70,29 @@ def test_average_feature(ref):
         else:
             s, a = o.average_feature(s, v, k)
         np.testing.assert_allclose(a, af.avg, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('num_classes,new_coords', [(80, False), (2, False), (1, False), (80, True), (3, True)])
+def test_yolo_decode_against_the_reference_kernels(num_classes, new_coords):
+    """np_oracle.yolo_decode against the reference's own CalDetection / CalDetection_NewCoords (plugins/yolo_layer.cu:
+    127-230), compiled for the host from the reference file by oracle/yolo_layer_ref.py (CUDA's __expf becomes expf):
+    row order, output layout and class arg-max identical, the NEW_COORDS variant (no exponential in it) bit for bit,
+    the sigmoid variant to the last bits of exp()."""
+    import yolo_layer_ref
+    if not yolo_layer_ref.available():
+        pytest.skip('needs /root/reference')
+    rng = np.random.default_rng(num_classes + 7 * new_coords)
+    anchors = [12, 16, 19, 36, 40, 28]
+    for (H, W), in_wh in (((19, 19), (608, 608)), ((20, 36), (1152, 640)), ((1, 1), (32, 32))):
+        head = (rng.uniform(0, 1, ((5 + num_classes) * 3, H, W)) if new_coords
+                else rng.normal(0, 2.5, ((5 + num_classes) * 3, H, W))).astype(np.float32)
+        if num_classes > 1:
+            head[5 + 1, 0, 0] = head[5, 0, 0]          # a tie between two class logits: the first one wins
+        ref = yolo_layer_ref.decode(head, anchors, num_classes, in_wh, 1.05, new_coords)
+        got = o.yolo_decode(head, anchors, num_classes, in_wh, 1.05, new_coords)
+        assert ref.shape == got.shape == (3 * H * W, 7)
+        np.testing.assert_array_equal(got[:, 5], ref[:, 5])
+        if new_coords:
+            np.testing.assert_array_equal(got, ref)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=2e-6)
