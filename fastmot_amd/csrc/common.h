@@ -159,12 +159,13 @@ struct fm_ctx {
     std::vector<hipEvent_t> trace_ev;
     std::vector<int> trace_tag;
     std::atomic<int> trace_n{0};
+    std::atomic<bool> trace_on{false};   // set once the two vectors are in place, cleared before they are taken away
     hipEvent_t trace_base = nullptr;
 };
 
 // one timed event on stream `s` (no-op unless a trace is running; both host threads of a context may call it)
 inline void fm_trace_mark(fm_ctx* ctx, hipStream_t s, int tag) {
-    if (ctx->trace_ev.empty()) return;
+    if (!ctx->trace_on.load(std::memory_order_acquire)) return;
     const int i = ctx->trace_n.fetch_add(1);
     if (i >= (int)ctx->trace_ev.size()) return;
     ctx->trace_tag[i] = tag;

@@ -35,7 +35,7 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
 // and preprocessed, 12 network done, 13 decode done; 20 / 21 post-processing begins / ends; 30 / 31 next frame's H2D
 // copy; 32 / 33 ReID crop + network; 40 / 41 LK launch.
 extern "C" int fm_trace_start(fm_ctx* ctx, int cap, int64_t* host_ns) {
-    FM_CHECK_ARG(ctx && cap > 0 && host_ns && ctx->trace_ev.empty());
+    FM_CHECK_ARG(ctx && cap > 0 && host_ns && !ctx->trace_on.load() && ctx->trace_ev.empty());
     FM_HIP(hipDeviceSynchronize());
     std::vector<hipEvent_t> evs(cap);
     for (auto& e : evs) FM_HIP(hipEventCreate(&e));
@@ -48,11 +48,13 @@ extern "C" int fm_trace_start(fm_ctx* ctx, int cap, int64_t* host_ns) {
     ctx->trace_tag.assign(cap, 0);
     ctx->trace_n = 0;
     ctx->trace_ev = std::move(evs);
+    ctx->trace_on.store(true, std::memory_order_release);
     return 0;
 }
 
 extern "C" int fm_trace_read(fm_ctx* ctx, int cap, int32_t* tags, float* ms, int* n) {
     FM_CHECK_ARG(ctx && tags && ms && n);
+    ctx->trace_on.store(false, std::memory_order_release);
     FM_HIP(hipDeviceSynchronize());
     std::vector<hipEvent_t> evs = std::move(ctx->trace_ev);
     ctx->trace_ev.clear();
