@@ -40,6 +40,7 @@ def build(force=False):
     (OUT / 'yolo_layer_kernels.inc').write_text('\n'.join(lines[b:e]) + '\n')
     res = subprocess.run(['g++', '-O2', '-ffp-contract=off', '-shared', '-fPIC', '-I', str(HERE), '-o', str(LIB), str(src)],
                          capture_output=True, text=True)
+    (OUT / 'yolo_layer_kernels.inc').unlink()        # reference text: needed by the compiler only, never kept
     if res.returncode != 0:
         raise RuntimeError('g++ failed:\n' + res.stderr)
     return LIB
