@@ -298,7 +298,8 @@ int fm_host_alloc(size_t bytes, void** out);
 int fm_host_free(void* p);
 /* Next-frame prefetch (no counterpart in the reference, whose detector is synchronous per step): the
  * detector network can be started on frame t+1 while frame t is still in the ReID / association stages.
- * fm_frame_upload_next copies a host frame into the second upload slot (asynchronously, detector stream),
+ * fm_frame_upload_next copies a host frame into the second upload slot (asynchronously; the detector pass on it waits
+ * for the copy's event),
  * fm_frame_ring_select_next points at a resident frame; fm_detect_async_next = fm_detect_async on that
  * frame; fm_frame_promote_next makes it the current frame of the next step without another upload. */
 int fm_frame_upload_next(fm_ctx* ctx, const uint8_t* bgr);
@@ -337,8 +338,9 @@ typedef struct fm_yolo_cfg {
 int fm_detect_configure(fm_ctx* ctx, const fm_yolo_cfg* cfg);
 /* YOLODetector.detect_async (detector.py:270-273): preprocess (bilinear resize in u8, BGR->RGB,
  * /255, detector.py:289-300) -> network -> head decode (plugins/yolo_layer.cu:127-230) ->
- * score/class filter -> per-class DIoU-NMS -> box filter (detector.py:322-365), all enqueued on
- * the detector stream; only the surviving detections are copied to the host. */
+ * score/class filter -> per-class DIoU-NMS -> box filter (detector.py:322-365); network and decode on the detector
+ * stream, sort / NMS / filter behind them on a stream of their own; only the surviving detections reach the host
+ * (written to page-locked memory by the last kernel). */
 int fm_detect_async(fm_ctx* ctx);
 /* YOLODetector.postprocess (detector.py:275-287): waits for the stream, returns detections sorted
  * by class id.  Returns FM_ERR_STATE if the candidate list overflowed. */
