@@ -30,10 +30,11 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(1, str(ROOT / 'tests'))        # the synthetic workload (tests/synthetic.py) is test / bench infrastructure
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 RING = 32
-SETTLE_MIN, SETTLE_MAX = 150, 450
+SETTLE_MIN, SETTLE_MAX, SETTLE_CHECK = 150, 450, 10
 
 # BASELINE.json configs that fit one GPU.  [0] is the detector-disabled CPU plumbing case and [3] is config[1]
 # on 8 GPUs (= --gpus 8 --config 1); both are covered by the parity tests / the scaling run, not bench lines.
@@ -74,7 +75,7 @@ def build_mot(cfg, video, gallery_sync=None, nms_candidates=1500):
     passes).  The tracker is fed the scripted detections either way."""
     import fastmot_amd.mot as mot_mod
     from fastmot_amd.detector import YOLODetector
-    from fastmot_amd.utils.synthetic import InjectedYOLODetector, scripted_head_weights
+    from synthetic import InjectedYOLODetector, scripted_head_weights
     mot_mod.YOLODetector = InjectedYOLODetector
     tcfg = tracker_cfg()
     if gallery_sync is not None:
@@ -119,6 +120,12 @@ def cpu_leg(cfg, video, mot, budget_s=20.0):
                                           emb, budget_s=budget_s, labels=cfg['labels'])
     parity = e2e_check.compare(hip[:done], ora)
     parity['oracle'] = 'oracle/cpu_tracker.py + cv_oracle.py on the same frames, detections and HIP embeddings'
+    # the detector's OWN output on a frame of the timed clip (the tracker is fed scripted detections): preprocess,
+    # decode of the engine's head tensors, candidate sort, DIoU-NMS and box filters against the oracle
+    import detector_check
+    chain, _ = detector_check.check(mot.detector, video.frames[0])
+    parity['detector_chain'] = chain
+    parity['detector_chain_identical'] = chain['detector_chain_identical']
     base = {'value': round(done / dt, 3), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
             'sample': f'{done} frames of the same {cfg["size"][0]}x{cfg["size"][1]}/{video.n_ids}-detection '
                       f'synthetic clip (detector_frame_skip={cfg["skip"]}); numpy port of KLT+Kalman+association '
@@ -204,7 +211,7 @@ def main():
     from fastmot_amd.detector import DeviceFrame
     models.allow_random_weights()          # no weight files offline: seeded random parameters (stated in `data`)
     from fastmot_amd.runtime import get_context
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     ctx = get_context()                    # device = LOCAL_RANK (torchrun convention)
 
     # Collectives of the harness itself (barrier around the timed region, max over ranks).  Default: the library's own
@@ -266,11 +273,24 @@ def main():
 
     frames = resident if args.resident else pinned
 
+    def all_ranks(flag):
+        """True iff `flag` holds on every rank (one small collective on the harness channel; N = 1: the flag)."""
+        if ctl is not None:
+            return bool(np.all(ctl.allgather_small([1.0 if flag else 0.0]) > 0.5))
+        if dist is not None:
+            t = torch.tensor([1.0 if flag else 0.0], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
+        return bool(flag)
+
     def settle(start):
         """Untimed settle phase before the warm-up the command line asks for: a fresh process runs its first few
         hundred steps slower (GPU clocks ramping, hipGraphs instantiated, the prediction worker and the RANSAC pool
         asleep), and a short `--steps 20 --warmup 5` run would time exactly that.  At least SETTLE_MIN steps, then
-        until the last 20 step times lie within 3 % of their median, at most SETTLE_MAX."""
+        until the last 20 step times lie within 3 % of their median, at most SETTLE_MAX.  The decision to stop is
+        taken every SETTLE_CHECK steps and, with N > 1, by ALL ranks together: every rank runs the same number of
+        steps, hence the same number of gallery collectives (a rank that stopped on its own clock would leave the
+        others waiting in an exchange it never issues -- ADVICE r3)."""
         times = []
         s = start
         while s - start < SETTLE_MAX:
@@ -278,14 +298,15 @@ def main():
             run(1, s, frames, False)
             times.append(time.perf_counter() - t0)
             s += 1
-            if s - start >= SETTLE_MIN:
+            if s - start >= SETTLE_MIN and (s - start - SETTLE_MIN) % SETTLE_CHECK == 0:
                 last = np.array(times[-20:])
-                if np.all(np.abs(last - np.median(last)) <= 0.03 * np.median(last)):
+                if all_ranks(np.all(np.abs(last - np.median(last)) <= 0.03 * np.median(last))):
                     break
         return s
 
     pos = settle(0)
     settle_steps = pos
+    fence()                                # every rank enters warm-up and timed region at the same exchange index
     run(args.warmup, pos, frames, args.prefetch)
     pos += args.warmup
     elapsed, net_ms = timed(args.steps, pos, frames, args.prefetch)

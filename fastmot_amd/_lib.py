@@ -671,17 +671,6 @@ def _bind_flow(cls):
         check(self.lib.fm_flow_lk(self._ctx, C.c_int(n), _ptr(p), _ptr(nxt), _ptr(status), _ptr(err)))
         return nxt, status, err
 
-    def flow_lk_diag(self, n_capture=0):
-        """Diagnostic read-out of the LK kernel variants (option 'lk_variant'): 16 counters, and for the capture
-        variant (headers [n, 4], records [n, 80, 12, 64]) of the last call."""
-        counters = np.zeros(16, np.int32)
-        hdr = rec = None
-        if n_capture:
-            hdr = np.zeros((n_capture, 4), np.int32)
-            rec = np.zeros((n_capture, 80, 12, 64), np.int32)
-        check(self.lib.fm_flow_lk_diag_read(self._ctx, _ptr(counters), C.c_int(n_capture), _ptr(hdr), _ptr(rec)))
-        return counters, hdr, rec
-
     def gallery_unique_id(self):
         buf = C.create_string_buffer(128)
         check(self.lib.fm_gallery_unique_id(buf))
@@ -704,16 +693,6 @@ def _bind_flow(cls):
 
     def gallery_destroy(self, channel=0):
         check(self.lib.fm_gallery_destroy(self._ctx, C.c_int(channel)))
-
-    def diag_pkhaz(self, variant, waves=600, iters=2000):
-        out = np.zeros(8, np.int32)
-        check(self.lib.fm_diag_pkhaz(self._ctx, C.c_int(variant), C.c_int(waves), C.c_int(iters), _ptr(out)))
-        return out
-
-    def diag_pkhaz2(self, victim, aggressor, launches=16):
-        out = np.zeros(8, np.int32)
-        check(self.lib.fm_diag_pkhaz2(self._ctx, C.c_int(victim), C.c_int(aggressor), C.c_int(launches), _ptr(out)))
-        return out
 
     def flow_estimate(self, prev_pts, cur_pts, status, begins, ends, bg_begin, bg_end, track_tlbr, size,
                       ransac_max_iter, ransac_conf, inlier_thresh):
@@ -746,7 +725,7 @@ def _bind_flow(cls):
     for fn in (flow_configure, flow_init, flow_begin, track_predict_async,
                track_predict_wait, flow_swap, flow_targets, flow_prepare, flow_predict, flow_detect,
                flow_background,
-               flow_lk, flow_lk_diag, diag_pkhaz, diag_pkhaz2, gallery_unique_id, gallery_init,
+               flow_lk, gallery_unique_id, gallery_init,
                gallery_allgather_async, gallery_allgather_wait, gallery_destroy, flow_estimate, flow_read_image):
         setattr(cls, fn.__name__, fn)
 

@@ -9,6 +9,9 @@
 #include <string>
 #include <vector>
 #include "../../include/fastmot_hip.h"
+#ifdef FM_DIAG
+#include "../../include/fastmot_hip_diag.h"
+#endif
 
 #define FM_ERR_HIP (-1)
 #define FM_ERR_ARG (-2)
@@ -160,16 +163,23 @@ struct fm_ctx {
     std::vector<int> trace_tag;
     std::atomic<int> trace_n{0};
     std::atomic<bool> trace_on{false};   // set once the two vectors are in place, cleared before they are taken away
+    std::atomic<int> trace_busy{0};      // fm_trace_mark calls in flight (the prediction worker marks too): fm_trace_read
+                                         // takes the vectors away only when none is left
     hipEvent_t trace_base = nullptr;
 };
 
 // one timed event on stream `s` (no-op unless a trace is running; both host threads of a context may call it)
 inline void fm_trace_mark(fm_ctx* ctx, hipStream_t s, int tag) {
     if (!ctx->trace_on.load(std::memory_order_acquire)) return;
-    const int i = ctx->trace_n.fetch_add(1);
-    if (i >= (int)ctx->trace_ev.size()) return;
-    ctx->trace_tag[i] = tag;
-    (void)hipEventRecord(ctx->trace_ev[i], s);
+    ctx->trace_busy.fetch_add(1);                               // (seq_cst on both sides of the handshake)
+    if (ctx->trace_on.load()) {       // (re-checked: a reader that disarmed waits for busy == 0)
+        const int i = ctx->trace_n.fetch_add(1);
+        if (i < (int)ctx->trace_ev.size()) {
+            ctx->trace_tag[i] = tag;
+            (void)hipEventRecord(ctx->trace_ev[i], s);
+        }
+    }
+    ctx->trace_busy.fetch_sub(1);
 }
 
 int fm_ensure_slots(fm_ctx* ctx, int max_slot_plus_1);

@@ -2,6 +2,7 @@
 // Replaces the buffer + stream plumbing of fastmot/utils/inference.py:7-125 (HostDeviceMem,
 // TRTInference) with plain HIP: one ctx per video stream, four HIP streams, pinned mirrors.
 #include "common.h"
+#include <sched.h>
 #include <cstring>
 #include <cstdlib>
 #include <cmath>
@@ -22,7 +23,15 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "zero_copy_tracks")) ctx->opt_zero_copy_tracks = value;
     else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
     else if (!strcmp(key, "use_graphs")) ctx->opt_use_graphs = value;
-    else if (!strcmp(key, "lk_variant")) ctx->opt_lk_variant = value;
+    else if (!strcmp(key, "lk_variant")) {
+#ifndef FM_DIAG
+        if (value != 0) {
+            fm_set_error("option 'lk_variant' needs a diagnostic build of the library (-DFM_DIAG)");
+            return FM_ERR_ARG;
+        }
+#endif
+        ctx->opt_lk_variant = value;
+    }
     else {
         fm_set_error("unknown option '%s'", key);
         return FM_ERR_ARG;
@@ -54,7 +63,8 @@ extern "C" int fm_trace_start(fm_ctx* ctx, int cap, int64_t* host_ns) {
 
 extern "C" int fm_trace_read(fm_ctx* ctx, int cap, int32_t* tags, float* ms, int* n) {
     FM_CHECK_ARG(ctx && tags && ms && n);
-    ctx->trace_on.store(false, std::memory_order_release);
+    ctx->trace_on.store(false, std::memory_order_seq_cst);
+    while (ctx->trace_busy.load(std::memory_order_seq_cst) > 0) sched_yield();     // marks of the other host thread
     FM_HIP(hipDeviceSynchronize());
     std::vector<hipEvent_t> evs = std::move(ctx->trace_ev);
     ctx->trace_ev.clear();

@@ -218,14 +218,20 @@ __global__ void rows_filter_kernel(const float* __restrict__ rows, int n, Filter
 // ------------------------------------------------------------------------------------ sort
 // rank sort by (class asc, box_conf desc, original index asc); K is read from the device counter.  Every workgroup
 // ranks 256 candidates against all K: the sort keys of 256 candidates at a time are staged in LDS as ONE 64-bit integer
-// each -- class (14 bits) | ~bits(box_conf) (32 bits; confidences are non-negative floats, whose bit patterns order
-// like their values) | original index (18 bits) -- and read by all lanes at the same address (broadcast): K^2 integer
-// comparisons from LDS instead of K^2 dependent global reads (K = 1500: 1.24 ms -> ~10 us).
+// each -- class (8 bits: emit_candidate admits classes < 128) | descending-order key of box_conf (32 bits) | original
+// index (24 bits: fm_detect_configure / fm_filter_dets refuse more rows than that) -- and read by all lanes at the same
+// address (broadcast): K^2 integer comparisons from LDS instead of K^2 dependent global reads (K = 1500: 1.24 ms ->
+// ~10 us).  The confidence key is the usual order-preserving map of IEEE bits (negative values: all bits flipped,
+// others: sign bit set), inverted for the descending order, so a negative or -0.0 confidence (a NEW_COORDS head without
+// its logistic activation, rows from the test hook) ranks where the float comparison puts it.
+constexpr int FM_SORT_INDEX_BITS = 24;
 __device__ __forceinline__ uint64_t sort_key(const float* r) {
-    const uint64_t cls = (uint64_t)(uint32_t)(int)r[5] & 0x3fffull;
-    const uint64_t inv_score = (uint32_t)~__float_as_uint(r[4]);
-    const uint64_t ord = (uint64_t)(uint32_t)__float_as_int(r[7]) & 0x3ffffull;
-    return (cls << 50) | (inv_score << 18) | ord;
+    const uint64_t cls = (uint64_t)(uint32_t)(int)r[5] & 0xffull;
+    const uint32_t b = __float_as_uint(r[4] + 0.0f);                       // (-0.0 + 0.0 = +0.0: equal to +0.0, as it compares)
+    const uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    const uint64_t inv_score = (uint32_t)~asc;
+    const uint64_t ord = (uint64_t)(uint32_t)__float_as_int(r[7]) & ((1ull << FM_SORT_INDEX_BITS) - 1);
+    return (cls << 56) | (inv_score << FM_SORT_INDEX_BITS) | ord;
 }
 
 __global__ __launch_bounds__(256) void rank_sort_kernel(const float* __restrict__ cand, float* __restrict__ sorted,
@@ -801,6 +807,15 @@ extern "C" int fm_frame_read(fm_ctx* ctx, uint8_t* bgr) {
 extern "C" int fm_detect_configure(fm_ctx* ctx, const fm_yolo_cfg* cfg) {
     FM_CHECK_ARG(ctx && cfg);
     FM_CHECK_ARG(cfg->n_heads >= 0 && cfg->n_heads <= FM_MAX_HEADS && cfg->num_classes > 0 && cfg->num_classes <= 128);
+    {
+        // the candidate sort packs a row's original index into FM_SORT_INDEX_BITS bits of its key
+        long long rows = 0;
+        for (int i = 0; i < cfg->n_heads; ++i) {
+            FM_CHECK_ARG(cfg->n_anchors[i] > 0 && cfg->n_anchors[i] <= FM_MAX_ANCHORS && cfg->grid_w[i] > 0 && cfg->grid_h[i] > 0);
+            rows += (long long)cfg->grid_w[i] * cfg->grid_h[i] * cfg->n_anchors[i];
+        }
+        FM_CHECK_ARG(rows < (1ll << FM_SORT_INDEX_BITS));
+    }
     int rc = ensure_det(ctx);
     if (rc) return rc;
     DetState* d = ctx->det;
@@ -895,6 +910,7 @@ extern "C" int fm_detect_sync(fm_ctx* ctx, fm_det48* out, int cap, int* n) {
 
 extern "C" int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* out, int cap, int* n_out) {
     FM_CHECK_ARG(ctx && ctx->det && ctx->det->configured && n >= 0 && out && n_out);
+    FM_CHECK_ARG(n < (1 << FM_SORT_INDEX_BITS));          // (the sort key's index field)
     DetState* d = ctx->det;
     hipStream_t s = ctx->s_det;
     FM_HIP(hipStreamSynchronize(s));

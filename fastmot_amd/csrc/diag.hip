@@ -13,6 +13,7 @@
 // wave-uniform operands and counts the lanes whose result differs from lane 0's.
 // variant 0: the chain as compiled; 1: the swapped multiply writes a fresh register pair; 2: one more wait state
 // (s_nop) between the two multiplies; 3: s_nop 3 between every pair; 4: plain (unpacked) v_mul / v_fma arithmetic.
+#ifdef FM_DIAG      // compiled to an empty object in the shipped library (build with FASTMOT_EXTRA_HIPCC_FLAGS=-DFM_DIAG)
 #include "common.h"
 
 namespace {
@@ -254,3 +255,4 @@ extern "C" int fm_diag_pkhaz2(fm_ctx* ctx, int victim, int aggressor, int launch
     FM_HIP(hipMemcpy(out8, d_out, sizeof(int32_t) * 8, hipMemcpyDeviceToHost));
     return 0;
 }
+#endif  // FM_DIAG

@@ -653,6 +653,7 @@ __global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int 
     }
 }
 
+#ifdef FM_DIAG      // diagnostic builds only (FASTMOT_EXTRA_HIPCC_FLAGS=-DFM_DIAG, include/fastmot_hip_diag.h)
 // ---- diagnostic variants of the LK kernel (round 3: bisect of the results that differ under load).
 // MODE 0: window sums as DPP scans (the production arithmetic), 1: through LDS (no cross-lane VALU operation),
 // 2: both, compared, re-evaluated on a mismatch (counters say which of the two changed its mind).
@@ -864,6 +865,8 @@ __global__ __launch_bounds__(1024) FM_SGPR_CAP void lk_diag_kernel(LKArgs a, int
         }
     }
 }
+
+#endif  // FM_DIAG
 
 // ---- foreground-mask bookkeeping: rect k sees pixel p as foreground iff no rect j<k covers p.
 // Only earlier rects that intersect rect k can cover its pixels: the host passes that (short) list.
@@ -1768,6 +1771,7 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
             // or ordered the ReID network behind it; see the note at lk_wave_body for what was actually wrong)
             const int threads = 256, lds_req = 0;
             const dim3 grid((unsigned)(((size_t)n * 64 + threads - 1) / threads));
+#ifdef FM_DIAG
             if (ctx->opt_lk_variant > 0 && a.win == 5) {
                 const int v = ctx->opt_lk_variant;
                 if (!f->lk_diag) {
@@ -1798,6 +1802,9 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
                 }
 #undef FM_LK_DIAG_LAUNCH
             } else {
+#else
+            {
+#endif
                 const dim3 grid2((unsigned)((((size_t)n + 1) / 2 * 64 + threads - 1) / threads));     // two points per wavefront
                 fm_trace_mark(ctx, s, 40);
                 if (a.win == 5)
@@ -1822,6 +1829,7 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
     return 0;
 }
 
+#ifdef FM_DIAG
 // diagnostic read-out of the LK variants: 16 counters (reset afterwards), and for the capture variant the per-point
 // headers [n][4] and records [n][LK_CAP_MAXREC][8][64] of the last call
 extern "C" int fm_flow_lk_diag_read(fm_ctx* ctx, int32_t* counters, int n, int32_t* hdr, int32_t* records) {
@@ -1838,6 +1846,8 @@ extern "C" int fm_flow_lk_diag_read(fm_ctx* ctx, int32_t* counters, int n, int32
     }
     return 0;
 }
+
+#endif  // FM_DIAG
 
 extern "C" int fm_flow_read_image(fm_ctx* ctx, int which, uint8_t* out, int* w, int* h) {
     FM_CHECK_ARG(ctx && ctx->flow && out && w && h);
@@ -2043,6 +2053,7 @@ extern "C" int fm_debug_gftt_stamps(long long* out512) {
 }
 #endif
 
+#ifdef FM_DIAG
 // ---------------------------------------------------------------------------------------------------
 // Diagnostic kernel (scripts/stress_spin.py): a long, fully deterministic computation on the flow stream,
 // used to tell a bug in a kernel of this library from a platform issue when kernels on other streams run
@@ -2086,3 +2097,4 @@ extern "C" int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsig
     memcpy(out_host, f->lk_out.h, bytes);
     return 0;
 }
+#endif  // FM_DIAG

@@ -11,6 +11,8 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
+#include <string>
 
 namespace {
 
@@ -29,12 +31,14 @@ struct Rccl {
 
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    static std::string why;                              // the load error, kept: dlerror() hands a message out once
+    std::call_once(once, [] {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
+            const char* e = dlerror();
+            why = e ? e : "dlopen failed";
         }
         if (r.handle) {
             r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
@@ -42,10 +46,11 @@ Rccl* rccl() {
             r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
             r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+            if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) why = "missing symbols";
         }
-    }
+    });
     if (!r.handle || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) {
-        fm_set_error("librccl.so could not be loaded: %s", r.handle ? "missing symbols" : dlerror());
+        fm_set_error("librccl.so could not be loaded: %s", why.c_str());
         return nullptr;
     }
     return &r;
@@ -74,8 +79,7 @@ struct GalleryState {
     bool pending = false;
 };
 
-static void gallery_free_channel(fm_ctx* ctx, int channel) {
-    GalleryState* g = ctx->gallery[channel];
+static void gallery_state_free(GalleryState* g) {
     if (!g) return;
     if (g->pending) (void)hipEventSynchronize(g->ev1);
     if (g->comm) {
@@ -90,11 +94,29 @@ static void gallery_free_channel(fm_ctx* ctx, int channel) {
         if (e) (void)hipEventDestroy(e);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
+}
+
+static void gallery_free_channel(fm_ctx* ctx, int channel) {
+    gallery_state_free(ctx->gallery[channel]);
     ctx->gallery[channel] = nullptr;
 }
 
 void fm_gallery_free(fm_ctx* ctx) {
     for (int c = 0; c < FM_GALLERY_CHANNELS; ++c) gallery_free_channel(ctx, c);
+}
+
+static int gallery_state_build(GalleryState* g, Rccl* r, const char* id128) {
+    FM_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    FM_HIP(hipEventCreate(&g->ev0));
+    FM_HIP(hipEventCreate(&g->ev1));
+    FM_HIP(hipHostMalloc(&g->send_host, g->row_bytes, hipHostMallocDefault));
+    FM_HIP(hipHostMalloc(&g->recv_host, g->row_bytes * g->world, hipHostMallocDefault));
+    FM_HIP(hipMalloc(&g->send_dev, g->row_bytes));
+    FM_HIP(hipMalloc(&g->recv_dev, g->row_bytes * g->world));
+    UniqueId id;
+    memcpy(id.internal, id128, kUniqueIdBytes);
+    FM_RCCL(r->CommInitRank(&g->comm, g->world, id, g->rank));
+    return 0;
 }
 
 // rank 0 creates the communicator id; the application hands the 128 bytes to the other ranks (any channel)
@@ -118,19 +140,16 @@ extern "C" int fm_gallery_init(fm_ctx* ctx, int channel, int world, int rank, co
     Rccl* r = rccl();
     if (!r) return FM_ERR_STATE;
     FM_HIP(hipSetDevice(ctx->device));
+    // built aside and published to the context only when every step -- the communicator last -- has succeeded: a
+    // failed init leaves the channel empty, never a half-built state with a null communicator
     GalleryState* g = new GalleryState();
-    ctx->gallery[channel] = g;
     g->world = world; g->rank = rank; g->row_bytes = row_bytes;
-    FM_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-    FM_HIP(hipEventCreate(&g->ev0));
-    FM_HIP(hipEventCreate(&g->ev1));
-    FM_HIP(hipHostMalloc(&g->send_host, row_bytes, hipHostMallocDefault));
-    FM_HIP(hipHostMalloc(&g->recv_host, row_bytes * world, hipHostMallocDefault));
-    FM_HIP(hipMalloc(&g->send_dev, row_bytes));
-    FM_HIP(hipMalloc(&g->recv_dev, row_bytes * world));
-    UniqueId id;
-    memcpy(id.internal, id128, kUniqueIdBytes);
-    FM_RCCL(r->CommInitRank(&g->comm, world, id, rank));
+    const int rc = gallery_state_build(g, r, id128);
+    if (rc) {
+        gallery_state_free(g);
+        return rc;
+    }
+    ctx->gallery[channel] = g;
     return 0;
 }
 
@@ -151,6 +170,7 @@ extern "C" int fm_gallery_allgather_async(fm_ctx* ctx, int channel, const void* 
     }
     Rccl* r = rccl();
     if (!r) return FM_ERR_STATE;
+    FM_CHECK_ARG(g->comm != nullptr);
     memcpy(g->send_host, send_row, g->row_bytes);
     FM_HIP(hipEventRecord(g->ev0, g->stream));
     FM_HIP(hipMemcpyAsync(g->send_dev, g->send_host, g->row_bytes, hipMemcpyHostToDevice, g->stream));

@@ -6,8 +6,11 @@ track IDs are handed out (tracker.py:250-293) -- and the two hash tables iterate
 is small against the range (Numba shrinks the table after the difference and re-inserts, CPython builds the result in
 a fresh 8-slot table).  What the reference really executes is Numba 0.48 (`requirements.txt`), so that is the order
 reproduced here; oracle/numba_set.py is the full restatement of the container this closed form is tested against
-(tests/test_setorder.py).  Numba itself is not installable offline: the restatement follows the published source and
-is not pinned by a run of the real thing.
+(tests/test_setorder.py).  Pinned by the real thing since round 3: an Anaconda Numba 0.54.1 found in the image
+(oracle/real_numba.py, oracle/pin_with_numba.py) answers 996 cases around every table-growth boundary up to n = 700
+identically -- the fixture tests/golden/numba_set_order.npz, against which this module is tested on every machine.
+Open: the reference pins Numba 0.48, the pin ran 0.54.1 (the set implementation's published source is the same in
+both).
 
 Closed form: all keys k < n are smaller than the table (size >= 2 n, hash(k) = k), so `set(range(n))` holds key k in
 slot k and the survivors of the difference are met in ascending order.  If the table is at least four times the

@@ -47,8 +47,8 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
  * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
  * "host_lap_elems" (default 262144; LAP cost matrices up to this many elements are solved by the host
  * solver of the library, larger ones by the device kernels; 0 = always device), "use_graphs" (default 1;
- * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (default 0; > 0 selects an
- * instrumented variant of the LK kernel, see fm_flow_lk_diag_read).  Initial values can be set with the environment
+ * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (diagnostic builds only, include/fastmot_hip_diag.h;
+ * 0 is the only value the shipped library accepts).  Initial values can be set with the environment
  * variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP / FASTMOT_GRAPHS. */
 int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value);
 /* Event trace of a pipelined run (diagnostics; scripts/trace_pipeline.py).  fm_trace_start arms `cap` timed events and
@@ -416,18 +416,6 @@ int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, const double
 /* cv2.calcOpticalFlowPyrLK(prev_small, cur_small, pts) (flow.py:205-207): Scharr derivatives +
  * pyramidal LK for n points; then the frame buffers are swapped (flow.py:212-213). */
 int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next_pts, uint8_t* status, float* err);
-/* Diagnostics of the LK kernel (option "lk_variant" > 0 selects an instrumented variant of the kernel for
- * fm_flow_lk; no counterpart in the reference): 16 event counters, reset by the call; with hdr / records non-null the
- * capture of the last call, hdr [n][4] = HW_ID, XCC_ID, records written, workgroup; records [n][80][12][64]. */
-int fm_flow_lk_diag_read(fm_ctx* ctx, int32_t* counters, int n, int32_t* hdr, int32_t* records);
-/* Stand-alone reproducer of the packed-fp32 mis-execution that round 3's bisect found in the LK kernel (csrc/diag.hip,
- * DESIGN 5b): `waves` wavefronts x `iters` evaluations of the LK position update on the KLT stream;
- * out8[0..3] = lanes (per quarter of the wavefront) whose low result differed from lane 0's, out8[4..7] = high. */
-int fm_diag_pkhaz(fm_ctx* ctx, int variant, int waves, int iters, int32_t* out8);
-/* ... one packed instruction class (victim 0..5) checked per lane against unpacked arithmetic, `launches` launches on
- * the KLT stream while a synthetic neighbour kernel of instruction class `aggressor` (0..6, -1 = none) occupies the
- * ReID stream (csrc/diag.hip). */
-int fm_diag_pkhaz2(fm_ctx* ctx, int victim, int aggressor, int launches, int32_t* out8);
 /* swap without LK (failure paths of flow.py:191-196) */
 int fm_flow_swap(fm_ctx* ctx);
 /* second half of Flow.predict on the host side of the library (flow.py:215-263): camera motion by
@@ -478,9 +466,6 @@ int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const
                            const int32_t* slots, const int32_t* ages, const int32_t* sorted_idx, double age_penalty,
                            double* tlbr_out, uint8_t* lost_out);
 int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_done_out);
-/* diagnostic: a long deterministic kernel on the flow stream (mode bit 0: 32-lane butterflies, bit 1: byte
- * loads from the previous gray image); out_host: 256 * blocks words.  See scripts/stress_spin.py. */
-int fm_debug_spin(fm_ctx* ctx, int blocks, int iters, int mode, unsigned* out_host);
 /* LDS bytes FM_OP_LITECHAIN needs for c channels on h x w maps (<= 65536 to be launchable): the layer-table
  * builder decides with the same formula whether an OSNet block can use the chain kernel (no device needed) */
 size_t fm_litechain_lds_bytes(int c, int w, int h);

@@ -431,13 +431,16 @@ def yolo_decode(head, anchors, num_classes, in_wh, scale_xy, new_coords=False):
     return rows.reshape(-1, 7).astype(f32)
 
 
-def diou_nms(tlwhs, scores, thresh, beta=0.6):
+def diou_nms(tlwhs, scores, thresh, beta=0.6, tie_rank=None):
     """utils/rect.py:199-244 with the operand types Numba assigns (float32 rows; `- 1` and `/ 2`
     promote to float64; areas stay float32).  Deterministic order: descending score, ties by
-    ascending index (the reference's argsort is an unstable quicksort: tie order undefined)."""
+    ascending index (the reference's argsort is an unstable quicksort: tie order undefined).
+    `tie_rank` (optional, one number per row) replaces the index as the tie-breaker: the tests use it to
+    ask whether a result depends on the order the reference leaves undefined."""
     t = np.asarray(tlwhs, np.float32)
     n = len(t)
-    order = sorted(range(n), key=lambda i: (-float(scores[i]), i))
+    tr = np.arange(n) if tie_rank is None else np.asarray(tie_rank)
+    order = sorted(range(n), key=lambda i: (-float(scores[i]), tr[i]))
     areas = t[:, 2] * t[:, 3]                                    # float32
     tls = t[:, :2]
     brs = (t[:, :2] + t[:, 2:]).astype(np.float64) - 1
@@ -468,9 +471,9 @@ def diou_nms(tlwhs, scores, thresh, beta=0.6):
     return np.array(keep, int)
 
 
-def filter_dets(det_out, size, offset, label_mask, conf_thresh, nms_thresh, max_area, min_ar):
-    """YOLODetector._filter_dets (detector.py:322-365).  det_out float32 [n,7].
-    Returns (tlbr [m,4] f64, label [m] i64, conf [m] f64) sorted by class, then NMS keep order."""
+def filter_scale(det_out, size, offset, label_mask, conf_thresh):
+    """First half of YOLODetector._filter_dets (detector.py:329-341): class mask + score threshold, then the rows
+    scaled to pixels in place (float32).  Returns (rows float32 [k,7] in candidate order, their indices in det_out)."""
     d = np.asarray(det_out, np.float32)
     cls = d[:, 5].astype(int)
     ok = (cls >= 0) & (cls < len(label_mask))
@@ -482,11 +485,19 @@ def filter_dets(det_out, size, offset, label_mask, conf_thresh, nms_thresh, max_
     sz = np.append(np.asarray(size, np.float64), np.asarray(size, np.float64))
     d[:, :4] = (d[:, :4].astype(np.float64) * sz).astype(np.float32)
     d[:, :2] = (d[:, :2].astype(np.float64) - np.asarray(offset, np.float64)).astype(np.float32)
+    return d, idx
+
+
+def nms_finalize(d, nms_thresh, max_area, min_ar, tie_rank=None):
+    """Second half (detector.py:343-364) on scaled candidate rows `d` (float32 [k,7], candidate order): per-class
+    DIoU-NMS in ascending class order, to_tlbr, area / aspect filters.  Returns (tlbr f64, label i64, conf f64)."""
+    d = np.asarray(d, np.float32)
     tl, lb, cf = [], [], []
     for c in np.unique(d[:, 5]):
         rows = np.flatnonzero(d[:, 5] == c)
         # deterministic tie-break: original candidate index
-        k = diou_nms(d[rows, :4], d[rows, 4], nms_thresh)
+        k = diou_nms(d[rows, :4], d[rows, 4], nms_thresh,
+                     tie_rank=None if tie_rank is None else np.asarray(tie_rank)[rows])
         for r in rows[k]:
             x, y, w, h = (float(v) for v in d[r, :4])
             box = np.array([np.rint(x), np.rint(y), np.rint(x + w - 1.), np.rint(y + h - 1.)])
@@ -496,3 +507,10 @@ def filter_dets(det_out, size, offset, label_mask, conf_thresh, nms_thresh, max_
             if 0 < area <= max_area and ar >= min_ar:
                 tl.append(box); lb.append(int(d[r, 5])); cf.append(float(d[r, 4] * d[r, 6]))
     return (np.array(tl, np.float64).reshape(-1, 4), np.array(lb, np.int64), np.array(cf, np.float64))
+
+
+def filter_dets(det_out, size, offset, label_mask, conf_thresh, nms_thresh, max_area, min_ar):
+    """YOLODetector._filter_dets (detector.py:322-365).  det_out float32 [n,7].
+    Returns (tlbr [m,4] f64, label [m] i64, conf [m] f64) sorted by class, then NMS keep order."""
+    d, _ = filter_scale(det_out, size, offset, label_mask, conf_thresh)
+    return nms_finalize(d, nms_thresh, max_area, min_ar)

@@ -8,7 +8,7 @@ import bench
 from fastmot_amd import Track
 from fastmot_amd.detector import DeviceFrame
 from fastmot_amd.runtime import get_context
-from fastmot_amd.utils.synthetic import SyntheticVideo
+from synthetic import SyntheticVideo
 
 video = SyntheticVideo(bench.SIZE, n_ids=bench.N_DETS, n_frames=bench.RING, seed=100)
 ctx = get_context()

@@ -14,11 +14,14 @@ import os as _os
 _os.environ.setdefault('FASTMOT_RANDOM_WEIGHTS', '1')
 import sys, threading
 sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+sys.path.insert(1, _os.path.join(sys.path[0], 'tests'))
 import numpy as np
-from fastmot_amd.utils.synthetic import SyntheticVideo
+from synthetic import SyntheticVideo
 from fastmot_amd.flow import Flow
 from fastmot_amd.detector import DeviceFrame, bind_frame
 from fastmot_amd.runtime import get_context
+sys.path.insert(1, _os.path.dirname(_os.path.abspath(__file__)))
+from diag_bindings import flow_lk_diag, diag_pkhaz, diag_pkhaz2   # needs a -DFM_DIAG build
 from fastmot_amd.engine import HipNet, NET_EXTRACTOR, NET_DETECTOR
 from fastmot_amd.models import ReID, YOLO
 
@@ -66,15 +69,15 @@ for name, v in VARIANTS.items():
         r = ctx.flow_lk(pts)
         oks.append(same(r, k)[0])
         if v == (1 | 32):
-            _, hdr, rec = ctx.flow_lk_diag(NPTS)
+            _, hdr, rec = flow_lk_diag(ctx, NPTS)
             cap_idle[k] = (hdr.copy(), rec.copy())
-    c = ctx.flow_lk_diag()[0]
+    c = flow_lk_diag(ctx)[0]
     print(f'idle {name:<18} identical to production: {oks}  counters {c[:12].tolist()}', flush=True)
 # idle capture twice more: is the capture itself reproducible?
 ctx.set_option('lk_variant', 1 | 32)
 for k in range(2):
     ctx.flow_lk(pts)
-    _, hdr, rec = ctx.flow_lk_diag(NPTS)
+    _, hdr, rec = flow_lk_diag(ctx, NPTS)
     nrec = hdr[:, 2]
     eq = all(np.array_equal(rec[i, :nrec[i]], cap_idle[k][1][i, :nrec[i]]) for i in range(NPTS))
     print(f'idle capture parity {k}: records reproducible {eq}, records per point {nrec.min()}..{nrec.max()}', flush=True)
@@ -179,7 +182,7 @@ def analyse(i, hdr, rec, ref_hdr, ref_rec, verbose):
 def run(name, calls, capture=False, max_verbose=8):
     v = VARIANTS[name]
     ctx.set_option('lk_variant', v)
-    ctx.flow_lk_diag()
+    flow_lk_diag(ctx)
     bad_calls = bad_pts = 0
     kinds = {}
     places = []
@@ -193,13 +196,13 @@ def run(name, calls, capture=False, max_verbose=8):
         bad_calls += 1
         bad_pts += len(bad)
         if capture and bad_calls <= 40:
-            _, hdr, rec = ctx.flow_lk_diag(NPTS)
+            _, hdr, rec = flow_lk_diag(ctx, NPTS)
             for i in bad[:4]:
                 what, typ, where = analyse(int(i), hdr, rec, cap_idle[k][0], cap_idle[k][1], shown < max_verbose)
                 shown += 1
                 kinds[(what, typ)] = kinds.get((what, typ), 0) + 1
                 places.append(where)
-    c = ctx.flow_lk_diag()[0]
+    c = flow_lk_diag(ctx)[0]
     print(f'hammer={HAMMER} variant={name:<18} calls differing {bad_calls}/{calls}, points {bad_pts}; counters '
           f'[sum mismatch, dpp changed, lds changed, unresolved, dup-load mismatch, lanes disagree, iterations] = {c[:7].tolist()} disagreeing lanes by quarter {c[8:12].tolist()}', flush=True)
     if capture:

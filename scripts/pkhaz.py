@@ -6,6 +6,8 @@ import sys, threading
 sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import numpy as np
 from fastmot_amd.runtime import get_context
+sys.path.insert(1, _os.path.dirname(_os.path.abspath(__file__)))
+from diag_bindings import flow_lk_diag, diag_pkhaz, diag_pkhaz2   # needs a -DFM_DIAG build
 from fastmot_amd.engine import HipNet, NET_EXTRACTOR
 from fastmot_amd.models import ReID
 
@@ -20,7 +22,7 @@ def sweep(label):
     for v in range(5):
         tot = np.zeros(8, np.int64)
         for _ in range(LAUNCHES):
-            tot += ctx.diag_pkhaz(v, 600, 2000)
+            tot += diag_pkhaz(ctx, v, 600, 2000)
         print(f'{label:<22} variant {v} ({NAMES[v]:<38}) wrong lanes by quarter: low half {tot[:4].tolist()}  high half {tot[4:].tolist()}'
               f'  of {LAUNCHES * 600 * 2000} evaluations', flush=True)
 

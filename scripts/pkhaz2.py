@@ -5,6 +5,8 @@ import sys, threading
 sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import numpy as np
 from fastmot_amd.runtime import get_context
+sys.path.insert(1, _os.path.dirname(_os.path.abspath(__file__)))
+from diag_bindings import flow_lk_diag, diag_pkhaz, diag_pkhaz2   # needs a -DFM_DIAG build
 from fastmot_amd.engine import HipNet, NET_EXTRACTOR
 from fastmot_amd.models import ReID
 
@@ -17,7 +19,7 @@ AGG = {-1: 'none', 0: 'v_fma_mix_f32 op_sel:[1,0,0]', 1: 'v_fma_mix_f32 op_sel:[
 print(f'{L} launches x 600 wavefronts x 2000 evaluations per cell; cell = wrong lanes [q0, q1, q2, q3] low half / high half')
 for a, an in AGG.items():
     for v, vn in enumerate(VIC):
-        o = ctx.diag_pkhaz2(v, a, L)
+        o = diag_pkhaz2(ctx, v, a, L)
         print(f'neighbour {an:<30} victim {vn:<26} low {o[:4].tolist()} high {o[4:].tolist()}', flush=True)
 g, _ = ReID.get_model('OSNet025').build_graph()
 g.layers[:] = [d for d in g.layers if d['op'] == 16]
@@ -38,7 +40,7 @@ th = threading.Thread(target=hammer)
 th.start()
 try:
     for v, vn in enumerate(VIC):
-        o = ctx.diag_pkhaz2(v, -1, L)
+        o = diag_pkhaz2(ctx, v, -1, L)
         print(f'neighbour {"litechain_kernel x6 (OSNet)":<30} victim {vn:<26} low {o[:4].tolist()} high {o[4:].tolist()}', flush=True)
 finally:
     stop.append(1)

@@ -7,7 +7,7 @@ sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')
 import numpy as np
 from test_mot_gpu import build_mot
-from fastmot_amd.utils.synthetic import SyntheticVideo
+from synthetic import SyntheticVideo
 from fastmot_amd import Track
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8

@@ -36,7 +36,7 @@ def main():
     from fastmot_amd import Track, models
     models.allow_random_weights()
     from fastmot_amd.runtime import get_context
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     ctx = get_context()
     RING = bench.RING
     size = cfg['size']

@@ -5,8 +5,8 @@ weights are available offline, so detections are injected at the Detector.postpr
 while the detector network, decode and NMS still execute on the GPU."""
 import numpy as np
 
-from ..detector import YOLODetector, DET_DTYPE
-from ..models.graph import RandomWeights
+from fastmot_amd.detector import YOLODetector, DET_DTYPE
+from fastmot_amd.models.graph import RandomWeights
 
 
 class SyntheticVideo:
@@ -101,7 +101,8 @@ class ScriptedHeadWeights(RandomWeights):
     threshold with class `label`: with purely random heads nothing passes `conf_thresh` and the DIoU-NMS stage of a
     benchmark would run on an empty list.  The class logits get biases of +-4; the objectness rows of the weight are
     amplified by `obj_gain` (the random head's logits are all but constant over the image) and get the per-anchor
-    biases obj_bias[head][anchor] (heads in build order)."""
+    biases obj_bias[head][anchor] (heads in build order).  `label` may be a tuple of class ids: anchor a of every head
+    then votes for label[a % len(label)] (several classes among the candidates, BASELINE config[4])."""
 
     def __init__(self, seed, num_classes, label, obj_bias, obj_gain=1.0):
         super().__init__(seed)
@@ -115,7 +116,9 @@ class ScriptedHeadWeights(RandomWeights):
             b = p['bias'].reshape(-1, rec)
             b[:, 4] = np.asarray(self.obj_bias[self._head], np.float32)
             b[:, 5:] = -4.0
-            b[:, 5 + self.label] = 4.0
+            labels = self.label if isinstance(self.label, (tuple, list)) else (self.label,)
+            for a in range(len(b)):
+                b[a, 5 + labels[a % len(labels)]] = 4.0
             p['w'].reshape(-1, rec, *p['w'].shape[1:])[:, 4] *= self.obj_gain
             self._head += 1
         return p
@@ -126,12 +129,12 @@ def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.
     frames like `frame`: one calibration pass with an objectness bias that lets nothing through, then the bias of every
     (head, anchor) is set to the quantile of its objectness logits that leaves its share of the target above the
     threshold."""
-    from .. import models
+    from fastmot_amd import models
     m = models.YOLO.get_model(model)
     n_heads = len(m.LAYER_FACTORS)
     n_anchors = [len(a) // 2 for a in m.ANCHORS]
     CAL = -12.0
-    det = YOLODetector(size, (label,), model=model, conf_thresh=conf_thresh,
+    det = YOLODetector(size, tuple(label) if isinstance(label, (tuple, list)) else (label,), model=model, conf_thresh=conf_thresh,
                        weights=ScriptedHeadWeights(seed, m.NUM_CLASSES, label, [[CAL] * n for n in n_anchors], obj_gain))
     try:
         det.detect_async(frame)

@@ -24,6 +24,19 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f'missing exports: {missing}'
 
 
+def test_diagnostics_are_not_in_the_shipped_library():
+    """include/fastmot_hip_diag.h (round 3's bisect apparatus) exists only in -DFM_DIAG builds."""
+    from fastmot_amd import _lib, build
+    if '-DFM_DIAG' in build.FLAGS:
+        return
+    lib = _lib.load()
+    text = (ROOT / 'include' / 'fastmot_hip_diag.h').read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    diag = sorted(set(re.findall(r'\b(fm_[a-z0-9_]+)\s*\(', text)))
+    assert len(diag) == 4
+    assert not [s for s in diag if hasattr(lib, s)]
+
+
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
     from fastmot_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

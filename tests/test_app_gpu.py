@@ -2,12 +2,14 @@
 MOT (public detections, OSNet with seeded weights, KLT, Kalman, association) -> MOTChallenge result file ->
 CLEAR-MOT / IDF1 against the synthetic ground truth."""
 import json
+from pathlib import Path
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
 
 from fastmot_amd.utils import motchallenge as mc
-from fastmot_amd.utils.synthetic import SyntheticVideo
+from synthetic import SyntheticVideo
 from fastmot_amd.videoio import VideoIO, resize_bgr
 
 
@@ -49,7 +51,6 @@ def test_videoio_sources_and_queue(tmp_path):
 @pytest.mark.gpu
 def test_app_end_to_end(tmp_path):
     from PIL import Image
-    from fastmot_amd import app
     size, n_frames, n_ids = (960, 540), 24, 8
     video = SyntheticVideo(size, n_ids=n_ids, n_frames=n_frames, seed=5)
     seq = tmp_path / 'SYN-01'
@@ -66,7 +67,10 @@ def test_app_end_to_end(tmp_path):
         gt[f + 1] = [(i + 1, np.array([b[0], b[1], b[2] - b[0] + 1, b[3] - b[1] + 1])) for i, b in enumerate(video.gt[f])]
     (seq / 'det' / 'det.txt').write_text('\n'.join(det_rows) + '\n')
 
-    cfg = json.load(open(app.Path(app.__file__).parent / 'cfg' / 'mot.json'))
+    import fastmot_amd
+    from fastmot_amd.readahead import track_stream
+    from fastmot_amd.utils import ConfigDecoder
+    cfg = json.load(open(Path(fastmot_amd.__file__).parent / 'cfg' / 'mot.json'))
     cfg['resize_to'] = list(size)
     cfg['stream_cfg']['resolution'] = list(size)
     cfg['mot_cfg']['detector_type'] = 'PUBLIC'
@@ -74,9 +78,26 @@ def test_app_end_to_end(tmp_path):
     cfg['mot_cfg']['public_detector_cfg']['sequence_path'] = str(seq)
     (tmp_path / 'mot.json').write_text(json.dumps(cfg))
 
+    def run(txt_path, output_uri=None):
+        """What the reference's app.py does with `-i seq -c mot.json -m -t txt [-o uri]` (app.py:55-104), the frame
+        loop with one frame of read-ahead (fastmot_amd/readahead.py)."""
+        with open(tmp_path / 'mot.json') as f:
+            config = json.load(f, cls=ConfigDecoder, object_hook=lambda d: SimpleNamespace(**d))
+        stream = fastmot_amd.VideoIO(config.resize_to, str(seq / 'img1' / '%06d.png'), output_uri,
+                                     **vars(config.stream_cfg))
+        mot = fastmot_amd.MOT(config.resize_to, **vars(config.mot_cfg), draw=output_uri is not None)
+        mot.reset(stream.cap_dt)
+        txt_path.parent.mkdir(parents=True, exist_ok=True)
+        stream.start_capture()
+        try:
+            with open(txt_path, 'w') as txt:
+                n = track_stream(stream, mot, txt, config.resize_to, write_frames=output_uri is not None)
+        finally:
+            stream.release()
+        return n
+
     out = tmp_path / 'out' / 'SYN-01.txt'
-    rc = app.main(['-i', str(seq / 'img1' / '%06d.png'), '-c', str(tmp_path / 'mot.json'), '-m', '-t', str(out), '-q'])
-    assert rc == 0
+    assert run(out) == n_frames
     res = mc.read_txt(out)
     score = mc.evaluate({f: v for f, v in gt.items() if f in res or f > 1}, res)
     # public detections are the ground truth + 1 px jitter: everything is tracked, identities are stable
@@ -84,8 +105,7 @@ def test_app_end_to_end(tmp_path):
 
     # -o: the written frames carry the overlays (reference app.py:70-71 draws whenever an output is requested)
     out2 = tmp_path / 'out2' / 'SYN-01.txt'
-    rc = app.main(['-i', str(seq / 'img1' / '%06d.png'), '-c', str(tmp_path / 'mot.json'), '-m', '-t', str(out2),
-                   '-o', str(tmp_path / 'annotated' / '%06d.png'), '-q'])
-    assert rc == 0 and out2.read_text() == out.read_text()          # drawing does not change the tracks
+    assert run(out2, str(tmp_path / 'annotated' / '%06d.png')) == n_frames
+    assert out2.read_text() == out.read_text()          # drawing does not change the tracks
     last = np.asarray(Image.open(tmp_path / 'annotated' / f'{n_frames - 1:06d}.png'))[:, :, ::-1]
     assert last.shape == video.frames[-1].shape and (last != video.frames[-1]).any(axis=2).sum() > 400

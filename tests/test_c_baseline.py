@@ -8,7 +8,7 @@ import c_baseline as cb
 import cpu_tracker
 import cv_oracle as cv
 import scenes
-from fastmot_amd.utils.synthetic import SyntheticVideo
+from synthetic import SyntheticVideo
 
 
 @pytest.fixture(scope='module')

@@ -233,7 +233,7 @@ def test_lk_deterministic_while_other_streams_are_busy(ctx, hammer):
     from fastmot_amd.engine import HipNet, NET_EXTRACTOR
     from fastmot_amd.models import ReID
     from fastmot_amd.models.graph import Graph, RandomWeights
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     size = (960, 540)
     video = SyntheticVideo(size, n_ids=6, n_frames=2, seed=4)
     ctx.frame_configure(size[0], size[1], 2)
@@ -288,7 +288,7 @@ def test_lk_beside_the_detector(ctx):
     from fastmot_amd.detector import DeviceFrame
     from fastmot_amd.engine import HipNet, NET_DETECTOR
     from fastmot_amd.models import YOLO
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     size = (960, 540)
     video = SyntheticVideo(size, n_ids=6, n_frames=2, seed=4)
     ctx.frame_configure(size[0], size[1], 2)

@@ -105,7 +105,7 @@ def test_feature_extractor_batch_64_two_instances(ctx):
     """FeatureExtractor at batch 64 on a 1080p frame: the batch runs as two concurrent 32-crop network instances;
     every embedding equals the PyTorch reference run on the crops the device produced."""
     from fastmot_amd.feature_extractor import FeatureExtractor
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     size = (1920, 1080)
     video = SyntheticVideo(size, n_ids=64, n_frames=1, seed=7)
     boxes = video.detections(0).tlbr
@@ -148,7 +148,7 @@ def test_flow_predict_1080p_50_tracks(ctx):
     under the closest-first foreground mask), FAST background points, pyramidal LK on ~5-7 k points, RANSAC.
     Three consecutive frames: the second and third call reuse propagated keypoints."""
     from fastmot_amd.flow import Flow
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     size = (1920, 1080)
     video = SyntheticVideo(size, n_ids=50, n_frames=4, seed=100)
     flow = Flow(size, **vars(scenes.tracker_kwargs()['flow_cfg']))

@@ -24,7 +24,7 @@ import fastmot_amd.mot as mot_mod
 from fastmot_amd import Track
 from fastmot_amd.detector import YOLODetector
 from fastmot_amd.gallery import GallerySync
-from fastmot_amd.utils.synthetic import InjectedYOLODetector, SyntheticVideo
+from synthetic import InjectedYOLODetector, SyntheticVideo
 
 size = (960, 540)
 video = SyntheticVideo(size, n_ids=10, n_frames=40, seed=13)

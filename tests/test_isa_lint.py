@@ -51,10 +51,14 @@ def test_klt_kernels_have_no_modified_packed_fp32(tmp_path):
     selection) is the straight form, and the LK kernels contain none at all."""
     _, text = _asm(fm_build.CSRC / 'flow.hip', tmp_path)
     in_lk = False
+    seen = set()
     for line in text.splitlines():
         if line.startswith('_Z'):
-            in_lk = 'lk_wave_kernel' in line or 'lk_diag_kernel' in line
+            in_lk = any(k in line for k in ('lk_pair_kernel', 'lk_wave_kernel', 'lk_diag_kernel'))
+            if in_lk:
+                seen.add(line.split(':')[0])
         m = PACKED.match(line)
         if m:
             assert not in_lk, line
             assert 'op_sel' not in m.group(2), line
+    assert any('lk_pair_kernel' in k for k in seen), 'the production LK kernel was not found in the listing'

@@ -18,7 +18,7 @@ class TinyDet:
 def build_mot(size, video, skip):
     import fastmot_amd.mot as mot_mod
     from fastmot_amd.models import YOLO
-    from fastmot_amd.utils.synthetic import InjectedYOLODetector
+    from synthetic import InjectedYOLODetector
 
     class BenchTiny(YOLO):
         NUM_CLASSES = 2
@@ -43,7 +43,7 @@ def build_mot(size, video, skip):
 
 @pytest.mark.parametrize('skip', [1, 3])
 def test_mot_step_holds_identities(ctx, skip):
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     from fastmot_amd import Track
     size = (960, 540)
     video = SyntheticVideo(size, n_ids=12, n_frames=24, seed=3)
@@ -78,7 +78,7 @@ def test_next_frame_prefetch_changes_nothing(ctx, skip, resident):
     """MOT.step(frame, next_frame): the detector network of frame t+1 runs during frame t's ReID /
     association stages.  Tracks (ids, boxes, lifecycle) are bit-identical to strictly sequential steps, for
     uploaded host frames (second upload slot, promoted without re-upload) and for resident ring frames."""
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     from fastmot_amd.detector import DeviceFrame
     from fastmot_amd import Track
     size = (960, 540)
@@ -114,7 +114,7 @@ def test_native_prediction_worker_equals_python_thread(ctx, monkeypatch):
     fm_flow_predict + fm_trk_step in C, scatter after the join) gives the same tracks as Flow.predict +
     MultiTracker.apply_kalman on a second Python thread, frame by frame."""
     import fastmot_amd.mot as mot_mod
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     from fastmot_amd import Track
     size = (960, 540)
     video = SyntheticVideo(size, n_ids=10, n_frames=16, seed=11)
@@ -139,7 +139,7 @@ def test_native_prediction_worker_equals_python_thread(ctx, monkeypatch):
 def test_pipeline_is_deterministic(ctx):
     """The two-thread, four-stream pipeline gives the same tracks (ids, boxes, keypoint counts) on every run
     of the same clip (scripts/stress_determinism.py is the long version of this check)."""
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     from fastmot_amd import Track
     size = (960, 540)
     video = SyntheticVideo(size, n_ids=10, n_frames=12, seed=11)
@@ -162,7 +162,7 @@ def test_draw_overlays_do_not_change_tracking(ctx):
     """MOT(draw=True) renders the overlays of visualizer_cfg onto the caller's frame in place after each step
     (mot.py:166-167); the tracks are the same as without drawing, the frames differ from the originals exactly
     where something was drawn, and device-resident frames are rejected for drawing."""
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     from fastmot_amd.utils.visualization import Visualizer, get_color
     from fastmot_amd.detector import DeviceFrame
     from fastmot_amd import Track
@@ -209,7 +209,7 @@ def test_stage_trace_orders_a_pipelined_step(ctx):
     stream.  In a pipelined run every detector pass shows inputs-ready <= network-done <= decode-done, its
     post-processing begins after the decode, the ReID network of a frame begins after that frame's detections left the
     post-processing, and reading the trace disarms it (tracks are unaffected: same ids as an untraced run)."""
-    from fastmot_amd.utils.synthetic import SyntheticVideo
+    from synthetic import SyntheticVideo
     from fastmot_amd import Track
     size = (960, 540)
     video = SyntheticVideo(size, n_ids=10, n_frames=16, seed=11)

@@ -21,7 +21,7 @@ import scenes
 import fastmot_amd.mot as mot_mod
 from fastmot_amd import Track
 from fastmot_amd.detector import YOLODetector
-from fastmot_amd.utils.synthetic import InjectedYOLODetector, SyntheticVideo
+from synthetic import InjectedYOLODetector, SyntheticVideo
 
 size = (960, 540)
 video = SyntheticVideo(size, n_ids=12, n_frames=48, seed=40 + rank)
