@@ -82,7 +82,8 @@ def build_mot(cfg, video, gallery_sync=None, nms_candidates=1500):
         tcfg.gallery_sync = gallery_sync
     weights = None
     if nms_candidates:
-        weights = scripted_head_weights(cfg['size'], cfg['yolo'], cfg['labels'][0], video.frames[0], nms_candidates)
+        weights = scripted_head_weights(cfg['size'], cfg['yolo'], cfg['labels'] if len(cfg['labels']) > 1 else cfg['labels'][0],
+                                         video.frames[0], nms_candidates)
     try:
         mot = mot_mod.MOT(cfg['size'], detector_type='YOLO', detector_frame_skip=cfg['skip'], class_ids=cfg['labels'],
                           yolo_detector_cfg=SimpleNamespace(model=cfg['yolo'], conf_thresh=0.25, nms_thresh=0.5,

@@ -33,15 +33,33 @@ class ReID:
         return cls.__registry[name]
 
     @classmethod
+    def weight_file(cls):
+        """MODEL_PATH if it exists, else the same stem as a torchreid checkpoint (.pth, .pth.tar); None."""
+        if cls.MODEL_PATH is None:
+            return None
+        base = Path(cls.MODEL_PATH)
+        for cand in (base, base.with_suffix('.pth'), base.with_suffix('.pth.tar')):
+            if cand.is_file():
+                return cand
+        return None
+
+    @classmethod
     def build_graph(cls, weights=None, fuse_lightconv=True):
-        """Weights: the explicit source, else the torchreid checkpoint at MODEL_PATH if it exists
-        (models/torchreid_weights.py); a missing file raises FileNotFoundError unless seeded random
-        parameters were opted into (models.allow_random_weights())."""
+        """Weights: the explicit source, else the model file at MODEL_PATH -- the reference's ONNX export
+        (models/onnx_reader.py; fastmot/models/reid.py:97,106) or, next to it with the suffix .pth / .pth.tar, the
+        torchreid checkpoint it was exported from (models/torchreid_weights.py); a missing file raises
+        FileNotFoundError unless seeded random parameters were opted into (models.allow_random_weights())."""
         ckpt = None
         if weights is None:
-            if cls.MODEL_PATH is not None and Path(cls.MODEL_PATH).is_file():
+            path = cls.weight_file()
+            if path is not None:
                 from .torchreid_weights import TorchreidWeights
-                weights = ckpt = TorchreidWeights(cls.MODEL_PATH)
+                if path.suffix == '.onnx':
+                    from .onnx_reader import torchreid_state_dict_from_onnx
+                    weights = ckpt = TorchreidWeights(torchreid_state_dict_from_onnx(path, cls.CHANNELS,
+                                                                                     cls.OUTPUT_LAYOUT))
+                else:
+                    weights = ckpt = TorchreidWeights(path)
             else:
                 weights = missing_weights(cls, seed=1)
         out = osnet_graph(cls, weights, fuse_lightconv)
@@ -128,7 +146,7 @@ def osnet_graph(model, weights, fuse_lightconv=True):
 
 class OSNet025(ReID):
     ENGINE_PATH = Path(__file__).parent / 'osnet_x0_25_msmt17.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'osnet_x0_25_msmt17.pth'
+    MODEL_PATH = Path(__file__).parent / 'osnet_x0_25_msmt17.onnx'
     INPUT_SHAPE = (3, 256, 128)
     OUTPUT_LAYOUT = 512
     METRIC = 'euclidean'
@@ -138,7 +156,7 @@ class OSNet025(ReID):
 class OSNet10(ReID):
     """Multi-source model trained on MSMT17, DukeMTMC, and CUHK03, not provided."""
     ENGINE_PATH = Path(__file__).parent / 'osnet_x1_0_msdc.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'osnet_x1_0_msdc.pth'
+    MODEL_PATH = Path(__file__).parent / 'osnet_x1_0_msdc.onnx'
     INPUT_SHAPE = (3, 256, 128)
     OUTPUT_LAYOUT = 512
     METRIC = 'cosine'

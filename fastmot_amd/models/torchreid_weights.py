@@ -14,7 +14,8 @@ checkpoint's state_dict is read directly.  The mapping below follows torchreid/m
     conv5                      Conv1x1
     fc.0 / fc.1                Linear + BatchNorm1d
 
-PyTorch is used for unpickling only (`torch.load`); a plain dict of arrays works as well.
+PyTorch is used for unpickling only (`torch.load`); a plain dict of arrays works as well -- that is how the
+reference's ONNX export of the same model arrives (models/onnx_reader.torchreid_state_dict_from_onnx).
 """
 import numpy as np
 
@@ -85,7 +86,12 @@ class TorchreidWeights:
         if bn:
             if bk is None:
                 raise KeyError(f'layer {name!r} has no batch norm in torchreid')
-            p.update(self._bn(bk, cout))
+            if bk + '.weight' in self.sd:
+                p.update(self._bn(bk, cout))
+            elif ck + '.bias' not in self.sd:
+                # (a source whose exporter folded BatchNorm into the conv -- ONNX, models/onnx_reader.py -- carries
+                # the folded bias instead of the four BatchNorm vectors)
+                raise KeyError(f'checkpoint has neither {bk}.* nor a folded {ck}.bias')
         return p
 
     def linear(self, name, cout, cin, bn=False):
@@ -93,7 +99,7 @@ class TorchreidWeights:
         p = dict(w=self._get(ck + '.weight', (cout, cin)))
         if ck + '.bias' in self.sd:
             p['bias'] = self._get(ck + '.bias', (cout,))
-        if bn:
+        if bn and (bk + '.weight' in self.sd or ck + '.bias' not in self.sd):
             p.update(self._bn(bk, cout))
         return p
 

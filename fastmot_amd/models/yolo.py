@@ -5,8 +5,9 @@ The reference builds a TensorRT engine from an ONNX file and appends the YoloLay
 (models/yolo.py:61-151); here `build_graph` emits the Darknet topology directly (semantics of
 scripts/yolo2onnx.py:558-863: Conv SAME + BN eps 1e-5 + mish/leaky/linear, shortcut = Add,
 route = concat with the most recent tensor first, maxpool SAME stride 1, nearest upsample) and
-the decode runs in detect.hip.  MODEL_PATH / ENGINE_PATH are kept as attributes: MODEL_PATH may
-point to Darknet weights; without a file the network runs with seeded random weights.
+the decode runs in detect.hip.  MODEL_PATH / ENGINE_PATH are kept as attributes: MODEL_PATH is the reference's ONNX
+file (read by models/onnx_reader.py; the Darknet .weights / .cfg of the same stem work as well); without a file
+the descriptor raises, or runs with seeded random weights when that was opted into.
 """
 import os
 from pathlib import Path
@@ -50,30 +51,60 @@ class YOLO:
 
     @classmethod
     def cfg_path(cls):
-        """Darknet cfg next to the weights (the reference converts cfg + weights to ONNX offline,
-        scripts/yolo2onnx.py; here the cfg is read directly)."""
+        """Darknet cfg next to the model file (the reference converts cfg + weights to ONNX offline,
+        scripts/yolo2onnx.py; here a cfg is read directly when there is one)."""
         return cls.MODEL_PATH.with_suffix('.cfg') if cls.MODEL_PATH is not None else None
+
+    @classmethod
+    def weight_file(cls):
+        """MODEL_PATH (the reference's .onnx, models/yolo.py:155-156) if it exists, else the Darknet .weights of the
+        same stem it was converted from; None when neither is there."""
+        if cls.MODEL_PATH is None:
+            return None
+        base = Path(cls.MODEL_PATH)
+        for cand in (base, base.with_suffix('.weights')):
+            if cand.is_file():
+                return cand
+        return None
 
     @classmethod
     def build_graph(cls, weights=None):
         """-> (Graph, [head output views])  heads in LAYER_FACTORS order.
 
-        Weights: the explicit `weights` source, else the Darknet file at MODEL_PATH; when that file is
-        missing this raises FileNotFoundError like the reference does, unless seeded random parameters were
-        opted into (models.allow_random_weights(), benchmarks / tests).  Topology: the Darknet cfg next to MODEL_PATH if it exists (any
-        YOLOv3/v4/-tiny/Scaled-YOLOv4 cfg, models/darknet.py), else the built-in yolov4.cfg table."""
+        Weights: the explicit `weights` source, else the model file: the ONNX file scripts/yolo2onnx.py wrote
+        (models/onnx_reader.py) or the Darknet .weights next to it; when neither exists this raises
+        FileNotFoundError like the reference does, unless seeded random parameters were opted into
+        (models.allow_random_weights(), benchmarks / tests).  Topology, in this order: the Darknet cfg next to the
+        model file (any YOLOv3/v4/-tiny/Scaled-YOLOv4 cfg, models/darknet.py); the node list of the ONNX file itself
+        (rebuilt into cfg sections, onnx_reader.darknet_cfg_from_onnx); the built-in yolov4.cfg table / Scaled-YOLOv4
+        generators."""
         real = None
+        onnx_model = None
         if weights is None:
-            if cls.MODEL_PATH is not None and Path(cls.MODEL_PATH).is_file():
-                weights = real = DarknetWeights(cls.MODEL_PATH)
-            else:
+            path = cls.weight_file()
+            if path is None:
                 weights = missing_weights(cls, seed=0)
+            elif path.suffix == '.onnx':
+                from .onnx_reader import OnnxDarknetWeights
+                weights = real = OnnxDarknetWeights(path)
+                onnx_model = weights.model
+            else:
+                weights = real = DarknetWeights(path)
         cfg = cls.cfg_path()
+        text = None
         if cfg is not None and cfg.is_file():
-            g, heads, meta = darknet_graph(cfg.read_text(), weights, in_hw=cls.INPUT_SHAPE[1:])
+            text, origin = cfg.read_text(), str(cfg)
+        elif onnx_model is not None:
+            from .onnx_reader import darknet_cfg_from_onnx
+            text, origin = darknet_cfg_from_onnx(onnx_model, cls), f'the node list of {cls.MODEL_PATH}'
+            shape = onnx_model.data_inputs[0][1]
+            if tuple(shape[1:]) != tuple(cls.INPUT_SHAPE):      # (as models/yolo.py:120 of the reference asserts)
+                raise ValueError(f'{cls.MODEL_PATH}: input {tuple(shape[1:])} != {cls.__name__}.INPUT_SHAPE {cls.INPUT_SHAPE}')
+        if text is not None:
+            g, heads, meta = darknet_graph(text, weights, in_hw=cls.INPUT_SHAPE[1:])
             if meta.get('classes') != cls.NUM_CLASSES or len(heads) != len(cls.LAYER_FACTORS) or \
                     meta.get('strides') != list(cls.LAYER_FACTORS) or meta.get('new_coords') != cls.NEW_COORDS:
-                raise ValueError(f'{cfg} does not describe {cls.__name__}: {meta}')
+                raise ValueError(f'{origin} does not describe {cls.__name__}: {meta}')
         elif cls.TOPOLOGY == 'yolov4':
             assert len(cls.LAYER_FACTORS) == len(cls.SCALES) == len(cls.ANCHORS)
             g, heads = yolov4_graph(cls, weights)
@@ -85,7 +116,8 @@ class YOLO:
         else:
             raise NotImplementedError(f'{cls.__name__}: no built-in layer table; put the Darknet cfg at {cfg}')
         if real is not None and real.remaining() != 0:
-            raise ValueError(f'{cls.MODEL_PATH}: {real.remaining()} bytes left after loading {cls.__name__}')
+            raise ValueError(f'{cls.weight_file()}: {real.remaining()} '
+                             f'{"layers" if onnx_model is not None else "bytes"} left after loading {cls.__name__}')
         return g, heads
 
 
@@ -188,7 +220,7 @@ def yolov4_graph(model, weights):
 
 class YOLOv4(YOLO):
     ENGINE_PATH = Path(__file__).parent / 'yolov4_crowdhuman.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov4_crowdhuman.weights'
+    MODEL_PATH = Path(__file__).parent / 'yolov4_crowdhuman.onnx'
     NUM_CLASSES = 2
     INPUT_SHAPE = (3, 512, 512)
     LAYER_FACTORS = [8, 16, 32]
@@ -202,7 +234,7 @@ class YOLOv4_608(YOLO):
     """BASELINE.json config[1]: Darknet yolov4.cfg at 608x608, 80 COCO classes (the configuration
     the 128.4 GFLOP figure refers to); anchors/scales of the public yolov4.cfg."""
     ENGINE_PATH = Path(__file__).parent / 'yolov4_608.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov4.weights'
+    MODEL_PATH = Path(__file__).parent / 'yolov4.onnx'
     NUM_CLASSES = 80
     INPUT_SHAPE = (3, 608, 608)
     LAYER_FACTORS = [8, 16, 32]
@@ -222,7 +254,7 @@ def _scaled(name, input_shape, factors, anchors, scales=2.0, builtin=None):
     return type(name, (YOLO,), dict(
         BUILTIN_CFG=builtin,
         ENGINE_PATH=Path(__file__).parent / f'{_file_name(name)}.hipnet',
-        MODEL_PATH=Path(__file__).parent / f'{_file_name(name)}.weights',
+        MODEL_PATH=Path(__file__).parent / f'{_file_name(name)}.onnx',
         NUM_CLASSES=1, LETTERBOX=True, NEW_COORDS=True, INPUT_SHAPE=input_shape, LAYER_FACTORS=factors,
         SCALES=[scales] * len(factors), ANCHORS=anchors, TOPOLOGY='darknet-cfg', __module__=__name__))
 
@@ -259,7 +291,7 @@ class YOLOv4P6_1280(YOLOv4P6):
 
 class YOLOv4Tiny(YOLO):
     ENGINE_PATH = Path(__file__).parent / 'yolov4-tiny.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov4-tiny.weights'
+    MODEL_PATH = Path(__file__).parent / 'yolov4-tiny.onnx'
     NUM_CLASSES = 1
     INPUT_SHAPE = (3, 416, 416)
     LAYER_FACTORS = [32, 16]
@@ -270,7 +302,7 @@ class YOLOv4Tiny(YOLO):
 
 class YOLOv3(YOLO):
     ENGINE_PATH = Path(__file__).parent / 'yolov3.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov3.weights'
+    MODEL_PATH = Path(__file__).parent / 'yolov3.onnx'
     NUM_CLASSES = 1
     INPUT_SHAPE = (3, 416, 416)
     LAYER_FACTORS = [32, 16, 8]
@@ -281,13 +313,13 @@ class YOLOv3(YOLO):
 
 class YOLOv3SPP(YOLOv3):
     ENGINE_PATH = Path(__file__).parent / 'yolov3-spp.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov3-spp.weights'
+    MODEL_PATH = Path(__file__).parent / 'yolov3-spp.onnx'
     INPUT_SHAPE = (3, 608, 608)
 
 
 class YOLOv3Tiny(YOLO):
     ENGINE_PATH = Path(__file__).parent / 'yolov3-tiny.hipnet'
-    MODEL_PATH = Path(__file__).parent / 'yolov3-tiny.weights'
+    MODEL_PATH = Path(__file__).parent / 'yolov3-tiny.onnx'
     NUM_CLASSES = 1
     INPUT_SHAPE = (3, 416, 416)
     LAYER_FACTORS = [32, 16]

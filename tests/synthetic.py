@@ -131,25 +131,38 @@ def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.
     threshold."""
     from fastmot_amd import models
     m = models.YOLO.get_model(model)
-    n_heads = len(m.LAYER_FACTORS)
     n_anchors = [len(a) // 2 for a in m.ANCHORS]
-    CAL = -12.0
-    det = YOLODetector(size, tuple(label) if isinstance(label, (tuple, list)) else (label,), model=model, conf_thresh=conf_thresh,
-                       weights=ScriptedHeadWeights(seed, m.NUM_CLASSES, label, [[CAL] * n for n in n_anchors], obj_gain))
-    try:
-        det.detect_async(frame)
-        det.postprocess()
-        rec = 5 + m.NUM_CLASSES
-        logits = []
-        for head in det.heads:
-            t = det.backend.read(head, 1)[0]                       # (h, w, anchors * rec)
-            logits.append(t.reshape(t.shape[0] * t.shape[1], -1, rec)[..., 4].astype(np.float64) - CAL)   # [cells, anchors]
-    finally:
-        det.backend.close()
-    total = sum(v.size for v in logits)
+    labels = tuple(label) if isinstance(label, (tuple, list)) else (label,)
     # class probability ~ sigmoid(4) = 0.982: box_conf * cls_prob >= thr  <=>  objectness logit >= logit(thr / 0.982)
     need = conf_thresh / (1.0 / (1.0 + np.exp(-4.0)))
     cut = float(np.log(need / (1.0 - need)))
-    share = min(0.5, target / total)                              # the same share of every (head, anchor)'s cells
-    bias = [[cut - float(np.quantile(v[:, a], 1.0 - share)) for a in range(v.shape[1])] for v in logits]
+    rec = 5 + m.NUM_CLASSES
+    # NEW_COORDS heads carry their logistic activation inside the network: the head tensor holds sigmoid(logit), which
+    # saturates -- the bias is then found in a few passes (quantiles commute with the monotonic sigmoid)
+    bias = [[-12.0 if not m.NEW_COORDS else 0.0] * n for n in n_anchors]
+    for _ in range(1 if not m.NEW_COORDS else 6):
+        det = YOLODetector(size, labels, model=model, conf_thresh=conf_thresh,
+                           weights=ScriptedHeadWeights(seed, m.NUM_CLASSES, label, bias, obj_gain))
+        try:
+            det.detect_async(frame)
+            det.postprocess()
+            vals = []
+            for head in det.heads:
+                t = det.backend.read(head, 1)[0]                       # (h, w, anchors * rec)
+                vals.append(t.reshape(t.shape[0] * t.shape[1], -1, rec)[..., 4].astype(np.float64))   # [cells, anchors]
+        finally:
+            det.backend.close()
+        total = sum(v.size for v in vals)
+        share = min(0.5, target / total)                              # the same share of every (head, anchor)'s cells
+        step = 0.0
+        for h, v in enumerate(vals):
+            for a in range(v.shape[1]):
+                q = float(np.quantile(v[:, a], 1.0 - share))
+                if m.NEW_COORDS:
+                    q = min(max(q, 1e-6), 1.0 - 1e-6)
+                    q = float(np.log(q / (1.0 - q)))
+                bias[h][a] += cut - q
+                step = max(step, abs(cut - q))
+        if step < 0.02:
+            break
     return ScriptedHeadWeights(seed, m.NUM_CLASSES, label, bias, obj_gain)
