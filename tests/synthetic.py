@@ -139,7 +139,7 @@ def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.
     rec = 5 + m.NUM_CLASSES
     # NEW_COORDS heads carry their logistic activation inside the network: the head tensor holds sigmoid(logit), which
     # saturates -- the bias is then found in a few passes (quantiles commute with the monotonic sigmoid)
-    bias = [[-12.0 if not m.NEW_COORDS else 0.0] * n for n in n_anchors]
+    bias = [[-12.0] * n for n in n_anchors]          # (lets nothing through: the candidate list cannot overflow)
     for _ in range(1 if not m.NEW_COORDS else 6):
         det = YOLODetector(size, labels, model=model, conf_thresh=conf_thresh,
                            weights=ScriptedHeadWeights(seed, m.NUM_CLASSES, label, bias, obj_gain))
@@ -159,7 +159,7 @@ def scripted_head_weights(size, model, label, frame, target=1500, conf_thresh=0.
             for a in range(v.shape[1]):
                 q = float(np.quantile(v[:, a], 1.0 - share))
                 if m.NEW_COORDS:
-                    q = min(max(q, 1e-6), 1.0 - 1e-6)
+                    q = min(max(q, 1e-30), 1.0 - 1e-7)
                     q = float(np.log(q / (1.0 - q)))
                 bias[h][a] += cut - q
                 step = max(step, abs(cut - q))

@@ -53,7 +53,11 @@ def test_detector_chain_equals_oracle_at_benchmark_size(ctx, case):
             res, dets = detector_check.check(det, video.frames[f])
             print(case, f, res)
             assert 600 <= res['candidates'] <= 4000, res          # the regime the bench times (~1500)
-            assert res['detections'] >= 1 and res['detections'] < res['candidates'] // 4, res
+            # (classic heads: ~1500 -> a handful, the dense-suppression regime; NEW_COORDS heads with random box logits
+            # spread anchor-sized boxes over the grid: hundreds survive -- the scan kernel's other regime)
+            assert 1 <= res['detections'] < res['candidates'], res
+            if case.startswith('config1'):
+                assert res['detections'] < res['candidates'] // 50, res
             if len(c['labels']) > 1:
                 assert len(np.unique(dets.label)) > 1, 'candidates of several classes expected'
                 assert (np.diff(dets.label) >= 0).all()

@@ -29,7 +29,7 @@ CASES = {'mini_v4': dc.MINI_V4, 'mini_tiny': dc.MINI_TINY}
 
 class MiniV4(YOLO):
     NUM_CLASSES = 2
-    INPUT_SHAPE = (3, 64, 64)
+    INPUT_SHAPE = (3, 64, 96)
     LAYER_FACTORS = [2, 4]
     SCALES = [1.2, 1.1]
     ANCHORS = [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146]]
@@ -351,7 +351,7 @@ def test_models_from_onnx_files_on_the_engine(ctx, tmp_path, monkeypatch):
     g, heads = MiniV4.build_graph()
     cfg = darknet.parse_cfg(dc.MINI_V4)
     blob = dc.random_weights_file(cfg, seed=11)
-    xin = torch.from_numpy(np.random.default_rng(2).uniform(0, 1, (1, 3, 64, 64)).astype(np.float32))
+    xin = torch.from_numpy(np.random.default_rng(2).uniform(0, 1, (1, 3, 64, 96)).astype(np.float32))
     ref = dc.torch_darknet(cfg, blob, xin)
     eng = HipNet(ctx, NET_DETECTOR, g, 1, reuse_buffers=False)
     eng.write(g.input, xin.numpy().transpose(0, 2, 3, 1).astype(np.float16))
