@@ -128,23 +128,156 @@ def cpu_leg(cfg, video, mot, budget_s=20.0):
     parity['detector_chain'] = chain
     parity['detector_chain_identical'] = chain['detector_chain_identical']
     base = {'value': round(done / dt, 3), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+            'implementation': 'numpy-port: oracle/cpu_tracker.py + cv_oracle.py (also the checker of `parity`)',
             'sample': f'{done} frames of the same {cfg["size"][0]}x{cfg["size"][1]}/{video.n_ids}-detection '
                       f'synthetic clip (detector_frame_skip={cfg["skip"]}); numpy port of KLT+Kalman+association '
                       '(oracle/), detector+ReID networks excluded (injected), NOT the Numba-compiled reference'}
     return base, parity
 
 
+def _compiled_worker(args):
+    """One host process = one independent video stream through the compiled CPU port (multi-core leg)."""
+    cfg, seed, budget_s = args
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except ImportError:
+        pass
+    sys.path.insert(0, str(ROOT / 'oracle'))
+    import c_baseline
+    from synthetic import SyntheticVideo
+    video = SyntheticVideo(cfg['size'], n_ids=cfg['n_dets'], n_frames=8, seed=seed)
+    r = c_baseline.time_clip(cfg, video, tracker_cfg(), budget_s)
+    return r['value']
+
+
 def compiled_baseline(cfg, video, budget_s=10.0):
-    """kind=compiled-port: the same CPU path with the parts the reference runs as compiled code (OpenCV KLT / RANSAC)
-    in plain C (oracle/c_baseline.c, -O3, single thread) under the same Python orchestration -- the 'Numba-class
-    proxy' of SURVEY.md section 8d; None when gcc / the library is unavailable."""
+    """cpu_baseline, kind=port (compiled): the reference's TensorRT-disabled CPU path with the parts the reference
+    runs as compiled code (OpenCV KLT / RANSAC) in plain C (oracle/c_baseline.c, gcc -O3, no fast-math) under the
+    reference's Python orchestration -- the 'Numba-class proxy' of SURVEY.md section 8d.  Timed on ONE thread on the
+    bench clip, and on ALL usable cores as that many independent streams (the path shards by stream, one process
+    each, as it does across GPUs); None when gcc / the library is unavailable."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     try:
         import c_baseline
         c_baseline.lib()
     except (ImportError, OSError, RuntimeError):
         return None
-    return c_baseline.time_clip(cfg, video, tracker_cfg(), budget_s)
+    one = c_baseline.time_clip(cfg, video, tracker_cfg(), budget_s)
+    one['kind'] = 'port'
+    one['implementation'] = 'compiled-port: oracle/c_baseline.c (gcc -O3) under the reference\'s Python orchestration'
+    cores = usable_cpus()
+    if cores > 1:
+        import multiprocessing as mp
+        try:
+            with mp.get_context('fork').Pool(cores) as pool:
+                t0 = time.perf_counter()
+                rates = pool.map(_compiled_worker, [(cfg, 200 + i, budget_s) for i in range(cores)])
+                wall = time.perf_counter() - t0
+            one['all_cores'] = {'value': round(float(sum(rates)), 2), 'unit': 'frames/s', 'cores': cores,
+                                'how': f'{cores} independent streams, one single-threaded process each (sum of their '
+                                       f'rates; {wall:.0f} s wall incl. building each process\'s clip)'}
+        except (OSError, RuntimeError) as err:
+            one['all_cores'] = {'error': str(err)}
+    return one
+
+
+def reference_numba_constant():
+    """The reference's OWN tracker stage (Kalman + association + life cycle; KLT scripted, networks injected) with its
+    @njit functions compiled by a real Numba, timed in the BUILD container (no Numba runs on the GPU box): a labelled
+    constant with its provenance file, not a measurement of this run."""
+    path = ROOT / 'profiles' / 'r03_reference_numba_timing.txt'
+    try:
+        line = next(l for l in path.read_text().splitlines() if l.startswith('s50_skip1'))
+        fps = float(line.split('=')[-1].split('frames/s')[0])
+    except (OSError, StopIteration, ValueError):
+        return None
+    return {'value': fps, 'unit': 'frames/s', 'cores': 1, 'kind': 'reference (partial: Kalman + association + life cycle '
+            'only, no KLT / detector / ReID)', 'measured': 'build container, not this run',
+            'source': 'profiles/r03_reference_numba_timing.txt (oracle/time_reference.py --real-numba, Numba 0.54.1)'}
+
+
+HBM_PEAK_GBS, PCIE_PEAK_GBS, FP64_PEAK_TFLOPS = 8000.0, 63.0, 78.6      # MI355X_MICROARCH.md chip table (spec)
+
+# stage boundaries the library stamps with HIP events on the stage's own stream (fm_trace_mark, csrc/*.hip)
+STAGE_TAGS = (('detector preprocess (resize + BGR->RGB + fp16 NHWC)', 14, 11), ('detector network (conv engine)', 11, 12),
+              ('head decode + threshold + compaction', 12, 13), ('candidate sort', 20, 22), ('DIoU-NMS bit matrix', 22, 23),
+              ('NMS scan + box filters + write-back', 23, 21), ('next frame H2D copy', 30, 31),
+              ('ReID crop + resize + normalise', 32, 34), ('ReID network (OSNet) + head', 34, 35),
+              ('embedding export to pinned memory', 35, 33), ('KLT gray + pyramid + Scharr', 42, 43),
+              ('KLT keypoint bookkeeping + GFTT', 44, 45), ('KLT background FAST', 46, 47), ('KLT pyramidal LK', 40, 41),
+              ('Kalman warp + predict + KLT update', 50, 51), ('Kalman detection update', 52, 53),
+              ('pairwise cost terms (cdist + Mahalanobis + IoU)', 54, 55), ('stage cost gather + gate', 56, 57))
+
+
+def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
+    """per-stage achieved GB/s or TFLOP/s and roofline fraction INSIDE the pipelined step.
+    Durations: HIP events on each stage's own stream (fm_trace_*), median over the occurrences in `n_steps` traced
+    steps; work: the algorithmic bytes / FLOPs of DESIGN.md section 3 for this configuration.  Latency-bound stages
+    (serial scans, tiny launches) are reported in microseconds with their share of a step."""
+    ctx.synchronize()
+    ctx.trace_start(128 * (n_steps + 4))
+    run_steps(n_steps)
+    ctx.synchronize()
+    tags, ms = ctx.trace_read()
+    W, H = cfg['size']
+    D = T = cfg['n_dets']
+    m = mot.detector.model
+    _, in_h, in_w = m.INPUT_SHAPE
+    det_flops, _ = mot.detector.backend.cost(1)
+    ext = mot.extractors[0]
+    ext_flops, ext_bytes = ext.backend.cost(D)
+    head_bytes = sum((5 + m.NUM_CLASSES) * (len(a) // 2) * (in_h // f) * (in_w // f) * 4 for a, f in zip(m.ANCHORS, m.LAYER_FACTORS))
+    _, eh, ew = ext.model.INPUT_SHAPE
+    K = max(mot.detector.last_candidates, 1)
+    flow = cfg.get('flow_scale', 0.5)
+    px0 = int(W * flow) * int(H * flow)
+    pyr_px = sum(px0 / 4 ** l for l in range(6))
+    work = {
+        14: ('hbm', W * H * 3 + in_w * in_h * 8 * 2, 'frame u8 in + fp16 NHWC(8) out'),
+        11: ('mfma', det_flops, 'conv FLOPs (2 MAC)'),
+        12: ('hbm', head_bytes, 'fp32 head tensors in'),
+        20: ('latency', None, f'K = {K} candidates, K^2 key comparisons from LDS'),
+        22: ('latency', None, f'K^2/2 = {K * K // 2} pair tests (fp32 IoU pre-test, exact fp64 DIoU near the threshold)'),
+        23: ('latency', None, f'greedy scan over {-(-K // 64)} chunks of 64, one workgroup'),
+        30: ('pcie', W * H * 3, 'frame u8'),
+        32: ('hbm', D * eh * ew * 8 * 2, 'fp16 NHWC(8) crops out (+ <= crop pixels in)'),
+        34: ('hbm', ext_bytes, f'activations + weights fp16; {ext_flops / 1e9:.1f} GFLOP'),
+        35: ('latency', None, f'{D} x 512 fp32'),
+        42: ('hbm', W * H * 3 + W * H + px0 + pyr_px * 5.25, 'frame in, gray + half + 6-level pyramid + int16 Scharr pairs out'),
+        44: ('latency', None, f'{T} track crops: rect / ellipse / mask filters, min-eigenvalue map, corner selection'),
+        46: ('latency', None, 'FAST-9/16 + NMS on the 0.1-scale background image'),
+        40: ('latency', None, 'VALU issue: <= 6 levels x <= 10 iterations x 25 taps per point, one wavefront per 2 points'),
+        50: ('latency', T * 576 * 2, 'fp64 state read + write, one wavefront per track'),
+        52: ('latency', T * 576 * 2, 'fp64 state read + write'),
+        54: ('fp64', 6.0 * T * D * 512, 'fp64 FLOPs'),
+        56: ('latency', None, 'cascade stages of one update'),
+    }
+    out = []
+    for name, a, b in STAGE_TAGS:
+        ta = np.sort(ms[tags == a].astype(np.float64))
+        tb = np.sort(ms[tags == b].astype(np.float64))
+        n = min(len(ta), len(tb))
+        if n < 4:
+            continue
+        d = (tb[:n] - ta[:n])[n // 8:]                      # (the first steps of the window still fill the pipeline)
+        us = float(np.median(d)) * 1e3
+        per_step = n / n_steps
+        bound, amount, what = work[a]
+        row = {'stage': name, 'us': round(us, 2), 'per_step': round(per_step, 2), 'bound': bound, 'work': what}
+        if amount and us > 0:
+            if bound in ('hbm', 'pcie', 'latency'):
+                row['GB/s'] = round(amount / us / 1e3, 1)
+                peak = PCIE_PEAK_GBS if bound == 'pcie' else HBM_PEAK_GBS
+                row['frac'] = round(amount / us / 1e3 / peak, 4)
+                row['peak'] = f'{peak:g} GB/s'
+            else:
+                row['TFLOP/s'] = round(amount / us / 1e6, 3)
+                peak = MFMA_PEAK_TFLOPS if bound == 'mfma' else FP64_PEAK_TFLOPS
+                row['frac'] = round(amount / us / 1e6 / peak, 5)
+                row['peak'] = f'{peak:g} TFLOP/s'
+        out.append(row)
+    return out
 
 
 def usable_cpus():
@@ -166,16 +299,20 @@ def flow_threads_for(local_world):
     return max(1, min(7, share - 2))
 
 
-def pmc_traffic():
-    """(bytes per conv launch, source) from the committed rocprofv3 PMC passes (profiles/*_pmc_conv.json, produced
-    by scripts/collect_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of the detector network; FETCH_SIZE
+def pmc_traffic(n_conv_launches=None):
+    """(bytes per conv launch, source, stale) from the newest committed rocprofv3 PMC passes (profiles/*_pmc_conv.json,
+    produced by scripts/collect_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of the detector network; FETCH_SIZE
     doubled per the gfx950 note of MI355X_MICROARCH.md).  PMC counters cannot be collected from inside this process,
-    hence the file; None when it is absent."""
-    for name in ('r03_pmc_conv.json', 'r02_pmc_conv.json', 'r01_pmc_conv.json'):
+    hence the file; `stale` is True when the file counted another number of conv launches per frame than the network
+    of this run has (the kernels changed since the passes were taken); None when no file is there."""
+    for name in ('r04_pmc_conv.json', 'r03_pmc_conv.json', 'r02_pmc_conv.json', 'r01_pmc_conv.json'):
         try:
             with open(ROOT / 'profiles' / name) as f:
-                return json.load(f)['traffic_bytes_per_launch'], f'profiles/{name} (separate rocprofv3 --pmc passes)'
-        except (OSError, KeyError, ValueError):
+                d = json.load(f)
+            per_frame = d['launches'] / d['replays']
+            stale = n_conv_launches is not None and abs(per_frame - n_conv_launches) > 0.5
+            return d['traffic_bytes_per_launch'], f'profiles/{name} (separate rocprofv3 --pmc passes)', bool(stale)
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return None
 
@@ -330,6 +467,16 @@ def main():
             pos += nv + 4
             variants[key] = round(nv / dt, 2)
 
+    stages_roof = None
+    if world == 1 and not args.no_variants:
+        def traced(n):
+            nonlocal pos
+            run(n, pos, pinned, args.prefetch)
+            pos += n
+        run(4, pos, pinned, args.prefetch)
+        pos += 4
+        stages_roof = stage_rooflines(ctx, cfg, mot, traced)
+
     if rank == 0:
         flops, _ = mot.detector.backend.cost(1)
         n_launch = len(mot.detector.graph.layers)
@@ -337,7 +484,9 @@ def main():
         achieved = flops / (net_avg_ms * 1e-3) / 1e12
         from fastmot_amd.utils import Profiler
         stages = {k: round(Profiler.get_avg_millis(k), 3) for k in ('preproc', 'detect', 'track', 'extract', 'assoc')}
-        traffic = pmc_traffic() if args.config == 1 else None            # the PMC passes are of YOLOv4@608
+        from fastmot_amd.models import graph as _G
+        n_conv = sum(1 for d in mot.detector.graph.layers if d['op'] in (_G.OP_CONV, _G.OP_CONVS, _G.OP_RESBLOCK))
+        traffic = pmc_traffic(n_conv) if args.config == 1 else None      # the PMC passes are of YOLOv4@608
         metric = ('end-to-end tracker FPS @1080p/50 dets' if args.config == 1 else
                   f'end-to-end tracker FPS @{size[0]}x{size[1]}/{cfg["n_dets"]} dets, detector_frame_skip={cfg["skip"]} '
                   f'({cfg["name"]})')
@@ -359,6 +508,7 @@ def main():
                                                                          'fm_gallery_* control channel (RCCL via the C ABI, no torch in the process)'),
                        'host_threads_per_rank': {'ransac_pool': os.environ.get('FASTMOT_FLOW_THREADS', 'library default'),
                                                  'usable_cpus': usable_cpus()},
+                       'numa': dict(getattr(ctx, 'numa', {}), pinned_frames_node=__import__('fastmot_amd.runtime', fromlist=['x']).numa_node_of(host_frames)),
                        'gallery_allgather': None if sync is None else sync.stats(),
                        'visible_tracks': len(list(mot.visible_tracks())),
                        'yolo_candidates_nms_in': mot.detector.last_candidates,
@@ -372,19 +522,27 @@ def main():
                          # HBM-side bytes per launch: NOT measured in this run (PMC counters cannot be collected from
                          # inside the process) but read from the committed rocprofv3 --pmc passes of the same network
                          'traffic': traffic[0] if traffic else None, 'traffic_source': traffic[1] if traffic else None,
+                         'traffic_stale': traffic[2] if traffic else None,
                          'flop_per_frame': flops, 'net_ms_per_frame': round(net_avg_ms, 4),
                          'avg_launch_us': round(net_avg_ms * 1e3 / n_launch, 3)},
         }
         out['config']['settle_steps_untimed'] = settle_steps
+        if stages_roof is not None:
+            out['stage_roofline'] = stages_roof
         if variants is not None:
             out['variants'] = variants
             # what the UNMODIFIED reference app.py gets (it calls mot.step(frame), no next_frame): first-class number
             out['sequential_fps'] = variants['h2d_sequential_fps']
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'], out['parity'] = cpu_leg(cfg, video, mot)
+            port, out['parity'] = cpu_leg(cfg, video, mot)
             comp = compiled_baseline(cfg, video)
-            if comp is not None:
-                out['cpu_baseline_compiled'] = comp
+            # the mandatory baseline is the compiled port (1 thread + all usable cores); the numpy port -- the parity
+            # checker, ~12x slower -- rides along; the reference's own Numba-compiled tracker stage is a labelled constant
+            out['cpu_baseline'] = comp if comp is not None else port
+            out['cpu_baseline_numpy_port'] = port
+            ref = reference_numba_constant()
+            if ref is not None and args.config == 1:
+                out['reference_numba_tracker_stage'] = ref
         print('stage ms (Profiler, incl. warmup):', stages, file=sys.stderr)
         print(json.dumps(out), flush=True)
     if sync is not None:

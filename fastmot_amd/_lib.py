@@ -75,6 +75,12 @@ def device_count():
     return n
 
 
+def device_pci_bus_id(device):
+    buf = C.create_string_buffer(64)
+    check(load().fm_device_pci_bus_id(C.c_int(device), buf, C.c_int(64)))
+    return buf.value.decode().lower()
+
+
 class HipContext:
     """One context = one GPU = one video stream (fm_ctx)."""
 
@@ -529,7 +535,7 @@ class FlowCfg(C.Structure):
     _fields_ = [('small_w', C.c_int32), ('small_h', C.c_int32), ('bg_w', C.c_int32), ('bg_h', C.c_int32),
                 ('win_size', C.c_int32), ('max_level', C.c_int32), ('max_count', C.c_int32),
                 ('epsilon', C.c_double), ('fast_thresh', C.c_int32), ('max_corners', C.c_int32),
-                ('block_size', C.c_int32), ('quality_level', C.c_double)]
+                ('block_size', C.c_int32), ('quality_level', C.c_double), ('gray_coeff_bits', C.c_int32)]
 
 
 def _bind_flow(cls):

@@ -745,6 +745,7 @@ extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* 
     char* in = ctx->as_in.dev<char>();
     char* pr = ctx->as_pair.dev<char>();
     const size_t shmem = (size_t)ctx->feat_dim * 4 + 32 * sizeof(double);
+    fm_trace_mark(ctx, ctx->s_main, 54);
     hipLaunchKernelGGL(pairwise_kernel, dim3(nT), dim3(256), shmem, ctx->s_main, nT, nD, metric,
                        ctx->feat_dim, (const int32_t*)(in + offs[0]), (const double*)(in + offs[1]),
                        (const double*)(in + offs[3]), ctx->mean, ctx->cov, ctx->feat_avg, ctx->feat_cnt,
@@ -752,6 +753,7 @@ extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* 
                        (double*)(pr + 2 * mat),
                        (uint8_t*)(pr + 3 * mat));
     FM_HIP(hipGetLastError());
+    fm_trace_mark(ctx, ctx->s_main, 55);
     return 0;
 }
 
@@ -801,6 +803,7 @@ extern "C" int fm_assoc_stage(fm_ctx* ctx, int stage, int solver, int nr, const 
     const size_t mat = sizeof(double) * (size_t)nT * nD;
     char* in = ctx->as_in.dev<char>();
     char* pr = ctx->as_pair.dev<char>();
+    fm_trace_mark(ctx, ctx->s_main, 56);
     hipLaunchKernelGGL(stage_cost_kernel, dim3((nr * nc + 255) / 256), dim3(256), 0, ctx->s_main, stage,
                        nr, nc, nD, (const int32_t*)(si + offs[0]), (const int32_t*)(si + offs[1]),
                        (const int64_t*)(si + offs[2]), (const int64_t*)(in + ctx->as_off[4]),
@@ -808,6 +811,7 @@ extern "C" int fm_assoc_stage(fm_ctx* ctx, int stage, int solver, int nr, const 
                        (const double*)pr, (const double*)(pr + mat), (const double*)(pr + 2 * mat),
                        motion_weight, max_cost, fill_val, cost_dst);
     FM_HIP(hipGetLastError());
+    fm_trace_mark(ctx, ctx->s_main, 57);
     if (host_lap) FM_HIP(hipStreamSynchronize(ctx->s_main));
     else if (cost_out)   // tests / debugging only
         FM_HIP(hipMemcpyAsync(ctx->as_cost.h, ctx->as_cost.d, cbytes, hipMemcpyDeviceToHost, ctx->s_main));

@@ -86,6 +86,12 @@ extern "C" int fm_ctx_bind_thread(fm_ctx* ctx) {
     return 0;
 }
 
+extern "C" int fm_device_pci_bus_id(int device, char* buf, int buflen) {
+    FM_CHECK_ARG(buf && buflen >= 16);
+    FM_HIP(hipDeviceGetPCIBusId(buf, buflen, device));
+    return 0;
+}
+
 extern "C" int fm_device_count(void) {
     int n = 0;
     FM_HIP(hipGetDeviceCount(&n));

@@ -557,8 +557,10 @@ static int flush_post(fm_ctx* ctx, DetState* d) {
     fm_trace_mark(ctx, sp, 20);
     hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, sp, d->cand[slot], d->sorted[slot],
                        d->counters[slot], cap);
+    fm_trace_mark(ctx, sp, 22);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, sp, d->sorted[slot],
                        d->counters[slot], cap, d->cfg.nms_thresh, d->mask[slot]);
+    fm_trace_mark(ctx, sp, 23);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), sp, d->sorted[slot],
                        d->counters[slot], cap, d->mask[slot], d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets[slot],
                        d->dets_host[slot], cap < DetState::PREFIX ? cap : DetState::PREFIX, d->counters_host[slot]);
@@ -872,6 +874,7 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     if (frame == ctx->frame_own2 && ctx->ev_next_upload) FM_HIP(hipStreamWaitEvent(s, ctx->ev_next_upload, 0));
     int rc = acquire_slot(d, s);
     if (rc) return rc;
+    fm_trace_mark(ctx, s, 14);
     if ((rc = enqueue_preprocess(ctx, d, net, frame))) return rc;
     FM_HIP(hipEventRecord(d->ev0[d->wr], s));
     fm_trace_mark(ctx, s, 11);

@@ -214,11 +214,13 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
                            ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes + (size_t)off * 4, b,
                            (f16*)net->bufs[e->input_tensor], e->in_w, e->in_h, t.c);
         FM_HIP(hipGetLastError());
+        fm_trace_mark(ctx, s, 34);
         net->emb_offset = off;
         int rc = fm_net_run_internal(ctx, FM_NET_EXTRACTOR, b);
         net->emb_offset = 0;
         if (rc) return rc;
     }
+    fm_trace_mark(ctx, s, 35);
     if ((rc_exp = export_embeddings(ctx, e, n, s))) return rc_exp;
     fm_trace_mark(ctx, s, 33);
     ctx->emb_n = n;

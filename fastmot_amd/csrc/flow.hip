@@ -94,12 +94,21 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i;
 }
 
-// ---- cvtColor BGR2GRAY, 8 bit (OpenCV 4.x RGB2Gray<uchar>: 15-bit fixed point)
-__global__ void gray_kernel(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, int n) {
+// ---- cvtColor BGR2GRAY, 8 bit: OpenCV's RGB2Gray<uchar>, (B cb + G cg + R cr + (1 << (bits - 1))) >> bits with the
+// 14-bit coefficients 1868 / 9617 / 4899 (up to the 4.2 era: the reference pins 4.1.1) or the 15-bit ones
+// 3735 / 19235 / 9798 (later 4.x) -- fm_flow_cfg.gray_coeff_bits
+struct GrayCoeffs { int cb, cg, cr, bits; };
+__host__ __device__ inline GrayCoeffs gray_coeffs(int bits) {
+    return bits == 15 ? GrayCoeffs{3735, 19235, 9798, 15} : GrayCoeffs{1868, 9617, 4899, 14};
+}
+__device__ __forceinline__ int to_gray(const uint8_t* p, GrayCoeffs c) {
+    return (p[0] * c.cb + p[1] * c.cg + p[2] * c.cr + (1 << (c.bits - 1))) >> c.bits;
+}
+
+__global__ void gray_kernel(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, int n, GrayCoeffs c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint8_t* p = bgr + (size_t)i * 3;
-    gray[i] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+    gray[i] = (uint8_t)to_gray(bgr + (size_t)i * 3, c);
 }
 
 struct LinCoef { int s0, s1; int a0, a1; };
@@ -204,7 +213,8 @@ __device__ __forceinline__ int scharr_px(const uint8_t* __restrict__ src, int w,
 // BGR frame -> gray (full resolution) + the half-resolution optical-flow image (cv2.resize's exact-2x path =
 // INTER_AREA 2x2 mean of the gray pixels): one thread per 2x2 block, the frame is read once.
 __global__ __launch_bounds__(256) void gray_half_kernel(const uint8_t* __restrict__ bgr, int W, int H,
-                                                        uint8_t* __restrict__ gray, uint8_t* __restrict__ half) {
+                                                        uint8_t* __restrict__ gray, uint8_t* __restrict__ half,
+                                                        GrayCoeffs c) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;      // half-resolution coordinates
     const int hw = W >> 1;
     if (x >= hw) return;
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void gray_half_kernel(const uint8_t* __restric
         const uint8_t* p = bgr + ((size_t)(2 * y + j) * W + 2 * x) * 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            g[j][i] = (p[3 * i] * 3735 + p[3 * i + 1] * 19235 + p[3 * i + 2] * 9798 + (1 << 14)) >> 15;
+            g[j][i] = to_gray(p + 3 * i, c);
         *reinterpret_cast<uint16_t*>(gray + (size_t)(2 * y + j) * W + 2 * x) = (uint16_t)(g[j][0] | (g[j][1] << 8));
     }
     half[(size_t)y * hw + x] = (uint8_t)((g[0][0] + g[0][1] + g[1][0] + g[1][1] + 2) >> 2);
@@ -1449,8 +1459,9 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set, hipStream_t s) {
     if (f->W == 2 * f->lw[0] && f->H == 2 * f->lh[0] && (f->W & 1) == 0) {
         // gray + half-resolution image in one pass over the frame; levels 0-2 as one launch each
         // (derivatives + next level); everything from level 3 on in one workgroup
+        fm_trace_mark(ctx, s, 42);
         hipLaunchKernelGGL(gray_half_kernel, dim3((f->lw[0] + 255) / 256, f->lh[0]), dim3(256), 0, s, ctx->frame_cur,
-                           f->W, f->H, f->gray[set], f->pyr[set][0]);
+                           f->W, f->H, f->gray[set], f->pyr[set][0], gray_coeffs(f->cfg.gray_coeff_bits));
         const int tail = f->levels > 3 ? 3 : f->levels;        // levels >= 3 (<= ~8 k pixels at 1080p): one workgroup
         for (int l = 0; l < tail; ++l) {
             const bool has_next = l + 1 < f->levels;
@@ -1472,9 +1483,11 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set, hipStream_t s) {
             hipLaunchKernelGGL(pyr_tail_kernel, dim3(1), dim3(1024), 0, s, t);
         }
         FM_HIP(hipGetLastError());
+        fm_trace_mark(ctx, s, 43);
         return 0;
     }
-    hipLaunchKernelGGL(gray_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->frame_cur, f->gray[set], n);
+    hipLaunchKernelGGL(gray_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->frame_cur, f->gray[set], n,
+                       gray_coeffs(f->cfg.gray_coeff_bits));
     hipLaunchKernelGGL(resize_linear_kernel, dim3((f->lw[0] + 255) / 256, f->lh[0]), dim3(256), 0, s,
                        f->gray[set], f->W, f->H, f->pyr[set][0], f->lw[0], f->lh[0]);
     for (int l = 1; l < f->levels; ++l)
@@ -1494,6 +1507,7 @@ extern "C" int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg) {
     FM_CHECK_ARG(ctx && cfg && ctx->frame_w > 0);
     FM_CHECK_ARG((cfg->win_size == 3 || cfg->win_size == 5) && cfg->max_level >= 0 && cfg->max_level < MAX_LEVELS);   // LK window instances
     FM_CHECK_ARG(cfg->block_size == 3 || cfg->block_size == 5);
+    FM_CHECK_ARG(cfg->gray_coeff_bits == 0 || cfg->gray_coeff_bits == 14 || cfg->gray_coeff_bits == 15);
     FM_HIP(hipDeviceSynchronize());
     if (ctx->flow) fm_flow_free(ctx->flow);
     FlowState* f = new FlowState();
@@ -1987,6 +2001,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         // needy flags / min distances are consumed by the eig / select kernels: device copies (behind the upload)
         uint8_t* d_needy = reinterpret_cast<uint8_t*>(db + o_dneedy);
         int32_t* d_md = reinterpret_cast<int32_t*>(db + o_dmd);
+        fm_trace_mark(ctx, s, 44);
         hipLaunchKernelGGL(prepare_kernel, dim3(nT), dim3(PREP_BLK), 0, s, f->v_rects, ov,
                            reinterpret_cast<const float*>(db + o_kps), reinterpret_cast<const int32_t*>(db + o_kpoff),
                            feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(dbo + q_area),
@@ -2000,12 +2015,14 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
                            reinterpret_cast<const double*>(db + o_box), reinterpret_cast<float*>(ho + q_pts), pts_cap,
                            reinterpret_cast<int32_t*>(dbo + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(dbo + q_off),
                            gftt_lds_bytes(max_area) / 4);
+        fm_trace_mark(ctx, s, 45);
     }
     // background keypoints under the final mask: four small dependent launches that share nothing with the per-track
     // branch above except the uploaded rects -- they run on the side stream (behind the new frame's pyramid, which is
     // shorter than the per-track branch) and join at the end of the call
     hipStream_t sb = ctx->s_flow2;
     const int bw = f->cfg.bg_w, bh = f->cfg.bg_h;
+    fm_trace_mark(ctx, sb, 46);
     // (the fork event is recorded behind the upload only: the branch must not wait for the per-track kernels)
     hipLaunchKernelGGL(resize_linear_kernel, dim3((bw + 255) / 256, bh), dim3(256), 0, sb, f->gray[f->prev], f->W,
                        f->H, f->bg_img, bw, bh);
@@ -2019,6 +2036,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, sb, d_flag, bw, bh,
                        reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, nullptr,
                        reinterpret_cast<int32_t*>(dbo + q_tot));
+    fm_trace_mark(ctx, sb, 47);
     FM_HIP(hipEventRecord(ctx->ev_bg, sb));
     hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(1), 0, s, tot, reinterpret_cast<int32_t*>(dbo + q_tot));
     FM_HIP(hipGetLastError());

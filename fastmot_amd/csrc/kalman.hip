@@ -357,11 +357,13 @@ extern "C" int fm_trk_step_ops(fm_ctx* ctx, int ops, int n, const int32_t* slots
     memcpy(fr.r, ctx->frame_rect, sizeof(double) * 4);
     char* d = zc ? h : ctx->io0.dev<char>();
     char* o = zc ? ctx->io1.host<char>() : ctx->io1.dev<char>();
+    fm_trace_mark(ctx, ctx->s_main, 50);
     hipLaunchKernelGGL(kf_step_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, ctx->s_main, n,
                        (const int32_t*)(d + o_slots), Hm, (const double*)(d + o_klt),
                        (const uint8_t*)(d + o_has), (const double*)(d + o_mult), ctx->mean, ctx->cov,
                        ctx->kf, fr, (double*)o, (uint8_t*)(o + o_lost), ops);
     FM_HIP(hipGetLastError());
+    fm_trace_mark(ctx, ctx->s_main, 51);
     if (!zc) FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     memcpy(tlbr_out, ctx->io1.host<char>(), sizeof(double) * 4 * n);
@@ -390,10 +392,12 @@ extern "C" int fm_trk_update_det(fm_ctx* ctx, int n, const int32_t* slots, const
     memcpy(fr.r, ctx->frame_rect, sizeof(double) * 4);
     char* d = zc ? h : ctx->io0.dev<char>();
     char* o = zc ? ctx->io1.host<char>() : ctx->io1.dev<char>();
+    fm_trace_mark(ctx, ctx->s_main, 52);
     hipLaunchKernelGGL(kf_update_det_kernel, dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0,
                        ctx->s_main, n, (const int32_t*)(d + o_slots), (const double*)(d + o_det),
                        ctx->mean, ctx->cov, ctx->kf, fr, (double*)o, (uint8_t*)(o + o_lost));
     FM_HIP(hipGetLastError());
+    fm_trace_mark(ctx, ctx->s_main, 53);
     if (!zc) FM_HIP(hipMemcpyAsync(ctx->io1.h, ctx->io1.d, out_bytes, hipMemcpyDeviceToHost, ctx->s_main));
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     memcpy(tlbr_out, ctx->io1.host<char>(), sizeof(double) * 4 * n);

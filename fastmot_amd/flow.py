@@ -24,12 +24,18 @@ class Flow:
                  inlier_thresh=4,
                  bg_feat_thresh=10,
                  obj_feat_params=None,
-                 opt_flow_params=None):
+                 opt_flow_params=None,
+                 gray_coeff_bits=14):
         """Parameters / range checks: fastmot/flow.py:17-79.  Deviation from the reference:
         flow.py:92-93 tests `opt_flow_params is None` with the condition inverted (user LK
         parameters are silently ignored and Flow(size) crashes); here given parameters are
         applied and None keeps the defaults -- identical results for cfg/mot.json, whose LK
-        parameters equal the defaults."""
+        parameters equal the defaults.
+
+        gray_coeff_bits (not in the reference: there it is whatever the installed OpenCV does): fixed-point width of
+        cv2.cvtColor(BGR2GRAY) -- 14 (B 1868, G 9617, R 4899: OpenCV's RGB2Gray<uchar> up to the 4.2 era, i.e. the
+        4.1.1 the reference's Dockerfile pins) or 15 (3735 / 19235 / 9798: later 4.x).  The two differ by one grey
+        level on a fraction of the pixels; DESIGN.md section 7 says what is known about which is right."""
         self.size = size
         assert 0 < bg_feat_scale_factor[0] <= 1 and 0 < bg_feat_scale_factor[1] <= 1
         self.bg_feat_scale_factor = bg_feat_scale_factor
@@ -49,6 +55,8 @@ class Flow:
         self.inlier_thresh = inlier_thresh
         assert bg_feat_thresh >= 0
         self.bg_feat_thresh = bg_feat_thresh
+        assert gray_coeff_bits in (14, 15)
+        self.gray_coeff_bits = gray_coeff_bits
 
         self.obj_feat_params = {"maxCorners": 1000, "qualityLevel": 0.06, "blockSize": 3}
         self.opt_flow_params = {"winSize": (5, 5), "maxLevel": 5, "criteria": (3, 10, 0.03)}
@@ -90,6 +98,7 @@ class Flow:
         cfg.max_corners = self.obj_feat_params['maxCorners']
         cfg.block_size = self.obj_feat_params['blockSize']
         cfg.quality_level = self.obj_feat_params['qualityLevel']
+        cfg.gray_coeff_bits = self.gray_coeff_bits
         ctx.flow_configure(cfg)
         self._configured = True
 

@@ -38,6 +38,10 @@ int fm_ctx_destroy(fm_ctx* ctx);
 const char* fm_last_error(void);
 /* number of visible HIP devices (<0 on error) */
 int fm_device_count(void);
+/* PCI address ("0000:c1:00.0") of HIP device `device`: the host side uses it to find the GPU's NUMA node
+ * (/sys/bus/pci/devices/<id>/numa_node) and binds the stream's process to it before any page-locked memory is
+ * allocated (fastmot_amd/runtime.py) -- the per-frame H2D copy of 6.2 MB reads that memory. */
+int fm_device_pci_bus_id(int device, char* buf, int buflen);
 /* blocks until every stream of the ctx is idle (TRTInference.synchronize, inference.py:119-121) */
 int fm_ctx_synchronize(fm_ctx* ctx);
 /* makes the context's device current for the calling host thread; every additional host thread that
@@ -381,6 +385,9 @@ typedef struct fm_flow_cfg {
     int32_t fast_thresh;          /* bg_feat_thresh */
     int32_t max_corners, block_size;
     double quality_level;         /* obj_feat_params */
+    int32_t gray_coeff_bits;      /* cv2.cvtColor(BGR2GRAY) fixed point: 14 = B 1868, G 9617, R 4899 (OpenCV <= 4.2-era
+                                   * RGB2Gray<uchar>, what the reference's pinned 4.1.1 computes as far as it can be
+                                   * established offline), 15 = 3735 / 19235 / 9798 (later 4.x); 0 = 14.  DESIGN.md 7 */
 } fm_flow_cfg;
 int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg);
 /* Flow.init (flow.py:121-133): BGR->gray + optical-flow resize (+pyramid) of the current device frame

@@ -23,9 +23,12 @@ static inline int reflect101(int i, int n) {
 }
 
 /* ---------------------------------------------------------------- images */
-void cb_bgr2gray(const uint8_t* bgr, int n, uint8_t* gray) {
+/* bits: 14 (1868 / 9617 / 4899, OpenCV up to the 4.2 era) or 15 (3735 / 19235 / 9798); cv_oracle.bgr2gray */
+void cb_bgr2gray(const uint8_t* bgr, int n, uint8_t* gray, int bits) {
+    const int cb = bits == 15 ? 3735 : 1868, cg = bits == 15 ? 19235 : 9617, cr = bits == 15 ? 9798 : 4899;
+    const int sh = bits == 15 ? 15 : 14;
     for (int i = 0; i < n; ++i)
-        gray[i] = (uint8_t)((bgr[3 * i] * 3735 + bgr[3 * i + 1] * 19235 + bgr[3 * i + 2] * 9798 + (1 << 14)) >> 15);
+        gray[i] = (uint8_t)((bgr[3 * i] * cb + bgr[3 * i + 1] * cg + bgr[3 * i + 2] * cr + (1 << (sh - 1))) >> sh);
 }
 
 static void lin_coef(int d, double scale, int ssize, int* s0, int* s1, int* a0, int* a1) {

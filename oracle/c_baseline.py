@@ -56,10 +56,11 @@ class _Level(C.Structure):
     _fields_ = [('I', C.c_void_p), ('J', C.c_void_p), ('D', C.c_void_p), ('w', C.c_int), ('h', C.c_int)]
 
 
-def bgr2gray(img):
+def bgr2gray(img, bits=None):
+    import cv_oracle
     img = np.ascontiguousarray(img, np.uint8)
     out = np.empty(img.shape[:2], np.uint8)
-    lib().cb_bgr2gray(_p(img), C.c_int(out.size), _p(out))
+    lib().cb_bgr2gray(_p(img), C.c_int(out.size), _p(out), C.c_int(cv_oracle.GRAY_COEFF_BITS if bits is None else bits))
     return out
 
 

@@ -101,8 +101,10 @@ class OracleFlow:
     """Flow.init / Flow.predict on real frames with cv_oracle (flow.py:121-264)."""
 
     def __init__(self, size, bg_scale=(0.1, 0.1), opt_scale=(0.5, 0.5), feat_density=0.005, feat_dist_factor=0.06,
-                 ransac_max_iter=500, ransac_conf=0.99, max_error=100, inlier_thresh=4, bg_feat_thresh=10, cv_impl=None):
+                 ransac_max_iter=500, ransac_conf=0.99, max_error=100, inlier_thresh=4, bg_feat_thresh=10, cv_impl=None,
+                 gray_coeff_bits=None):
         self.cv = cv_impl if cv_impl is not None else cv      # cv_oracle (numpy) or c_baseline (compiled C)
+        self.gray_bits = gray_coeff_bits                      # None = cv_oracle.GRAY_COEFF_BITS (14)
         self.size = size
         self.bg_scale, self.opt_scale = bg_scale, opt_scale
         self.feat_density, self.feat_dist_factor = feat_density, feat_dist_factor
@@ -114,11 +116,11 @@ class OracleFlow:
         self.bg_keypoints = self.prev_bg_keypoints = np.empty((0, 2), np.float32)
 
     def init(self, frame):
-        self.prev_gray = self.cv.bgr2gray(frame)
+        self.prev_gray = self.cv.bgr2gray(frame, self.gray_bits)
         self.prev_small = self.cv.resize_linear_u8(self.prev_gray, self.small_sz)
 
     def predict(self, frame, tracks):
-        gray = self.cv.bgr2gray(frame)
+        gray = self.cv.bgr2gray(frame, self.gray_bits)
         small = self.cv.resize_linear_u8(gray, self.small_sz)
         tracks.sort(reverse=True)
         empty = np.empty((0, 2), np.float32)

@@ -55,13 +55,23 @@ def resize_nearest(img, dsize):
     return img[ys][:, xs]
 
 
-def bgr2gray(img):
-    """cv2.cvtColor(COLOR_BGR2GRAY) for uint8 (imgproc/color_rgb: RGB2Gray<uchar>, 15-bit fixed
-    point in 4.x: B*3735 + G*19235 + R*9798, descale (x + (1 << 14)) >> 15)."""
+# cv2.cvtColor(BGR2GRAY) fixed-point width.  OpenCV's RGB2Gray<uchar> (imgproc/color_rgb) used the 14-bit constants of
+# color.hpp (B2Y 1868, G2Y 9617, R2Y 4899, yuv_shift 14 -- with the comment "can be changed to 15-shift coeffs") up to the
+# 4.2 era and switched to 15 bits (3735 / 19235 / 9798) later in 4.x.  The reference pins OpenCV 4.1.1 (Dockerfile:5;
+# README says >= 3.3): 14 is the default here, in the kernels (fm_flow_cfg.gray_coeff_bits) and in c_baseline.c.
+# Neither source tree is on this disk: PARITY UNPINNED, both widths are implemented and tested.
+GRAY_COEFF_BITS = 14
+GRAY_COEFFS = {14: (1868, 9617, 4899), 15: (3735, 19235, 9798)}
+
+
+def bgr2gray(img, bits=None):
+    """cv2.cvtColor(COLOR_BGR2GRAY) for uint8: (B cb + G cg + R cr + (1 << (bits - 1))) >> bits."""
+    bits = GRAY_COEFF_BITS if bits is None else bits
+    cb, cg, cr = GRAY_COEFFS[bits]
     b = img[..., 0].astype(np.int64)
     g = img[..., 1].astype(np.int64)
     r = img[..., 2].astype(np.int64)
-    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+    return ((b * cb + g * cg + r * cr + (1 << (bits - 1))) >> bits).astype(np.uint8)
 
 
 def reid_preprocess(frame, tlbrs, in_wh=(128, 256)):

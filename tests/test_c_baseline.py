@@ -16,6 +16,26 @@ def clip():
     return SyntheticVideo((640, 360), n_ids=8, n_frames=6, seed=3)
 
 
+def test_gray_conversion_both_opencv_generations(clip):
+    """cv2.cvtColor(BGR2GRAY) exists in two fixed-point widths across OpenCV 4.x (cv_oracle.GRAY_COEFF_BITS): both are
+    implemented everywhere (kernels: fm_flow_cfg.gray_coeff_bits), the default is the 14-bit set of the 4.1.1 the
+    reference pins.  Known answers by hand, numpy port == compiled port, and how far apart the two are."""
+    assert cv.GRAY_COEFF_BITS == 14
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [17, 130, 201], [200, 100, 50]]], np.uint8)
+    # (B cb + G cg + R cr + half) >> bits, by hand
+    want14 = [(b * 1868 + g * 9617 + r * 4899 + 8192) >> 14 for b, g, r in px[0].tolist()]
+    want15 = [(b * 3735 + g * 19235 + r * 9798 + 16384) >> 15 for b, g, r in px[0].tolist()]
+    assert want14 == [255, 0, 29, 150, 76, 138, 96] and want15[:5] == [255, 0, 29, 150, 76]
+    np.testing.assert_array_equal(cv.bgr2gray(px, 14)[0], want14)
+    np.testing.assert_array_equal(cv.bgr2gray(px, 15)[0], want15)
+    np.testing.assert_array_equal(cv.bgr2gray(px)[0], want14)                       # the default
+    f = clip.frames[0]
+    for bits in (14, 15):
+        np.testing.assert_array_equal(cb.bgr2gray(f, bits), cv.bgr2gray(f, bits))
+    d = cv.bgr2gray(f, 14).astype(int) - cv.bgr2gray(f, 15).astype(int)
+    assert np.abs(d).max() == 1 and 0.001 < (d != 0).mean() < 0.2                   # one grey level on a fraction of the pixels
+
+
 def test_images_exact(clip):
     f = clip.frames[0]
     g = cv.bgr2gray(f)

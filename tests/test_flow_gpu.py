@@ -46,6 +46,24 @@ def make_flow(size):
     return Flow(size, **vars(kw))
 
 
+@pytest.mark.parametrize('bits', [14, 15])
+def test_gray_both_opencv_generations(ctx, bits):
+    """Flow(gray_coeff_bits=...): the gray image and everything derived from it follow the chosen OpenCV generation
+    (14-bit coefficients = the default = the reference's pinned 4.1.1, 15-bit = later 4.x), both paths of the
+    conversion (the fused gray + half-resolution kernel at an exact 2x scale, the plain kernel otherwise)."""
+    for size, scale in (((640, 360), (0.5, 0.5)), ((600, 338), (0.4, 0.4))):
+        f0 = textured_frame(*size, 5)
+        kw = dict(vars(scenes.tracker_kwargs()['flow_cfg']))
+        kw.update(opt_flow_scale_factor=scale, gray_coeff_bits=bits)
+        flow = Flow(size, **kw)
+        flow.init(f0)
+        g0 = cv.bgr2gray(f0, bits)
+        np.testing.assert_array_equal(ctx.flow_read_image(0), g0)
+        small = cv.resize_linear_u8(g0, (round(scale[0] * size[0]), round(scale[1] * size[1])))
+        np.testing.assert_array_equal(ctx.flow_read_image(2), small)
+    assert (cv.bgr2gray(f0, 14) != cv.bgr2gray(f0, 15)).any()
+
+
 def test_images_pyramid_lk(ctx):
     size = (640, 360)
     f0, f1 = textured_frame(*size, 1), textured_frame(*size, 1, shift=(4, 2))
