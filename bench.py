@@ -201,7 +201,9 @@ HBM_PEAK_GBS, PCIE_PEAK_GBS, FP64_PEAK_TFLOPS = 8000.0, 63.0, 78.6      # MI355X
 
 # stage boundaries the library stamps with HIP events on the stage's own stream (fm_trace_mark, csrc/*.hip)
 STAGE_TAGS = (('detector preprocess (resize + BGR->RGB + fp16 NHWC)', 14, 11), ('detector network (conv engine)', 11, 12),
-              ('head decode + threshold + compaction', 12, 13), ('candidate sort', 20, 22), ('DIoU-NMS bit matrix', 22, 23),
+              ('head decode + threshold + compaction', 12, 13),
+              ('candidate sort + greedy DIoU-NMS + box filters + write-back (whole post-processing)', 20, 21),
+              ('candidate sort', 20, 22), ('DIoU-NMS bit matrix', 22, 23),
               ('NMS scan + box filters + write-back', 23, 21), ('next frame H2D copy', 30, 31),
               ('ReID crop + resize + normalise', 32, 34), ('ReID network (OSNet) + head', 34, 35),
               ('embedding export to pinned memory', 35, 33), ('KLT gray + pyramid + Scharr', 42, 43),
@@ -237,7 +239,7 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
         14: ('hbm', W * H * 3 + in_w * in_h * 8 * 2, 'frame u8 in + fp16 NHWC(8) out'),
         11: ('mfma', det_flops, 'conv FLOPs (2 MAC)'),
         12: ('hbm', head_bytes, 'fp32 head tensors in'),
-        20: ('latency', None, f'K = {K} candidates, K^2 key comparisons from LDS'),
+        20: ('latency', None, f'K = {K} candidates over conf_thresh: K^2 key comparisons from LDS, then one round per NMS survivor'),
         22: ('latency', None, f'K^2/2 = {K * K // 2} pair tests (fp32 IoU pre-test, exact fp64 DIoU near the threshold)'),
         23: ('latency', None, f'greedy scan over {-(-K // 64)} chunks of 64, one workgroup'),
         30: ('pcie', W * H * 3, 'frame u8'),

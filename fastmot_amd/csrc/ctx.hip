@@ -23,6 +23,9 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "zero_copy_tracks")) ctx->opt_zero_copy_tracks = value;
     else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
     else if (!strcmp(key, "use_graphs")) ctx->opt_use_graphs = value;
+    else if (!strcmp(key, "nms_path")) {
+        ctx->opt_nms_general = value != 0;
+    }
     else if (!strcmp(key, "lk_variant")) {
 #ifndef FM_DIAG
         if (value != 0) {

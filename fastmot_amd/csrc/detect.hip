@@ -39,6 +39,12 @@ struct DetState {
     bool used[NSLOT] = {false, false};
     hipEvent_t ev_dec[NSLOT] = {nullptr, nullptr};  // candidates of the pass complete (stream that produced them)
     int post_pending = -1;                          // slot whose sort + NMS has not been enqueued yet (flush_post)
+    bool general_post = false;                      // the three-kernel sort / bit matrix / scan path (more than 4096 candidates,
+                                                    // fm_ctx option "nms_path" = 1); default: nms_greedy_kernel
+    static constexpr int GREEDY_RETRY = 1024;       // passes on the general path before the greedy kernel gets another try
+    int general_passes = 0;
+    int greedy_kmax = 2048, greedy_shrink = 0;      // LDS capacity (candidates) of the next greedy launches; passes since it was too large
+    bool sorted_valid[NSLOT] = {false, false};      // d->sorted[slot] holds the pass's sorted rows (general path / test hook)
     static constexpr int PREFIX = 2048;        // detections copied back with the pass (more: synchronous fallback)
     fm_det48* dets_host[NSLOT] = {nullptr, nullptr};
     int32_t* counters_host[NSLOT] = {nullptr, nullptr};
@@ -259,6 +265,37 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(o + 4) = r1;
 }
 
+// The same rank sort with ALL K keys staged in LDS at once (dynamic LDS: 8 bytes per candidate of capacity; used
+// whenever that fits, i.e. up to 16384 candidates): the chunked version above pays one dependent global round trip and
+// two barriers per 256 keys -- six in a row for the ~1500 candidates of the benchmark, on a GPU whose memory system is
+// busy with the detector and ReID networks -- this one pays a single round trip with every load of the workgroup in
+// flight, then compares out of LDS two keys per ds_read_b128 (broadcast: every lane reads the same address).
+__global__ __launch_bounds__(256) void rank_sort_lds_kernel(const float* __restrict__ cand, float* __restrict__ sorted,
+                                                            const int32_t* __restrict__ counters, int cap) {
+    __builtin_amdgcn_s_setprio(3);         // (latency-critical side work beside the networks' bulk wavefronts)
+    extern __shared__ uint64_t all_keys[];
+    const int K = min(counters[0], cap);
+    if ((int)blockIdx.x * 256 >= K) return;
+    const int Kp = (K + 1) & ~1;                                  // (an odd K: one padding key that ranks last)
+    for (int j = threadIdx.x; j < Kp; j += 256) all_keys[j] = j < K ? sort_key(cand + (size_t)j * 8) : ~0ull;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K) return;
+    const uint64_t ki = all_keys[i];
+    int rank = 0;
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(all_keys);
+#pragma unroll 8
+    for (int t = 0; t < Kp / 2; ++t) {
+        const ulonglong2 k = k2[t];
+        rank += (k.x < ki ? 1 : 0) + (k.y < ki ? 1 : 0);
+    }
+    const float* ri = cand + (size_t)i * 8;
+    float* o = sorted + (size_t)rank * 8;
+    const float4 r0 = *reinterpret_cast<const float4*>(ri), r1 = *reinterpret_cast<const float4*>(ri + 4);
+    *reinterpret_cast<float4*>(o) = r0;
+    *reinterpret_cast<float4*>(o + 4) = r1;
+}
+
 // ------------------------------------------------------------------------------------ NMS
 // suppression test of utils/rect.py:216-241 for pair (i keeps, j candidate), same class.
 __device__ __forceinline__ bool diou_suppresses(const float* a, const float* b, double thresh) {
@@ -292,6 +329,7 @@ __device__ __forceinline__ bool diou_suppresses(const float* a, const float* b, 
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ sorted,
                                                        const int32_t* __restrict__ counters, int cap,
                                                        double thresh, uint64_t* __restrict__ mask) {
+    __builtin_amdgcn_s_setprio(3);
     const int K = min(counters[0], cap);
     const int rb = blockIdx.x;
     const int kw = (K + 63) / 64;
@@ -336,7 +374,24 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
         const float ih = fminf(a_y1, cb[1] + cb[3]) - fmaxf(a[1], cb[1]);
         if (iw <= 0.f || ih <= 0.f) continue;
         const float inter = iw * ih;
-        if (inter <= cut * (a_area + cb[2] * cb[3] - inter)) continue;
+        const float uni = a_area + cb[2] * cb[3] - inter;
+        if (inter <= cut * uni) continue;
+        // second stage, still float32: the whole DIoU = IoU - (d / c)^0.6 with the hardware log2 / exp2 (centre
+        // distance d and enclosing diagonal c as in rect.py:231-240; the -1 / +1 of the pixel convention cancel in
+        // both).  Its error is a few 1e-6 absolute; a pair is decided here when the estimate is 1e-4 or more away
+        // from the threshold, and only the rest -- a handful per frame -- pays for the reference's float64 arithmetic
+        // and its pow().  In the dense regime of the benchmark (1500 candidates -> a handful) nearly every pair that
+        // passes the IoU pre-test used to take that path: ~10^6 float64 pow() per frame.
+        {
+            const float b_x1 = cb[0] + cb[2], b_y1 = cb[1] + cb[3];
+            const float ew = fmaxf(a_x1, b_x1) - fminf(a[0], cb[0]), eh = fmaxf(a_y1, b_y1) - fminf(a[1], cb[1]);
+            const float dx = 0.5f * ((a[0] + a_x1) - (cb[0] + b_x1)), dy = 0.5f * ((a[1] + a_y1) - (cb[1] + b_y1));
+            const float q = (dx * dx + dy * dy) / (ew * ew + eh * eh);
+            const float est = inter / uni - (q > 0.f ? __builtin_amdgcn_exp2f(0.6f * __builtin_amdgcn_logf(q)) : 0.f);
+            if (est > (float)thresh + 1e-4f) { bits |= (1ull << b); continue; }
+            if (est < (float)thresh - 1e-4f) continue;
+            // (a NaN estimate -- degenerate boxes -- fails both comparisons and takes the exact path)
+        }
         if (diou_suppresses(a, cb, thresh)) bits |= (1ull << b);
     }
     mask[(size_t)w * cap + i] = bits;                   // word-major: the scan reads a word of many rows at once
@@ -344,100 +399,102 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
 
 // greedy scan in sorted order + final box filter (detector.py:356-364), one workgroup.  Chunk by chunk of 64
 // candidates: the bits "removed by an earlier survivor" of chunk c are the OR of mask word c over all SURVIVING rows
-// before the chunk -- a gather over the word-major mask that all 256 lanes issue one chunk AHEAD (for the rows whose
-// fate is known) so that its latency hides behind the serial part: wavefront 0 resolves the chunk's own 64 x 64 block
-// in registers (lane b holds row b's word, 64 uniform steps).  Per chunk: two barriers, one wave reduction, 64 scalar
-// steps -- no dependent memory round trip (K = 1500: 5.1 ms -> ~20 us).  The survivors are then filtered and written
-// in order (prefix counts over the keep bits).
+// before the chunk -- a gather over the word-major mask.  Wavefronts 1..15 do all the memory work: the loads for chunk
+// c are issued (unconditionally, row indices clamped) during iteration c-2 and only looked at when iteration c begins,
+// when the survivors of every earlier chunk are known: two iterations of slack for the memory round trip, no register
+// rotation (two register sets used alternately, the loop is unrolled by two).  They publish removed(c) and the chunk's
+// own 64 x 64 diagonal block through LDS; wavefront 0 touches LDS only: it resolves the block in scalar registers
+// (lane b holds row b's word, one step per survivor).  Per chunk: two barriers, no memory round trip on the critical path.
+// History: 5.1 ms -> 68 us in round 3 (inside the pipeline; every chunk still waited for the loads it had just issued,
+// in both roles: profiles/r03_bench_kernel_stats.txt) -> round 4 this structure.
+// The survivors are then filtered and written in order (prefix counts over the keep bits).
 __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict__ sorted,
                                                        int32_t* __restrict__ counters, int cap,
                                                        const uint64_t* __restrict__ mask, double max_area,
                                                        double min_ar, fm_det48* __restrict__ dets,
                                                        fm_det48* __restrict__ dets_host, int prefix,
                                                        int32_t* __restrict__ counters_host) {
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ uint64_t keep[];       // [cap/64] survivors
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = min(counters[0], cap);
     const int kw = (K + 63) / 64;
-    // OR of mask word w over the surviving rows i < lim (keep bits of those rows are final): the share of one of the
-    // 960 lanes of wavefronts 1..15 (wavefront 0 keeps its memory queue short, see below): the gather is bound by the
-    // bytes ONE workgroup can keep in flight, hence the wide workgroup
-    auto gather = [&](int w, int lim) {
+    constexpr int GU = 9;                    // 960 lanes x 9 rows = 8640 >= any capacity alloc_post admits
+    struct Set { uint64_t g[GU]; uint64_t dg; };
+    // loads for chunk x: word x of the rows before the chunk (the lane's share, clamped into them) + for wavefront 1
+    // the chunk's own diagonal block
+    auto issue = [&](int x, Set& t) {
+        const uint64_t* col = mask + (size_t)x * cap;
+        const int g = tid - 64, last = max(x * 64 - 1, 0);
+#pragma unroll
+        for (int u = 0; u < GU; ++u) t.g[u] = col[min(u * 960 + g, last)];
+        t.dg = col[min(x * 64 + lane, K - 1)];             // (rows beyond K are never looked at)
+    };
+    auto reduce = [&](int x, const Set& t) {
         uint64_t acc = 0;
-        const uint64_t* col = mask + (size_t)w * cap;
-        const int g = tid - 64;
-        for (int i0 = 0; i0 < lim; i0 += 960 * 8) {
-            uint64_t t[8];
+        const int g = tid - 64, lim = x * 64;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * 960 + g;
-                t[u] = (i < lim && ((keep[i >> 6] >> (i & 63)) & 1ull)) ? col[i] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc |= t[u];
+        for (int u = 0; u < GU; ++u) {
+            const int i = u * 960 + g;
+            // (branch-free: a select on a value still in flight is compiled into an exec-masked branch, behind which
+            // hipcc's wait counts fall back to "everything outstanding" -- including the other set's newer loads)
+            const uint64_t on = 0ull - (uint64_t)((i < lim ? 1u : 0u) & (uint32_t)((keep[min(i, lim - 1 < 0 ? 0 : lim - 1) >> 6] >> (i & 63)) & 1ull));
+            acc |= t.g[u] & on;
         }
         return acc;
     };
     // barrier that waits for this wave's LDS traffic only: __syncthreads() would also drain the global loads in flight
     // (its fence waits for vmcnt(0)) and expose their latency in every chunk
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    // Roles: wavefronts 1..15 gather (many loads, consumed one chunk later), wavefront 0 resolves (two loads per chunk:
-    // the compiler can count them and wait for exactly the older ones; mixed with the gather it waited for everything).
-    // Two chunks of lead.  removed(c) = OR of mask word c over the surviving rows before chunk c =
-    //     P[c]  (rows before chunk c-2, gathered by wavefronts 1..15 during iteration c-2, consumed two barriers later)
-    //   | tailA[c] masked by the survivors of chunk c-2 | tailB[c] masked by the survivors of chunk c-1 (wavefront 0,
-    //     one word per lane each, loaded during iteration c-2 like the chunk's own diagonal block diag[c]).
     __shared__ unsigned long long rem_word[2];             // removed bits of the chunk being resolved (double buffered)
+    __shared__ uint64_t diag[2][64];                       // its diagonal block: row b's word (double buffered)
     if (tid < 2) rem_word[tid] = 0;
-    auto word_at = [&](int w, int i) -> uint64_t { return (w < kw && i < K) ? mask[(size_t)w * cap + i] : 0ull; };
-    uint64_t p_cur = 0, p_nxt = 0;                         // P[c], P[c+1]   (wavefronts 1..15)
-    uint64_t ta_cur = 0, tb_cur = 0, dg_cur = 0;           // tailA / tailB / diag of chunk c     (wavefront 0)
-    uint64_t ta_nxt = 0, tb_nxt = 0, dg_nxt = 0;           // ... of chunk c + 1
-    uint64_t kept_1 = 0, kept_2 = 0;                       // survivors of chunks c-1, c-2
-    if (wave == 0) {
-        dg_cur = word_at(0, lane);
-        tb_nxt = word_at(1, lane);                         // chunk 1: rows of chunk 0
-        dg_nxt = word_at(1, 64 + lane);
-    }
     __syncthreads();
-    for (int c = 0; c < kw; ++c) {
-        uint64_t p_new = 0, ta_new = 0, tb_new = 0, dg_new = 0;
-        if (wave > 0) {
-            if (p_cur) atomicOr(&rem_word[c & 1], (unsigned long long)p_cur);
-            if (c + 2 < kw) p_new = gather(c + 2, c * 64);
-        } else {
-            if (c + 2 < kw) {
-                ta_new = word_at(c + 2, c * 64 + lane);
-                tb_new = word_at(c + 2, (c + 1) * 64 + lane);
-                dg_new = word_at(c + 2, (c + 2) * 64 + lane);
-            }
-            const uint64_t t = (((kept_2 >> lane) & 1ull) ? ta_cur : 0ull) | (((kept_1 >> lane) & 1ull) ? tb_cur : 0ull);
-            if (t) atomicOr(&rem_word[c & 1], (unsigned long long)t);
+    if (wave > 0) {
+        Set A, B;                                          // chunk c's loads live in A for even c, in B for odd c
+        if (kw > 0) issue(0, A);
+        if (kw > 1) issue(1, B);
+        auto step = [&](int c, Set& mine) {
+            const uint64_t r = reduce(c, mine);            // (waits for the loads issued two iterations ago)
+            if (r) atomicOr(&rem_word[c & 1], (unsigned long long)r);
+            if (wave == 1) diag[c & 1][lane] = mine.dg;
+            if (c + 2 < kw) issue(c + 2, mine);
+            lds_barrier();
+            lds_barrier();
+        };
+        for (int c = 0; c < kw; c += 2) {
+            step(c, A);
+            if (c + 1 < kw) step(c + 1, B);
         }
-        lds_barrier();
-        if (wave == 0) {
+    } else {
+        for (int c = 0; c < kw; ++c) {
+            lds_barrier();
             const uint64_t rem_v = rem_word[c & 1];
+            const uint64_t dg = diag[c & 1][lane];
             // (scalar registers from here on: wave-uniform bookkeeping)
             uint64_t rem = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem_v) |
                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rem_v >> 32)) << 32);
             if (c == kw - 1 && (K & 63)) rem |= ~0ull << (K & 63);         // rows beyond K do not exist
-            // the lowest candidate not removed yet survives and removes its row's bits; repeat until none is left
+            // the lowest candidate not removed yet survives and removes its row's bits; repeat until none is left.  Only
+            // survivors whose row removes something INSIDE the chunk need a step of the serial loop (two v_readlane and a
+            // dependent scalar chain, ~100 cycles): the survivors between two of them are decided in one mask operation --
+            // where most candidates survive (the benchmark's scripted heads: ~1000 of 1555) that is 40 -> ~10 steps a chunk
+            const uint64_t acts = __ballot(dg != 0);                           // rows that remove anything in this chunk
             uint64_t kept = 0;
             uint64_t avail = ~rem;
-            while (avail) {
-                const int b = __builtin_ctzll(avail);
-                const uint64_t row = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dg_cur, b) |
-                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dg_cur >> 32), b) << 32);
-                kept |= 1ull << b;
+            for (;;) {
+                const uint64_t cand = avail & acts;
+                if (!cand) break;
+                const int b = __builtin_ctzll(cand);
+                const uint64_t row = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dg, b) |
+                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dg >> 32), b) << 32);
+                kept |= avail & ((2ull << b) - 1ull);                          // b and the row-less survivors below it
                 avail &= ~row & (~1ull << b);                                  // rows only carry bits above b
             }
+            kept |= avail;
             if (lane == 0) { keep[c] = kept; rem_word[c & 1] = 0; }
-            kept_2 = kept_1; kept_1 = kept;
+            lds_barrier();
         }
-        p_cur = p_nxt; p_nxt = p_new;
-        ta_cur = ta_nxt; tb_cur = tb_nxt; dg_cur = dg_nxt;
-        ta_nxt = ta_new; tb_nxt = tb_new; dg_nxt = dg_new;
-        lds_barrier();
     }
     // final filter of the survivors, in order
     __shared__ int base;
@@ -479,6 +536,199 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
     if (tid == 0) {
         counters[2] = base;
         counters_host[0] = counters[0]; counters_host[1] = counters[1]; counters_host[2] = base; counters_host[3] = counters[3];
+    }
+}
+
+// (out of line for the greedy kernel below: the float64 pow() inside costs ~100 registers, inlined it set the register
+// count of the whole kernel although a handful of pairs per frame reach it)
+__device__ __attribute__((noinline)) bool diou_suppresses_call(float a0, float a1, float a2, float a3, float b0, float b1,
+                                                               float b2, float b3, double thresh) {
+    const float a[4] = {a0, a1, a2, a3}, b[4] = {b0, b1, b2, b3};
+    return diou_suppresses(a, b, thresh);
+}
+
+// ------------------------------------------------------------------------------------ greedy NMS, survivor by survivor
+// Round 4.  The bit matrix + chunked scan above cost 10 + 20 us on an idle GPU and 42 + 88 us inside the pipelined step:
+// every dependent trip to memory takes microseconds there (the detector and ReID networks keep the memory system
+// saturated), the scan makes one per 64 candidates, and the bit matrix does K^2 / 2 pair tests whatever the outcome.
+// This kernel is the reference's greedy loop itself (rect.py:199-244) on the SORTED candidate list, one round per
+// SURVIVOR, for up to 4096 candidates in one workgroup of modest footprint (8 wavefronts, <= 128 registers, a few KB .. 64 KB of LDS: it finds room on a
+// busy GPU; a 1024-thread / 113 KB first version with the sort inside waited a millisecond for an empty CU):
+//   * thread t keeps the sorted candidates t, t + 256, ... in registers (box, class) and their alive bits;
+//   * a round: the survivor's box is broadcast from LDS, every thread tests its own alive candidates of that class
+//     behind it (float32 estimates first, the reference's float64 DIoU for the close calls -- diou_suppresses), the
+//     alive bits go to a 64-word bitmap by ballot, wavefront 0 finds the next alive candidate: two barriers;
+//   * the survivors are filtered (to_tlbr, area, aspect ratio) and written in order at the end.
+// Memory is touched three times: sorted rows in, the survivors' confidences in, detections out.  Cost ~ (survivors) x
+// ~0.2 us instead of K^2 / 2 pair tests + K / 64 memory round trips: what a real detector produces (tens of objects, a few
+// hundred candidates) and the benchmark's dense regime (1500 -> a handful) finish in a few us; all-disjoint boxes degrade
+// linearly.  More candidates than the launch provided LDS for (kmax, chosen from the previous pass): the kernel reports
+// "not handled" (counters[3]) and collect() runs the bit matrix + scan for that pass.
+constexpr int NG_T = 512, NG_CPT = 8, NG_NW = NG_T / 64, NG_KMAX = NG_T * NG_CPT;
+static inline size_t ng_lds_bytes(int kmax) { return (size_t)kmax * 20 + 64 * 8 + 64; }
+constexpr int NG_MAX_ROUNDS = 96;      // survivors the greedy kernel resolves before it hands the pass to the bit matrix + scan
+
+__global__ __launch_bounds__(NG_T, 4) void nms_greedy_kernel(const float* __restrict__ sorted, int32_t* __restrict__ counters,
+                                                          int cap, int kmax, double thresh, double max_area, double min_ar,
+                                                          fm_det48* __restrict__ dets, fm_det48* __restrict__ dets_host,
+                                                          int prefix, int32_t* __restrict__ counters_host) {
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) char ng_sm[];
+    float4* sbox = reinterpret_cast<float4*>(ng_sm);                              // [kmax] boxes in sorted order
+    float* scls = reinterpret_cast<float*>(ng_sm + (size_t)kmax * 16);            // [kmax] their classes
+    uint64_t* alive_w = reinterpret_cast<uint64_t*>(ng_sm + (size_t)kmax * 20);   // [64] bitmap of the sorted list
+    int32_t* misc = reinterpret_cast<int32_t*>(ng_sm + (size_t)kmax * 20 + 512);  // [0] current survivor, [1] base, [2 .. 2 + NG_NW) wave counts
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = min(counters[0], cap);
+    if (K > kmax) {                                      // (uniform) not handled here: the host runs the general path
+        if (tid == 0) {
+            counters[3] = 1;
+            counters_host[0] = counters[0]; counters_host[1] = counters[1]; counters_host[2] = 0; counters_host[3] = 1;
+        }
+        return;
+    }
+    // ---- the thread's share of the sorted list: candidates tid + NG_T u; wavefront w owns bitmap words w + NG_NW u
+    float4 box[NG_CPT];
+    float cls[NG_CPT];
+    unsigned alive = 0, kept = 0;                        // bit u: candidate tid + NG_T u is alive / is a survivor
+#pragma unroll
+    for (int u = 0; u < NG_CPT; ++u) {
+        const int j = tid + NG_T * u;
+        const float* r = sorted + (size_t)min(j, max(K - 1, 0)) * 8;
+        box[u] = *reinterpret_cast<const float4*>(r);
+        cls[u] = r[5];
+    }
+#pragma unroll
+    for (int u = 0; u < NG_CPT; ++u) {
+        const int j = tid + NG_T * u;
+        alive |= (j < K ? 1u : 0u) << u;
+        if (j < K) { sbox[j] = box[u]; scls[j] = cls[u]; }
+        const uint64_t bal = __ballot(j < K);
+        if (lane == 0) alive_w[wave + NG_NW * u] = bal;
+    }
+    if (tid == 0) misc[0] = K > 0 ? 0 : -1;
+    const float cut = (float)thresh - 1e-3f;
+    __syncthreads();
+    // ---- one round per survivor (at most NG_MAX_ROUNDS: a frame whose candidates mostly SURVIVE -- hundreds of rounds --
+    // is cheaper through the bit matrix + scan; the pass is then flagged like one with too many candidates)
+    for (int round = 0;; ++round) {
+        const int s = __builtin_amdgcn_readfirstlane(misc[0]);
+        if (s < 0) break;
+        if (round >= NG_MAX_ROUNDS) {                    // (uniform)
+            if (tid == 0) {
+                counters[3] = 2;
+                counters_host[0] = counters[0]; counters_host[1] = counters[1]; counters_host[2] = 0; counters_host[3] = 2;
+            }
+            return;
+        }
+        const float4 a4 = sbox[s];
+        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+        const float a_x1 = a[0] + a[2], a_y1 = a[1] + a[3], a_area = a[2] * a[3];
+        const float a_cls = scls[s];
+        // float32 stages for the thread's candidates (unrolled), the close calls are collected in `need` and get the
+        // reference's float64 arithmetic one at a time below: ONE copy of that code (pow() included)
+        unsigned need = 0;
+#pragma unroll
+        for (int u = 0; u < NG_CPT; ++u) {
+            const int j = tid + NG_T * u;
+            if (j == s) kept |= 1u << u;
+            if (((alive >> u) & 1u) && j > s && cls[u] == a_cls) {
+                const float4 c = box[u];
+                const float b_x1 = c.x + c.z, b_y1 = c.y + c.w;
+                const float iw = fminf(a_x1, b_x1) - fmaxf(a[0], c.x);
+                const float ih = fminf(a_y1, b_y1) - fmaxf(a[1], c.y);
+                if (iw > 0.f && ih > 0.f) {
+                    const float inter = iw * ih;
+                    const float uni = a_area + c.z * c.w - inter;
+                    if (!(inter <= cut * uni)) {
+                        const float ew = fmaxf(a_x1, b_x1) - fminf(a[0], c.x), eh = fmaxf(a_y1, b_y1) - fminf(a[1], c.y);
+                        const float dx = 0.5f * ((a[0] + a_x1) - (c.x + b_x1)), dy = 0.5f * ((a[1] + a_y1) - (c.y + b_y1));
+                        const float q = (dx * dx + dy * dy) / (ew * ew + eh * eh);
+                        const float est = inter / uni - (q > 0.f ? __builtin_amdgcn_exp2f(0.6f * __builtin_amdgcn_logf(q)) : 0.f);
+                        if (est > (float)thresh + 1e-4f) alive &= ~(1u << u);
+                        else if (!(est < (float)thresh - 1e-4f)) need |= 1u << u;      // (NaN lands here too)
+                    }
+                }
+            }
+        }
+        while (need) {
+            const int u = __builtin_ctz(need);
+            need &= need - 1;
+            const float4 c = sbox[tid + NG_T * u];       // (from LDS: indexing the register copies by a run-time u
+                                                         //  would move them to scratch memory)
+            if (diou_suppresses_call(a[0], a[1], a[2], a[3], c.x, c.y, c.z, c.w, thresh)) alive &= ~(1u << u);
+        }
+#pragma unroll
+        for (int u = 0; u < NG_CPT; ++u) {
+            const uint64_t bal = __ballot((alive >> u) & 1u);
+            if (lane == 0) alive_w[wave + NG_NW * u] = bal;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // next alive candidate behind s: lane l looks at bitmap word l
+            uint64_t w = alive_w[lane];
+            const int ws = s >> 6;
+            if (lane < ws) w = 0;
+            else if (lane == ws) w &= (s & 63) == 63 ? 0ull : (~0ull << ((s & 63) + 1));
+            const uint64_t nz = __ballot(w != 0);
+            int next = -1;
+            if (nz) {
+                const int fl = __builtin_ctzll(nz);
+                const uint64_t ww = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, fl) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), fl) << 32);
+                next = fl * 64 + __builtin_ctzll(ww);
+            }
+            if (lane == 0) misc[0] = next;
+        }
+        __syncthreads();
+    }
+    // ---- final filter of the survivors, in sorted order (to_tlbr, area, aspect ratio: detector.py:356-364)
+    if (tid == 0) misc[1] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NG_CPT; ++u) {
+        if ((int)NG_T * u >= K) break;                   // (uniform)
+        const int j = tid + NG_T * u;
+        bool ok = false;
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if ((kept >> u) & 1u) {
+            const float4 b = box[u];
+            const double xmin = b.x, ymin = b.y;
+            t0 = rint(xmin); t1 = rint(ymin);
+            t2 = rint(xmin + (double)b.z - 1.); t3 = rint(ymin + (double)b.w - 1.);
+            const double bw = t2 - t0 + 1, bh = t3 - t1 + 1;
+            const double area = (bw <= 0 || bh <= 0) ? 0. : bw * bh;
+            const double ar = bw > 0 ? bh / bw : 0.;
+            ok = area > 0 && area <= max_area && ar >= min_ar;
+        }
+        const uint64_t bal = __ballot(ok);
+        if (lane == 0) misc[2 + wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        const int base = misc[1];
+        int off = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        for (int wv = 0; wv < wave; ++wv) off += misc[2 + wv];
+        if (ok) {
+            const float* r = sorted + (size_t)j * 8;
+            fm_det48 d;
+            d.tlbr[0] = t0; d.tlbr[1] = t1; d.tlbr[2] = t2; d.tlbr[3] = t3;
+            d.label = (int64_t)r[5];
+            d.conf = (double)(r[4] * r[6]);     // float32 product (detector.py:362)
+            dets[off] = d;
+            if (off < prefix) dets_host[off] = d;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int n = base;
+            for (int wv = 0; wv < NG_NW; ++wv) n += misc[2 + wv];
+            misc[1] = n;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int n = misc[1];
+        counters[2] = n;
+        counters[3] = 0;
+        counters_host[0] = counters[0]; counters_host[1] = counters[1]; counters_host[2] = n; counters_host[3] = 0;
     }
 }
 
@@ -537,6 +787,64 @@ FilterArgs filter_args(DetState* d, int slot) {
     return fa;
 }
 
+// the general three-kernel path: sort, suppression bit matrix, chunked scan (any number of candidates up to the capacity)
+static int launch_rank_sort(DetState* d, int slot, hipStream_t sp);
+static int enqueue_general_post(fm_ctx* ctx, DetState* d, int slot, hipStream_t sp, bool sorted_already = false) {
+    const int cap = d->cap;
+    if (!sorted_already) {
+        int rc = launch_rank_sort(d, slot, sp);
+        if (rc) return rc;
+    }
+    fm_trace_mark(ctx, sp, 22);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, sp, d->sorted[slot],
+                       d->counters[slot], cap, d->cfg.nms_thresh, d->mask[slot]);
+    fm_trace_mark(ctx, sp, 23);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), sp, d->sorted[slot],
+                       d->counters[slot], cap, d->mask[slot], d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets[slot],
+                       d->dets_host[slot], cap < DetState::PREFIX ? cap : DetState::PREFIX, d->counters_host[slot]);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_rank_sort(DetState* d, int slot, hipStream_t sp) {
+    const int cap = d->cap;
+    static bool configured = false;
+    if (!configured) {
+        FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rank_sort_lds_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * (16384 + 2))));
+        configured = true;
+    }
+    if (cap <= 16384)
+        hipLaunchKernelGGL(rank_sort_lds_kernel, dim3(cap / 256 + 1), dim3(256), sizeof(uint64_t) * (cap + 2), sp,
+                           d->cand[slot], d->sorted[slot], d->counters[slot], cap);
+    else
+        hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, sp, d->cand[slot], d->sorted[slot],
+                           d->counters[slot], cap);
+    FM_HIP(hipGetLastError());
+    d->sorted_valid[slot] = true;
+    return 0;
+}
+
+// sort + the greedy kernel (LDS for `greedy_kmax` candidates, chosen from the candidate counts of the passes collected so
+// far; a pass with more is flagged by the kernel and collect() runs the bit matrix + scan for it)
+static int enqueue_greedy_post(fm_ctx* ctx, DetState* d, int slot, hipStream_t sp) {
+    static bool configured = false;
+    if (!configured) {
+        FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ng_lds_bytes(NG_KMAX)));
+        configured = true;
+    }
+    int rc = launch_rank_sort(d, slot, sp);
+    if (rc) return rc;
+    fm_trace_mark(ctx, sp, 22);
+    const int kmax = d->greedy_kmax < d->cap ? d->greedy_kmax : (d->cap < NG_KMAX ? d->cap : NG_KMAX);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(1), dim3(NG_T), ng_lds_bytes(kmax), sp, d->sorted[slot], d->counters[slot],
+                       d->cap, kmax, d->cfg.nms_thresh, d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets[slot],
+                       d->dets_host[slot], d->cap < DetState::PREFIX ? d->cap : DetState::PREFIX, d->counters_host[slot]);
+    FM_HIP(hipGetLastError());
+    return 0;
+}
+
 // sort + NMS + final filter + read-back of the result of the pass in `slot`, on a low-priority stream of their own
 // (s_up) behind the event that marks the pass's candidates complete.  The NMS scan is one workgroup for tens of
 // microseconds: on the detector stream it kept the next frame's network waiting (1500 candidates per frame: 603 -> 667
@@ -555,16 +863,8 @@ static int flush_post(fm_ctx* ctx, DetState* d) {
     hipStream_t sp = ctx->s_up;
     FM_HIP(hipStreamWaitEvent(sp, d->ev_dec[slot], 0));
     fm_trace_mark(ctx, sp, 20);
-    hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, sp, d->cand[slot], d->sorted[slot],
-                       d->counters[slot], cap);
-    fm_trace_mark(ctx, sp, 22);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, sp, d->sorted[slot],
-                       d->counters[slot], cap, d->cfg.nms_thresh, d->mask[slot]);
-    fm_trace_mark(ctx, sp, 23);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), sp, d->sorted[slot],
-                       d->counters[slot], cap, d->mask[slot], d->cfg.max_area, d->cfg.min_aspect_ratio, d->dets[slot],
-                       d->dets_host[slot], cap < DetState::PREFIX ? cap : DetState::PREFIX, d->counters_host[slot]);
-    FM_HIP(hipGetLastError());
+    int rc_p = (d->general_post || ctx->opt_nms_general) ? enqueue_general_post(ctx, d, slot, sp) : enqueue_greedy_post(ctx, d, slot, sp);
+    if (rc_p) return rc_p;
     // (The counters and a bounded prefix of the detections -- they are few; the rest, rare, is fetched at collection
     // time -- are written to page-locked host memory by the scan kernel itself.  As two hipMemcpyAsync they were handed
     // to a copy engine as soon as they were enqueued, i.e. while the pass they wait for still had a millisecond to run,
@@ -611,6 +911,32 @@ int collect(fm_ctx* ctx, DetState* d, hipStream_t s, fm_det48* out, int cap_out,
     int rc_f = flush_post(ctx, d);
     if (rc_f) return rc_f;
     FM_HIP(hipEventSynchronize(d->ev_done[slot]));
+    if (d->counters_host[slot][3] != 0 && !d->counters_host[slot][1]) {
+        // the greedy kernel did not take the pass -- more candidates than it was given LDS for (1), or more survivors than
+        // its round budget (2: most candidates survive, the bit matrix + scan is the cheaper tool): the pass (sorted
+        // already, candidates untouched) goes through the general path now, and so do the following ones -- for good
+        // beyond NG_KMAX candidates, otherwise until the greedy kernel is tried again GREEDY_RETRY passes later
+        const int why = d->counters_host[slot][3];
+        hipStream_t sp = ctx->s_up;
+        int rc_g = enqueue_general_post(ctx, d, slot, sp, d->sorted_valid[slot]);
+        if (rc_g) return rc_g;
+        FM_HIP(hipStreamSynchronize(sp));
+        if (why == 2 || d->counters_host[slot][0] > NG_KMAX) {
+            d->general_post = true;
+            d->general_passes = 0;
+        }
+    } else if (d->general_post && d->counters_host[slot][0] <= NG_KMAX * 3 / 4 && ++d->general_passes >= DetState::GREEDY_RETRY) {
+        d->general_post = false;
+    }
+    {   // LDS of the next greedy launches: room for 1.25 x the largest of the recent counts, in steps of 512
+        const int k = d->counters_host[slot][0];
+        int want = ((k + k / 4 + 511) / 512) * 512;
+        if (want < 512) want = 512;
+        if (want > NG_KMAX) want = NG_KMAX;
+        if (want > d->greedy_kmax) d->greedy_kmax = want;
+        else if (want < d->greedy_kmax && ++d->greedy_shrink >= 64) { d->greedy_kmax = want; d->greedy_shrink = 0; }
+        else if (want == d->greedy_kmax) d->greedy_shrink = 0;
+    }
     d->rd = (slot + 1) % DetState::NSLOT;
     --d->pending;
     d->last = slot;
@@ -827,6 +1153,7 @@ extern "C" int fm_detect_configure(fm_ctx* ctx, const fm_yolo_cfg* cfg) {
     d->rd = d->wr;            // a new detector: nothing of the previous one is collected any more
     d->pending = 0;
     d->cfg = *cfg;
+    d->general_post = ctx->opt_nms_general != 0;
     if ((rc = alloc_post(d, cfg->max_candidates > 0 ? cfg->max_candidates : 8192))) return rc;
     FM_HIP(hipMemcpy(d->label_mask, cfg->label_mask, 128, hipMemcpyHostToDevice));
     d->configured = true;

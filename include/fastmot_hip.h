@@ -50,7 +50,9 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
 /* tunables: "zero_copy_tracks" (default 2048; batches up to this many tracks / boxes exchange kernel
  * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
  * "host_lap_elems" (default 262144; LAP cost matrices up to this many elements are solved by the host
- * solver of the library, larger ones by the device kernels; 0 = always device), "use_graphs" (default 1;
+ * solver of the library, larger ones by the device kernels; 0 = always device), "nms_path" (default 0: the fused sort + greedy
+ * DIoU-NMS kernel for up to 4096 candidates per frame, the three-kernel sort / bit-matrix / scan path beyond; 1 = always
+ * the latter), "use_graphs" (default 1;
  * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (diagnostic builds only, include/fastmot_hip_diag.h;
  * 0 is the only value the shipped library accepts).  Initial values can be set with the environment
  * variables FASTMOT_ZERO_COPY / FASTMOT_HOST_LAP / FASTMOT_GRAPHS. */

@@ -1,3 +1,4 @@
 export TMPDIR=/tmp FASTMOT_RANDOM_WEIGHTS=1
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04c; mkdir -p $O; cd $R
-timeout 900 python -m pytest tests/test_detector_chain_gpu.py tests/test_onnx_reader.py -m gpu -q -s 2>&1 | grep "^config\|^E  \|passed\|failed\|^tests.*Error" | cut -c1-1200 > $O/chain.txt; cat $O/chain.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04i; mkdir -p $O; cd $R
+timeout 600 python -m pytest tests/test_detect_gpu.py -m gpu -q -x 2>&1 | tail -15 > $O/tests.txt; cat $O/tests.txt
+timeout 600 python bench.py --no-cpu-baseline > $O/bench_n1.json 2> $O/bench_n1.err; tail -2 $O/bench_n1.err; cut -c1-200 $O/bench_n1.json

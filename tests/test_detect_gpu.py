@@ -41,8 +41,17 @@ class TinyLetterbox(TinyYOLO):
     SCALES = [2.0, 2.0, 2.0]
 
 
+@pytest.fixture(params=['fused', 'general'])
+def nms_path(ctx, request):
+    """Both device paths of the candidate sort + DIoU-NMS: the fused greedy kernel (default, up to 4096 candidates) and
+    the three-kernel sort / bit-matrix / scan path (fm_ctx option "nms_path" = 1; beyond 4096 candidates automatically)."""
+    ctx.set_option('nms_path', 1 if request.param == 'general' else 0)
+    yield request.param
+    ctx.set_option('nms_path', 0)
+
+
 @pytest.mark.parametrize('tag,n_cls', [('p', 1), ('q', 3)])
-def test_filter_dets_matches_reference(ctx, golden_dir, tag, n_cls):
+def test_filter_dets_matches_reference(ctx, golden_dir, tag, n_cls, nms_path):
     g = np.load(golden_dir / 'nms_kat.npz')
     det = YOLODetector((1920, 1080), tuple(range(n_cls)), model='TinyYOLO' if n_cls <= 3 else None,
                        conf_thresh=0.25, nms_thresh=0.5, max_area=800000, min_aspect_ratio=1.2)
@@ -52,17 +61,36 @@ def test_filter_dets_matches_reference(ctx, golden_dir, tag, n_cls):
     np.testing.assert_allclose(out.conf, g[f'{tag}_conf'], rtol=1e-7)
 
 
-def test_filter_dets_random_vs_oracle(ctx):
+def test_filter_dets_random_vs_oracle(ctx, nms_path):
     rng = np.random.default_rng(5)
     det = YOLODetector((1920, 1080), (0, 2), model='TinyYOLO', conf_thresh=0.3, nms_thresh=0.45,
                        max_area=200000, min_aspect_ratio=0.5)
-    for n in (0, 1, 7, 600, 3000):
+    for n in (0, 1, 7, 64, 65, 600, 3000):
         rows = np.stack([rng.uniform(0, 0.9, n), rng.uniform(0, 0.8, n), rng.uniform(0.01, 0.15, n),
                          rng.uniform(0.02, 0.3, n), rng.uniform(0, 1, n), rng.integers(0, 3, n),
                          rng.uniform(0.3, 1, n)], 1).astype(np.float32)
         out = ctx.filter_dets(rows)
         lm = np.array([True, False, True])
         tl, lb, cf = o.filter_dets(rows, [1920, 1080], [0, 0], lm, 0.3, 0.45, 200000, 0.5)
+        np.testing.assert_array_equal(out.tlbr, tl)
+        np.testing.assert_array_equal(out.label, lb)
+        np.testing.assert_allclose(out.conf, cf, rtol=1e-7)
+
+
+def test_filter_dets_more_candidates_than_the_fused_kernel_holds(ctx):
+    """> 4096 candidates over the threshold: the fused kernel flags the pass, the general path takes it over (and the
+    following passes, until the count has fallen again); results equal the oracle throughout."""
+    rng = np.random.default_rng(9)
+    det = YOLODetector((1920, 1080), (0, 1, 2), model='TinyYOLO', conf_thresh=0.3, nms_thresh=0.45,
+                       max_area=200000, min_aspect_ratio=0.5, max_candidates=16384)
+    lm = np.array([True, True, True])
+    for n in (5000, 9000, 2000, 300, 5000):
+        rows = np.stack([rng.uniform(0, 0.9, n), rng.uniform(0, 0.8, n), rng.uniform(0.01, 0.15, n),
+                         rng.uniform(0.02, 0.3, n), rng.uniform(0, 1, n), rng.integers(0, 3, n),
+                         rng.uniform(0.4, 1, n)], 1).astype(np.float32)
+        out = ctx.filter_dets(rows, cap=16384)
+        tl, lb, cf = o.filter_dets(rows, [1920, 1080], [0, 0], lm, 0.3, 0.45, 200000, 0.5)
+        assert ctx.detect_last_counts()[0] == int(((rows[:, 4] * rows[:, 6]) >= np.float32(0.3)).sum())
         np.testing.assert_array_equal(out.tlbr, tl)
         np.testing.assert_array_equal(out.label, lb)
         np.testing.assert_allclose(out.conf, cf, rtol=1e-7)
