@@ -55,6 +55,11 @@ void fm_net_free(NetState* n) {
     if (n->weights) (void)hipFree(n->weights);
     if (n->gates) (void)hipFree(n->gates);
     if (n->ws) (void)hipFree(n->ws);
+    if (n->ws_side) (void)hipFree(n->ws_side);
+    for (hipEvent_t e : n->layer_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {n->ev_fork, n->ev_join})
+        if (e) (void)hipEventDestroy(e);
     for (auto& g : n->graphs) (void)hipGraphExecDestroy(g.second);
     delete n;
 }
@@ -123,6 +128,31 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
     net->gate_c = gate_channels;
     net->ws_floats = (size_t)16 << 20;   // 64 MB of fp32 split-K partials
     FM_HIP(hipMalloc(&net->ws, net->ws_floats * sizeof(float)));
+    {
+        bool branches = false;
+        for (size_t i = 0; i < net->layers.size(); ++i) {
+            const fm_layer& L = net->layers[i];
+            FM_CHECK_ARG((L.branch == 0 || L.branch == 1) && L.wait_for < (int)i);
+            FM_CHECK_ARG(L.wait_for < 0 || (net->layers[L.wait_for].signal && net->layers[L.wait_for].branch != L.branch));
+            branches |= L.branch != 0;
+        }
+        if (branches) {
+            // the second stream: one of the context's own idle streams where there is one (the context already drives
+            // more streams than the runtime has hardware queues; a further one changes which of them share a queue)
+            // (taken by a fourth ReID instance, or another network than the detector: the table runs as one chain in
+            // table order, which honours every dependency of the two-branch plan)
+            net->side = which == FM_NET_DETECTOR && !ctx->ext_net_x[FM_MAX_EXTRA_EXTRACTORS - 1]
+                            ? ctx->s_ext_x[FM_MAX_EXTRA_EXTRACTORS - 1] : nullptr;
+        }
+        if (net->side) {
+            FM_HIP(hipMalloc(&net->ws_side, net->ws_floats * sizeof(float)));
+            net->layer_ev.assign(net->layers.size(), nullptr);
+            for (size_t i = 0; i < net->layers.size(); ++i)
+                if (net->layers[i].signal) FM_HIP(hipEventCreateWithFlags(&net->layer_ev[i], hipEventDisableTiming));
+            FM_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+            FM_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+        }
+    }
     if (n_gates > 0) {
         FM_CHECK_ARG(gate_channels > 0);
         FM_HIP(hipMalloc(&net->gates, sizeof(float) * (size_t)n_gates * max_batch * gate_channels * GATE_SLOT_TILES));
@@ -135,10 +165,11 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
     return 0;
 }
 
-static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
+static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B, hipStream_t s = nullptr, float* ws = nullptr) {
     const fm_tensor& ti = net->tensors[L.in[0]];
     const fm_tensor& to = net->tensors[L.out];
-    hipStream_t s = net->stream;
+    if (!s) s = net->stream;
+    if (!ws) ws = net->ws;
     const f16* in0 = (const f16*)net->bufs[L.in[0]];
     f16* out = (f16*)net->bufs[L.out];
     switch (L.op) {
@@ -166,7 +197,7 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             FM_CHECK_ARG((ti.h + 2 * L.pad - L.k) / L.stride + 1 == p.Ho);
             FM_CHECK_ARG(L.out_coff + p.cout_store <= to.c && L.in_coff[0] + L.cin <= ti.c);
             if (L.op == FM_OP_CONVS) return launch_conv_streamed(p, s);
-            return launch_conv(p, net->ws, net->ws_floats, s);
+            return launch_conv(p, ws, net->ws_floats, s);
         }
         case FM_OP_DWCONV3:
             return launch_dwconv3(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
@@ -302,10 +333,27 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
 // gate kernels index gate[n*C + c] with C = the gated channel count; buffers are spaced by
 // max_batch*gate_c so any C <= gate_c fits.
 static int run_layers_eager(fm_ctx* ctx, NetState* net, int batch) {
-    for (const fm_layer& L : net->layers) {
-        int rc = run_layer(ctx, net, L, batch);
-        if (rc) return rc;
+    if (!net->side) {
+        for (const fm_layer& L : net->layers) {
+            int rc = run_layer(ctx, net, L, batch);
+            if (rc) return rc;
+        }
+        return 0;
     }
+    // two-branch schedule: branch 1 on the second stream, forked from / joined into the network's stream by events (under
+    // stream capture these become the parallel paths of the hipGraph)
+    FM_HIP(hipEventRecord(net->ev_fork, net->stream));
+    FM_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
+    for (size_t i = 0; i < net->layers.size(); ++i) {
+        const fm_layer& L = net->layers[i];
+        hipStream_t s = L.branch ? net->side : net->stream;
+        if (L.wait_for >= 0) FM_HIP(hipStreamWaitEvent(s, net->layer_ev[L.wait_for], 0));
+        int rc = run_layer(ctx, net, L, batch, s, L.branch ? net->ws_side : net->ws);
+        if (rc) return rc;
+        if (L.signal) FM_HIP(hipEventRecord(net->layer_ev[i], s));
+    }
+    FM_HIP(hipEventRecord(net->ev_join, net->side));
+    FM_HIP(hipStreamWaitEvent(net->stream, net->ev_join, 0));
     return 0;
 }
 

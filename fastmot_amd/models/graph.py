@@ -33,7 +33,8 @@ class fm_layer(C.Structure):
                 ('cin', C.c_int32), ('cout', C.c_int32), ('k', C.c_int32), ('stride', C.c_int32),
                 ('pad', C.c_int32), ('act', C.c_int32), ('hid', C.c_int32), ('up', C.c_int32),
                 ('gate', C.c_int32 * 4),
-                ('w_off', C.c_int64), ('b_off', C.c_int64), ('w2_off', C.c_int64), ('b2_off', C.c_int64)]
+                ('w_off', C.c_int64), ('b_off', C.c_int64), ('w2_off', C.c_int64), ('b2_off', C.c_int64),
+                ('branch', C.c_int32), ('wait_for', C.c_int32), ('signal', C.c_int32), ('reserved_', C.c_int32)]
 
 
 def ceil_to(x, m):
@@ -450,38 +451,149 @@ class Graph:
         return dst
 
     # ---------------------------------------------------------------- C tables
-    def plan_arena(self, max_batch, reuse):
+    def plan_arena(self, max_batch, reuse, before=None):
         """Byte offsets of the tensors in one activation arena.  With `reuse`, tensors whose live
         ranges [first writer/reader layer, last layer touching them] do not overlap share bytes
         (greedy first-fit by decreasing size).  The network input and the graph outputs are read /
-        written outside the layer sequence and therefore stay live for the whole run."""
+        written outside the layer sequence and therefore stay live for the whole run.
+        before (two-branch schedules, plan_branches): before[b] = set of layers that are complete when layer b starts;
+        two tensors then share bytes only if every access of one happens before every access of the other (table order
+        alone does not say so any more)."""
         n = len(self.tensors)
         size = [ceil_to(max_batch * h * w * c * (4 if f32 else 2), 256) for (h, w, c, f32) in self.tensors]
         first, last = [10**9] * n, [-1] * n
+        acc = [[] for _ in range(n)]
         for li, d in enumerate(self.layers):
             touched = [v.tid for v in d['ins']] + [d['out'].tid] + ([d['res'].tid] if d['res'] is not None else [])
             for t in touched:
                 first[t], last[t] = min(first[t], li), max(last[t], li)
+                if not acc[t] or acc[t][-1] != li:
+                    acc[t].append(li)
         persistent = {self.input.tid} | {v.tid for v in self.outputs}
         for t in range(n):
             if t in persistent or not reuse or last[t] < 0:
                 first[t], last[t] = -1, 10**9
+
+        def disjoint(t, u):
+            """all accesses of t are over before u is touched, or the other way round"""
+            if first[t] < 0 or first[u] < 0:
+                return False
+            if before is None:
+                return last[t] < first[u] or last[u] < first[t]
+            return all(a in before[b] for a in acc[t] for b in acc[u]) or all(b in before[a] for a in acc[t] for b in acc[u])
         offsets = [0] * n
-        placed = []                      # (offset, size, first, last)
+        placed = []                      # (offset, size, tensor)
         for t in sorted(range(n), key=lambda i: -size[i]):
-            cands = sorted((o, s) for (o, s, f, l) in placed if not (last[t] < f or l < first[t]))
+            cands = sorted((o, s) for (o, s, u) in placed if not disjoint(t, u))
             off = 0
             for o, s in cands:
                 if off + size[t] <= o:
                     break
                 off = max(off, o + s)
             offsets[t] = off
-            placed.append((off, size[t], first[t], last[t]))
-        total = max((o + s for (o, s, _, _) in placed), default=0)
+            placed.append((off, size[t], t))
+        total = max((o + s for (o, s, _) in placed), default=0)
         return offsets, total
 
-    def tables(self, max_batch=1, reuse=False):
-        offsets, arena = self.plan_arena(max_batch, reuse)
+    @staticmethod
+    def happens_before(plan):
+        """before[b] = layers guaranteed complete when layer b starts under a two-branch plan: the earlier layers of its
+        own branch, the layer it waits for, and everything before those."""
+        before = []
+        prev = [-1, -1]
+        for i, (br, wait, _) in enumerate(plan):
+            s = set()
+            for p in (prev[br], wait):
+                if p >= 0:
+                    s |= before[p]
+                    s.add(p)
+            before.append(s)
+            prev[br] = i
+        return before
+
+    def plan_branches(self, max_batch, offsets=None):
+        """Two-stream schedule of the layer sequence: -> [(branch, wait_for, signal)] per layer (fm_layer).
+
+        The table order is one valid serial order; batch-1 networks leave most of the GPU idle in their small layers, and
+        some of them do not depend on each other: a YOLO head's 3x3 + 1x1 and the PAN path that continues from the same
+        tensor, the two 1x1 convs that fill the halves of a concat.  Dependencies are derived from MEMORY, not from the
+        table's tensor ids alone: layer b (later) depends on layer a if one writes what the other reads or writes --
+        same tensor and intersecting channel ranges, or (with the shared arena) different tensors whose byte ranges
+        intersect.  Layers are then list-scheduled in table order onto two branches with a rough duration model
+        (launch floor + FLOPs + bytes); every branch keeps table order, so hazards inside a branch are ordered by its
+        stream, and a cross-branch dependency becomes one event wait.  Results are bit-identical to the chain: the same
+        kernels on the same data."""
+        n = len(self.layers)
+        size = [max_batch * h * w * c * (4 if f32 else 2) for (h, w, c, f32) in self.tensors]
+
+        def foot(d):
+            reads = [(v.tid, v.coff, v.coff + v.cpad) for v in d['ins']]
+            if d['res'] is not None:
+                reads.append((d['res'].tid, d['res'].coff, d['res'].coff + d['res'].cpad))
+            o = d['out']
+            return reads, [(o.tid, o.coff, o.coff + max(o.cpad, ceil_to(d.get('cout', 0) or o.c, 8)))]
+
+        def clash(x, y):
+            if x[0] == y[0]:
+                return x[1] < y[2] and y[1] < x[2]
+            if offsets is None:
+                return False
+            ax, ay = offsets[x[0]], offsets[y[0]]
+            return ax < ay + size[y[0]] and ay < ax + size[x[0]]
+        feet = [foot(d) for d in self.layers]
+        gate_users = {}
+        deps = [set() for _ in range(n)]
+        for b in range(n):
+            rb, wb = feet[b]
+            for a in range(b):
+                ra, wa = feet[a]
+                if any(clash(x, y) for x in wb for y in ra + wa) or any(clash(x, y) for x in rb for y in wa):
+                    deps[b].add(a)
+            for gslot in self.layers[b]['gates']:                # gate / pool slots are shared scratch: keep their users ordered
+                if gslot >= 0:
+                    deps[b].update(gate_users.get(gslot, ()))
+                    gate_users.setdefault(gslot, []).append(b)
+        flops = self.layer_flops(max_batch) if hasattr(self, 'layer_flops') else None
+
+        def est(i):
+            d = self.layers[i]
+            r, w = feet[i]
+            by = sum((c1 - c0) * self.tensors[t][0] * self.tensors[t][1] * 2 for t, c0, c1 in r + w) * max_batch
+            k = d.get('k', 1) or 1
+            fl = 2.0 * k * k * (d.get('cin', 0) or 0) * (d.get('cout', 0) or 0) * d['out'].h * d['out'].w * max_batch
+            return 4e-6 + fl / 200e12 + by / 2e12
+        finish, branch = [0.0] * n, [0] * n
+        free = [0.0, 0.0]
+        for i in range(n):
+            best = None
+            for s in (0, 1):
+                start = free[s]
+                for j in deps[i]:
+                    start = max(start, finish[j] + (1.5e-6 if branch[j] != s else 0.0))
+                if best is None or start < best[0] - 2e-6:       # the side branch has to win by more than a launch gap
+                    best = (start, s)
+            branch[i] = best[1]
+            finish[i] = best[0] + est(i)
+            free[best[1]] = finish[i]
+        if n:
+            branch[n - 1] = 0 if all(b == 0 for b in branch[:-1]) else branch[n - 1]
+        wait, signal = [-1] * n, [0] * n
+        waited = [-1, -1]                                        # per branch: newest layer of the other branch already waited for
+        for i in range(n):
+            s = branch[i]
+            other = [j for j in deps[i] if branch[j] != s]
+            if other and max(other) > waited[s]:
+                wait[i] = max(other)
+                signal[wait[i]] = 1
+                waited[s] = wait[i]
+        return list(zip(branch, wait, signal))
+
+    def tables(self, max_batch=1, reuse=False, branches=False):
+        plan = self.plan_branches(max_batch) if branches else None
+        if plan is not None and not any(b for b, _, _ in plan):
+            plan = None                                          # nothing to run side by side: one chain
+        self.branch_plan = plan
+        offsets, arena = self.plan_arena(max_batch, reuse, self.happens_before(plan) if plan is not None else None)
         self.arena_bytes = arena
         ts = (fm_tensor * len(self.tensors))()
         for i, (h, w, c, f32) in enumerate(self.tensors):
@@ -504,6 +616,7 @@ class Graph:
                 setattr(L, key, d[key])
             for j in range(4):
                 L.gate[j] = d['gates'][j] if j < len(d['gates']) else -1
+            L.branch, L.wait_for, L.signal = plan[i] if plan is not None else (0, -1, 0)
             ls[i] = L
         blob = bytes(self.blob) + b'\0' * 64
         return ts, ls, blob

@@ -260,6 +260,12 @@ typedef struct fm_layer {
                           * the [upsample] layer of yolo2onnx.py:806-836 folded into its producer */
     int32_t gate[4];
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob (16 B aligned) */
+    /* Two-branch schedule of the layer sequence (models/graph.py plan_branches; all zero / -1 = one chain): the layers
+     * of branch 1 run on a second stream beside branch 0 (e.g. a YOLO head's 3x3 + 1x1 beside the PAN path that
+     * continues from the same tensor), each branch in table order.  wait_for: index of a layer of the OTHER branch
+     * whose completion this layer waits for (-1: none; earlier waits of its branch cover the rest), signal: some layer
+     * of the other branch waits for this one.  Captured into the hipGraph as parallel paths. */
+    int32_t branch, wait_for, signal, reserved_;
 } fm_layer;
 
 /* weights: CONV  w = fp16 [ceil32(cout)][ceil64(k*k*cin)] (K order kh,kw,cin), b = f32[ceil32(cout)]
