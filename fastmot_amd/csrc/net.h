@@ -28,6 +28,9 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s);
+// persistent streaming kernel for the memory-bound stride-1 1x1 layers (conv1x1.hip); *taken: the layer was one of them
+int launch_conv1x1_stream(const ConvParams& p, hipStream_t s, bool* taken);
+void conv1x1_stream_enable(int on);
 
 struct NetState {
     int which = 0, max_batch = 0;

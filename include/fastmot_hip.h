@@ -50,7 +50,9 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
 /* tunables: "zero_copy_tracks" (default 2048; batches up to this many tracks / boxes exchange kernel
  * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
  * "host_lap_elems" (default 262144; LAP cost matrices up to this many elements are solved by the host
- * solver of the library, larger ones by the device kernels; 0 = always device), "nms_path" (default 0: the fused sort + greedy
+ * solver of the library, larger ones by the device kernels; 0 = always device), "conv1x1_stream" (default 0; 1: memory-bound stride-1 1x1
+ * layers on large maps take the persistent streaming kernel of csrc/conv1x1.hip -- bit-identical, measured slower, kept for
+ * the record; read when a network's graph is captured), "nms_path" (default 0: the fused sort + greedy
  * DIoU-NMS kernel for up to 4096 candidates per frame, the three-kernel sort / bit-matrix / scan path beyond; 1 = always
  * the latter), "use_graphs" (default 1;
  * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (diagnostic builds only, include/fastmot_hip_diag.h;

@@ -1,7 +1,6 @@
 export TMPDIR=/tmp FASTMOT_RANDOM_WEIGHTS=1
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04j; mkdir -p $O; cd $R
-timeout 600 python -m pytest tests/test_branch_plan.py tests/test_detect_gpu.py -m gpu -q -x 2>&1 | tail -15 > $O/tests.txt; cat $O/tests.txt
-timeout 600 python bench.py --no-cpu-baseline > $O/bench_n1.json 2> $O/bench_n1.err; tail -2 $O/bench_n1.err; cut -c1-200 $O/bench_n1.json
-FASTMOT_BRANCHES=0 timeout 600 python bench.py --no-cpu-baseline > $O/bench_nobranch.json 2> /dev/null; cut -c1-200 $O/bench_nobranch.json
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04k; mkdir -p $O; cd $R
+timeout 600 python -m pytest tests/test_conv_gpu.py -m gpu -q -x -k "streaming_1x1 or single_conv" 2>&1 | tail -15 > $O/tests.txt; cat $O/tests.txt
 cd /tmp && rm -rf /tmp/tr && rocprofv3 --kernel-trace -d /tmp/tr -o t -- python $R/scripts/trace_net.py 0 > /dev/null 2>&1
 cd $R && python scripts/layer_roofline.py /tmp/tr > $O/yolo_layer_roofline.txt 2>&1; tail -3 $O/yolo_layer_roofline.txt
+timeout 600 python bench.py --no-cpu-baseline > $O/bench_n1.json 2> $O/bench_n1.err; tail -2 $O/bench_n1.err; cut -c1-200 $O/bench_n1.json

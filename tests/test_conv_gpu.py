@@ -486,3 +486,39 @@ def test_yolov4_small_input(ctx, monkeypatch, resblock):
     for i, hd in enumerate(heads):
         close(net.read(hd, 1), nhwc(bufs32[hd.tid][:, :hd.c]), rel=5e-2, abs_=1e-2, what=f'head {i} vs fp32')
     net.close()
+
+
+@pytest.mark.parametrize('cin,cout,h,w,n,act,extra', [
+    (64, 128, 76, 76, 1, 'mish', ''),          # CSP stage entry (merged siblings)
+    (64, 64, 96, 80, 1, 'mish', 'slice'),      # reads a channel slice, writes a concat slice
+    (128, 64, 70, 70, 1, 'mish', ''),          # ragged last tile (4900 pixels)
+    (128, 128, 64, 64, 2, 'leaky', ''),        # batch 2
+    (256, 128, 76, 76, 1, 'leaky', 'slice'),   # PAN lateral conv
+    (256, 256, 68, 68, 1, 'mish', ''),
+    (256, 255, 76, 76, 1, 'linear', 'f32'),    # 76 x 76 head: ragged cout, fp32 output
+    (128, 255, 72, 72, 1, 'logistic', 'f32'),  # NEW_COORDS head
+])
+def test_streaming_1x1_conv_equals_the_tiled_kernel(ctx, cin, cout, h, w, n, act, extra):
+    """conv1x1.hip (persistent workgroups, weights in registers, pixel tiles one ahead) against conv.hip on the same
+    layer: BIT-identical outputs (same MFMA order, same fp32 epilogue), and both against PyTorch."""
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.normal(0, 1, (n, h, w, cin + (64 if extra == 'slice' else 0))).astype(np.float16)
+    outs = []
+    for stream in (0, 1):
+        ctx.set_option('conv1x1_stream', stream)
+        g = Graph(RandomWeights(seed=cin + 3 * cout), (h, w), x.shape[-1])
+        src = g.input.slice(64, cin) if extra == 'slice' else g.input
+        dst = g.new(h, w, cout + 64).slice(64, cout) if extra == 'slice' else None
+        y = g.conv('c', src, cout, 1, 1, act, dst=dst, bn=extra != 'f32', f32_out=extra == 'f32')
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        for graphs in (1, 1):                       # eager validation + capture, then replay
+            net.write(g.input, x)
+            net.run(n)
+        outs.append(net.read(y, n))
+        if stream:
+            bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+            close(outs[-1], nhwc(bufs[y.tid][:, y.coff:y.coff + cout]), what=f'1x1 {cin}->{cout}')
+        net.close()
+    ctx.set_option('conv1x1_stream', 0)
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    np.testing.assert_array_equal(outs[0], outs[1])
