@@ -275,20 +275,25 @@ __global__ __launch_bounds__(256) void rank_sort_lds_kernel(const float* __restr
     __builtin_amdgcn_s_setprio(3);         // (latency-critical side work beside the networks' bulk wavefronts)
     extern __shared__ uint64_t all_keys[];
     const int K = min(counters[0], cap);
-    if ((int)blockIdx.x * 256 >= K) return;
-    const int Kp = (K + 1) & ~1;                                  // (an odd K: one padding key that ranks last)
+    // a workgroup ranks 64 candidates, four lanes each: every lane counts the smaller keys in its quarter of the list
+    // (four times the wavefronts of one-lane-per-candidate for the same K^2 comparisons: the chain of a lane -- LDS read,
+    // two 64-bit compares, add -- is latency bound, more wavefronts hide it)
+    if ((int)blockIdx.x * 64 >= K) return;
+    const int Kp = (K + 7) & ~7;                                  // (padding keys rank last)
     for (int j = threadIdx.x; j < Kp; j += 256) all_keys[j] = j < K ? sort_key(cand + (size_t)j * 8) : ~0ull;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= K) return;
-    const uint64_t ki = all_keys[i];
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    const uint64_t ki = all_keys[min(i, Kp - 1)];
     int rank = 0;
-    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(all_keys);
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(all_keys) + q * (Kp / 8);
 #pragma unroll 8
-    for (int t = 0; t < Kp / 2; ++t) {
+    for (int t = 0; t < Kp / 8; ++t) {
         const ulonglong2 k = k2[t];
         rank += (k.x < ki ? 1 : 0) + (k.y < ki ? 1 : 0);
     }
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (i >= K || q != 0) return;
     const float* ri = cand + (size_t)i * 8;
     float* o = sorted + (size_t)rank * 8;
     const float4 r0 = *reinterpret_cast<const float4*>(ri), r1 = *reinterpret_cast<const float4*>(ri + 4);
@@ -811,11 +816,11 @@ static int launch_rank_sort(DetState* d, int slot, hipStream_t sp) {
     static bool configured = false;
     if (!configured) {
         FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rank_sort_lds_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * (16384 + 2))));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * (16384 + 8))));
         configured = true;
     }
     if (cap <= 16384)
-        hipLaunchKernelGGL(rank_sort_lds_kernel, dim3(cap / 256 + 1), dim3(256), sizeof(uint64_t) * (cap + 2), sp,
+        hipLaunchKernelGGL(rank_sort_lds_kernel, dim3(cap / 64 + 1), dim3(256), sizeof(uint64_t) * (cap + 8), sp,
                            d->cand[slot], d->sorted[slot], d->counters[slot], cap);
     else
         hipLaunchKernelGGL(rank_sort_kernel, dim3(cap / 256 + 1), dim3(256), 0, sp, d->cand[slot], d->sorted[slot],

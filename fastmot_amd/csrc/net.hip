@@ -30,6 +30,8 @@ int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
                      int W, int C, hipStream_t s);
 int launch_conv_streamed(const ConvParams& p, hipStream_t s);
 bool resblock_supported(int C, int M);
+int launch_cspstage(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, int out_coff, const f16* w, const float* b,
+                    int N, int H, int W, int C, int M, int act, hipStream_t s);
 int launch_resblock(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, int out_coff, const f16* w1,
                     const float* b1, const f16* w2, const float* b2, int N, int H, int W, int C, int M, int act1,
                     int act2, hipStream_t s);
@@ -291,6 +293,10 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B, hipSt
                                    (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                    (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
                                    B, ti.h, ti.w, L.cin, L.hid, L.act, L.act, s);
+        case FM_OP_CSPSTAGE:
+            FM_CHECK_ARG(!to.f32 && to.h == ti.h && to.w == ti.w && L.in_coff[0] + L.cin <= ti.c && L.out_coff + L.cout <= to.c);
+            return launch_cspstage(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, (const f16*)(net->weights + L.w_off),
+                                   (const float*)(net->weights + L.b_off), B, ti.h, ti.w, L.cin, L.hid, L.act, s);
         case FM_OP_ADD: {
             FM_CHECK_ARG(L.n_in == 2);
             const fm_tensor& tb = net->tensors[L.in[1]];
@@ -463,6 +469,11 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *flops = 2.0 * 10 * L.cin * L.hid * pout;
             *bytes = (pin + pout) * L.cin * 2 + 10.0 * L.cin * L.hid * 2;
             break;
+        case FM_OP_CSPSTAGE:      /* the five convs of the stage; bytes: d in, stage output out, weights */
+            *flops = 2.0 * (L.cin * 2 * L.cin + L.cin * L.hid + 9 * L.hid * L.cin + L.cin * L.cin + 2 * L.cin * L.cout) * pout;
+            *bytes = pin * L.cin * 2 + pout * L.cout * 2 +
+                     2.0 * (L.cin * 2 * L.cin + L.cin * L.hid + 9 * L.hid * L.cin + L.cin * L.cin + 2 * L.cin * L.cout);
+            break;
         case FM_OP_SPP: *bytes = (pin + 3 * pout) * L.cin * 2; break;
         case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
         case FM_OP_GATE_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
@@ -480,7 +491,7 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
     FM_CHECK_ARG(net != nullptr);
     double f = 0, b = 0;
     for (const fm_layer& L : net->layers)
-        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK) {
+        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK || L.op == FM_OP_CSPSTAGE) {
             double lf, lb;
             layer_cost(net, L, batch, &lf, &lb);
             f += lf;
@@ -510,7 +521,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
             FM_HIP(hipEventSynchronize(e1));
             float ms = 0;
             FM_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK) { tc += ms; ++nc; } else { to += ms; ++no; }
+            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK || L.op == FM_OP_CSPSTAGE) { tc += ms; ++nc; } else { to += ms; ++no; }
         }
     FM_HIP(hipEventDestroy(e0));
     FM_HIP(hipEventDestroy(e1));

@@ -15,7 +15,7 @@ import numpy as np
 LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN) = range(17)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CSPSTAGE) = range(18)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
@@ -125,6 +125,9 @@ class Graph:
         self.n_gates = 0
         self.gate_c = 8
         self.use_stem = True   # small-Cin first layers go to the LDS-patch stem kernel
+        # the first CSP stage of CSPDarknet53 (4 launches on the 304 x 304 map) as one launch (cspstage.hip): bit-identical,
+        # measured SLOWER (73 us against 59 us, profiles/r04_cspstage_ab.txt) -> off unless FASTMOT_CSPSTAGE=1
+        self.use_cspstage = os.environ.get('FASTMOT_CSPSTAGE', '0') == '1'
         # darknet residual units (1x1, 3x3, shortcut) as one fused launch (resblock.hip)
         self.use_resblock = os.environ.get('FASTMOT_RESBLOCK', '1') != '0'
         # the four LightConv streams of an OSNet block as one launch (litechain.hip) instead of one per depth
@@ -244,6 +247,34 @@ class Graph:
                     w_off=self._push(self._pack_frag(w1h)), b_off=self._push(b1),
                     w2_off=self._push(self._pack_frag(w2h)), b2_off=self._push(b2), name=name2,
                     res_ref=(w1h.astype(np.float32), b1, w2h.astype(np.float32), b2))
+        return dst
+
+    @staticmethod
+    def cspstage_supported(c, mid):
+        return c == 64 and mid == 32
+
+    def cspstage(self, names, d, mid, cout, act='mish', dst=None):
+        """First CSP stage of CSPDarknet53 behind its stride-2 conv `d`, in one launch (cspstage.hip):
+        [b | A] = act(1x1 d) ; b' = b + act(3x3 act(1x1 b)) ; c = act(1x1 b') ; out = act(1x1 [c | A]).
+        names: the six Darknet layers in cfg order (route branch A, residual branch b, bottleneck 1x1, 3x3, post 1x1,
+        stage output 1x1) -- parameters are drawn in that order, like the unfused layers."""
+        h = d.c
+        assert self.cspstage_supported(h, mid) and d.cpad == h and cout == h
+        if dst is None:
+            dst = self.new(d.h, d.w, cout)
+        (wa, ba), (wb, bb) = (fold_bn(self.wsrc.conv(n, h, h, 1, bn=True)) for n in names[:2])
+        w3a, b3a = fold_bn(self.wsrc.conv(names[2], mid, h, 1, bn=True))
+        w3b, b3b = fold_bn(self.wsrc.conv(names[3], h, mid, 3, bn=True))
+        w4, b4 = fold_bn(self.wsrc.conv(names[4], h, h, 1, bn=True))
+        w5, b5 = fold_bn(self.wsrc.conv(names[5], cout, 2 * h, 1, bn=True))
+        w2, b2 = np.concatenate([wb, wa]), np.concatenate([bb, ba])          # [b | A], as the merged sibling conv writes them
+        mats = [np.asarray(w, np.float32).astype(np.float16) for w in (w2, w3a, w3b, w4, w5)]
+        blob = np.concatenate([self._pack_frag(w).reshape(-1) for w in mats])
+        bias = np.concatenate([np.asarray(b, np.float32) for b in (b2, b3a, b3b, b4, b5)])
+        self._layer(op=OP_CSPSTAGE, ins=[d], out=dst, cin=h, cout=cout, k=3, stride=1, pad=1, act=ACT[act], hid=mid,
+                    w_off=self._push(blob), b_off=self._push(bias), name=names[5],
+                    csp_ref=tuple((w.astype(np.float32), np.asarray(b, np.float32))
+                                  for w, b in zip(mats, (b2, b3a, b3b, b4, b5))))
         return dst
 
     def dwconv3(self, name, x, act='relu', dst=None):
@@ -631,4 +662,7 @@ class Graph:
             elif d['op'] == OP_RESBLOCK:
                 o = d['out']
                 total += 2 * 10 * d['cin'] * d['hid'] * o.h * o.w * batch
+            elif d['op'] == OP_CSPSTAGE:
+                o, c, m = d['out'], d['cin'], d['hid']
+                total += 2 * (2 * c * c + c * m + 9 * m * c + c * c + 2 * c * d['cout']) * o.h * o.w * batch
         return total

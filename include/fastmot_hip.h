@@ -234,6 +234,10 @@ enum {
                           * launch (litechain.hip): stream s writes out channels [out_coff + s*cin, +cin);
                           * w_off / w2_off / b_off = the 10 parameter sets stacked in (stream, level) order,
                           * each laid out as for FM_OP_LITECONV; gate[s] = GAP partial slot of stream s       */
+    FM_OP_CSPSTAGE = 17, /* fused first CSP stage of CSPDarknet53 (cspstage.hip): in[0] = d (cin = 64 channels) ->
+                          * [b | A] = act(1x1 64->128) -> residual unit on b (1x1 64->hid, 3x3 hid->64, + b) -> c = act(1x1
+                          * 64->64) -> out = act(1x1 [c | A] 128 -> cout = 64).  w_off: the five matrices in MFMA
+                          * fragment order, concatenated in that order; b_off: their biases (float32) likewise  */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */
@@ -483,6 +487,8 @@ int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const
                            const int32_t* slots, const int32_t* ages, const int32_t* sorted_idx, double age_penalty,
                            double* tlbr_out, uint8_t* lost_out);
 int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_done_out);
+/* 1 if FM_OP_CSPSTAGE exists for c channels / a bottleneck of mid channels (the table builder asks) */
+int fm_cspstage_supported(int c, int mid);
 /* LDS bytes FM_OP_LITECHAIN needs for c channels on h x w maps (<= 65536 to be launchable): the layer-table
  * builder decides with the same formula whether an OSNet block can use the chain kernel (no device needed) */
 size_t fm_litechain_lds_bytes(int c, int w, int h);

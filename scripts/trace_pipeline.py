@@ -20,7 +20,12 @@ import bench  # noqa: E402
 
 NAMES = {10: 'det: stream reaches the pass', 11: 'det: inputs ready, preprocessed', 12: 'det: network done',
          13: 'det: decode done', 20: 'post: begins', 21: 'post: ends', 30: 'copy(next): begins', 31: 'copy(next): ends',
-         32: 'reid: begins', 33: 'reid: ends', 40: 'lk: begins', 41: 'lk: ends'}
+         32: 'reid: begins', 33: 'reid: ends', 40: 'lk: begins', 41: 'lk: ends',
+         14: 'det: preprocess begins', 22: 'post: sort done', 23: 'post: bit matrix done', 34: 'reid: crops done',
+         35: 'reid: network done', 42: 'klt: pyramid begins', 43: 'klt: pyramid done', 44: 'klt: keypoint kernels begin',
+         45: 'klt: keypoint kernels done', 46: 'klt: background FAST begins', 47: 'klt: background FAST done',
+         50: 'kalman step begins', 51: 'kalman step done', 52: 'kalman update begins', 53: 'kalman update done',
+         54: 'assoc: pairwise begins', 55: 'assoc: pairwise done', 56: 'assoc: stage cost begins', 57: 'assoc: stage cost done'}
 
 
 def main():

@@ -522,3 +522,47 @@ def test_streaming_1x1_conv_equals_the_tiled_kernel(ctx, cin, cout, h, w, n, act
     ctx.set_option('conv1x1_stream', 0)
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+class _MiniV4(YOLO):
+    NUM_CLASSES = 2
+    INPUT_SHAPE = (3, 96, 160)
+    LAYER_FACTORS = [8, 16, 32]
+    SCALES = [1.2, 1.1, 1.05]
+    ANCHORS = [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146], [142, 110, 192, 243, 459, 401]]
+
+
+def _csp_graphs(monkeypatch):
+    out = []
+    for mode in ('0', '1'):
+        monkeypatch.setenv('FASTMOT_CSPSTAGE', mode)
+        g, heads = _MiniV4.build_graph(RandomWeights(seed=11))
+        out.append((g, heads))
+    from fastmot_amd.models import graph as G
+    assert not any(d['op'] == G.OP_CSPSTAGE for d in out[0][0].layers)
+    assert sum(d['op'] == G.OP_CSPSTAGE for d in out[1][0].layers) == 1
+    assert len(out[0][0].layers) == len(out[1][0].layers) + 3          # four launches -> one
+    return out
+
+
+def test_fused_csp_stage_equals_the_four_launches(ctx, monkeypatch):
+    """cspstage.hip: the first CSP stage of CSPDarknet53 in one launch -- head tensors BIT-identical to the table with the
+    four separate launches (same MFMA order, same fp16 rounding points), on a map whose edge tiles are ragged
+    (48 x 80 pixels at the stage: 6 x 10 tiles), graph replay included; and the fused table against PyTorch."""
+    (g0, h0), (g1, h1) = _csp_graphs(monkeypatch)
+    _, H, W = _MiniV4.INPUT_SHAPE
+    x = np.random.default_rng(5).uniform(0, 1, (1, H, W, 3)).astype(np.float16)
+    outs = []
+    for g, heads in ((g0, h0), (g1, h1)):
+        net = HipNet(ctx, NET_DETECTOR, g, 1, reuse_buffers=True)
+        for _ in range(2):
+            net.write(g.input, x)
+            net.run(1)
+        outs.append([net.read(h, 1) for h in heads])
+        net.close()
+    for a, b in zip(*outs):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        np.testing.assert_array_equal(a, b)
+    bufs, _ = torch_ref.run_graph(g1, nchw(x.astype(np.float32)))
+    for h, got in zip(h1, outs[1]):
+        close(got, nhwc(bufs[h.tid][:, h.coff:h.coff + h.c]), what='head behind the fused CSP stage')
