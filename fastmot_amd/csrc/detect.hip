@@ -405,9 +405,9 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
 // greedy scan in sorted order + final box filter (detector.py:356-364), one workgroup.  Chunk by chunk of 64
 // candidates: the bits "removed by an earlier survivor" of chunk c are the OR of mask word c over all SURVIVING rows
 // before the chunk -- a gather over the word-major mask.  Wavefronts 1..15 do all the memory work: the loads for chunk
-// c are issued (unconditionally, row indices clamped) during iteration c-2 and only looked at when iteration c begins,
-// when the survivors of every earlier chunk are known: two iterations of slack for the memory round trip, no register
-// rotation (two register sets used alternately, the loop is unrolled by two).  They publish removed(c) and the chunk's
+// c are issued (unconditionally, row indices clamped) during iteration c-3 and only looked at when iteration c begins,
+// when the survivors of every earlier chunk are known: three iterations of slack for the memory round trip (three
+// groups of wavefronts take turns, see below).  They publish removed(c) and the chunk's
 // own 64 x 64 diagonal block through LDS; wavefront 0 touches LDS only: it resolves the block in scalar registers
 // (lane b holds row b's word, one step per survivor).  Per chunk: two barriers, no memory round trip on the critical path.
 // History: 5.1 ms -> 68 us in round 3 (inside the pipeline; every chunk still waited for the loads it had just issued,
@@ -424,66 +424,87 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = min(counters[0], cap);
     const int kw = (K + 63) / 64;
-    constexpr int GU = 9;                    // 960 lanes x 9 rows = 8640 >= any capacity alloc_post admits
-    struct Set { uint64_t g[GU]; uint64_t dg; };
-    // loads for chunk x: word x of the rows before the chunk (the lane's share, clamped into them) + for wavefront 1
-    // the chunk's own diagonal block
-    auto issue = [&](int x, Set& t) {
-        const uint64_t* col = mask + (size_t)x * cap;
-        const int g = tid - 64, last = max(x * 64 - 1, 0);
+    // Two chunks (128 candidates) per iteration.  Wavefronts 1..15 form three groups of five (320 lanes); group g owns the
+    // iterations j = g (mod 3).  A group's loads for iteration j + 3 are issued right after it has published iteration j and
+    // are looked at three iterations later -- nothing else of that wavefront touches memory in between, so the compiler's own
+    // wait (it waits for everything outstanding) costs nothing and the round trip has three iterations' time.  (One group
+    // with alternating register sets did not get there: hipcc's wait counts across the loop's back edge fall to
+    // "everything outstanding".)  Per iteration the group publishes, for the chunks c0 = 2j and c1 = 2j + 1:
+    //   rem[0], rem[1]  OR of mask word c0 / c1 over the SURVIVING rows before chunk c0 (their fate is known by then),
+    //   d0, od, d1      the 64 x 64 blocks (rows of c0, word c0), (rows of c0, word c1), (rows of c1, word c1),
+    // and wavefront 0 -- LDS only -- resolves c0 in scalar registers, folds c0's survivors' rows of `od` into rem[1],
+    // resolves c1.  Two barriers per 128 candidates.
+    constexpr int GU = 8, GROWS = 320 * GU;  // rows whose loads are pipelined: 2560; beyond that (rare) they are fetched at use
+    const int grp = wave > 0 ? (wave - 1) % 3 : 0, gl = wave > 0 ? ((wave - 1) / 3) * 64 + lane : 0;
+    const int niter = (kw + 1) / 2;
+    struct Set { uint64_t g0[GU], g1[GU]; uint64_t d0, od, d1; };
+    auto issue = [&](int j, Set& t) {
+        const int c0 = 2 * j, c1 = min(2 * j + 1, kw - 1);
+        const uint64_t* col0 = mask + (size_t)c0 * cap;
+        const uint64_t* col1 = mask + (size_t)c1 * cap;
+        const int last = max(c0 * 64 - 1, 0);
 #pragma unroll
-        for (int u = 0; u < GU; ++u) t.g[u] = col[min(u * 960 + g, last)];
-        t.dg = col[min(x * 64 + lane, K - 1)];             // (rows beyond K are never looked at)
+        for (int u = 0; u < GU; ++u)
+            if (u == 0 || u * 320 <= last) {                                   // (uniform: only the rows that exist)
+                const int i = min(u * 320 + gl, last);
+                t.g0[u] = col0[i];
+                t.g1[u] = col1[i];
+            }
+        t.d0 = col0[min(c0 * 64 + lane, K - 1)];           // (rows beyond K are never looked at)
+        t.od = col1[min(c0 * 64 + lane, K - 1)];
+        t.d1 = col1[min(c1 * 64 + lane, K - 1)];
     };
-    auto reduce = [&](int x, const Set& t) {
-        uint64_t acc = 0;
-        const int g = tid - 64, lim = x * 64;
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int i = u * 960 + g;
-            // (branch-free: a select on a value still in flight is compiled into an exec-masked branch, behind which
-            // hipcc's wait counts fall back to "everything outstanding" -- including the other set's newer loads)
-            const uint64_t on = 0ull - (uint64_t)((i < lim ? 1u : 0u) & (uint32_t)((keep[min(i, lim - 1 < 0 ? 0 : lim - 1) >> 6] >> (i & 63)) & 1ull));
-            acc |= t.g[u] & on;
-        }
-        return acc;
+    auto alive = [&](int i, int lim) -> uint64_t {         // all ones iff row i < lim survived (branch-free)
+        return 0ull - (uint64_t)((i < lim ? 1u : 0u) & (uint32_t)((keep[min(i, lim - 1 < 0 ? 0 : lim - 1) >> 6] >> (i & 63)) & 1ull));
     };
     // barrier that waits for this wave's LDS traffic only: __syncthreads() would also drain the global loads in flight
-    // (its fence waits for vmcnt(0)) and expose their latency in every chunk
+    // (its fence waits for vmcnt(0)) and expose their latency in every iteration
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    __shared__ unsigned long long rem_word[2];             // removed bits of the chunk being resolved (double buffered)
-    __shared__ uint64_t diag[2][64];                       // its diagonal block: row b's word (double buffered)
-    if (tid < 2) rem_word[tid] = 0;
+    __shared__ unsigned long long rem_word[2][2];          // [iteration parity][c0, c1]: removed bits, double buffered
+    __shared__ uint64_t blocks[2][3][64];                  // [iteration parity][d0, od, d1][row]
+    if (tid < 4) rem_word[tid >> 1][tid & 1] = 0;
     __syncthreads();
     if (wave > 0) {
-        Set A, B;                                          // chunk c's loads live in A for even c, in B for odd c
-        if (kw > 0) issue(0, A);
-        if (kw > 1) issue(1, B);
-        auto step = [&](int c, Set& mine) {
-            const uint64_t r = reduce(c, mine);            // (waits for the loads issued two iterations ago)
-            if (r) atomicOr(&rem_word[c & 1], (unsigned long long)r);
-            if (wave == 1) diag[c & 1][lane] = mine.dg;
-            if (c + 2 < kw) issue(c + 2, mine);
+        Set mine;
+        if (grp < niter) issue(grp, mine);
+        int turn = grp;
+        for (int j = 0; j < niter; ++j) {
+            if (j == turn) {                               // (wave-uniform)
+                const int lim = 2 * j * 64;
+                uint64_t r0 = 0, r1 = 0;                   // (the first use waits for the loads issued three iterations ago)
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    if (u * 320 >= lim) break;             // (uniform)
+                    const uint64_t on = alive(u * 320 + gl, lim);
+                    r0 |= mine.g0[u] & on;
+                    r1 |= mine.g1[u] & on;
+                }
+                for (int i0 = GROWS; i0 < lim; i0 += 320) {                    // more than 2560 candidates: not pipelined
+                    const int i = i0 + gl;
+                    if (i < lim && ((keep[i >> 6] >> (i & 63)) & 1ull)) {
+                        r0 |= mask[(size_t)(2 * j) * cap + i];
+                        r1 |= mask[(size_t)min(2 * j + 1, kw - 1) * cap + i];
+                    }
+                }
+                if (r0) atomicOr(&rem_word[j & 1][0], (unsigned long long)r0);
+                if (r1) atomicOr(&rem_word[j & 1][1], (unsigned long long)r1);
+                if (wave <= 3) {
+                    blocks[j & 1][0][lane] = mine.d0;
+                    blocks[j & 1][1][lane] = mine.od;
+                    blocks[j & 1][2][lane] = mine.d1;
+                }
+                if (j + 3 < niter) issue(j + 3, mine);
+                turn += 3;
+            }
             lds_barrier();
             lds_barrier();
-        };
-        for (int c = 0; c < kw; c += 2) {
-            step(c, A);
-            if (c + 1 < kw) step(c + 1, B);
         }
     } else {
-        for (int c = 0; c < kw; ++c) {
-            lds_barrier();
-            const uint64_t rem_v = rem_word[c & 1];
-            const uint64_t dg = diag[c & 1][lane];
-            // (scalar registers from here on: wave-uniform bookkeeping)
-            uint64_t rem = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem_v) |
-                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rem_v >> 32)) << 32);
-            if (c == kw - 1 && (K & 63)) rem |= ~0ull << (K & 63);         // rows beyond K do not exist
-            // the lowest candidate not removed yet survives and removes its row's bits; repeat until none is left.  Only
-            // survivors whose row removes something INSIDE the chunk need a step of the serial loop (two v_readlane and a
-            // dependent scalar chain, ~100 cycles): the survivors between two of them are decided in one mask operation --
-            // where most candidates survive (the benchmark's scripted heads: ~1000 of 1555) that is 40 -> ~10 steps a chunk
+        // the lowest candidate not removed yet survives and removes its row's bits; repeat until none is left.  Only
+        // survivors whose row removes something INSIDE the chunk need a step of the serial loop (two v_readlane and a
+        // dependent scalar chain, ~100 cycles): the survivors between two of them are decided in one mask operation --
+        // where most candidates survive (the benchmark's scripted heads: ~1000 of 1555) that is 40 -> ~10 steps a chunk
+        auto resolve = [&](uint64_t rem, uint64_t dg) -> uint64_t {
             const uint64_t acts = __ballot(dg != 0);                           // rows that remove anything in this chunk
             uint64_t kept = 0;
             uint64_t avail = ~rem;
@@ -496,8 +517,34 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
                 kept |= avail & ((2ull << b) - 1ull);                          // b and the row-less survivors below it
                 avail &= ~row & (~1ull << b);                                  // rows only carry bits above b
             }
-            kept |= avail;
-            if (lane == 0) { keep[c] = kept; rem_word[c & 1] = 0; }
+            return kept | avail;
+        };
+        auto uniform64 = [](uint64_t v) -> uint64_t {                          // (scalar registers: wave-uniform bookkeeping)
+            return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+                   ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+        };
+        for (int j = 0; j < niter; ++j) {
+            lds_barrier();
+            const int c0 = 2 * j, c1 = 2 * j + 1;
+            const uint64_t d0 = blocks[j & 1][0][lane], od = blocks[j & 1][1][lane], d1 = blocks[j & 1][2][lane];
+            uint64_t rem0 = uniform64(rem_word[j & 1][0]);
+            if (c0 == kw - 1 && (K & 63)) rem0 |= ~0ull << (K & 63);           // rows beyond K do not exist
+            const uint64_t kept0 = resolve(rem0, d0);
+            uint64_t kept1 = 0;
+            if (c1 < kw) {
+                // chunk c0's survivors remove their rows' bits of word c1
+                if (((kept0 >> lane) & 1ull) && od) atomicOr(&rem_word[j & 1][1], (unsigned long long)od);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                uint64_t rem1 = uniform64(rem_word[j & 1][1]);
+                if (c1 == kw - 1 && (K & 63)) rem1 |= ~0ull << (K & 63);
+                kept1 = resolve(rem1, d1);
+            }
+            if (lane == 0) {
+                keep[c0] = kept0;
+                if (c1 < kw) keep[c1] = kept1;
+                rem_word[j & 1][0] = 0;
+                rem_word[j & 1][1] = 0;
+            }
             lds_barrier();
         }
     }
