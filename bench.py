@@ -259,10 +259,16 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
     for name, a, b in STAGE_TAGS:
         ta = np.sort(ms[tags == a].astype(np.float64))
         tb = np.sort(ms[tags == b].astype(np.float64))
-        n = min(len(ta), len(tb))
+        # An occurrence is the FIRST start mark since the previous end mark up to that end mark (both marks sit on one
+        # stream, in order).  Marks may repeat inside an occurrence -- a batch larger than the ReID network's maximum
+        # runs in chunks, each with its own crop / network marks -- so pairing the i-th start with the i-th end is wrong
+        # as soon as the counts differ (round 4's first config[4] table had a negative crop stage from exactly that).
+        first = np.searchsorted(ta, np.concatenate(([-np.inf], tb[:-1])), side='right')   # first start after the previous end
+        ok = (first < len(ta)) & (ta[np.minimum(first, len(ta) - 1)] <= tb) if len(ta) and len(tb) else np.zeros(0, bool)
+        n = int(ok.sum())
         if n < 4:
             continue
-        d = (tb[:n] - ta[:n])[n // 8:]                      # (the first steps of the window still fill the pipeline)
+        d = (tb[ok] - ta[first[ok]])[n // 8:]               # (the first steps of the window still fill the pipeline)
         us = float(np.median(d)) * 1e3
         per_step = n / n_steps
         bound, amount, what = work[a]

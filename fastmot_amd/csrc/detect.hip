@@ -280,9 +280,12 @@ __global__ __launch_bounds__(256) void rank_sort_lds_kernel(const float* __restr
     // two 64-bit compares, add -- is latency bound, more wavefronts hide it)
     if ((int)blockIdx.x * 64 >= K) return;
     const int Kp = (K + 7) & ~7;                                  // (padding keys rank last)
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    // this lane's own row is fetched together with the keys (one memory round trip for both, the kernel is a chain of them)
+    const float* ri = cand + (size_t)min(i, K - 1) * 8;
+    const float4 r0 = *reinterpret_cast<const float4*>(ri), r1 = *reinterpret_cast<const float4*>(ri + 4);
     for (int j = threadIdx.x; j < Kp; j += 256) all_keys[j] = j < K ? sort_key(cand + (size_t)j * 8) : ~0ull;
     __syncthreads();
-    const int i = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
     const uint64_t ki = all_keys[min(i, Kp - 1)];
     int rank = 0;
     const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(all_keys) + q * (Kp / 8);
@@ -294,9 +297,7 @@ __global__ __launch_bounds__(256) void rank_sort_lds_kernel(const float* __restr
     rank += __shfl_xor(rank, 1);
     rank += __shfl_xor(rank, 2);
     if (i >= K || q != 0) return;
-    const float* ri = cand + (size_t)i * 8;
     float* o = sorted + (size_t)rank * 8;
-    const float4 r0 = *reinterpret_cast<const float4*>(ri), r1 = *reinterpret_cast<const float4*>(ri + 4);
     *reinterpret_cast<float4*>(o) = r0;
     *reinterpret_cast<float4*>(o + 4) = r1;
 }
@@ -328,78 +329,83 @@ __device__ __forceinline__ bool diou_suppresses(const float* a, const float* b, 
     return !(diou <= thresh);
 }
 
-// mask[w][i] bit b = candidate j = 64*w + b (j > i, same class) is suppressed by i.  One workgroup per block of 64
-// rows (lane = row) and 4 column words (one per wavefront), the 64 column boxes of a word staged in LDS.  Workgroups
-// beyond K exit at once (the grid is sized for the capacity, K is only known on the device).
+// mask[w][i] bit b = candidate j = 64*w + b (j > i, same class) is suppressed by i.  A task is one 64 x 64 block of the
+// upper triangle (rows rb*64.., column word w >= rb); a workgroup takes tasks blockIdx.x, + gridDim.x, ...  (the grid
+// is fixed, K is only known on the device).  Inside a task lane = row, and each of the four wavefronts tests 16 of the 64
+// columns (staged in LDS once per task) and writes its quarter of the mask word: the per-lane loop over the columns is a
+// dependent chain of ~60 instructions per column with divergent exits -- a quarter of it per wavefront and four times
+// the wavefronts (1300 for the benchmark's 1555 candidates, the chip has 1024 SIMDs) took the kernel from 24 to 15 us
+// inside the pipeline.
+constexpr int NMS_MASK_GRID = 1024;
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ sorted,
                                                        const int32_t* __restrict__ counters, int cap,
                                                        double thresh, uint64_t* __restrict__ mask) {
     __builtin_amdgcn_s_setprio(3);
     const int K = min(counters[0], cap);
-    const int rb = blockIdx.x;
     const int kw = (K + 63) / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int w = rb + blockIdx.y * 4 + wave;           // this wavefront's column word
-    if (rb * 64 >= K || w >= kw) return;
-    const int i = rb * 64 + lane;
-    __shared__ float cols[4][64][8];
-    float a[8];
-    {
-        const int ii = min(i, K - 1);
-        const float4 r0 = *reinterpret_cast<const float4*>(sorted + (size_t)ii * 8);
-        const float4 r1 = *reinterpret_cast<const float4*>(sorted + (size_t)ii * 8 + 4);
-        a[0] = r0.x; a[1] = r0.y; a[2] = r0.z; a[3] = r0.w; a[4] = r1.x; a[5] = r1.y; a[6] = r1.z; a[7] = r1.w;
-    }
-    {
-        const int j = w * 64 + lane;
-        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-        if (j < K) {
-            c0 = *reinterpret_cast<const float4*>(sorted + (size_t)j * 8);
-            c1 = *reinterpret_cast<const float4*>(sorted + (size_t)j * 8 + 4);
-        }
-        *reinterpret_cast<float4*>(&cols[wave][lane][0]) = c0;
-        *reinterpret_cast<float4*>(&cols[wave][lane][4]) = c1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (i >= K) return;
-    uint64_t bits = 0;
-    const int nb = min(64, K - w * 64);
-    const float a_x1 = a[0] + a[2], a_y1 = a[1] + a[3], a_area = a[2] * a[3];
+    const int ntask = kw * (kw + 1) / 2;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    __shared__ float cols[64][8];
     const float cut = (float)thresh - 1e-3f;            // slack far above the float32 error of the estimate below
-    for (int b = 0; b < nb; ++b) {
-        if (w * 64 + b <= i) continue;
-        const float* cb = cols[wave][b];
-        if (cb[5] != a[5]) continue;
-        // float32 estimate of the IoU (the +1 pixel convention of rect.py included): DIoU <= IoU, so a pair whose
-        // estimate stays clearly below the threshold cannot be suppressed; only the rest pays for the exact float64
-        // arithmetic (and its pow) of the reference
-        const float iw = fminf(a_x1, cb[0] + cb[2]) - fmaxf(a[0], cb[0]);
-        const float ih = fminf(a_y1, cb[1] + cb[3]) - fmaxf(a[1], cb[1]);
-        if (iw <= 0.f || ih <= 0.f) continue;
-        const float inter = iw * ih;
-        const float uni = a_area + cb[2] * cb[3] - inter;
-        if (inter <= cut * uni) continue;
-        // second stage, still float32: the whole DIoU = IoU - (d / c)^0.6 with the hardware log2 / exp2 (centre
-        // distance d and enclosing diagonal c as in rect.py:231-240; the -1 / +1 of the pixel convention cancel in
-        // both).  Its error is a few 1e-6 absolute; a pair is decided here when the estimate is 1e-4 or more away
-        // from the threshold, and only the rest -- a handful per frame -- pays for the reference's float64 arithmetic
-        // and its pow().  In the dense regime of the benchmark (1500 candidates -> a handful) nearly every pair that
-        // passes the IoU pre-test used to take that path: ~10^6 float64 pow() per frame.
+    for (int t = blockIdx.x; t < ntask; t += gridDim.x) {
+        // t = w (w + 1) / 2 + rb, 0 <= rb <= w
+        int w = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+        while (w * (w + 1) / 2 > t) --w;
+        while ((w + 1) * (w + 2) / 2 <= t) ++w;
+        const int rb = t - w * (w + 1) / 2;
+        const int i = rb * 64 + lane;
+        float a[8];
         {
-            const float b_x1 = cb[0] + cb[2], b_y1 = cb[1] + cb[3];
-            const float ew = fmaxf(a_x1, b_x1) - fminf(a[0], cb[0]), eh = fmaxf(a_y1, b_y1) - fminf(a[1], cb[1]);
-            const float dx = 0.5f * ((a[0] + a_x1) - (cb[0] + b_x1)), dy = 0.5f * ((a[1] + a_y1) - (cb[1] + b_y1));
-            const float q = (dx * dx + dy * dy) / (ew * ew + eh * eh);
-            const float est = inter / uni - (q > 0.f ? __builtin_amdgcn_exp2f(0.6f * __builtin_amdgcn_logf(q)) : 0.f);
-            if (est > (float)thresh + 1e-4f) { bits |= (1ull << b); continue; }
-            if (est < (float)thresh - 1e-4f) continue;
-            // (a NaN estimate -- degenerate boxes -- fails both comparisons and takes the exact path)
+            const int ii = min(i, K - 1);
+            const float4 r0 = *reinterpret_cast<const float4*>(sorted + (size_t)ii * 8);
+            const float4 r1 = *reinterpret_cast<const float4*>(sorted + (size_t)ii * 8 + 4);
+            a[0] = r0.x; a[1] = r0.y; a[2] = r0.z; a[3] = r0.w; a[4] = r1.x; a[5] = r1.y; a[6] = r1.z; a[7] = r1.w;
         }
-        if (diou_suppresses(a, cb, thresh)) bits |= (1ull << b);
+        if (threadIdx.x < 128) {                        // 64 columns x two float4
+            const int j = min(w * 64 + (threadIdx.x >> 1), K - 1);
+            *reinterpret_cast<float4*>(&cols[threadIdx.x >> 1][(threadIdx.x & 1) * 4]) =
+                *reinterpret_cast<const float4*>(sorted + (size_t)j * 8 + (threadIdx.x & 1) * 4);
+        }
+        __syncthreads();
+        uint32_t bits = 0;
+        const int b0 = q * 16, nb = min(16, K - w * 64 - b0);
+        const float a_x1 = a[0] + a[2], a_y1 = a[1] + a[3], a_area = a[2] * a[3];
+        for (int bb = 0; bb < nb; ++bb) {
+            const int b = b0 + bb;
+            if (w * 64 + b <= i) continue;
+            const float* cb = cols[b];
+            if (cb[5] != a[5]) continue;
+            // float32 estimate of the IoU (the +1 pixel convention of rect.py included): DIoU <= IoU, so a pair whose
+            // estimate stays clearly below the threshold cannot be suppressed; only the rest pays for the exact float64
+            // arithmetic (and its pow) of the reference
+            const float iw = fminf(a_x1, cb[0] + cb[2]) - fmaxf(a[0], cb[0]);
+            const float ih = fminf(a_y1, cb[1] + cb[3]) - fmaxf(a[1], cb[1]);
+            if (iw <= 0.f || ih <= 0.f) continue;
+            const float inter = iw * ih;
+            const float uni = a_area + cb[2] * cb[3] - inter;
+            if (inter <= cut * uni) continue;
+            // second stage, still float32: the whole DIoU = IoU - (d / c)^0.6 with the hardware log2 / exp2 (centre
+            // distance d and enclosing diagonal c as in rect.py:231-240; the -1 / +1 of the pixel convention cancel in
+            // both).  Its error is a few 1e-6 absolute; a pair is decided here when the estimate is 1e-4 or more away
+            // from the threshold, and only the rest -- a handful per frame -- pays for the reference's float64 arithmetic
+            // and its pow().  In the dense regime of the benchmark (1500 candidates) nearly every pair that passes the
+            // IoU pre-test used to take that path: ~10^6 float64 pow() per frame.
+            {
+                const float b_x1 = cb[0] + cb[2], b_y1 = cb[1] + cb[3];
+                const float ew = fmaxf(a_x1, b_x1) - fminf(a[0], cb[0]), eh = fmaxf(a_y1, b_y1) - fminf(a[1], cb[1]);
+                const float dx = 0.5f * ((a[0] + a_x1) - (cb[0] + b_x1)), dy = 0.5f * ((a[1] + a_y1) - (cb[1] + b_y1));
+                const float qq = (dx * dx + dy * dy) / (ew * ew + eh * eh);
+                const float est = inter / uni - (qq > 0.f ? __builtin_amdgcn_exp2f(0.6f * __builtin_amdgcn_logf(qq)) : 0.f);
+                if (est > (float)thresh + 1e-4f) { bits |= (1u << bb); continue; }
+                if (est < (float)thresh - 1e-4f) continue;
+                // (a NaN estimate -- degenerate boxes -- fails both comparisons and takes the exact path)
+            }
+            if (diou_suppresses(a, cb, thresh)) bits |= (1u << bb);
+        }
+        // word-major (the scan reads a word of many rows at once); this wavefront's 16 bits of the word
+        if (i < K) reinterpret_cast<uint16_t*>(mask)[((size_t)w * cap + i) * 4 + q] = (uint16_t)bits;
+        __syncthreads();                                // (cols is reused by the next task)
     }
-    mask[(size_t)w * cap + i] = bits;                   // word-major: the scan reads a word of many rows at once
 }
 
 // greedy scan in sorted order + final box filter (detector.py:356-364), one workgroup.  Chunk by chunk of 64
@@ -848,7 +854,7 @@ static int enqueue_general_post(fm_ctx* ctx, DetState* d, int slot, hipStream_t 
         if (rc) return rc;
     }
     fm_trace_mark(ctx, sp, 22);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, (cap / 64 + 3) / 4), dim3(256), 0, sp, d->sorted[slot],
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(std::min(NMS_MASK_GRID, (cap / 64) * (cap / 64 + 1) / 2)), dim3(256), 0, sp, d->sorted[slot],
                        d->counters[slot], cap, d->cfg.nms_thresh, d->mask[slot]);
     fm_trace_mark(ctx, sp, 23);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), sizeof(uint64_t) * (cap / 64), sp, d->sorted[slot],

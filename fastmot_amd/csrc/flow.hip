@@ -46,8 +46,9 @@ struct FlowState {
     int nT = 0, rect_cap = 0;
     int32_t* rects = nullptr;                       // [nT][4] inclusive integer rects
     DevBuf tgt_in, tgt_out, det_in, det_out, lk_in, lk_out, bg_out;
-    float* eig = nullptr;                           // scratch for GFTT
-    size_t eig_cap = 0;
+    unsigned long long* eig = nullptr;              // GFTT scratch: local-maximum keys, 1024 slots per tile (eig_cap tiles)
+    uint2* tile_stat = nullptr;                     // per tile: maximum bits, key count (eig_cap entries)
+    size_t eig_cap = 0;                             // capacity in tiles
     int32_t* ov_idx = nullptr;                      // overlap lists (earlier rects intersecting rect k)
     int32_t* ov_off = nullptr;
     int ov_cap = 0;
@@ -73,7 +74,7 @@ void fm_flow_free(FlowState* f) {
     for (int st = 0; st < 2; ++st)
         for (int l = 0; l < MAX_LEVELS; ++l)
             if (f->deriv[st][l]) (void)hipFree(f->deriv[st][l]);
-    for (void* p : {(void*)f->bg_img, (void*)f->rects, (void*)f->eig, (void*)f->ov_idx, (void*)f->ov_off, (void*)f->bg_flags,
+    for (void* p : {(void*)f->bg_img, (void*)f->rects, (void*)f->eig, (void*)f->tile_stat, (void*)f->ov_idx, (void*)f->ov_off, (void*)f->bg_flags,
                     (void*)f->lk_diag, (void*)f->lk_cap, (void*)f->lk_cap_hdr})
         if (p) (void)hipFree(p);
     for (DevBuf* b : {&f->tgt_in, &f->tgt_out, &f->det_in, &f->det_out, &f->lk_in, &f->lk_out, &f->bg_out})
@@ -982,7 +983,25 @@ __global__ __launch_bounds__(PREP_BLK) FM_SGPR_CAP void prepare_kernel(const int
     auto covered = [&](int x, int y) { return in_lds ? covered_lds(s_ov, cnt, x, y) : covered_by(rects, list, cnt, x, y); };
     int c = 0, kept = 0;
     if (cnt == 0) c = tid == 0 ? w * h : 0;
-    else {
+    else if (in_lds) {
+        // uncovered pixels, 64 columns of one row per step: OR of the column ranges of the rects that cross the row
+        // (the per-pixel loop below is h * w * cnt rect tests: 95 us for the 300 tracks of a 4K stream)
+        const int nwords = (w + 63) >> 6;
+        const float inv_nw = 1.f / (float)nwords;
+        for (int q = tid; q < h * nwords; q += PREP_BLK) {
+            const int yy = fast_div(q, nwords, inv_nw), wd = q - yy * nwords;
+            const int y = r1 + yy, xa = r0 + wd * 64;
+            const int nbits = min(64, w - wd * 64);
+            unsigned long long bits = 0ull;
+            for (int j = 0; j < cnt; ++j) {
+                const int4 rr = *reinterpret_cast<const int4*>(s_ov + 4 * j);
+                const int lo = max(rr.x - xa, 0), hi = min(rr.z - xa, 63);          // inclusive bit range
+                if (y >= rr.y && y <= rr.w && lo <= hi) bits |= (~0ull >> (63 - hi)) & (~0ull << lo);
+            }
+            const unsigned long long valid = nbits == 64 ? ~0ull : ((1ull << nbits) - 1ull);
+            c += __popcll(~bits & valid);
+        }
+    } else {
         const float inv_w = 1.f / (float)w;
         for (int i = tid; i < w * h; i += PREP_BLK) {
             const int y = fast_div(i, w, inv_w), x = i - y * w;
@@ -1033,35 +1052,174 @@ __device__ __forceinline__ void sobel_at(const uint8_t* img, int stride, const C
     dy = gy * scale;
 }
 
-__global__ FM_SGPR_CAP void eig_kernel(const uint8_t* __restrict__ img, int stride, const CropArgs* __restrict__ crops,
-                           float* __restrict__ eig, int block_size, const uint8_t* __restrict__ needy) {
-    const CropArgs c = crops[blockIdx.y];
+// One pass over a crop does everything of goodFeaturesToTrack that is per pixel: the min-eigenvalue map (never stored),
+// its masked maximum and the 3 x 3 local maxima among the unmasked pixels -- the only pixels the selection below can
+// pick, whatever the threshold (quality * maximum) turns out to be.  A workgroup owns 32 x 32 pixels (four per lane; with
+// 32 x 8 the kernel was bound by the chain of dependent loads every workgroup starts with -- crop, overlap list, rects,
+// pixels -- times the 60000 workgroups of a 4K frame with 300 tracks: 213 us): Sobel pair once per
+// position of the haloed tile into LDS, box sums for the tile and a one-pixel ring (the local-maximum test), then per
+// tile (tile T of the crop is tile c.eig_off + T of the call):
+//   tile_stat[..].x   float bits of the tile's masked maximum (0 if none: the reference's maximum starts at 0 too)
+//   tile_stat[..].y   number of local maxima, their keys (value bits << 32 | raster index) in cand[1024 * tile + 0 ..]
+// (the order of the keys does not matter: they are unique and get sorted).  No atomics: a first version appended to one
+// list per crop and kept one maximum per crop with device-scope atomics -- 1600 of them on the same two addresses per
+// crop, 640 us for the kernel.  Round 3 computed nine Sobel pairs per pixel (81 loads, 54 border reflections), stored
+// the map, and the selection kernel scanned it twice with one workgroup per track: at 4K / 300 tracks 311 us + ~190 of
+// the selection's 413 us.  Same values, same order of additions (rows inside, then down): bit-identical maps, so the
+// same corners.
+constexpr int EIG_TW = 32, EIG_TH = 32, EIG_TPX = EIG_TW * EIG_TH;
+template <int R>
+__global__ __launch_bounds__(256) FM_SGPR_CAP void eig_cand_kernel(const uint8_t* __restrict__ img, int stride,
+                                                                   const CropArgs* __restrict__ crops,
+                                                                   const int32_t* __restrict__ rects, Overlaps ov,
+                                                                   const uint8_t* __restrict__ needy,
+                                                                   uint2* __restrict__ tile_stat,
+                                                                   unsigned long long* __restrict__ cand) {
+    const int t = blockIdx.y, tid = threadIdx.x;
+    const CropArgs c = crops[t];
     if (needy && !needy[c.k]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.w * c.h) return;
-    const int y = fast_div(i, c.w, 1.f / (float)c.w), x = i - y * c.w;
-    const float scale = 1.f / (4.f * block_size * 255.f);
-    float sxx = 0.f, sxy = 0.f, syy = 0.f;
-    const int r = block_size / 2;
-    for (int j = -r; j <= r; ++j) {
-        float rxx = 0.f, rxy = 0.f, ryy = 0.f;
-        for (int ii = -r; ii <= r; ++ii) {
+    const int tiles_x = (c.w + EIG_TW - 1) / EIG_TW, tiles_y = (c.h + EIG_TH - 1) / EIG_TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * EIG_TW, y0 = ty * EIG_TH;
+    constexpr int EW = EIG_TW + 2, EH = EIG_TH + 2, HW = EW + 2 * R, HH = EH + 2 * R, BS = 2 * R + 1;
+    __shared__ float2 s_d[HH * HW];
+    __shared__ float s_e[EH * EW];
+    __shared__ __attribute__((aligned(16))) int s_ov[4 * OV_LDS];
+    const int32_t* list = ov.idx + ov.off[c.k];
+    const int lcnt = ov.off[c.k + 1] - ov.off[c.k];
+    const bool ov_lds = lcnt <= OV_LDS;
+    if (ov_lds && tid < 4 * lcnt) s_ov[tid] = rects[4 * list[tid >> 2] + (tid & 3)];
+    // map values wanted: the tile and one ring around it, inside the crop; Sobel pairs: R further (reflected at the crop edge)
+    const int ex_lo = max(x0 - 1, 0), ex_hi = min(x0 + EIG_TW + 1, c.w);
+    const int ey_lo = max(y0 - 1, 0), ey_hi = min(y0 + EIG_TH + 1, c.h);
+    const float scale = 1.f / (4.f * BS * 255.f);
+    for (int q = tid; q < HH * HW; q += 256) {
+        const int hy = q / HW, hx = q - hy * HW;
+        const int px = x0 - 1 - R + hx, py = y0 - 1 - R + hy;
+        if (px >= ex_lo - R && px < ex_hi + R && py >= ey_lo - R && py < ey_hi + R) {
             float dx, dy;
-            sobel_at(img, stride, c, reflect101(x + ii, c.w), reflect101(y + j, c.h), scale, dx, dy);
-            rxx += dx * dx; rxy += dx * dy; ryy += dy * dy;
+            if (px >= 1 && px < c.w - 1 && py >= 1 && py < c.h - 1) {
+                // inside the crop nothing is reflected (eight reflections with their loops were two thirds of the
+                // instructions of a position)
+                const uint8_t* r0 = img + (size_t)(c.y0 + py - 1) * stride + c.x0 + px - 1;
+                const uint8_t* r1 = r0 + stride;
+                const uint8_t* r2 = r1 + stride;
+                const int v00 = r0[0], v01 = r0[1], v02 = r0[2], v10 = r1[0], v12 = r1[2], v20 = r2[0], v21 = r2[1], v22 = r2[2];
+                dx = (float)((v02 + 2 * v12 + v22) - (v00 + 2 * v10 + v20)) * scale;
+                dy = (float)((v20 + 2 * v21 + v22) - (v00 + 2 * v01 + v02)) * scale;
+            } else {
+                sobel_at(img, stride, c, reflect101(px, c.w), reflect101(py, c.h), scale, dx, dy);
+            }
+            s_d[q] = make_float2(dx, dy);
         }
-        sxx += rxx; sxy += rxy; syy += ryy;
     }
-    const float a = sxx * 0.5f, b = sxy, cc = syy * 0.5f;
-    eig[c.eig_off + i] = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+    __syncthreads();
+    // the mask of the tile, one 32-bit word per row (bit = covered by an earlier track's rect): one lane per row walks
+    // the rect list once instead of every pixel walking it
+    __shared__ uint32_t s_rowmask[EIG_TH];
+    if (ov_lds && lcnt && tid >= 256 - EIG_TH) {
+        const int row = tid - (256 - EIG_TH), yy = c.y0 + y0 + row, xa = c.x0 + x0;
+        uint32_t bits = 0u;
+        for (int j = 0; j < lcnt; ++j) {
+            const int4 rr = *reinterpret_cast<const int4*>(s_ov + 4 * j);
+            const int lo = max(rr.x - xa, 0), hi = min(rr.z - xa, EIG_TW - 1);      // inclusive bit range
+            if (yy >= rr.y && yy <= rr.w && lo <= hi) bits |= (~0u >> (31 - hi)) & (~0u << lo);
+        }
+        s_rowmask[row] = bits;
+    }
+    for (int q = tid; q < EH * EW; q += 256) {
+        const int ey = q / EW, ex = q - ey * EW;
+        const int cx = x0 - 1 + ex, cy = y0 - 1 + ey;
+        if (cx < ex_lo || cx >= ex_hi || cy < ey_lo || cy >= ey_hi) continue;
+        float sxx = 0.f, sxy = 0.f, syy = 0.f;
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+            float rxx = 0.f, rxy = 0.f, ryy = 0.f;
+#pragma unroll
+            for (int ii = 0; ii < BS; ++ii) {
+                const float2 d = s_d[(ey + j) * HW + ex + ii];
+                rxx += d.x * d.x; rxy += d.x * d.y; ryy += d.y * d.y;
+            }
+            sxx += rxx; sxy += rxy; syy += ryy;
+        }
+        const float a = sxx * 0.5f, b = sxy, cc = syy * 0.5f;
+        s_e[q] = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+    }
+    __syncthreads();
+    // a lane's pixels: column lx of rows ly, ly + 8, ...
+    constexpr int NR = EIG_TH / 8;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lx = tid & (EIG_TW - 1), ly = tid / EIG_TW;
+    const int x = x0 + lx;
+    __shared__ float s_wmax[4];
+    __shared__ int s_wcnt[NR * 4];
+    float m = 0.f;
+    float val[NR];
+    unsigned long long bal[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int yl = ly + 8 * k, y = y0 + yl;
+        const bool valid = x < c.w && y < c.h;
+        const float* ec = s_e + (yl + 1) * EW + lx + 1;
+        const float v = valid ? *ec : 0.f;
+        bool open = valid && v > 0.f;               // (the masked maximum starts at 0; a candidate is > threshold >= 0)
+        if (open && lcnt)
+            open = !(ov_lds ? (bool)((s_rowmask[yl] >> lx) & 1u) : covered_by(rects, list, lcnt, c.x0 + x, c.y0 + y));
+        m = fmaxf(m, open ? v : 0.f);
+        // val >= its 8 neighbours (dilate inside the crop), 1-px border skipped
+        bool emit = open && x >= 1 && y >= 1 && x < c.w - 1 && y < c.h - 1;
+        if (emit) {
+#pragma unroll
+            for (int j = -1; j <= 1; ++j)
+#pragma unroll
+                for (int ii = -1; ii <= 1; ++ii)
+                    if (ec[j * EW + ii] > v) emit = false;
+        }
+        val[k] = emit ? v : 0.f;                    // (an emitted value is > 0)
+        bal[k] = __ballot(emit);
+        if (lane == 0) s_wcnt[k * 4 + wave] = __popcll(bal[k]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) s_wmax[wave] = m;
+    __syncthreads();
+    const size_t tile = c.eig_off + blockIdx.x;
+    int before = 0;                                 // keys of the (row group, wavefront) pairs ahead of this one
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        for (int q = 0; q < wave; ++q) before += s_wcnt[k * 4 + q];
+        if (val[k] > 0.f)
+            cand[tile * EIG_TPX + before + __popcll(bal[k] & ((1ull << lane) - 1ull))] =
+                ((unsigned long long)__float_as_uint(val[k]) << 32) | (unsigned)((y0 + ly + 8 * k) * c.w + x);
+        for (int q = wave; q < 4; ++q) before += s_wcnt[k * 4 + q];
+    }
+    if (tid == 0)
+        tile_stat[tile] = make_uint2(__float_as_uint(fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]))),
+                                     (unsigned)before);
 }
 
-// one block per needy track: masked max -> threshold -> 3x3 local maxima -> bitonic sort in LDS ->
-// min-distance selection on a cell grid (cell = minDistance, <= 4 accepted corners per cell, the
-// same 3x3-cell neighbourhood test as featureselect.cpp) -> ellipse filter.
-// The min-eigenvalue crop is staged in LDS first (one coalesced pass; the two scans below read every value
-// ten times): with the map in global memory the scans were a chain of dependent L2 round trips per
-// iteration and the kernel took 180-330 us on the benchmark crops.
+// tiles of a crop / of the largest crop (grid.x of eig_cand_kernel)
+static int eig_tiles(const CropArgs& c) { return ((c.w + EIG_TW - 1) / EIG_TW) * ((c.h + EIG_TH - 1) / EIG_TH); }
+static int eig_max_tiles(const std::vector<CropArgs>& crops) {
+    int m = 0;
+    for (const CropArgs& c : crops) m = std::max(m, eig_tiles(c));
+    return m;
+}
+static void launch_eig(hipStream_t s, const uint8_t* img, int stride, const CropArgs* d_crops, int n, int max_tiles,
+                       const int32_t* rects, Overlaps ov, int block_size, const uint8_t* needy, uint2* tile_stat,
+                       unsigned long long* cand) {
+    if (block_size == 3)
+        hipLaunchKernelGGL(eig_cand_kernel<1>, dim3(max_tiles, n), dim3(256), 0, s, img, stride, d_crops, rects, ov, needy,
+                           tile_stat, cand);
+    else   // (fm_flow_configure admits 3 and 5)
+        hipLaunchKernelGGL(eig_cand_kernel<2>, dim3(max_tiles, n), dim3(256), 0, s, img, stride, d_crops, rects, ov, needy,
+                           tile_stat, cand);
+}
+
+// one block per needy track: threshold (quality * the crop's masked maximum) over the crop's local maxima -- both
+// from eig_cand_kernel -> sort in LDS -> min-distance selection on a cell grid (cell = minDistance, <= 4 accepted corners
+// per cell, the same 3x3-cell neighbourhood test as featureselect.cpp) -> ellipse filter.
 #ifdef FM_GFTT_TIMING
 __device__ long long g_gftt_stamps[64][8];
 #define GFTT_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 64) g_gftt_stamps[blockIdx.x][i] = __builtin_readcyclecounter();
@@ -1073,15 +1231,15 @@ constexpr int GFTT_MAX_CELLS = 1536;     // x 4 slots x 4 B = 24 KB
 constexpr int GFTT_BLK = 1024;
 
 __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const CropArgs* __restrict__ crops,
-                                                               const int32_t* __restrict__ rects, Overlaps ov,
-                                                               const float* __restrict__ eig, float quality,
+                                                               const uint2* __restrict__ tile_stat,
+                                                               const unsigned long long* __restrict__ cand, float quality,
                                                                int max_corners, const int32_t* __restrict__ min_dist,
                                                                const double* __restrict__ full_tlbr,
                                                                float* __restrict__ pts_out, int cap,
                                                                int32_t* __restrict__ counts,
                                                                const uint8_t* __restrict__ needy,
                                                                int32_t* __restrict__ compact_total,
-                                                               int32_t* __restrict__ compact_off, int eig_lds_floats) {
+                                                               int32_t* __restrict__ compact_off) {
     const int t = blockIdx.x, tid = threadIdx.x;
     const CropArgs c = crops[t];
     if (needy && !needy[c.k]) {            // enough propagated keypoints: nothing to detect
@@ -1091,64 +1249,47 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
         }
         return;
     }
-    extern __shared__ __attribute__((aligned(16))) float s_eig[];
     GFTT_STAMP(0)
-    const int npx = c.w * c.h;
-    const bool staged = npx <= eig_lds_floats;
-    const float* eg = eig + c.eig_off;
-    if (staged)
-        for (int i = tid; i < npx; i += GFTT_BLK) s_eig[i] = eg[i];
-    const float* e = staged ? s_eig : eg;
-    const int32_t* list = ov.idx + ov.off[c.k];
-    const int lcnt = ov.off[c.k + 1] - ov.off[c.k];
-    __shared__ __attribute__((aligned(16))) int s_ov[4 * OV_LDS];
-    const bool ov_lds = lcnt <= OV_LDS;
-    if (ov_lds && tid < 4 * lcnt) s_ov[tid] = rects[4 * list[tid >> 2] + (tid & 3)];
-    __shared__ float red[GFTT_BLK];
     __shared__ int s_n;
     __shared__ unsigned long long keys[GFTT_MAX_CAND];
     __shared__ __attribute__((aligned(16))) int cells[GFTT_MAX_CELLS * 4];
-    __syncthreads();
-    auto covered = [&](int x, int y) {
-        return ov_lds ? covered_lds(s_ov, lcnt, x, y) : covered_by(rects, list, lcnt, x, y);
-    };
+    __shared__ float s_red[GFTT_BLK / 64];
+    __shared__ int s_tcnt[GFTT_BLK];
     const float inv_w = 1.f / (float)c.w;
-    // masked maximum (minMaxLoc with mask)
-    float mx = 0.f;
-    for (int i = tid; i < npx; i += GFTT_BLK) {
-        if (lcnt == 0) mx = fmaxf(mx, e[i]);
-        else {
-            const int y = fast_div(i, c.w, inv_w), x = i - y * c.w;
-            if (!covered(c.x0 + x, c.y0 + y)) mx = fmaxf(mx, e[i]);
-        }
-    }
-    red[tid] = mx;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    for (int off = GFTT_BLK / 2; off > 0; off >>= 1) {
-        if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+    const int ntiles = ((c.w + EIG_TW - 1) / EIG_TW) * ((c.h + EIG_TH - 1) / EIG_TH);   // (tiles of eig_cand_kernel)
+    const uint2* ts = tile_stat + c.eig_off;
+    // (minMaxLoc with mask) * qualityLevel
+    {
+        float m = 0.f;
+        for (int q = tid; q < ntiles; q += GFTT_BLK) m = fmaxf(m, __uint_as_float(ts[q].x));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((tid & 63) == 0) s_red[tid >> 6] = m;
+        if (tid == 0) s_n = 0;
         __syncthreads();
     }
-    const float thr = red[0] * quality;
-    __syncthreads();
+    float mx = 0.f;
+#pragma unroll
+    for (int q = 0; q < GFTT_BLK / 64; ++q) mx = fmaxf(mx, s_red[q]);
+    const float thr = mx * quality;
     GFTT_STAMP(1)
-    // candidates: val > thr, val >= 8 neighbours (dilate inside the crop), mask set, 1-px border skipped.
-    // key = (float bits of val << 32) | raster index : descending 64-bit order == (val desc, index desc),
-    // the order of std::sort(..., greaterThanPtr) in featureselect.cpp
-    for (int i = tid; i < npx; i += GFTT_BLK) {
-        const float v = e[i];
-        if (!(v > thr) || v == 0.f) continue;
-        const int y = fast_div(i, c.w, inv_w), x = i - y * c.w;
-        if (x < 1 || y < 1 || x >= c.w - 1 || y >= c.h - 1) continue;
-        bool is_max = true;
-#pragma unroll
-        for (int j = -1; j <= 1; ++j)
-#pragma unroll
-            for (int ii = -1; ii <= 1; ++ii)
-                if (e[i + j * c.w + ii] > v) is_max = false;
-        if (!is_max || (lcnt && covered(c.x0 + x, c.y0 + y))) continue;
-        const int slot = atomicAdd(&s_n, 1);
-        if (slot < GFTT_MAX_CAND) keys[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
+    // candidates: local maxima with val > thr.  key = (float bits of val << 32) | raster index : descending 64-bit
+    // order == (val desc, index desc), the order of std::sort(..., greaterThanPtr) in featureselect.cpp
+    for (int base = 0; base < ntiles; base += GFTT_BLK) {
+        __syncthreads();
+        s_tcnt[tid] = base + tid < ntiles ? (int)ts[base + tid].y : 0;
+        __syncthreads();
+        const int nt = min(GFTT_BLK, ntiles - base);
+        for (int q = tid; q < nt * 64; q += GFTT_BLK) {                   // 64 slots per tile and step; a tile rarely has more
+            const int tl = q >> 6, cnt = s_tcnt[tl];
+            const unsigned long long* cl = cand + (c.eig_off + base + tl) * EIG_TPX;
+            for (int e = q & 63; e < cnt; e += 64) {
+                const unsigned long long k = cl[e];
+                if (!(__uint_as_float((unsigned)(k >> 32)) > thr)) continue;
+                const int slot = atomicAdd(&s_n, 1);
+                if (slot < GFTT_MAX_CAND) keys[slot] = k;
+            }
+        }
     }
     __syncthreads();
     GFTT_STAMP(2)
@@ -1160,7 +1301,8 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
     if (n <= GFTT_BLK) {
         // rank sort: keys are unique (the raster index is part of them), so a key's position is the number of larger
         // keys -- n broadcast LDS reads per thread, no dependent passes (the 55 passes of the bitonic network for
-        // ~550 candidates took 36 k cycles, each one an LDS round trip)
+        // ~550 candidates took 36 k cycles, each one an LDS round trip).  Beyond one key per thread the network wins:
+        // ranking up to four keys per thread in one sweep took 290 k cycles for 2200 candidates, the network 143 k.
         const unsigned long long mine = tid < n ? keys[tid] : 0ull;
         int rank = 0, q = 0;
         for (; q + 8 <= n; q += 8) {                  // eight reads in flight (a lone wavefront per SIMD has no other
@@ -1287,7 +1429,7 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
     __syncthreads();
     GFTT_STAMP(4)
 #ifdef FM_GFTT_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 64) { g_gftt_stamps[blockIdx.x][6] = n; g_gftt_stamps[blockIdx.x][7] = ((long long)npx << 20) | s_acc; }
+    if (threadIdx.x == 0 && blockIdx.x < 64) { g_gftt_stamps[blockIdx.x][6] = n; g_gftt_stamps[blockIdx.x][7] = ((long long)(c.w * c.h) << 20) | s_acc; }
 #endif
     // _ellipse_filter (flow.py:297-306): pts (f32) + offset (f32), then float64 ellipse test -- flags in
     // parallel, order-preserving compaction by ballot ranks
@@ -1366,81 +1508,99 @@ __global__ void fast_score_kernel(const uint8_t* __restrict__ img, int w, int h,
     score[(size_t)y * w + x] = sc;
 }
 
-// NMS + mask (INTER_NEAREST sample of the final foreground mask at the keypoint) -> flag per pixel
-__global__ void fast_flag_kernel(const int32_t* __restrict__ score, int w, int h,
-                                 const int32_t* __restrict__ rects, int nT, int full_w, int full_h,
-                                 uint8_t* __restrict__ flag) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y >= h) return;
-    const int i = y * w + x;
+// NMS + mask (INTER_NEAREST sample of the final foreground mask at the keypoint) -> flag per pixel, and the number
+// of flags of every 256-pixel segment of the raster (one workgroup each).  The track rects are staged in LDS: with 300
+// tracks every keypoint candidate walks all of them.
+constexpr int FAST_SEG = 256, FAST_RECT_LDS = 1024;
+__global__ __launch_bounds__(FAST_SEG) void fast_flag_kernel(const int32_t* __restrict__ score, int w, int h,
+                                                             const int32_t* __restrict__ rects, int nT, int full_w,
+                                                             int full_h, uint8_t* __restrict__ flag,
+                                                             int32_t* __restrict__ seg_cnt) {
+    __shared__ __attribute__((aligned(16))) int s_rect[4 * FAST_RECT_LDS];
+    __shared__ int s_wave[FAST_SEG / 64];
+    const bool in_lds = nT <= FAST_RECT_LDS;
+    if (in_lds)
+        for (int q = threadIdx.x; q < nT; q += FAST_SEG)
+            *reinterpret_cast<int4*>(s_rect + 4 * q) = *reinterpret_cast<const int4*>(rects + 4 * q);
+    __syncthreads();
+    const int i = blockIdx.x * FAST_SEG + threadIdx.x;
     bool kp = false;
-    const int s = score[i];
-    if (s > 0 && x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
-        kp = s > score[i - 1] && s > score[i + 1] && s > score[i - w - 1] && s > score[i - w] &&
-             s > score[i - w + 1] && s > score[i + w - 1] && s > score[i + w] && s > score[i + w + 1];
-        if (kp) {
-            const int fx = min((int)floor((double)x * ((double)full_w / w)), full_w - 1);
-            const int fy = min((int)floor((double)y * ((double)full_h / h)), full_h - 1);
-            if (covered_any(rects, nT, fx, fy)) kp = false;
+    if (i < w * h) {
+        const int y = i / w, x = i - y * w;
+        const int s = score[i];
+        if (s > 0 && x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
+            kp = s > score[i - 1] && s > score[i + 1] && s > score[i - w - 1] && s > score[i - w] &&
+                 s > score[i - w + 1] && s > score[i + w - 1] && s > score[i + w] && s > score[i + w + 1];
+            if (kp) {
+                const int fx = min((int)floor((double)x * ((double)full_w / w)), full_w - 1);
+                const int fy = min((int)floor((double)y * ((double)full_h / h)), full_h - 1);
+                if (in_lds ? covered_lds(s_rect, nT, fx, fy) : covered_any(rects, nT, fx, fy)) kp = false;
+            }
         }
+        flag[i] = kp ? 1 : 0;
     }
-    flag[i] = kp ? 1 : 0;
+    const int n = __popcll(__ballot(kp));
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
 
-// raster-order compaction with ONE block-wide scan: thread t owns a contiguous pixel segment
-__global__ __launch_bounds__(1024) void fast_compact_kernel(const uint8_t* __restrict__ flag, int w, int h,
-                                                            float* __restrict__ pts, int cap,
-                                                            int32_t* __restrict__ n_out,
-                                                            const int32_t* __restrict__ new_total,
-                                                            int32_t* __restrict__ totals_host) {
-    __shared__ int s_cnt[1024];
-    const int tid = threadIdx.x;
-    const int total = w * h;
-    const int seg = (total + 1023) / 1024;
-    const int b = tid * seg, e = min(b + seg, total);
-    int cnt = 0;
-    for (int i = b; i < e; ++i) cnt += flag[i];
-    s_cnt[tid] = cnt;
+// raster-order compaction, one workgroup per segment: its first output slot is the sum of the earlier segments' counts
+// (a few hundred values, summed by every workgroup for itself), inside the segment ballot ranks.  (One workgroup walking
+// the whole raster with a block-wide scan took 250 us on the 384 x 216 background image of a 4K stream, most of it
+// single stores into the pinned result block.)
+__global__ __launch_bounds__(FAST_SEG) void fast_compact_kernel(const uint8_t* __restrict__ flag, int w, int h,
+                                                                const int32_t* __restrict__ seg_cnt,
+                                                                float* __restrict__ pts, int cap,
+                                                                int32_t* __restrict__ n_out,
+                                                                const int32_t* __restrict__ new_total,
+                                                                int32_t* __restrict__ totals_host) {
+    __shared__ int s_red[FAST_SEG / 64], s_wave[FAST_SEG / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int part = 0;
+    for (int q = tid; q < (int)blockIdx.x; q += FAST_SEG) part += seg_cnt[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    const int i = blockIdx.x * FAST_SEG + tid;
+    const bool on = i < w * h && flag[i];
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) { s_red[wave] = part; s_wave[wave] = __popcll(bal); }
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? s_cnt[tid - off] : 0;
-        __syncthreads();
-        s_cnt[tid] += v;
-        __syncthreads();
+    int pos = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    for (int q = 0; q < wave; ++q) pos += s_wave[q];
+    pos += __popcll(bal & ((1ull << lane) - 1ull));
+    if (on && pos < cap) {
+        const int y = i / w;
+        *reinterpret_cast<float2*>(pts + 2 * (size_t)pos) = make_float2((float)(i - y * w), (float)y);
     }
-    int pos = s_cnt[tid] - cnt;
-    for (int i = b; i < e; ++i)
-        if (flag[i]) {
-            if (pos < cap) {
-                pts[2 * pos] = (float)(i % w);
-                pts[2 * pos + 1] = (float)(i / w);
-            }
-            ++pos;
-        }
-    if (tid == 1023) {
-        *n_out = s_cnt[1023];
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const int total = s_red[0] + s_red[1] + s_red[2] + s_red[3] + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        *n_out = total;
         if (totals_host) {            // [0] = new keypoints (gftt_select_kernel, earlier on this stream), [1] = background
             if (new_total) totals_host[0] = new_total[0];
-            totals_host[1] = s_cnt[1023];
+            totals_host[1] = total;
         }
     }
+}
+
+// scratch of the background branch inside FlowState::bg_flags: score map | 8 counters | segment counts | flag bytes
+struct FastBufs { int32_t* score; int32_t* counters; int32_t* seg_cnt; uint8_t* flag; int nseg; };
+static size_t fast_bufs_bytes(int bw, int bh) {
+    const size_t npx = (size_t)bw * bh, nseg = (npx + FAST_SEG - 1) / FAST_SEG;
+    return sizeof(int32_t) * (npx + 8 + nseg) + npx;
+}
+static FastBufs fast_bufs(int32_t* base, int bw, int bh) {
+    const size_t npx = (size_t)bw * bh, nseg = (npx + FAST_SEG - 1) / FAST_SEG;
+    FastBufs b;
+    b.score = base;
+    b.counters = base + npx;
+    b.seg_cnt = b.counters + 8;
+    b.flag = reinterpret_cast<uint8_t*>(b.seg_cnt + nseg);
+    b.nseg = (int)nseg;
+    return b;
 }
 
 __global__ void copy_total_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) { dst[0] = src[0]; }
-
-// dynamic LDS of gftt_select_kernel: the min-eigenvalue crop (up to GFTT_EIG_LDS floats next to ~65 KB of static
-// arrays; 160 KB per workgroup on gfx950).  Larger crops (4K frames) are read from global memory.
-constexpr int GFTT_EIG_LDS = 23 * 1024;
-
-int gftt_lds_bytes(int max_area) {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gftt_select_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GFTT_EIG_LDS * 4);
-        configured = true;
-    }
-    return (max_area <= GFTT_EIG_LDS ? max_area : 0) * 4;
-}
 
 // The KLT stream, for every launch that may read the pyramid of the newest frame: that pyramid is built on s_flow2
 // (fm_flow_begin) so that the keypoint preparation -- which only reads the PREVIOUS frame's images -- runs beside
@@ -1533,9 +1693,10 @@ extern "C" int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg) {
     for (int st = 0; st < 2; ++st)
         for (int l = 0; l < f->levels; ++l) FM_HIP(hipMalloc(&f->deriv[st][l], (size_t)f->lw[l] * f->lh[l] * 4));
     FM_HIP(hipMalloc(&f->bg_img, (size_t)cfg->bg_w * cfg->bg_h));
-    FM_HIP(hipMalloc(&f->bg_flags, sizeof(int32_t) * ((size_t)cfg->bg_w * cfg->bg_h + 8) + (size_t)cfg->bg_w * cfg->bg_h));
-    f->eig_cap = (size_t)4 * f->W * f->H;
-    FM_HIP(hipMalloc(&f->eig, sizeof(float) * f->eig_cap));
+    FM_HIP(hipMalloc(&f->bg_flags, fast_bufs_bytes(cfg->bg_w, cfg->bg_h)));
+    f->eig_cap = (size_t)4 * f->W * f->H / EIG_TPX;
+    FM_HIP(hipMalloc(&f->eig, sizeof(unsigned long long) * EIG_TPX * f->eig_cap));
+    FM_HIP(hipMalloc(&f->tile_stat, sizeof(uint2) * f->eig_cap));
     return 0;
 }
 
@@ -1666,19 +1827,17 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
     const int32_t* hrects = reinterpret_cast<const int32_t*>(f->tgt_in.host<char>());
     std::vector<CropArgs> crops(n);
     size_t off = 0;
-    int max_area = 0;
     for (int i = 0; i < n; ++i) {
         FM_CHECK_ARG(track_idx[i] >= 0 && track_idx[i] < f->nT);
         const int32_t* r = hrects + 4 * track_idx[i];
         CropArgs c;
         c.x0 = r[0]; c.y0 = r[1]; c.w = r[2] - r[0] + 1; c.h = r[3] - r[1] + 1; c.k = track_idx[i];
         c.eig_off = off;
-        off += (size_t)c.w * c.h;
-        max_area = std::max(max_area, c.w * c.h);
+        off += (size_t)eig_tiles(c);
         crops[i] = c;
     }
     if (off > f->eig_cap) {
-        fm_set_error("GFTT scratch too small (%zu > %zu px)", off, f->eig_cap);
+        fm_set_error("GFTT scratch too small (%zu > %zu tiles)", off, f->eig_cap);
         return FM_ERR_STATE;
     }
     const size_t o_crop = 0, o_md = sizeof(CropArgs) * n, o_box = (o_md + sizeof(int32_t) * n + 15) & ~size_t(15);
@@ -1693,15 +1852,14 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
     memcpy(hb + o_box, track_tlbr, sizeof(double) * 4 * n);
     FM_HIP(hipMemcpyAsync(f->det_in.d, hb, in_bytes, hipMemcpyHostToDevice, s));
     char* db = f->det_in.dev<char>();
-    hipLaunchKernelGGL(eig_kernel, dim3((max_area + 255) / 256, n), dim3(256), 0, s, f->gray[f->prev], f->W,
-                       reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, nullptr);
+    launch_eig(s, f->gray[f->prev], f->W, reinterpret_cast<const CropArgs*>(db + o_crop), n, eig_max_tiles(crops),
+               f->v_rects, Overlaps{f->v_ov_idx, f->v_ov_off}, f->cfg.block_size, nullptr, f->tile_stat, f->eig);
     float* d_pts = f->det_out.dev<float>();
     int32_t* d_cnt = reinterpret_cast<int32_t*>(d_pts + 2 * (size_t)n * cap);
-    hipLaunchKernelGGL(gftt_select_kernel, dim3(n), dim3(GFTT_BLK), gftt_lds_bytes(max_area), s, reinterpret_cast<const CropArgs*>(db + o_crop),
-                       f->v_rects, Overlaps{f->v_ov_idx, f->v_ov_off}, f->eig, (float)f->cfg.quality_level,
+    hipLaunchKernelGGL(gftt_select_kernel, dim3(n), dim3(GFTT_BLK), 0, s, reinterpret_cast<const CropArgs*>(db + o_crop),
+                       f->tile_stat, f->eig, (float)f->cfg.quality_level,
                        f->cfg.max_corners, reinterpret_cast<const int32_t*>(db + o_md),
-                       reinterpret_cast<const double*>(db + o_box), d_pts, cap, d_cnt, nullptr, nullptr, nullptr,
-                       gftt_lds_bytes(max_area) / 4);
+                       reinterpret_cast<const double*>(db + o_box), d_pts, cap, d_cnt, nullptr, nullptr, nullptr);
     FM_HIP(hipGetLastError());
     FM_HIP(hipMemcpyAsync(f->det_out.h, f->det_out.d, out_bytes, hipMemcpyDeviceToHost, s));
     FM_HIP(hipStreamSynchronize(s));
@@ -1722,11 +1880,12 @@ extern "C" int fm_flow_background(fm_ctx* ctx, int cap, float* pts_out, int* n_o
                        f->H, f->bg_img, bw, bh);
     hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_img, bw, bh,
                        f->cfg.fast_thresh, f->bg_flags);
-    int32_t* d_n = f->bg_flags + (size_t)bw * bh;
-    uint8_t* d_flag = reinterpret_cast<uint8_t*>(d_n + 8);
-    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, s, f->bg_flags, bw, bh, f->v_rects,
-                       f->nT, f->W, f->H, d_flag);
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, s, d_flag, bw, bh, f->bg_out.dev<float>(), cap, d_n, nullptr, nullptr);
+    const FastBufs fb = fast_bufs(f->bg_flags, bw, bh);
+    int32_t* d_n = fb.counters;
+    hipLaunchKernelGGL(fast_flag_kernel, dim3(fb.nseg), dim3(FAST_SEG), 0, s, fb.score, bw, bh, f->v_rects, f->nT, f->W,
+                       f->H, fb.flag, fb.seg_cnt);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(fb.nseg), dim3(FAST_SEG), 0, s, fb.flag, bw, bh, fb.seg_cnt,
+                       f->bg_out.dev<float>(), cap, d_n, nullptr, nullptr);
     FM_HIP(hipGetLastError());
     FM_HIP(hipMemcpyAsync(f->bg_out.host<char>() + sizeof(float) * 2 * cap, d_n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     FM_HIP(hipMemcpyAsync(f->bg_out.h, f->bg_out.d, sizeof(float) * 2 * cap, hipMemcpyDeviceToHost, s));
@@ -1907,7 +2066,6 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     std::vector<int32_t> irect(4 * (size_t)nT), ov_off(nT + 1, 0), ov_idx;
     std::vector<CropArgs> crops(nT);
     size_t eig_total = 0;
-    int max_area = 0;
     for (int k = 0; k < nT; ++k) {
         for (int e = 0; e < 4; ++e) irect[4 * k + e] = (int32_t)inside_tlbr[4 * k + e];
         const int32_t* a = &irect[4 * k];
@@ -1918,8 +2076,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         ov_off[k + 1] = (int32_t)ov_idx.size();
         CropArgs c;
         c.x0 = a[0]; c.y0 = a[1]; c.w = a[2] - a[0] + 1; c.h = a[3] - a[1] + 1; c.k = k; c.eig_off = eig_total;
-        eig_total += (size_t)c.w * c.h;
-        max_area = std::max(max_area, c.w * c.h);
+        eig_total += (size_t)eig_tiles(c);
         crops[k] = c;
     }
     const int n_ov = (int)ov_idx.size();
@@ -1933,7 +2090,10 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
     if (eig_total > f->eig_cap) {
         FM_HIP(hipFree(f->eig));
         f->eig = nullptr;
-        FM_HIP(hipMalloc(&f->eig, sizeof(float) * eig_total * 2));
+        FM_HIP(hipFree(f->tile_stat));
+        f->tile_stat = nullptr;
+        FM_HIP(hipMalloc(&f->eig, sizeof(unsigned long long) * EIG_TPX * eig_total * 2));
+        FM_HIP(hipMalloc(&f->tile_stat, sizeof(uint2) * eig_total * 2));
         f->eig_cap = eig_total * 2;
     }
     if (nT > f->rect_cap) {
@@ -2007,14 +2167,13 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
                            feat_density, feat_dist_factor, reinterpret_cast<int32_t*>(dbo + q_area),
                            reinterpret_cast<uint8_t*>(dbo + q_keep), d_needy, d_md,
                            reinterpret_cast<uint8_t*>(dbo + q_needy));
-        hipLaunchKernelGGL(eig_kernel, dim3((max_area + 255) / 256, nT), dim3(256), 0, s, f->gray[f->prev], f->W,
-                           reinterpret_cast<const CropArgs*>(db + o_crop), f->eig, f->cfg.block_size, d_needy);
-        hipLaunchKernelGGL(gftt_select_kernel, dim3(nT), dim3(GFTT_BLK), gftt_lds_bytes(max_area), s,
-                           reinterpret_cast<const CropArgs*>(db + o_crop), f->v_rects, ov, f->eig,
+        launch_eig(s, f->gray[f->prev], f->W, reinterpret_cast<const CropArgs*>(db + o_crop), nT, eig_max_tiles(crops),
+                   f->v_rects, ov, f->cfg.block_size, d_needy, f->tile_stat, f->eig);
+        hipLaunchKernelGGL(gftt_select_kernel, dim3(nT), dim3(GFTT_BLK), 0, s,
+                           reinterpret_cast<const CropArgs*>(db + o_crop), f->tile_stat, f->eig,
                            (float)f->cfg.quality_level, f->cfg.max_corners, d_md,
                            reinterpret_cast<const double*>(db + o_box), reinterpret_cast<float*>(ho + q_pts), pts_cap,
-                           reinterpret_cast<int32_t*>(dbo + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(dbo + q_off),
-                           gftt_lds_bytes(max_area) / 4);
+                           reinterpret_cast<int32_t*>(dbo + q_cnt), d_needy, tot, reinterpret_cast<int32_t*>(dbo + q_off));
         fm_trace_mark(ctx, s, 45);
     }
     // background keypoints under the final mask: four small dependent launches that share nothing with the per-track
@@ -2028,12 +2187,12 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
                        f->H, f->bg_img, bw, bh);
     hipLaunchKernelGGL(fast_score_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, sb, f->bg_img, bw, bh,
                        f->cfg.fast_thresh, f->bg_flags);
-    uint8_t* d_flag = reinterpret_cast<uint8_t*>(f->bg_flags + (size_t)bw * bh + 8);
+    const FastBufs fb = fast_bufs(f->bg_flags, bw, bh);
     FM_HIP(hipStreamWaitEvent(sb, ctx->ev_prep, 0));
-    hipLaunchKernelGGL(fast_flag_kernel, dim3((bw + 63) / 64, bh), dim3(64), 0, sb, f->bg_flags, bw, bh, f->v_rects,
-                       nT, f->W, f->H, d_flag);
+    hipLaunchKernelGGL(fast_flag_kernel, dim3(fb.nseg), dim3(FAST_SEG), 0, sb, fb.score, bw, bh, f->v_rects, nT, f->W,
+                       f->H, fb.flag, fb.seg_cnt);
     // the last kernels of the two branches put the totals into the result block
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(1), dim3(1024), 0, sb, d_flag, bw, bh,
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(fb.nseg), dim3(FAST_SEG), 0, sb, fb.flag, bw, bh, fb.seg_cnt,
                        reinterpret_cast<float*>(ho + q_bg), bg_cap, tot + 1, nullptr,
                        reinterpret_cast<int32_t*>(dbo + q_tot));
     fm_trace_mark(ctx, sb, 47);
