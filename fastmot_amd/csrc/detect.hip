@@ -408,16 +408,26 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
     }
 }
 
-// greedy scan in sorted order + final box filter (detector.py:356-364), one workgroup.  Chunk by chunk of 64
-// candidates: the bits "removed by an earlier survivor" of chunk c are the OR of mask word c over all SURVIVING rows
-// before the chunk -- a gather over the word-major mask.  Wavefronts 1..15 do all the memory work: the loads for chunk
-// c are issued (unconditionally, row indices clamped) during iteration c-3 and only looked at when iteration c begins,
-// when the survivors of every earlier chunk are known: three iterations of slack for the memory round trip (three
-// groups of wavefronts take turns, see below).  They publish removed(c) and the chunk's
-// own 64 x 64 diagonal block through LDS; wavefront 0 touches LDS only: it resolves the block in scalar registers
-// (lane b holds row b's word, one step per survivor).  Per chunk: two barriers, no memory round trip on the critical path.
-// History: 5.1 ms -> 68 us in round 3 (inside the pipeline; every chunk still waited for the loads it had just issued,
-// in both roles: profiles/r03_bench_kernel_stats.txt) -> round 4 this structure.
+// greedy scan in sorted order + final box filter (detector.py:356-364), one workgroup.  Two chunks of 64 candidates
+// (c0 = 2j, c1 = 2j + 1) per iteration j.  The bits "removed by an earlier survivor" of a chunk are the OR of its mask
+// word over all SURVIVING rows before the chunk -- a gather over the word-major mask.
+//   wavefronts 1..15  do all the memory work, in three groups of five (320 lanes) that own the iterations j = g (mod 3).
+//                     The loads of iteration j are issued (unconditionally, row indices clamped) three iterations ahead,
+//                     right after the group has published its previous one, and nothing else of that wavefront touches
+//                     memory in between: the compiler's own wait (everything outstanding) costs nothing and the round
+//                     trip has three iterations' time.  (One group with alternating register sets did not get there:
+//                     hipcc's wait counts across the loop's back edge fall to "everything outstanding".)
+//                     The group publishes iteration j WHILE wavefront 0 resolves iteration j - 1, so it only knows the
+//                     survivors before chunk p0 = 2j - 2:
+//                       rem[0], rem[1]   OR of mask word c0 / c1 over the surviving rows before chunk p0,
+//                       seven 64 x 64 blocks: (rows p0 | p1) x (word c0 | c1), and (c0, c0), (c0, c1), (c1, c1).
+//   wavefront 0       touches LDS only: it folds the rows of the previous iteration's survivors (its own registers) and
+//                     of c0's survivors into rem, and resolves each chunk in scalar registers (lane b holds row b's
+//                     word of the diagonal block, one step per survivor that removes anything).
+// One barrier per 128 candidates, no memory round trip and no gather on the critical path.
+// History: 5.1 ms -> 68 us in round 3 (inside the pipeline; every chunk still waited for the loads it had just issued, in
+// both roles: profiles/r03_bench_kernel_stats.txt) -> round 4: 107 us at the benchmark's ~1000 survivors of 1555 -> 41 us
+// with gather and resolve in turns (two barriers per 128) -> this structure.
 // The survivors are then filtered and written in order (prefix counts over the keep bits).
 __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict__ sorted,
                                                        int32_t* __restrict__ counters, int cap,
@@ -430,25 +440,24 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = min(counters[0], cap);
     const int kw = (K + 63) / 64;
-    // Two chunks (128 candidates) per iteration.  Wavefronts 1..15 form three groups of five (320 lanes); group g owns the
-    // iterations j = g (mod 3).  A group's loads for iteration j + 3 are issued right after it has published iteration j and
-    // are looked at three iterations later -- nothing else of that wavefront touches memory in between, so the compiler's own
-    // wait (it waits for everything outstanding) costs nothing and the round trip has three iterations' time.  (One group
-    // with alternating register sets did not get there: hipcc's wait counts across the loop's back edge fall to
-    // "everything outstanding".)  Per iteration the group publishes, for the chunks c0 = 2j and c1 = 2j + 1:
-    //   rem[0], rem[1]  OR of mask word c0 / c1 over the SURVIVING rows before chunk c0 (their fate is known by then),
-    //   d0, od, d1      the 64 x 64 blocks (rows of c0, word c0), (rows of c0, word c1), (rows of c1, word c1),
-    // and wavefront 0 -- LDS only -- resolves c0 in scalar registers, folds c0's survivors' rows of `od` into rem[1],
-    // resolves c1.  Two barriers per 128 candidates.
     constexpr int GU = 8, GROWS = 320 * GU;  // rows whose loads are pipelined: 2560; beyond that (rare) they are fetched at use
     const int grp = wave > 0 ? (wave - 1) % 3 : 0, gl = wave > 0 ? ((wave - 1) / 3) * 64 + lane : 0;
     const int niter = (kw + 1) / 2;
-    struct Set { uint64_t g0[GU], g1[GU]; uint64_t d0, od, d1; };
+    // the rows the final filter will want (candidates tid and tid + 1024) are fetched now: one memory round trip less
+    // behind the scan
+    float4 pre[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float* r = sorted + (size_t)min(u * 1024 + tid, max(K - 1, 0)) * 8;
+        pre[u][0] = *reinterpret_cast<const float4*>(r);
+        pre[u][1] = *reinterpret_cast<const float4*>(r + 4);
+    }
+    struct Set { uint64_t g0[GU], g1[GU]; uint64_t blk[7]; };
     auto issue = [&](int j, Set& t) {
         const int c0 = 2 * j, c1 = min(2 * j + 1, kw - 1);
         const uint64_t* col0 = mask + (size_t)c0 * cap;
         const uint64_t* col1 = mask + (size_t)c1 * cap;
-        const int last = max(c0 * 64 - 1, 0);
+        const int last = max((c0 - 2) * 64 - 1, 0);
 #pragma unroll
         for (int u = 0; u < GU; ++u)
             if (u == 0 || u * 320 <= last) {                                   // (uniform: only the rows that exist)
@@ -456,9 +465,14 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
                 t.g0[u] = col0[i];
                 t.g1[u] = col1[i];
             }
-        t.d0 = col0[min(c0 * 64 + lane, K - 1)];           // (rows beyond K are never looked at)
-        t.od = col1[min(c0 * 64 + lane, K - 1)];
-        t.d1 = col1[min(c1 * 64 + lane, K - 1)];
+        if (wave <= 3) {                                   // the group's first wavefront publishes the blocks
+            // (rows beyond K, or before the list for j = 0, are never looked at: their survivor bits are 0)
+            const int rp0 = min(max((c0 - 2) * 64 + lane, 0), K - 1), rp1 = min(max((c0 - 1) * 64 + lane, 0), K - 1);
+            const int r0 = min(c0 * 64 + lane, K - 1), r1 = min(c1 * 64 + lane, K - 1);
+            t.blk[0] = col0[rp0]; t.blk[1] = col1[rp0];
+            t.blk[2] = col0[rp1]; t.blk[3] = col1[rp1];
+            t.blk[4] = col0[r0]; t.blk[5] = col1[r0]; t.blk[6] = col1[r1];
+        }
     };
     auto alive = [&](int i, int lim) -> uint64_t {         // all ones iff row i < lim survived (branch-free)
         return 0ull - (uint64_t)((i < lim ? 1u : 0u) & (uint32_t)((keep[min(i, lim - 1 < 0 ? 0 : lim - 1) >> 6] >> (i & 63)) & 1ull));
@@ -467,42 +481,50 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
     // (its fence waits for vmcnt(0)) and expose their latency in every iteration
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     __shared__ unsigned long long rem_word[2][2];          // [iteration parity][c0, c1]: removed bits, double buffered
-    __shared__ uint64_t blocks[2][3][64];                  // [iteration parity][d0, od, d1][row]
+    __shared__ uint64_t blocks[2][7][64];                  // [iteration parity][block][row]
     if (tid < 4) rem_word[tid >> 1][tid & 1] = 0;
     __syncthreads();
     if (wave > 0) {
         Set mine;
+        // reduce the rows whose fate is known (before chunk 2j - 2) and hand iteration j to wavefront 0
+        auto publish = [&](int j) {
+            const int lim = (2 * j - 2) * 64;
+            uint64_t r0 = 0, r1 = 0;                       // (the first use waits for the loads issued three iterations ago)
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                if (u * 320 >= lim) break;                 // (uniform)
+                const uint64_t on = alive(u * 320 + gl, lim);
+                r0 |= mine.g0[u] & on;
+                r1 |= mine.g1[u] & on;
+            }
+            for (int i0 = GROWS; i0 < lim; i0 += 320) {                        // more than 2560 candidates: not pipelined
+                const int i = i0 + gl;
+                if (i < lim && ((keep[i >> 6] >> (i & 63)) & 1ull)) {
+                    r0 |= mask[(size_t)(2 * j) * cap + i];
+                    r1 |= mask[(size_t)min(2 * j + 1, kw - 1) * cap + i];
+                }
+            }
+            if (r0) atomicOr(&rem_word[j & 1][0], (unsigned long long)r0);
+            if (r1) atomicOr(&rem_word[j & 1][1], (unsigned long long)r1);
+            if (wave <= 3) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) blocks[j & 1][q][lane] = mine.blk[q];
+            }
+        };
         if (grp < niter) issue(grp, mine);
         int turn = grp;
+        if (grp == 0 && niter > 0) {
+            publish(0);
+            if (3 < niter) issue(3, mine);
+            turn = 3;
+        }
+        lds_barrier();
         for (int j = 0; j < niter; ++j) {
-            if (j == turn) {                               // (wave-uniform)
-                const int lim = 2 * j * 64;
-                uint64_t r0 = 0, r1 = 0;                   // (the first use waits for the loads issued three iterations ago)
-#pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    if (u * 320 >= lim) break;             // (uniform)
-                    const uint64_t on = alive(u * 320 + gl, lim);
-                    r0 |= mine.g0[u] & on;
-                    r1 |= mine.g1[u] & on;
-                }
-                for (int i0 = GROWS; i0 < lim; i0 += 320) {                    // more than 2560 candidates: not pipelined
-                    const int i = i0 + gl;
-                    if (i < lim && ((keep[i >> 6] >> (i & 63)) & 1ull)) {
-                        r0 |= mask[(size_t)(2 * j) * cap + i];
-                        r1 |= mask[(size_t)min(2 * j + 1, kw - 1) * cap + i];
-                    }
-                }
-                if (r0) atomicOr(&rem_word[j & 1][0], (unsigned long long)r0);
-                if (r1) atomicOr(&rem_word[j & 1][1], (unsigned long long)r1);
-                if (wave <= 3) {
-                    blocks[j & 1][0][lane] = mine.d0;
-                    blocks[j & 1][1][lane] = mine.od;
-                    blocks[j & 1][2][lane] = mine.d1;
-                }
-                if (j + 3 < niter) issue(j + 3, mine);
+            if (j + 1 == turn && turn < niter) {           // (wave-uniform) iteration j + 1 beside wavefront 0's iteration j
+                publish(turn);
+                if (turn + 3 < niter) issue(turn + 3, mine);
                 turn += 3;
             }
-            lds_barrier();
             lds_barrier();
         }
     } else {
@@ -529,28 +551,45 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
             return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
                    ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
         };
+        uint64_t kp0 = 0, kp1 = 0;                                             // survivors of the previous iteration's chunks
+        lds_barrier();
         for (int j = 0; j < niter; ++j) {
-            lds_barrier();
             const int c0 = 2 * j, c1 = 2 * j + 1;
-            const uint64_t d0 = blocks[j & 1][0][lane], od = blocks[j & 1][1][lane], d1 = blocks[j & 1][2][lane];
-            uint64_t rem0 = uniform64(rem_word[j & 1][0]);
+            unsigned long long* rw = rem_word[j & 1];
+            const uint64_t (*bk)[64] = blocks[j & 1];
+            // rows of the previous iteration's survivors: not known yet when the helpers reduced
+            if ((kp0 >> lane) & 1ull) {
+                const uint64_t a0 = bk[0][lane], a1 = bk[1][lane];
+                if (a0) atomicOr(&rw[0], (unsigned long long)a0);
+                if (a1) atomicOr(&rw[1], (unsigned long long)a1);
+            }
+            if ((kp1 >> lane) & 1ull) {
+                const uint64_t b0 = bk[2][lane], b1 = bk[3][lane];
+                if (b0) atomicOr(&rw[0], (unsigned long long)b0);
+                if (b1) atomicOr(&rw[1], (unsigned long long)b1);
+            }
+            const uint64_t d0 = bk[4][lane], od = bk[5][lane], d1 = bk[6][lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint64_t rem0 = uniform64(rw[0]);
             if (c0 == kw - 1 && (K & 63)) rem0 |= ~0ull << (K & 63);           // rows beyond K do not exist
             const uint64_t kept0 = resolve(rem0, d0);
             uint64_t kept1 = 0;
             if (c1 < kw) {
                 // chunk c0's survivors remove their rows' bits of word c1
-                if (((kept0 >> lane) & 1ull) && od) atomicOr(&rem_word[j & 1][1], (unsigned long long)od);
+                if (((kept0 >> lane) & 1ull) && od) atomicOr(&rw[1], (unsigned long long)od);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                uint64_t rem1 = uniform64(rem_word[j & 1][1]);
+                uint64_t rem1 = uniform64(rw[1]);
                 if (c1 == kw - 1 && (K & 63)) rem1 |= ~0ull << (K & 63);
                 kept1 = resolve(rem1, d1);
             }
             if (lane == 0) {
                 keep[c0] = kept0;
                 if (c1 < kw) keep[c1] = kept1;
-                rem_word[j & 1][0] = 0;
-                rem_word[j & 1][1] = 0;
+                rw[0] = 0;
+                rw[1] = 0;
             }
+            kp0 = kept0;
+            kp1 = kept1;
             lds_barrier();
         }
     }
@@ -563,7 +602,18 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
         const int i = i0 + tid;
         bool ok = false;
         double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        const float* r = sorted + (size_t)min(i, K - 1) * 8;
+        float r[8];
+        {
+            float4 q0, q1;
+            if (i0 == 0) { q0 = pre[0][0]; q1 = pre[0][1]; }
+            else if (i0 == 1024) { q0 = pre[1][0]; q1 = pre[1][1]; }
+            else {
+                const float* rp = sorted + (size_t)min(i, K - 1) * 8;
+                q0 = *reinterpret_cast<const float4*>(rp);
+                q1 = *reinterpret_cast<const float4*>(rp + 4);
+            }
+            r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w;
+        }
         if (i < K && ((keep[i >> 6] >> (i & 63)) & 1ull)) {
             // to_tlbr (utils/rect.py:49-57) on float64 copies of the float32 row
             const double xmin = r[0], ymin = r[1];
