@@ -14,6 +14,10 @@ void liteconv_tiling(int C, int W, int H, int* th, int* tw, int* tiles_x, int* t
 int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* wpw,
                      int kpad, const f16* wdw, const float* bias, int N, int H, int W, int C, int act,
                      float* const* gap, hipStream_t s);
+int launch_gatedconv(const f16* const* in, const int* in_cs, const int* in_coff, const float* const* parts, int tiles,
+                     const f16* x2, int x2_cs, int x2_coff, int c2, const f16* res, int res_cs, int res_coff, f16* out,
+                     int out_cs, int out_coff, const f16* w, const float* bias, int kpad, const f16* w1, const float* b1,
+                     const f16* w2, const float* b2, int N, int HW, int C, int hid, int cout, int act, hipStream_t s);
 int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
                      int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
                      int out_cs, int out_coff, const float* const* part, int tiles, hipStream_t s);
@@ -270,6 +274,49 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B, hipSt
                                     (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
                                     out, to.c, L.out_coff, L.gate[0] >= 0 ? parts : nullptr, tiles, s);
         }
+        case FM_OP_GATEDCONV: {
+            // streams in in[0..3] (cin channels each), their tile sums in the gate slots; res_mode FM_RES_CONCAT: the
+            // tensor `res` holds the second K segment (cin2 channels), FM_RES_BEFORE_ACT: the identity shortcut
+            const f16* ins[4];
+            int cs[4], co[4];
+            const float* parts[4];
+            FM_CHECK_ARG(L.n_in == 4 && !to.f32 && to.h == ti.h && to.w == ti.w && L.out_coff + L.cout <= to.c);
+            int th, tw, tx, ty;
+            liteconv_tiling(L.cin, ti.w, ti.h, &th, &tw, &tx, &ty);
+            for (int i = 0; i < 4; ++i) {
+                const fm_tensor& tg = net->tensors[L.in[i]];
+                FM_CHECK_ARG(tg.h == ti.h && tg.w == ti.w && L.in_coff[i] + L.cin <= tg.c);
+                FM_CHECK_ARG(L.gate[i] >= 0 && L.gate[i] < net->n_gates);
+                ins[i] = (const f16*)net->bufs[L.in[i]];
+                cs[i] = tg.c;
+                co[i] = L.in_coff[i];
+                parts[i] = net->gates + (size_t)L.gate[i] * net->max_batch * net->gate_c * GATE_SLOT_TILES;
+            }
+            const f16 *x2 = nullptr, *res = nullptr;
+            int x2_cs = 0, x2_coff = 0, c2 = 0, res_cs = 0, res_coff = 0;
+            if (L.res_mode == FM_RES_CONCAT) {
+                const fm_tensor& tr = net->tensors[L.res];
+                FM_CHECK_ARG(L.cin2 > 0 && tr.h == ti.h && tr.w == ti.w && L.res_coff + L.cin2 <= tr.c);
+                x2 = (const f16*)net->bufs[L.res]; x2_cs = tr.c; x2_coff = L.res_coff; c2 = L.cin2;
+            } else if (L.res_mode == FM_RES_BEFORE_ACT) {
+                const fm_tensor& tr = net->tensors[L.res];
+                FM_CHECK_ARG(tr.h == ti.h && tr.w == ti.w && L.res_coff + L.cout <= tr.c);
+                res = (const f16*)net->bufs[L.res]; res_cs = tr.c; res_coff = L.res_coff;
+            } else {
+                FM_CHECK_ARG(L.res_mode == FM_RES_NONE);
+            }
+            // gate MLP blob at w2_off: fc1 [hid][cin] fp16 | b1 f32 | fc2 [cin][hid] fp16 | b2 f32, sections 16 B aligned
+            auto al16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+            const char* gb = net->weights + L.w2_off;
+            const size_t o_b1 = al16((size_t)L.hid * L.cin * 2), o_w2 = o_b1 + al16((size_t)L.hid * 4);
+            const size_t o_b2 = o_w2 + al16((size_t)L.cin * L.hid * 2);
+            const int kpad = ((((L.cin + 15) & ~15) + ((c2 + 15) & ~15)) + 63) & ~63;   // two segments of whole K steps
+            return launch_gatedconv(ins, cs, co, parts, tx * ty, x2, x2_cs, x2_coff, c2, res, res_cs, res_coff, out, to.c,
+                                    L.out_coff, (const f16*)(net->weights + L.w_off),
+                                    (const float*)(net->weights + L.b_off), kpad, (const f16*)gb,
+                                    (const float*)(gb + o_b1), (const f16*)(gb + o_w2), (const float*)(gb + o_b2), B,
+                                    ti.h * ti.w, L.cin, L.hid, L.cout, L.act, s);
+        }
         case FM_OP_STEMCONV:
             FM_CHECK_ARG(!to.f32 && (ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h &&
                          (ti.w + 2 * L.pad - L.k) / L.stride + 1 == to.w && L.out_coff + ((L.cout + 7) & ~7) <= to.c);
@@ -461,6 +508,11 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *bytes = (pin + 4 * pout) * L.cin * 2 + 10.0 * L.cin * L.cout * 2;
             break;
         case FM_OP_GATED_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
+        case FM_OP_GATEDCONV:
+            *flops = 2.0 * pout * L.cout * (L.cin + L.cin2) + 2.0 * pin * 4 * L.cin;
+            *bytes = pin * (4.0 * L.cin + L.cin2) * 2 + pout * L.cout * 2 * (L.res_mode == FM_RES_BEFORE_ACT ? 2 : 1) +
+                     (double)((L.cout + 31) & ~31) * (L.cin + L.cin2) * 2;
+            break;
         case FM_OP_STEMCONV:
             *flops = 2.0 * L.k * L.k * 3 * L.cout * pout;
             *bytes = pin * 8 + pout * L.cout * 2;

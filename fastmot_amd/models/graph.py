@@ -15,10 +15,11 @@ import numpy as np
 LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CSPSTAGE) = range(18)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CSPSTAGE,
+ OP_GATEDCONV) = range(19)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
-RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
+RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT, RES_CONCAT = 0, 1, 2, 3
 
 
 class fm_tensor(C.Structure):
@@ -34,7 +35,7 @@ class fm_layer(C.Structure):
                 ('pad', C.c_int32), ('act', C.c_int32), ('hid', C.c_int32), ('up', C.c_int32),
                 ('gate', C.c_int32 * 4),
                 ('w_off', C.c_int64), ('b_off', C.c_int64), ('w2_off', C.c_int64), ('b2_off', C.c_int64),
-                ('branch', C.c_int32), ('wait_for', C.c_int32), ('signal', C.c_int32), ('reserved_', C.c_int32)]
+                ('branch', C.c_int32), ('wait_for', C.c_int32), ('signal', C.c_int32), ('cin2', C.c_int32)]
 
 
 def ceil_to(x, m):
@@ -132,6 +133,9 @@ class Graph:
         self.use_resblock = os.environ.get('FASTMOT_RESBLOCK', '1') != '0'
         # the four LightConv streams of an OSNet block as one launch (litechain.hip) instead of one per depth
         self.use_lightchain = os.environ.get('FASTMOT_LITECHAIN', '1') != '0'
+        # tail of an OSNet block (gate, gated sum, conv3 + shortcut) as one launch (gatedconv.hip): measured slower than
+        # the two launches it replaces (profiles/r04_gatedconv_ab.txt) -- off unless FASTMOT_GATEDCONV=1
+        self.use_gatedconv = os.environ.get('FASTMOT_GATEDCONV', '0') == '1'
         # convs with at most this many output pixels per sample and a long reduction take the streamed
         # kernel (K split inside the workgroup, convs.hip) instead of the LDS-tiled one + split-K reduce
         self.convs_max_pixels = int(os.environ.get('FASTMOT_CONVS_MAXP', '1444'))
@@ -154,7 +158,7 @@ class Graph:
 
     def _layer(self, **kw):
         d = dict(op=0, ins=[], out=None, res=None, res_mode=RES_NONE, cin=0, cout=0, k=1, stride=1, pad=0,
-                 act=0, hid=0, up=1, gates=[], w_off=0, b_off=0, w2_off=0, b2_off=0)
+                 act=0, hid=0, up=1, gates=[], w_off=0, b_off=0, w2_off=0, b2_off=0, cin2=0)
         d.update(kw)
         self.layers.append(d)
         return d
@@ -463,6 +467,50 @@ class Graph:
                     gate_ref=(w1[:, :c].astype(np.float32), p1['bias'], w2[:c].astype(np.float32), p2['bias']))
         return dst
 
+    def gated_conv(self, name, conv_name, xs, hid, parts, cout, act='relu', x2=None, res=None, wb=None, dst=None):
+        """Tail of an OSNet block in one launch (FM_OP_GATEDCONV, gatedconv.hip): act(conv1x1([gated_sum(xs) | x2]) (+ res)).
+        xs: the four stream views with their tile-sum slots `parts`; x2: second K segment (a stage's first block: the
+        block input, `wb` = ([W3 | Wd], b3 + bd)); res: identity shortcut, added before the activation."""
+        x = xs[0]
+        c = x.c
+        assert len(xs) == 4 and len(parts) == 4 and all(v.c == c and v.coff % 8 == 0 for v in xs) and c % 8 == 0
+        assert x2 is None or res is None
+        c2 = x2.c if x2 is not None else 0
+        assert c2 % 8 == 0 and cout % 8 == 0
+        p1 = self.wsrc.conv(name + '.fc1', hid, c, 1, bn=False)
+        p2 = self.wsrc.conv(name + '.fc2', c, hid, 1, bn=False)
+        w1 = p1['w'].reshape(hid, c).astype(np.float16)
+        w2 = p2['w'].reshape(c, hid).astype(np.float16)
+        b1, b2 = p1['bias'].astype(np.float32), p2['bias'].astype(np.float32)
+        blob = bytearray()
+        for a in (w1, b1, w2, b2):                        # sections 16 B aligned (fastmot_hip.h: FM_OP_GATEDCONV)
+            blob += np.ascontiguousarray(a).tobytes()
+            blob += b'\0' * (-len(blob) % 16)
+        if wb is not None:
+            w, b = (np.asarray(a, np.float32) for a in wb)
+        else:
+            w, b = fold_bn(self.wsrc.conv(conv_name, cout, c, 1, bn=True))
+        K = c + c2
+        assert w.shape == (cout, K, 1, 1) and b.shape == (cout,)
+        w16 = w.astype(np.float16)
+        cpad = ceil_to(cout, 32)
+        c16 = ceil_to(c, 16)                              # two K segments of whole 16-channel steps (gatedconv.hip)
+        packed = np.zeros((cpad, ceil_to(c16 + ceil_to(c2, 16), 64)), np.float16)
+        packed[:cout, :c] = w16.reshape(cout, K)[:, :c]
+        packed[:cout, c16:c16 + c2] = w16.reshape(cout, K)[:, c:]
+        bias = np.zeros(cpad, np.float32)
+        bias[:cout] = b
+        if dst is None:
+            dst = self.new(x.h, x.w, cout)
+        self._layer(op=OP_GATEDCONV, ins=list(xs), out=dst, cin=c, cout=cout, hid=hid, act=ACT[act], cin2=c2,
+                    gates=list(parts), res=x2 if x2 is not None else res,
+                    res_mode=RES_CONCAT if x2 is not None else (RES_BEFORE_ACT if res is not None else RES_NONE),
+                    w_off=self._push(packed), b_off=self._push(bias),
+                    w2_off=self._push(np.frombuffer(bytes(blob), np.uint8)), name=name,
+                    gate_ref=(w1.astype(np.float32), p1['bias'], w2.astype(np.float32), p2['bias']),
+                    conv_ref=(w16.astype(np.float32), b))
+        return dst
+
     def gate_sum(self, xs, gids, dst=None):
         x = xs[0]
         if dst is None:
@@ -643,7 +691,7 @@ class Graph:
             else:
                 L.res, L.res_coff = -1, 0
             L.res_mode = d['res_mode']
-            for key in ('cin', 'cout', 'k', 'stride', 'pad', 'act', 'hid', 'up', 'w_off', 'b_off', 'w2_off', 'b2_off'):
+            for key in ('cin', 'cout', 'k', 'stride', 'pad', 'act', 'hid', 'up', 'w_off', 'b_off', 'w2_off', 'b2_off', 'cin2'):
                 setattr(L, key, d[key])
             for j in range(4):
                 L.gate[j] = d['gates'][j] if j < len(d['gates']) else -1
@@ -659,6 +707,9 @@ class Graph:
             if d['op'] in (OP_CONV, OP_STEMCONV, OP_CONVS):
                 o = d['out']
                 total += 2 * d['k'] * d['k'] * d['ins'][0].c * d['cout'] * o.h * o.w * batch
+            elif d['op'] == OP_GATEDCONV:
+                o = d['out']
+                total += 2 * (d['cin'] + d['cin2']) * d['cout'] * o.h * o.w * batch
             elif d['op'] == OP_RESBLOCK:
                 o = d['out']
                 total += 2 * 10 * d['cin'] * d['hid'] * o.h * o.w * batch

@@ -238,13 +238,21 @@ enum {
                           * [b | A] = act(1x1 64->128) -> residual unit on b (1x1 64->hid, 3x3 hid->64, + b) -> c = act(1x1
                           * 64->64) -> out = act(1x1 [c | A] 128 -> cout = 64).  w_off: the five matrices in MFMA
                           * fragment order, concatenated in that order; b_off: their biases (float32) likewise  */
+    FM_OP_GATEDCONV = 18,/* tail of an OSNet block in one launch (gatedconv.hip): out = act(W . [x2 | x] + b (+ res)) with
+                          * x2 = FM_OP_GATED_SUM of the four streams in[0..3] (cin channels each, tile sums in gate[0..3]),
+                          * never stored.  res_mode FM_RES_CONCAT: tensor `res` holds the second K segment x (cin2
+                          * channels; a stage's first block: weights [W3 | Wd], bias b3 + bd); FM_RES_BEFORE_ACT: `res`
+                          * is the identity shortcut (cin2 = 0).  w_off: fp16 [ceil32(cout)][ceil64(ceil16(cin) +
+                          * ceil16(cin2))], columns [0, cin) over x2, [ceil16(cin), + cin2) over x, zero elsewhere; b_off:
+                          * f32 [ceil32(cout)]; w2_off: the gate MLP, fc1 [hid][cin] fp16 | b1 f32 | fc2 [cin][hid] fp16 |
+                          * b2 f32, every section 16 B aligned                                                     */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */
 };
 enum { FM_ACT_LINEAR = 0, FM_ACT_LEAKY = 1, FM_ACT_MISH = 2, FM_ACT_RELU = 3, FM_ACT_LOGISTIC = 4,
        FM_ACT_SWISH = 5 };
-enum { FM_RES_NONE = 0, FM_RES_AFTER_ACT = 1, FM_RES_BEFORE_ACT = 2 };
+enum { FM_RES_NONE = 0, FM_RES_AFTER_ACT = 1, FM_RES_BEFORE_ACT = 2, FM_RES_CONCAT = 3 /* FM_OP_GATEDCONV only */ };
 
 typedef struct fm_tensor {
     int32_t h, w, c;     /* per-sample geometry, c = channel stride (multiple of 8) */
@@ -271,7 +279,8 @@ typedef struct fm_layer {
      * continues from the same tensor), each branch in table order.  wait_for: index of a layer of the OTHER branch
      * whose completion this layer waits for (-1: none; earlier waits of its branch cover the rest), signal: some layer
      * of the other branch waits for this one.  Captured into the hipGraph as parallel paths. */
-    int32_t branch, wait_for, signal, reserved_;
+    int32_t branch, wait_for, signal;
+    int32_t cin2;        /* FM_OP_GATEDCONV: channels of the second K segment (0: none) */
 } fm_layer;
 
 /* weights: CONV  w = fp16 [ceil32(cout)][ceil64(k*k*cin)] (K order kh,kw,cin), b = f32[ceil32(cout)]

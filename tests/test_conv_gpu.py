@@ -282,29 +282,34 @@ def test_lightconv_fused(ctx, c, h, w, n):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
-def test_osnet_fused_and_arena_reuse_identical(ctx):
-    """The production configuration (grouped fused LightConv, fused gated sum, conv3+downsample as one conv: 50 launches, activation
-    arena shared between tensors with disjoint live ranges) against the layer-per-kernel graph (173
-    launches, private buffers): arena reuse changes nothing bit for bit; the fused graph differs only
-    by the summation grouping of the gate's average pool."""
+def test_osnet_fused_and_arena_reuse_identical(ctx, monkeypatch):
+    """The production configuration (stream chains in one launch, gate + gated sum + conv3 + shortcut in one launch: 26
+    launches, activation arena shared between tensors with disjoint live ranges) against the layer-per-kernel graph (173
+    launches, private buffers): arena reuse changes nothing bit for bit; the fused graph differs only by the summation
+    grouping of the gate's average pool.  Both block tails are covered: the default one (FM_OP_GATED_SUM + conv3 as two
+    launches, 32 in total) and the one-launch tail (FM_OP_GATEDCONV, FASTMOT_GATEDCONV=1: 26 launches), which feeds the
+    matrix cores the same fp16 operands."""
     class Small(ReID.get_model('OSNet025')):
         INPUT_SHAPE = (3, 128, 64)
     rng = np.random.default_rng(3)
     x = rng.normal(0, 1, (6, 128, 64, 3)).astype(np.float16)
     ctx.feat_configure(512)
     embs = {}
-    for fuse, reuse in ((False, False), (True, False), (True, True)):
+    for fuse, reuse, tail in ((False, False, '1'), (True, False, '1'), (True, True, '1'), (True, True, '0')):
+        monkeypatch.setenv('FASTMOT_GATEDCONV', tail)
         g, _ = Small.build_graph(RandomWeights(seed=5), fuse_lightconv=fuse)
-        assert len(g.layers) == (32 if fuse else 173)      # 50 with one launch per stream depth (next test)
+        assert len(g.layers) == ((26 if tail == '1' else 32) if fuse else 173)   # 50 with one launch per stream depth (next test)
         net = HipNet(ctx, NET_EXTRACTOR, g, 6, reuse_buffers=reuse)
         for _ in range(2):                      # second run: stale arena contents must not matter
             net.write(g.input, x)
             net.run(6)
-        embs[fuse, reuse] = net.read_embeddings(6)
+        embs[fuse, reuse, tail] = net.read_embeddings(6)
         net.close()
-    np.testing.assert_array_equal(embs[True, False], embs[True, True])
-    assert np.abs(embs[True, True] - embs[False, False]).max() < 2e-3
-    assert (np.sum(embs[True, True] * embs[False, False], axis=1) > 0.9999).all()
+    np.testing.assert_array_equal(embs[True, False, '1'], embs[True, True, '1'])
+    for tail in '01':
+        assert np.abs(embs[True, True, tail] - embs[False, False, '1']).max() < 2e-3
+        assert (np.sum(embs[True, True, tail] * embs[False, False, '1'], axis=1) > 0.9999).all()
+    assert np.abs(embs[True, True, '1'] - embs[True, True, '0']).max() < 1e-3
 
 
 @pytest.mark.parametrize('c,hid,h,w,n,k', [(16, 1, 64, 32, 3, 4), (24, 1, 32, 16, 5, 4), (32, 2, 16, 8, 2, 4),

@@ -111,6 +111,22 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
                 hid = F.relu(xv.mean(dim=(2, 3)) @ w1.T + b1)
                 y = y + xv * torch.sigmoid(hid @ w2.T + b2)[:, :, None, None]
             wr(d['out'], y)
+        elif op == G.OP_GATEDCONV:
+            w1, b1, w2, b2 = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['gate_ref'])
+            y = 0
+            for v in d['ins']:
+                xv = rd(v)
+                hid = F.relu(xv.mean(dim=(2, 3)) @ w1.T + b1)
+                y = y + xv * torch.sigmoid(hid @ w2.T + b2)[:, :, None, None]
+            if emulate_fp16_storage:
+                y = y.half().float()
+            w, b = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['conv_ref'])
+            if d['res_mode'] == G.RES_CONCAT:
+                y = torch.cat([y, rd(d['res'])], dim=1)
+            y = F.conv2d(y, w, b)
+            if d['res_mode'] == G.RES_BEFORE_ACT:
+                y = y + rd(d['res'])
+            wr(d['out'], act_fn(y, d['act']))
         elif op == G.OP_SPP:
             c = d['cout']
             for i, k in enumerate((13, 9, 5)):
