@@ -212,6 +212,21 @@ STAGE_TAGS = (('detector preprocess (resize + BGR->RGB + fp16 NHWC)', 14, 11), (
               ('pairwise cost terms (cdist + Mahalanobis + IoU)', 54, 55), ('stage cost gather + gate', 56, 57))
 
 
+def stage_durations(t_start, t_end):
+    """Durations of a stage from the time stamps of its start and end marks.  An occurrence is the FIRST start mark since
+    the previous end mark, up to that end mark (both marks sit on one stream, in order).  Marks may repeat inside an
+    occurrence -- a batch larger than the ReID network's maximum runs in chunks, each with its own crop / network marks --
+    so pairing the i-th start with the i-th end is wrong as soon as the counts differ (round 4's first config[4] table
+    had a negative crop stage from exactly that)."""
+    ta = np.sort(np.asarray(t_start, np.float64))
+    tb = np.sort(np.asarray(t_end, np.float64))
+    if not len(ta) or not len(tb):
+        return np.zeros(0)
+    first = np.searchsorted(ta, np.concatenate(([-np.inf], tb[:-1])), side='right')    # first start after the previous end
+    ok = (first < len(ta)) & (ta[np.minimum(first, len(ta) - 1)] <= tb)
+    return tb[ok] - ta[first[ok]]
+
+
 def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
     """per-stage achieved GB/s or TFLOP/s and roofline fraction INSIDE the pipelined step.
     Durations: HIP events on each stage's own stream (fm_trace_*), median over the occurrences in `n_steps` traced
@@ -257,18 +272,11 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
     }
     out = []
     for name, a, b in STAGE_TAGS:
-        ta = np.sort(ms[tags == a].astype(np.float64))
-        tb = np.sort(ms[tags == b].astype(np.float64))
-        # An occurrence is the FIRST start mark since the previous end mark up to that end mark (both marks sit on one
-        # stream, in order).  Marks may repeat inside an occurrence -- a batch larger than the ReID network's maximum
-        # runs in chunks, each with its own crop / network marks -- so pairing the i-th start with the i-th end is wrong
-        # as soon as the counts differ (round 4's first config[4] table had a negative crop stage from exactly that).
-        first = np.searchsorted(ta, np.concatenate(([-np.inf], tb[:-1])), side='right')   # first start after the previous end
-        ok = (first < len(ta)) & (ta[np.minimum(first, len(ta) - 1)] <= tb) if len(ta) and len(tb) else np.zeros(0, bool)
-        n = int(ok.sum())
+        d = stage_durations(ms[tags == a], ms[tags == b])
+        n = len(d)
         if n < 4:
             continue
-        d = (tb[ok] - ta[first[ok]])[n // 8:]               # (the first steps of the window still fill the pipeline)
+        d = d[n // 8:]                                      # (the first steps of the window still fill the pipeline)
         us = float(np.median(d)) * 1e3
         per_step = n / n_steps
         bound, amount, what = work[a]
