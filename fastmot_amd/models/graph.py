@@ -486,8 +486,8 @@ class Graph:
         for a in (w1, b1, w2, b2):                        # sections 16 B aligned (fastmot_hip.h: FM_OP_GATEDCONV)
             blob += np.ascontiguousarray(a).tobytes()
             blob += b'\0' * (-len(blob) % 16)
-        if wb is not None:
-            w, b = (np.asarray(a, np.float32) for a in wb)
+        if wb is not None:      # (a callable: evaluated here, after the gate's parameters, like the two-launch tail reads them)
+            w, b = (np.asarray(a, np.float32) for a in (wb() if callable(wb) else wb))
         else:
             w, b = fold_bn(self.wsrc.conv(conv_name, cout, c, 1, bn=True))
         K = c + c2
