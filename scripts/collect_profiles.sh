@@ -24,6 +24,11 @@ timeout 300 python scripts/trace_pipeline.py --show 3 > $O/pipeline_trace.txt 2>
 cd /tmp && rm -rf /tmp/kt_$TAG && FASTMOT_GRAPHS=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o b -- python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-variants > $O/bench_under_rocprof.json 2> /dev/null
 cd $R && python scripts/rocpd_summary.py "$(find /tmp/kt_$TAG -name '*.db' | head -1)" > $O/bench_kernel_stats.txt 2>&1; head -30 $O/bench_kernel_stats.txt | cut -c1-160
 if [ -z "$QUICK" ]; then
+# the same for config[4] (4K, 300 tracks): the KLT keypoint kernels at the size DESIGN 3c is about
+cd /tmp && rm -rf /tmp/kt4_$TAG && FASTMOT_GRAPHS=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt4_$TAG -o b -- python $R/bench.py --config 4 --steps 20 --warmup 5 --no-cpu-baseline --no-variants > /dev/null 2>&1
+cd $R && python scripts/rocpd_summary.py "$(find /tmp/kt4_$TAG -name '*.db' | head -1)" > $O/bench_config4_kernel_stats.txt 2>&1; grep -E "gftt|eig|prepare|fast_|lk_pair" $O/bench_config4_kernel_stats.txt | cut -c1-160
+fi
+if [ -z "$QUICK" ]; then
 # stand-alone replays: per-layer roofline of the detector, dispatch list of the ReID network
 cd /tmp && rm -rf /tmp/tr_$TAG && rocprofv3 --kernel-trace -d /tmp/tr_$TAG -o t -- python $R/scripts/trace_net.py 0 > /dev/null 2>&1
 cd $R && python scripts/layer_roofline.py /tmp/tr_$TAG > $O/yolo_layer_roofline.txt 2>&1; tail -3 $O/yolo_layer_roofline.txt
