@@ -243,7 +243,12 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
     _, in_h, in_w = m.INPUT_SHAPE
     det_flops, _ = mot.detector.backend.cost(1)
     ext = mot.extractors[0]
-    ext_flops, ext_bytes = ext.backend.cost(D)
+    # The ReID marks bracket the step's extractor work: the crop stage ends at the first chunk's network mark (a batch
+    # larger than the network's maximum runs in chunks), the network stage at the end mark -- with one extractor per
+    # class (config[4]) the calls follow each other on the stream and the row spans all of them: the work is the step's.
+    d_call = D
+    d_chunk = min(-(-D // len(mot.extractors)), ext.backend.max_batch)
+    ext_flops, ext_bytes = ext.backend.cost(d_call)
     head_bytes = sum((5 + m.NUM_CLASSES) * (len(a) // 2) * (in_h // f) * (in_w // f) * 4 for a, f in zip(m.ANCHORS, m.LAYER_FACTORS))
     _, eh, ew = ext.model.INPUT_SHAPE
     K = max(mot.detector.last_candidates, 1)
@@ -258,8 +263,8 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
         22: ('latency', None, f'K^2/2 = {K * K // 2} pair tests (fp32 IoU pre-test, exact fp64 DIoU near the threshold)'),
         23: ('latency', None, f'greedy scan over {-(-K // 64)} chunks of 64, one workgroup'),
         30: ('pcie', W * H * 3, 'frame u8'),
-        32: ('hbm', D * eh * ew * 8 * 2, 'fp16 NHWC(8) crops out (+ <= crop pixels in)'),
-        34: ('hbm', ext_bytes, f'activations + weights fp16; {ext_flops / 1e9:.1f} GFLOP'),
+        32: ('hbm', d_chunk * eh * ew * 8 * 2, f'first chunk, {d_chunk} crops: fp16 NHWC(8) out (+ <= crop pixels in)'),
+        34: ('hbm', ext_bytes, f'{d_call} crops (all classes): activations + weights fp16; {ext_flops / 1e9:.1f} GFLOP'),
         35: ('latency', None, f'{D} x 512 fp32'),
         42: ('hbm', W * H * 3 + W * H + px0 + pyr_px * 5.25, 'frame in, gray + half + 6-level pyramid + int16 Scharr pairs out'),
         44: ('latency', None, f'{T} track crops: rect / ellipse / mask filters, min-eigenvalue map, corner selection'),
