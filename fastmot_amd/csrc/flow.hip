@@ -1331,102 +1331,136 @@ __global__ __launch_bounds__(GFTT_BLK) FM_SGPR_CAP void gftt_select_kernel(const
             }
     }
     GFTT_STAMP(3)
-    // greedy min-distance selection by the first wavefront
+    // Greedy min-distance selection (featureselect.cpp: candidates in sorted order, one is accepted iff no already
+    // accepted corner is closer than minDistance).
     const int md = min_dist[needy ? c.k : t];
     const int gw = (c.w + md - 1) / md, gh = (c.h + md - 1) / md;
     const bool use_grid = gw * gh <= GFTT_MAX_CELLS;
     __shared__ short acc_x[1024], acc_y[1024];
     __shared__ int s_acc;
+    __shared__ int s_surv[GFTT_BLK];
+    __shared__ int s_wcnt[GFTT_BLK / 64];
+    // a grid slot holds a corner as two int16 (y << 16 | x, crop coordinates < 16384); an empty slot holds a point far
+    // outside every crop, so that the distance test needs no "slot in use" branch
+    constexpr int GFTT_EMPTY = (int)0xC000C000u;          // (-16384, -16384)
     if (use_grid)
-        for (int i = tid; i < gw * gh * 4; i += GFTT_BLK) cells[i] = -1;
+        for (int i = tid; i < gw * gh * 4; i += GFTT_BLK) cells[i] = GFTT_EMPTY;
     if (tid == 0) s_acc = 0;
     __syncthreads();
-    // Greedy min-distance selection (featureselect.cpp: candidates in sorted order, one is accepted iff no
-    // already accepted corner is closer than minDistance) by the first wavefront, 64 candidates at a time:
-    //   1. every lane tests its candidate against the corners accepted BEFORE this batch (grid cells, or the
-    //      accepted list when the grid does not fit LDS);
-    //   2. the survivors are resolved in order inside the batch: the first survivor is accepted and knocks
-    //      out the later survivors closer than minDistance, repeat.
-    // Once the crop is covered nearly every candidate dies in step 1, so a batch costs one pass instead of
-    // 64 serial iterations.
-    if (tid < 64) {
-        const int md2 = md * md;
-        const float inv_md = 1.f / (float)md;
-        const int limit = min(max_corners, 1024);
-        int nacc = 0;
-        for (int base = 0; base < n && nacc < limit; base += 64) {
-            const int q = base + tid;
-            int x = 0, y = 0;
-            bool alive = q < n;
-            if (alive) {
-                const int ri = (int)(keys[q] & 0xffffffffu);
-                y = fast_div(ri, c.w, inv_w);
-                x = ri - y * c.w;
-                if (use_grid) {
-                    // the 3 x 3 neighbourhood as nine independent 16-byte reads (clamped, masked afterwards): one LDS
-                    // round trip per batch instead of up to 36 dependent ones (this loop was 57 % of the kernel:
-                    // 15.7 k cycles per batch of 64 candidates, scripts/gftt_timing.py)
-                    const int cx0 = fast_div(x, md, inv_md), cy0 = fast_div(y, md, inv_md);
-                    int4 cv[9];
+    const int md2 = md * md;
+    const float inv_md = 1.f / (float)md;
+    const int limit = min(max_corners, 1024);
+    // is an accepted corner closer than minDistance?  (grid cells; the accepted list [0, nacc) when the grid does not fit LDS)
+    auto blocked = [&](int x, int y, int nacc) -> bool {
+        bool hit = false;
+        if (use_grid) {
+            // the 3 x 3 neighbourhood as nine independent 16-byte reads (clamped, masked afterwards): one LDS round trip
+            // instead of up to 36 dependent ones (that loop was 57 % of the kernel: 15.7 k cycles per batch of 64
+            // candidates, scripts/gftt_timing.py)
+            const int cx0 = fast_div(x, md, inv_md), cy0 = fast_div(y, md, inv_md);
+            int4 cv[9];
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) {
-                        const int cyn = min(max(cy0 + j / 3 - 1, 0), gh - 1), cxn = min(max(cx0 + j % 3 - 1, 0), gw - 1);
-                        cv[j] = *reinterpret_cast<const int4*>(cells + (cyn * gw + cxn) * 4);
-                    }
+            for (int j = 0; j < 9; ++j) {
+                const int cyn = min(max(cy0 + j / 3 - 1, 0), gh - 1), cxn = min(max(cx0 + j % 3 - 1, 0), gw - 1);
+                cv[j] = *reinterpret_cast<const int4*>(cells + (cyn * gw + cxn) * 4);
+            }
+            // 36 slots, four instructions each: packed int16 difference, dot product with itself, compare, or.  (A clamped
+            // neighbour outside the grid repeats a cell that is tested anyway.)
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const int me = (y << 16) | x;
+            const s16x2 mev = *reinterpret_cast<const s16x2*>(&me);
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) {
-                        const int cyn = cy0 + j / 3 - 1, cxn = cx0 + j % 3 - 1;
-                        if (cyn < 0 || cyn >= gh || cxn < 0 || cxn >= gw) continue;
-                        const int pv[4] = {cv[j].x, cv[j].y, cv[j].z, cv[j].w};
+            for (int j = 0; j < 9; ++j) {
+                const int pv[4] = {cv[j].x, cv[j].y, cv[j].z, cv[j].w};
 #pragma unroll
-                        for (int sidx = 0; sidx < 4; ++sidx) {
-                            const int p = pv[sidx];
-                            if (p >= 0) {
-                                const int dx = x - (p & 0xffff), dy = y - (p >> 16);
-                                if (dx * dx + dy * dy < md2) alive = false;
-                            }
-                        }
-                    }
-                } else {
-                    for (int j = 0; j < nacc && alive; ++j) {
-                        const int dx = x - acc_x[j], dy = y - acc_y[j];
-                        if (dx * dx + dy * dy < md2) alive = false;
-                    }
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const s16x2 d = mev - *reinterpret_cast<const s16x2*>(&pv[sidx]);
+                    hit |= __builtin_amdgcn_sdot2(d, d, 0, false) < md2;
                 }
             }
-            // survivors are resolved in lane (= sorted) order with register traffic only; every accepted lane then
-            // files its own corner (list slot = its rank, grid slot by compare-and-swap) -- in parallel
-            unsigned long long mask = __ballot(alive);
-            unsigned long long accepted = 0ull;
-            const int nacc0 = nacc;
-            while (mask != 0ull && nacc < limit) {
-                const int first = __ffsll((long long)mask) - 1;
-                const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);
-                accepted |= 1ull << first;
-                ++nacc;
-                if (alive) {
-                    const int dx = x - fx, dy = y - fy;
-                    if (tid == first || dx * dx + dy * dy < md2) alive = false;
-                }
-                mask = __ballot(alive);
+        } else {
+            for (int j = 0; j < nacc && !hit; ++j) {
+                const int dx = x - acc_x[j], dy = y - acc_y[j];
+                if (dx * dx + dy * dy < md2) hit = true;
             }
-            if ((accepted >> tid) & 1ull) {
-                const int slot = nacc0 + __popcll(accepted & ((1ull << tid) - 1ull));
-                acc_x[slot] = (short)x;
-                acc_y[slot] = (short)y;
-                if (use_grid) {
-                    int* cell = cells + (fast_div(y, md, inv_md) * gw + fast_div(x, md, inv_md)) * 4;
-                    const int pk = (y << 16) | x;
-                    for (int sidx = 0; sidx < 4; ++sidx)
-                        if (atomicCAS(&cell[sidx], -1, pk) == -1) break;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();          // the grid / list writes are visible to the next batch
         }
-        if (tid == 0) s_acc = nacc;
+        return hit;
+    };
+    // The sorted list is walked in spans of 64, 128, 256, ... candidates.  Per span:
+    //   1. ALL wavefronts test the span's candidates against the corners accepted before the span -- whoever is blocked
+    //      now stays blocked (corners are only added) -- and the survivors are compacted in order;
+    //   2. the first wavefront takes the survivors 64 at a time: every lane re-tests its candidate (corners accepted
+    //      earlier in this span), then the batch is resolved in lane (= sorted) order with register traffic only: the
+    //      first survivor is accepted and knocks out the later ones closer than minDistance, repeat; every accepted lane
+    //      files its own corner (list slot = its rank, grid slot by compare-and-swap).
+    // Once the crop is covered nearly every candidate dies in step 1, on sixteen wavefronts instead of one: round 3 walked
+    // all candidates in step 2, ~6.5 k cycles per 64 whatever their fate (120 k cycles for 1000 candidates, 220 k for 2200:
+    // the longest phase of the kernel at 4K).
+    int nacc = 0;                                          // (first wavefront: corners accepted so far)
+    for (int start = 0, span = 64; start < n; start += span, span = min(span * 2, GFTT_BLK)) {
+        const int cnt = min(span, n - start);
+        int x = 0, y = 0;
+        bool alive = false;
+        if (tid < cnt) {
+            const int ri = (int)(keys[start + tid] & 0xffffffffu);
+            y = fast_div(ri, c.w, inv_w);
+            x = ri - y * c.w;
+            alive = start == 0 || !blocked(x, y, s_acc);
+        }
+        const unsigned long long sb = __ballot(alive);
+        if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(sb);
+        __syncthreads();
+        int nsurv = 0, before = 0;
+#pragma unroll
+        for (int q = 0; q < GFTT_BLK / 64; ++q) {
+            const int v = s_wcnt[q];
+            before += q < (tid >> 6) ? v : 0;
+            nsurv += v;
+        }
+        if (alive) s_surv[before + __popcll(sb & ((1ull << (tid & 63)) - 1ull))] = start + tid;
+        __syncthreads();
+        if (tid < 64) {
+            for (int base = 0; base < nsurv && nacc < limit; base += 64) {
+                bool live = base + tid < nsurv;
+                if (live) {
+                    const int ri = (int)(keys[s_surv[base + tid]] & 0xffffffffu);
+                    y = fast_div(ri, c.w, inv_w);
+                    x = ri - y * c.w;
+                    live = !blocked(x, y, nacc);
+                }
+                unsigned long long mask = __ballot(live);
+                unsigned long long accepted = 0ull;
+                const int nacc0 = nacc;
+                while (mask != 0ull && nacc < limit) {
+                    const int first = __ffsll((long long)mask) - 1;
+                    const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);
+                    accepted |= 1ull << first;
+                    ++nacc;
+                    if (live) {
+                        const int dx = x - fx, dy = y - fy;
+                        if (tid == first || dx * dx + dy * dy < md2) live = false;
+                    }
+                    mask = __ballot(live);
+                }
+                if ((accepted >> tid) & 1ull) {
+                    const int slot = nacc0 + __popcll(accepted & ((1ull << tid) - 1ull));
+                    acc_x[slot] = (short)x;
+                    acc_y[slot] = (short)y;
+                    if (use_grid) {
+                        int* cell = cells + (fast_div(y, md, inv_md) * gw + fast_div(x, md, inv_md)) * 4;
+                        const int pk = (y << 16) | x;
+                        for (int sidx = 0; sidx < 4; ++sidx)
+                            if (atomicCAS(&cell[sidx], GFTT_EMPTY, pk) == GFTT_EMPTY) break;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();          // the grid / list writes are visible to the next batch
+            }
+            if (tid == 0) s_acc = nacc;
+        }
+        __syncthreads();
+        if (s_acc >= limit) break;               // (uniform)
     }
-    __syncthreads();
     GFTT_STAMP(4)
 #ifdef FM_GFTT_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 64) { g_gftt_stamps[blockIdx.x][6] = n; g_gftt_stamps[blockIdx.x][7] = ((long long)(c.w * c.h) << 20) | s_acc; }
@@ -1617,12 +1651,15 @@ int flow_stream(fm_ctx* ctx, hipStream_t* out) {
 int build_pyramid(fm_ctx* ctx, FlowState* f, int set, hipStream_t s) {
     const int n = ctx->frame_w * ctx->frame_h;
     if (f->W == 2 * f->lw[0] && f->H == 2 * f->lh[0] && (f->W & 1) == 0) {
-        // gray + half-resolution image in one pass over the frame; levels 0-2 as one launch each
-        // (derivatives + next level); everything from level 3 on in one workgroup
+        // gray + half-resolution image in one pass over the frame; the large levels as one launch each
+        // (derivatives + next level); the small ones in one workgroup
         fm_trace_mark(ctx, s, 42);
         hipLaunchKernelGGL(gray_half_kernel, dim3((f->lw[0] + 255) / 256, f->lh[0]), dim3(256), 0, s, ctx->frame_cur,
                            f->W, f->H, f->gray[set], f->pyr[set][0], gray_coeffs(f->cfg.gray_coeff_bits));
-        const int tail = f->levels > 3 ? 3 : f->levels;        // levels >= 3 (<= ~8 k pixels at 1080p): one workgroup
+        // the levels of at most ~10 k pixels share one workgroup (1080p: from level 3; 4K: from level 4 -- level 3 of a
+        // 4K frame, 32 k pixels, in the tail made it 53 us long), the larger ones get a launch each
+        int tail = 0;
+        while (tail < f->levels && f->lw[tail] * f->lh[tail] > 10000) ++tail;
         for (int l = 0; l < tail; ++l) {
             const bool has_next = l + 1 < f->levels;
             hipLaunchKernelGGL(pyr_level_kernel, dim3((f->lw[l] + 255) / 256, f->lh[l] + (has_next ? f->lh[l + 1] : 0)),
@@ -1630,7 +1667,7 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set, hipStream_t s) {
                                reinterpret_cast<int*>(f->deriv[set][l]), has_next ? f->pyr[set][l + 1] : nullptr,
                                has_next ? f->lw[l + 1] : 0, has_next ? f->lh[l + 1] : 0);
         }
-        if (f->levels > 3) {
+        if (f->levels > tail) {
             PyrTail t{};
             for (int l = 0; l < f->levels; ++l) {
                 t.img[l] = f->pyr[set][l];
@@ -1638,7 +1675,7 @@ int build_pyramid(fm_ctx* ctx, FlowState* f, int set, hipStream_t s) {
                 t.w[l] = f->lw[l];
                 t.h[l] = f->lh[l];
             }
-            t.first = 3;
+            t.first = tail;
             t.levels = f->levels;
             hipLaunchKernelGGL(pyr_tail_kernel, dim3(1), dim3(1024), 0, s, t);
         }
@@ -1667,6 +1704,7 @@ extern "C" int fm_flow_configure(fm_ctx* ctx, const fm_flow_cfg* cfg) {
     FM_CHECK_ARG(ctx && cfg && ctx->frame_w > 0);
     FM_CHECK_ARG((cfg->win_size == 3 || cfg->win_size == 5) && cfg->max_level >= 0 && cfg->max_level < MAX_LEVELS);   // LK window instances
     FM_CHECK_ARG(cfg->block_size == 3 || cfg->block_size == 5);
+    FM_CHECK_ARG(ctx->frame_w <= 16384 && ctx->frame_h <= 16384);     // corner coordinates are packed as int16 pairs (gftt_select_kernel)
     FM_CHECK_ARG(cfg->gray_coeff_bits == 0 || cfg->gray_coeff_bits == 14 || cfg->gray_coeff_bits == 15);
     FM_HIP(hipDeviceSynchronize());
     if (ctx->flow) fm_flow_free(ctx->flow);
