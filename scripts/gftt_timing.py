@@ -19,7 +19,7 @@ for i, fr in enumerate(video.frames):
 mot = bench.build_mot(CFG, video)
 Track._count = 0
 mot.reset(1 / 30.)
-names = ['stage+max', 'candidates', 'sort', 'greedy', 'ellipse+out']
+names = ['tile maxima', 'gather', 'sort', 'greedy', 'ellipse+out']
 for s in range(12):
     mot.detector._frame_idx = s
     mot.step(DeviceFrame(s))
