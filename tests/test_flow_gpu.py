@@ -145,6 +145,77 @@ def test_targets_gftt_fast(ctx):
     assert len(kp) > 10
 
 
+def test_gftt_edge_crops(ctx):
+    """Corner detection on the crops the tiled kernel has to get right at its seams: one or two pixels wide, exactly one
+    32 x 32 tile, one pixel more than a tile, a frame corner, a crop with a strong min-distance (few cells), and a track
+    overlapped by 40 earlier ones (more than the 32 rects the kernels keep in LDS: the global overlap list).  Every
+    list must equal the restated goodFeaturesToTrack on the same crop and mask (bit-identical points, same order)."""
+    size = (640, 360)
+    f0 = textured_frame(*size, 11)
+    flow = make_flow(size)
+    flow.init(f0)
+    g0 = cv.bgr2gray(f0)
+    small = [[300 + 3 * i, 200 + 2 * i, 330 + 3 * i, 240 + 2 * i] for i in range(40)]       # 40 rects crossing the big one
+    rects = np.array(small + [
+        [280, 180, 460, 330],       # 40: overlapped by all 40 above
+        [10, 10, 10, 40],           # 41: one pixel wide
+        [20, 10, 21, 12],           # 42: 2 x 3
+        [40, 10, 42, 12],           # 43: 3 x 3 (one interior pixel)
+        [60, 20, 91, 51],           # 44: exactly one tile
+        [100, 20, 132, 52],         # 45: 33 x 33
+        [0, 0, 70, 9],              # 46: frame corner, 71 x 10
+        [560, 300, 639, 359],       # 47: bottom right corner of the frame
+        [200, 20, 263, 27],         # 48: 64 x 8
+    ], float)
+    off = np.zeros(len(rects) + 1, np.int32)
+    ctx.flow_targets(rects, np.empty((0, 2), np.float32), off)
+    mask = np.full((size[1], size[0]), 255, np.uint8)
+    masks = []
+    for r in rects.astype(int):
+        masks.append(mask[r[1]:r[3] + 1, r[0]:r[2] + 1].copy())
+        mask[r[1]:r[3] + 1, r[0]:r[2] + 1] = 0
+    idx = list(range(40, len(rects)))
+    mds = [7, 1, 1, 1, 3, 4, 2, 25, 2]
+    pts, cnt = ctx.flow_detect(idx, rects[idx], mds, cap=1000)
+    seen = 0
+    for i, (k, md) in enumerate(zip(idx, mds)):
+        r = rects[k].astype(int)
+        exp = cv.good_features_to_track(g0[r[1]:r[3] + 1, r[0]:r[2] + 1], masks[k], 1000, 0.06, md)
+        exp = exp.reshape(-1, 2) + np.array(r[:2], np.float32)
+        c = (rects[k][:2] + rects[k][2:]) / 2
+        ax = (rects[k][2:] - rects[k][:2] + 1) * 0.5
+        exp = exp[(((exp - c) / ax) ** 2).sum(1) <= 1.] if len(exp) else exp
+        got = pts[i, :cnt[i]]
+        assert len(got) == len(exp), (k, len(got), len(exp))
+        np.testing.assert_array_equal(got, exp)
+        seen += len(exp)
+    assert masks[40].any() and not masks[40].all() and seen > 40
+
+
+def test_fast_background_ragged_raster(ctx):
+    """Background FAST keypoints on a raster whose size is not a multiple of the compaction's 256-pixel segments
+    (65 x 37 = 2405), under a mask of three tracks: same keypoints, same raster order as the restatement."""
+    size = (650, 370)
+    f0 = textured_frame(*size, 21)
+    flow = make_flow(size)
+    flow.init(f0)
+    g0 = cv.bgr2gray(f0)
+    rects = np.array([[100, 100, 300, 300], [0, 0, 60, 369], [500, 20, 649, 120]], float)
+    ctx.flow_targets(rects, np.empty((0, 2), np.float32), np.zeros(4, np.int32))
+    mask = np.full((size[1], size[0]), 255, np.uint8)
+    for r in rects.astype(int):
+        mask[r[1]:r[3] + 1, r[0]:r[2] + 1] = 0
+    bg = ctx.flow_background()
+    bw, bh = int(size[0] * 0.1), int(size[1] * 0.1)
+    assert (bw * bh) % 256 != 0
+    bg_img = cv.resize_linear_u8(g0, (bw, bh))
+    kp = cv.fast_detect(bg_img, 10)
+    mask_small = cv.resize_nearest(mask, (bw, bh))
+    kp = kp[[mask_small[int(p[1] + 0.5), int(p[0] + 0.5)] != 0 for p in kp]]
+    np.testing.assert_array_equal(bg, kp)
+    assert len(kp) > 10
+
+
 def test_estimate_vs_oracle(ctx):
     rng = np.random.default_rng(9)
     size = (640, 360)
