@@ -77,6 +77,33 @@ def test_filter_dets_random_vs_oracle(ctx, nms_path):
         np.testing.assert_allclose(out.conf, cf, rtol=1e-7)
 
 
+@pytest.mark.parametrize('n', [63, 64, 65, 127, 128, 129, 191, 192, 193, 256, 2559, 2560, 2561, 2688, 2689, 2753])
+def test_filter_dets_chunk_boundaries(ctx, n):
+    """Candidate counts at the seams of the bit-matrix / scan path: 64-candidate chunks, two chunks per scan iteration,
+    an odd number of chunks, and the 2560 rows whose loads the scan pipelines (beyond them rows are fetched at use).
+    Every row passes the threshold, so K = n exactly; boxes cluster so that chains of suppression cross the chunks."""
+    rng = np.random.default_rng(n)
+    det = YOLODetector((1920, 1080), (0, 1, 2), model='TinyYOLO', conf_thresh=0.3, nms_thresh=0.45,
+                       max_area=200000, min_aspect_ratio=0.5, max_candidates=16384)
+    ctx.set_option('nms_path', 1)
+    try:
+        centres = rng.uniform(0.1, 0.8, (max(n // 12, 1), 2))
+        pick = rng.integers(0, len(centres), n)
+        rows = np.stack([centres[pick, 0] + rng.normal(0, 0.01, n), centres[pick, 1] + rng.normal(0, 0.01, n),
+                         rng.uniform(0.05, 0.08, n), rng.uniform(0.1, 0.16, n), rng.uniform(0.6, 1, n),
+                         rng.integers(0, 3, n), rng.uniform(0.6, 1, n)], 1).astype(np.float32)
+        out = ctx.filter_dets(rows, cap=16384)
+        assert ctx.detect_last_counts()[0] == n
+        lm = np.array([True, True, True])
+        tl, lb, cf = o.filter_dets(rows, [1920, 1080], [0, 0], lm, 0.3, 0.45, 200000, 0.5)
+        assert 0 < len(tl) < n
+        np.testing.assert_array_equal(out.tlbr, tl)
+        np.testing.assert_array_equal(out.label, lb)
+        np.testing.assert_allclose(out.conf, cf, rtol=1e-7)
+    finally:
+        ctx.set_option('nms_path', 0)
+
+
 def test_filter_dets_more_candidates_than_the_fused_kernel_holds(ctx):
     """> 4096 candidates over the threshold: the fused kernel flags the pass, the general path takes it over (and the
     following passes, until the count has fallen again); results equal the oracle throughout."""
