@@ -435,11 +435,6 @@ int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s)
     FM_CHECK_ARG((long)p.H * p.W < (1L << 24) && p.in_cs < (1 << 24) && (long)p.H * p.W * p.in_cs < (1L << 32));
     FM_CHECK_ARG(p.Kpad < (1 << 24) && (long)((p.Cout + 31) & ~31) * p.Kpad < (1L << 32));
     FM_CHECK_ARG(p.P < (1 << 22) && p.Kpad < (1 << 22));      // idiv_small (prologue index decompositions)
-    {
-        bool taken = false;
-        const int rc = launch_conv1x1_stream(p, s, &taken);
-        if (rc || taken) return rc;
-    }
     const int cout_pad = (p.Cout + 31) & ~31;
     auto tiles = [&](int bmc, int bnp) { return (long)((p.P + bnp - 1) / bnp) * ((cout_pad + bmc - 1) / bmc); };
     const int nk = p.Kpad / BK;

@@ -28,9 +28,6 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams& p, float* ws, size_t ws_floats, hipStream_t s);
-// persistent streaming kernel for the memory-bound stride-1 1x1 layers (conv1x1.hip); *taken: the layer was one of them
-int launch_conv1x1_stream(const ConvParams& p, hipStream_t s, bool* taken);
-void conv1x1_stream_enable(int on);
 
 struct NetState {
     int which = 0, max_batch = 0;
@@ -45,11 +42,6 @@ struct NetState {
     char* arena = nullptr;    // shared activation arena (tensors with offset >= 0)
     float* ws = nullptr;      // split-K partial sums (fp32)
     size_t ws_floats = 0;
-    // two-branch schedules (fm_layer.branch): the second stream, its own split-K workspace, one event per signalling layer
-    hipStream_t side = nullptr;
-    float* ws_side = nullptr;
-    std::vector<hipEvent_t> layer_ev;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<std::pair<long, hipGraphExec_t>> graphs;   // (batch, emb_offset) -> captured layer sequence
     bool use_graphs = true;
     int emb_offset = 0;   // row offset of FM_OP_HEAD outputs in ctx->emb (batched extraction)

@@ -14,10 +14,6 @@ void liteconv_tiling(int C, int W, int H, int* th, int* tw, int* tiles_x, int* t
 int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* wpw,
                      int kpad, const f16* wdw, const float* bias, int N, int H, int W, int C, int act,
                      float* const* gap, hipStream_t s);
-int launch_gatedconv(const f16* const* in, const int* in_cs, const int* in_coff, const float* const* parts, int tiles,
-                     const f16* x2, int x2_cs, int x2_coff, int c2, const f16* res, int res_cs, int res_coff, f16* out,
-                     int out_cs, int out_coff, const f16* w, const float* bias, int kpad, const f16* w1, const float* b1,
-                     const f16* w2, const float* b2, int N, int HW, int C, int hid, int cout, int act, hipStream_t s);
 int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const int* in_coff, int N, int HW,
                      int C, int hid, const f16* w1, const float* b1, const f16* w2, const float* b2, f16* out,
                      int out_cs, int out_coff, const float* const* part, int tiles, hipStream_t s);
@@ -34,8 +30,6 @@ int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
                      int W, int C, hipStream_t s);
 int launch_conv_streamed(const ConvParams& p, hipStream_t s);
 bool resblock_supported(int C, int M);
-int launch_cspstage(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, int out_coff, const f16* w, const float* b,
-                    int N, int H, int W, int C, int M, int act, hipStream_t s);
 int launch_resblock(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, int out_coff, const f16* w1,
                     const float* b1, const f16* w2, const float* b2, int N, int H, int W, int C, int M, int act1,
                     int act2, hipStream_t s);
@@ -61,11 +55,6 @@ void fm_net_free(NetState* n) {
     if (n->weights) (void)hipFree(n->weights);
     if (n->gates) (void)hipFree(n->gates);
     if (n->ws) (void)hipFree(n->ws);
-    if (n->ws_side) (void)hipFree(n->ws_side);
-    for (hipEvent_t e : n->layer_ev)
-        if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {n->ev_fork, n->ev_join})
-        if (e) (void)hipEventDestroy(e);
     for (auto& g : n->graphs) (void)hipGraphExecDestroy(g.second);
     delete n;
 }
@@ -134,31 +123,6 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
     net->gate_c = gate_channels;
     net->ws_floats = (size_t)16 << 20;   // 64 MB of fp32 split-K partials
     FM_HIP(hipMalloc(&net->ws, net->ws_floats * sizeof(float)));
-    {
-        bool branches = false;
-        for (size_t i = 0; i < net->layers.size(); ++i) {
-            const fm_layer& L = net->layers[i];
-            FM_CHECK_ARG((L.branch == 0 || L.branch == 1) && L.wait_for < (int)i);
-            FM_CHECK_ARG(L.wait_for < 0 || (net->layers[L.wait_for].signal && net->layers[L.wait_for].branch != L.branch));
-            branches |= L.branch != 0;
-        }
-        if (branches) {
-            // the second stream: one of the context's own idle streams where there is one (the context already drives
-            // more streams than the runtime has hardware queues; a further one changes which of them share a queue)
-            // (taken by a fourth ReID instance, or another network than the detector: the table runs as one chain in
-            // table order, which honours every dependency of the two-branch plan)
-            net->side = which == FM_NET_DETECTOR && !ctx->ext_net_x[FM_MAX_EXTRA_EXTRACTORS - 1]
-                            ? ctx->s_ext_x[FM_MAX_EXTRA_EXTRACTORS - 1] : nullptr;
-        }
-        if (net->side) {
-            FM_HIP(hipMalloc(&net->ws_side, net->ws_floats * sizeof(float)));
-            net->layer_ev.assign(net->layers.size(), nullptr);
-            for (size_t i = 0; i < net->layers.size(); ++i)
-                if (net->layers[i].signal) FM_HIP(hipEventCreateWithFlags(&net->layer_ev[i], hipEventDisableTiming));
-            FM_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
-            FM_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
-        }
-    }
     if (n_gates > 0) {
         FM_CHECK_ARG(gate_channels > 0);
         FM_HIP(hipMalloc(&net->gates, sizeof(float) * (size_t)n_gates * max_batch * gate_channels * GATE_SLOT_TILES));
@@ -171,11 +135,11 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
     return 0;
 }
 
-static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B, hipStream_t s = nullptr, float* ws = nullptr) {
+static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
     const fm_tensor& ti = net->tensors[L.in[0]];
     const fm_tensor& to = net->tensors[L.out];
-    if (!s) s = net->stream;
-    if (!ws) ws = net->ws;
+    hipStream_t s = net->stream;
+    float* ws = net->ws;
     const f16* in0 = (const f16*)net->bufs[L.in[0]];
     f16* out = (f16*)net->bufs[L.out];
     switch (L.op) {
@@ -274,49 +238,6 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B, hipSt
                                     (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
                                     out, to.c, L.out_coff, L.gate[0] >= 0 ? parts : nullptr, tiles, s);
         }
-        case FM_OP_GATEDCONV: {
-            // streams in in[0..3] (cin channels each), their tile sums in the gate slots; res_mode FM_RES_CONCAT: the
-            // tensor `res` holds the second K segment (cin2 channels), FM_RES_BEFORE_ACT: the identity shortcut
-            const f16* ins[4];
-            int cs[4], co[4];
-            const float* parts[4];
-            FM_CHECK_ARG(L.n_in == 4 && !to.f32 && to.h == ti.h && to.w == ti.w && L.out_coff + L.cout <= to.c);
-            int th, tw, tx, ty;
-            liteconv_tiling(L.cin, ti.w, ti.h, &th, &tw, &tx, &ty);
-            for (int i = 0; i < 4; ++i) {
-                const fm_tensor& tg = net->tensors[L.in[i]];
-                FM_CHECK_ARG(tg.h == ti.h && tg.w == ti.w && L.in_coff[i] + L.cin <= tg.c);
-                FM_CHECK_ARG(L.gate[i] >= 0 && L.gate[i] < net->n_gates);
-                ins[i] = (const f16*)net->bufs[L.in[i]];
-                cs[i] = tg.c;
-                co[i] = L.in_coff[i];
-                parts[i] = net->gates + (size_t)L.gate[i] * net->max_batch * net->gate_c * GATE_SLOT_TILES;
-            }
-            const f16 *x2 = nullptr, *res = nullptr;
-            int x2_cs = 0, x2_coff = 0, c2 = 0, res_cs = 0, res_coff = 0;
-            if (L.res_mode == FM_RES_CONCAT) {
-                const fm_tensor& tr = net->tensors[L.res];
-                FM_CHECK_ARG(L.cin2 > 0 && tr.h == ti.h && tr.w == ti.w && L.res_coff + L.cin2 <= tr.c);
-                x2 = (const f16*)net->bufs[L.res]; x2_cs = tr.c; x2_coff = L.res_coff; c2 = L.cin2;
-            } else if (L.res_mode == FM_RES_BEFORE_ACT) {
-                const fm_tensor& tr = net->tensors[L.res];
-                FM_CHECK_ARG(tr.h == ti.h && tr.w == ti.w && L.res_coff + L.cout <= tr.c);
-                res = (const f16*)net->bufs[L.res]; res_cs = tr.c; res_coff = L.res_coff;
-            } else {
-                FM_CHECK_ARG(L.res_mode == FM_RES_NONE);
-            }
-            // gate MLP blob at w2_off: fc1 [hid][cin] fp16 | b1 f32 | fc2 [cin][hid] fp16 | b2 f32, sections 16 B aligned
-            auto al16 = [](size_t v) { return (v + 15) & ~size_t(15); };
-            const char* gb = net->weights + L.w2_off;
-            const size_t o_b1 = al16((size_t)L.hid * L.cin * 2), o_w2 = o_b1 + al16((size_t)L.hid * 4);
-            const size_t o_b2 = o_w2 + al16((size_t)L.cin * L.hid * 2);
-            const int kpad = ((((L.cin + 15) & ~15) + ((c2 + 15) & ~15)) + 63) & ~63;   // two segments of whole K steps
-            return launch_gatedconv(ins, cs, co, parts, tx * ty, x2, x2_cs, x2_coff, c2, res, res_cs, res_coff, out, to.c,
-                                    L.out_coff, (const f16*)(net->weights + L.w_off),
-                                    (const float*)(net->weights + L.b_off), kpad, (const f16*)gb,
-                                    (const float*)(gb + o_b1), (const f16*)(gb + o_w2), (const float*)(gb + o_b2), B,
-                                    ti.h * ti.w, L.cin, L.hid, L.cout, L.act, s);
-        }
         case FM_OP_STEMCONV:
             FM_CHECK_ARG(!to.f32 && (ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h &&
                          (ti.w + 2 * L.pad - L.k) / L.stride + 1 == to.w && L.out_coff + ((L.cout + 7) & ~7) <= to.c);
@@ -340,10 +261,6 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B, hipSt
                                    (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                    (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
                                    B, ti.h, ti.w, L.cin, L.hid, L.act, L.act, s);
-        case FM_OP_CSPSTAGE:
-            FM_CHECK_ARG(!to.f32 && to.h == ti.h && to.w == ti.w && L.in_coff[0] + L.cin <= ti.c && L.out_coff + L.cout <= to.c);
-            return launch_cspstage(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, (const f16*)(net->weights + L.w_off),
-                                   (const float*)(net->weights + L.b_off), B, ti.h, ti.w, L.cin, L.hid, L.act, s);
         case FM_OP_ADD: {
             FM_CHECK_ARG(L.n_in == 2);
             const fm_tensor& tb = net->tensors[L.in[1]];
@@ -386,27 +303,10 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B, hipSt
 // gate kernels index gate[n*C + c] with C = the gated channel count; buffers are spaced by
 // max_batch*gate_c so any C <= gate_c fits.
 static int run_layers_eager(fm_ctx* ctx, NetState* net, int batch) {
-    if (!net->side) {
-        for (const fm_layer& L : net->layers) {
-            int rc = run_layer(ctx, net, L, batch);
-            if (rc) return rc;
-        }
-        return 0;
-    }
-    // two-branch schedule: branch 1 on the second stream, forked from / joined into the network's stream by events (under
-    // stream capture these become the parallel paths of the hipGraph)
-    FM_HIP(hipEventRecord(net->ev_fork, net->stream));
-    FM_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
-    for (size_t i = 0; i < net->layers.size(); ++i) {
-        const fm_layer& L = net->layers[i];
-        hipStream_t s = L.branch ? net->side : net->stream;
-        if (L.wait_for >= 0) FM_HIP(hipStreamWaitEvent(s, net->layer_ev[L.wait_for], 0));
-        int rc = run_layer(ctx, net, L, batch, s, L.branch ? net->ws_side : net->ws);
+    for (const fm_layer& L : net->layers) {
+        int rc = run_layer(ctx, net, L, batch);
         if (rc) return rc;
-        if (L.signal) FM_HIP(hipEventRecord(net->layer_ev[i], s));
     }
-    FM_HIP(hipEventRecord(net->ev_join, net->side));
-    FM_HIP(hipStreamWaitEvent(net->stream, net->ev_join, 0));
     return 0;
 }
 
@@ -508,11 +408,6 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *bytes = (pin + 4 * pout) * L.cin * 2 + 10.0 * L.cin * L.cout * 2;
             break;
         case FM_OP_GATED_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
-        case FM_OP_GATEDCONV:
-            *flops = 2.0 * pout * L.cout * (L.cin + L.cin2) + 2.0 * pin * 4 * L.cin;
-            *bytes = pin * (4.0 * L.cin + L.cin2) * 2 + pout * L.cout * 2 * (L.res_mode == FM_RES_BEFORE_ACT ? 2 : 1) +
-                     (double)((L.cout + 31) & ~31) * (L.cin + L.cin2) * 2;
-            break;
         case FM_OP_STEMCONV:
             *flops = 2.0 * L.k * L.k * 3 * L.cout * pout;
             *bytes = pin * 8 + pout * L.cout * 2;
@@ -520,11 +415,6 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
         case FM_OP_RESBLOCK:
             *flops = 2.0 * 10 * L.cin * L.hid * pout;
             *bytes = (pin + pout) * L.cin * 2 + 10.0 * L.cin * L.hid * 2;
-            break;
-        case FM_OP_CSPSTAGE:      /* the five convs of the stage; bytes: d in, stage output out, weights */
-            *flops = 2.0 * (L.cin * 2 * L.cin + L.cin * L.hid + 9 * L.hid * L.cin + L.cin * L.cin + 2 * L.cin * L.cout) * pout;
-            *bytes = pin * L.cin * 2 + pout * L.cout * 2 +
-                     2.0 * (L.cin * 2 * L.cin + L.cin * L.hid + 9 * L.hid * L.cin + L.cin * L.cin + 2 * L.cin * L.cout);
             break;
         case FM_OP_SPP: *bytes = (pin + 3 * pout) * L.cin * 2; break;
         case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
@@ -543,7 +433,7 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
     FM_CHECK_ARG(net != nullptr);
     double f = 0, b = 0;
     for (const fm_layer& L : net->layers)
-        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK || L.op == FM_OP_CSPSTAGE) {
+        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK) {
             double lf, lb;
             layer_cost(net, L, batch, &lf, &lb);
             f += lf;
@@ -573,7 +463,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
             FM_HIP(hipEventSynchronize(e1));
             float ms = 0;
             FM_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK || L.op == FM_OP_CSPSTAGE) { tc += ms; ++nc; } else { to += ms; ++no; }
+            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK) { tc += ms; ++nc; } else { to += ms; ++no; }
         }
     FM_HIP(hipEventDestroy(e0));
     FM_HIP(hipEventDestroy(e1));

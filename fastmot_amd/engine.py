@@ -14,14 +14,7 @@ class HipNet:
         """reuse_buffers: share activation memory between tensors with disjoint live ranges (the
         production setting; intermediate tensors can then not be read back after a run)."""
         self.ctx, self.which, self.graph, self.max_batch = ctx, which, graph, max_batch
-        # Two-branch schedule of the detector (layers that do not depend on each other side by side: models/graph.py
-        # plan_branches): OFF by default.  Measured in round 4 (gpurun_out/r04j, profiles/r04_branch_plan_ab.txt): results
-        # bit-identical, but ROCm 7.2 replays a hipGraph with parallel paths 3.6x SLOWER than the chain (detector pass 1.07 ->
-        # 3.85 ms inside the pipeline, 850 -> 249 frames/s) -- the runtime serialises the paths through its own
-        # streams with a synchronisation per edge.  FASTMOT_BRANCHES=1 switches it on (tests/test_branch_plan.py does).
-        import os
-        branches = which == NET_DETECTOR and os.environ.get('FASTMOT_BRANCHES', '0') == '1'
-        ts, ls, blob = graph.tables(max_batch, reuse_buffers, branches=branches)
+        ts, ls, blob = graph.tables(max_batch, reuse_buffers)
         self._keep = (ts, ls, blob)
         _lib.check(ctx.lib.fm_net_create(ctx.handle, C.c_int(which), C.c_int(max_batch), C.c_int(len(ts)), ts,
                                          C.c_int(len(ls)), ls, blob, C.c_size_t(len(blob)),

@@ -15,11 +15,10 @@ import numpy as np
 LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CSPSTAGE,
- OP_GATEDCONV) = range(19)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN) = range(17)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
-RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT, RES_CONCAT = 0, 1, 2, 3
+RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 
 
 class fm_tensor(C.Structure):
@@ -34,8 +33,7 @@ class fm_layer(C.Structure):
                 ('cin', C.c_int32), ('cout', C.c_int32), ('k', C.c_int32), ('stride', C.c_int32),
                 ('pad', C.c_int32), ('act', C.c_int32), ('hid', C.c_int32), ('up', C.c_int32),
                 ('gate', C.c_int32 * 4),
-                ('w_off', C.c_int64), ('b_off', C.c_int64), ('w2_off', C.c_int64), ('b2_off', C.c_int64),
-                ('branch', C.c_int32), ('wait_for', C.c_int32), ('signal', C.c_int32), ('cin2', C.c_int32)]
+                ('w_off', C.c_int64), ('b_off', C.c_int64), ('w2_off', C.c_int64), ('b2_off', C.c_int64)]
 
 
 def ceil_to(x, m):
@@ -126,16 +124,10 @@ class Graph:
         self.n_gates = 0
         self.gate_c = 8
         self.use_stem = True   # small-Cin first layers go to the LDS-patch stem kernel
-        # the first CSP stage of CSPDarknet53 (4 launches on the 304 x 304 map) as one launch (cspstage.hip): bit-identical,
-        # measured SLOWER (73 us against 59 us, profiles/r04_cspstage_ab.txt) -> off unless FASTMOT_CSPSTAGE=1
-        self.use_cspstage = os.environ.get('FASTMOT_CSPSTAGE', '0') == '1'
         # darknet residual units (1x1, 3x3, shortcut) as one fused launch (resblock.hip)
         self.use_resblock = os.environ.get('FASTMOT_RESBLOCK', '1') != '0'
         # the four LightConv streams of an OSNet block as one launch (litechain.hip) instead of one per depth
         self.use_lightchain = os.environ.get('FASTMOT_LITECHAIN', '1') != '0'
-        # tail of an OSNet block (gate, gated sum, conv3 + shortcut) as one launch (gatedconv.hip): measured slower than
-        # the two launches it replaces (profiles/r04_gatedconv_ab.txt) -- off unless FASTMOT_GATEDCONV=1
-        self.use_gatedconv = os.environ.get('FASTMOT_GATEDCONV', '0') == '1'
         # convs with at most this many output pixels per sample and a long reduction take the streamed
         # kernel (K split inside the workgroup, convs.hip) instead of the LDS-tiled one + split-K reduce
         self.convs_max_pixels = int(os.environ.get('FASTMOT_CONVS_MAXP', '1444'))
@@ -158,7 +150,7 @@ class Graph:
 
     def _layer(self, **kw):
         d = dict(op=0, ins=[], out=None, res=None, res_mode=RES_NONE, cin=0, cout=0, k=1, stride=1, pad=0,
-                 act=0, hid=0, up=1, gates=[], w_off=0, b_off=0, w2_off=0, b2_off=0, cin2=0)
+                 act=0, hid=0, up=1, gates=[], w_off=0, b_off=0, w2_off=0, b2_off=0)
         d.update(kw)
         self.layers.append(d)
         return d
@@ -251,34 +243,6 @@ class Graph:
                     w_off=self._push(self._pack_frag(w1h)), b_off=self._push(b1),
                     w2_off=self._push(self._pack_frag(w2h)), b2_off=self._push(b2), name=name2,
                     res_ref=(w1h.astype(np.float32), b1, w2h.astype(np.float32), b2))
-        return dst
-
-    @staticmethod
-    def cspstage_supported(c, mid):
-        return c == 64 and mid == 32
-
-    def cspstage(self, names, d, mid, cout, act='mish', dst=None):
-        """First CSP stage of CSPDarknet53 behind its stride-2 conv `d`, in one launch (cspstage.hip):
-        [b | A] = act(1x1 d) ; b' = b + act(3x3 act(1x1 b)) ; c = act(1x1 b') ; out = act(1x1 [c | A]).
-        names: the six Darknet layers in cfg order (route branch A, residual branch b, bottleneck 1x1, 3x3, post 1x1,
-        stage output 1x1) -- parameters are drawn in that order, like the unfused layers."""
-        h = d.c
-        assert self.cspstage_supported(h, mid) and d.cpad == h and cout == h
-        if dst is None:
-            dst = self.new(d.h, d.w, cout)
-        (wa, ba), (wb, bb) = (fold_bn(self.wsrc.conv(n, h, h, 1, bn=True)) for n in names[:2])
-        w3a, b3a = fold_bn(self.wsrc.conv(names[2], mid, h, 1, bn=True))
-        w3b, b3b = fold_bn(self.wsrc.conv(names[3], h, mid, 3, bn=True))
-        w4, b4 = fold_bn(self.wsrc.conv(names[4], h, h, 1, bn=True))
-        w5, b5 = fold_bn(self.wsrc.conv(names[5], cout, 2 * h, 1, bn=True))
-        w2, b2 = np.concatenate([wb, wa]), np.concatenate([bb, ba])          # [b | A], as the merged sibling conv writes them
-        mats = [np.asarray(w, np.float32).astype(np.float16) for w in (w2, w3a, w3b, w4, w5)]
-        blob = np.concatenate([self._pack_frag(w).reshape(-1) for w in mats])
-        bias = np.concatenate([np.asarray(b, np.float32) for b in (b2, b3a, b3b, b4, b5)])
-        self._layer(op=OP_CSPSTAGE, ins=[d], out=dst, cin=h, cout=cout, k=3, stride=1, pad=1, act=ACT[act], hid=mid,
-                    w_off=self._push(blob), b_off=self._push(bias), name=names[5],
-                    csp_ref=tuple((w.astype(np.float32), np.asarray(b, np.float32))
-                                  for w, b in zip(mats, (b2, b3a, b3b, b4, b5))))
         return dst
 
     def dwconv3(self, name, x, act='relu', dst=None):
@@ -467,50 +431,6 @@ class Graph:
                     gate_ref=(w1[:, :c].astype(np.float32), p1['bias'], w2[:c].astype(np.float32), p2['bias']))
         return dst
 
-    def gated_conv(self, name, conv_name, xs, hid, parts, cout, act='relu', x2=None, res=None, wb=None, dst=None):
-        """Tail of an OSNet block in one launch (FM_OP_GATEDCONV, gatedconv.hip): act(conv1x1([gated_sum(xs) | x2]) (+ res)).
-        xs: the four stream views with their tile-sum slots `parts`; x2: second K segment (a stage's first block: the
-        block input, `wb` = ([W3 | Wd], b3 + bd)); res: identity shortcut, added before the activation."""
-        x = xs[0]
-        c = x.c
-        assert len(xs) == 4 and len(parts) == 4 and all(v.c == c and v.coff % 8 == 0 for v in xs) and c % 8 == 0
-        assert x2 is None or res is None
-        c2 = x2.c if x2 is not None else 0
-        assert c2 % 8 == 0 and cout % 8 == 0
-        p1 = self.wsrc.conv(name + '.fc1', hid, c, 1, bn=False)
-        p2 = self.wsrc.conv(name + '.fc2', c, hid, 1, bn=False)
-        w1 = p1['w'].reshape(hid, c).astype(np.float16)
-        w2 = p2['w'].reshape(c, hid).astype(np.float16)
-        b1, b2 = p1['bias'].astype(np.float32), p2['bias'].astype(np.float32)
-        blob = bytearray()
-        for a in (w1, b1, w2, b2):                        # sections 16 B aligned (fastmot_hip.h: FM_OP_GATEDCONV)
-            blob += np.ascontiguousarray(a).tobytes()
-            blob += b'\0' * (-len(blob) % 16)
-        if wb is not None:      # (a callable: evaluated here, after the gate's parameters, like the two-launch tail reads them)
-            w, b = (np.asarray(a, np.float32) for a in (wb() if callable(wb) else wb))
-        else:
-            w, b = fold_bn(self.wsrc.conv(conv_name, cout, c, 1, bn=True))
-        K = c + c2
-        assert w.shape == (cout, K, 1, 1) and b.shape == (cout,)
-        w16 = w.astype(np.float16)
-        cpad = ceil_to(cout, 32)
-        c16 = ceil_to(c, 16)                              # two K segments of whole 16-channel steps (gatedconv.hip)
-        packed = np.zeros((cpad, ceil_to(c16 + ceil_to(c2, 16), 64)), np.float16)
-        packed[:cout, :c] = w16.reshape(cout, K)[:, :c]
-        packed[:cout, c16:c16 + c2] = w16.reshape(cout, K)[:, c:]
-        bias = np.zeros(cpad, np.float32)
-        bias[:cout] = b
-        if dst is None:
-            dst = self.new(x.h, x.w, cout)
-        self._layer(op=OP_GATEDCONV, ins=list(xs), out=dst, cin=c, cout=cout, hid=hid, act=ACT[act], cin2=c2,
-                    gates=list(parts), res=x2 if x2 is not None else res,
-                    res_mode=RES_CONCAT if x2 is not None else (RES_BEFORE_ACT if res is not None else RES_NONE),
-                    w_off=self._push(packed), b_off=self._push(bias),
-                    w2_off=self._push(np.frombuffer(bytes(blob), np.uint8)), name=name,
-                    gate_ref=(w1.astype(np.float32), p1['bias'], w2.astype(np.float32), p2['bias']),
-                    conv_ref=(w16.astype(np.float32), b))
-        return dst
-
     def gate_sum(self, xs, gids, dst=None):
         x = xs[0]
         if dst is None:
@@ -530,24 +450,18 @@ class Graph:
         return dst
 
     # ---------------------------------------------------------------- C tables
-    def plan_arena(self, max_batch, reuse, before=None):
+    def plan_arena(self, max_batch, reuse):
         """Byte offsets of the tensors in one activation arena.  With `reuse`, tensors whose live
         ranges [first writer/reader layer, last layer touching them] do not overlap share bytes
         (greedy first-fit by decreasing size).  The network input and the graph outputs are read /
-        written outside the layer sequence and therefore stay live for the whole run.
-        before (two-branch schedules, plan_branches): before[b] = set of layers that are complete when layer b starts;
-        two tensors then share bytes only if every access of one happens before every access of the other (table order
-        alone does not say so any more)."""
+        written outside the layer sequence and therefore stay live for the whole run."""
         n = len(self.tensors)
         size = [ceil_to(max_batch * h * w * c * (4 if f32 else 2), 256) for (h, w, c, f32) in self.tensors]
         first, last = [10**9] * n, [-1] * n
-        acc = [[] for _ in range(n)]
         for li, d in enumerate(self.layers):
             touched = [v.tid for v in d['ins']] + [d['out'].tid] + ([d['res'].tid] if d['res'] is not None else [])
             for t in touched:
                 first[t], last[t] = min(first[t], li), max(last[t], li)
-                if not acc[t] or acc[t][-1] != li:
-                    acc[t].append(li)
         persistent = {self.input.tid} | {v.tid for v in self.outputs}
         for t in range(n):
             if t in persistent or not reuse or last[t] < 0:
@@ -557,9 +471,7 @@ class Graph:
             """all accesses of t are over before u is touched, or the other way round"""
             if first[t] < 0 or first[u] < 0:
                 return False
-            if before is None:
-                return last[t] < first[u] or last[u] < first[t]
-            return all(a in before[b] for a in acc[t] for b in acc[u]) or all(b in before[a] for a in acc[t] for b in acc[u])
+            return last[t] < first[u] or last[u] < first[t]
         offsets = [0] * n
         placed = []                      # (offset, size, tensor)
         for t in sorted(range(n), key=lambda i: -size[i]):
@@ -574,105 +486,8 @@ class Graph:
         total = max((o + s for (o, s, _) in placed), default=0)
         return offsets, total
 
-    @staticmethod
-    def happens_before(plan):
-        """before[b] = layers guaranteed complete when layer b starts under a two-branch plan: the earlier layers of its
-        own branch, the layer it waits for, and everything before those."""
-        before = []
-        prev = [-1, -1]
-        for i, (br, wait, _) in enumerate(plan):
-            s = set()
-            for p in (prev[br], wait):
-                if p >= 0:
-                    s |= before[p]
-                    s.add(p)
-            before.append(s)
-            prev[br] = i
-        return before
-
-    def plan_branches(self, max_batch, offsets=None):
-        """Two-stream schedule of the layer sequence: -> [(branch, wait_for, signal)] per layer (fm_layer).
-
-        The table order is one valid serial order; batch-1 networks leave most of the GPU idle in their small layers, and
-        some of them do not depend on each other: a YOLO head's 3x3 + 1x1 and the PAN path that continues from the same
-        tensor, the two 1x1 convs that fill the halves of a concat.  Dependencies are derived from MEMORY, not from the
-        table's tensor ids alone: layer b (later) depends on layer a if one writes what the other reads or writes --
-        same tensor and intersecting channel ranges, or (with the shared arena) different tensors whose byte ranges
-        intersect.  Layers are then list-scheduled in table order onto two branches with a rough duration model
-        (launch floor + FLOPs + bytes); every branch keeps table order, so hazards inside a branch are ordered by its
-        stream, and a cross-branch dependency becomes one event wait.  Results are bit-identical to the chain: the same
-        kernels on the same data."""
-        n = len(self.layers)
-        size = [max_batch * h * w * c * (4 if f32 else 2) for (h, w, c, f32) in self.tensors]
-
-        def foot(d):
-            reads = [(v.tid, v.coff, v.coff + v.cpad) for v in d['ins']]
-            if d['res'] is not None:
-                reads.append((d['res'].tid, d['res'].coff, d['res'].coff + d['res'].cpad))
-            o = d['out']
-            return reads, [(o.tid, o.coff, o.coff + max(o.cpad, ceil_to(d.get('cout', 0) or o.c, 8)))]
-
-        def clash(x, y):
-            if x[0] == y[0]:
-                return x[1] < y[2] and y[1] < x[2]
-            if offsets is None:
-                return False
-            ax, ay = offsets[x[0]], offsets[y[0]]
-            return ax < ay + size[y[0]] and ay < ax + size[x[0]]
-        feet = [foot(d) for d in self.layers]
-        gate_users = {}
-        deps = [set() for _ in range(n)]
-        for b in range(n):
-            rb, wb = feet[b]
-            for a in range(b):
-                ra, wa = feet[a]
-                if any(clash(x, y) for x in wb for y in ra + wa) or any(clash(x, y) for x in rb for y in wa):
-                    deps[b].add(a)
-            for gslot in self.layers[b]['gates']:                # gate / pool slots are shared scratch: keep their users ordered
-                if gslot >= 0:
-                    deps[b].update(gate_users.get(gslot, ()))
-                    gate_users.setdefault(gslot, []).append(b)
-        flops = self.layer_flops(max_batch) if hasattr(self, 'layer_flops') else None
-
-        def est(i):
-            d = self.layers[i]
-            r, w = feet[i]
-            by = sum((c1 - c0) * self.tensors[t][0] * self.tensors[t][1] * 2 for t, c0, c1 in r + w) * max_batch
-            k = d.get('k', 1) or 1
-            fl = 2.0 * k * k * (d.get('cin', 0) or 0) * (d.get('cout', 0) or 0) * d['out'].h * d['out'].w * max_batch
-            return 4e-6 + fl / 200e12 + by / 2e12
-        finish, branch = [0.0] * n, [0] * n
-        free = [0.0, 0.0]
-        for i in range(n):
-            best = None
-            for s in (0, 1):
-                start = free[s]
-                for j in deps[i]:
-                    start = max(start, finish[j] + (1.5e-6 if branch[j] != s else 0.0))
-                if best is None or start < best[0] - 2e-6:       # the side branch has to win by more than a launch gap
-                    best = (start, s)
-            branch[i] = best[1]
-            finish[i] = best[0] + est(i)
-            free[best[1]] = finish[i]
-        if n:
-            branch[n - 1] = 0 if all(b == 0 for b in branch[:-1]) else branch[n - 1]
-        wait, signal = [-1] * n, [0] * n
-        waited = [-1, -1]                                        # per branch: newest layer of the other branch already waited for
-        for i in range(n):
-            s = branch[i]
-            other = [j for j in deps[i] if branch[j] != s]
-            if other and max(other) > waited[s]:
-                wait[i] = max(other)
-                signal[wait[i]] = 1
-                waited[s] = wait[i]
-        return list(zip(branch, wait, signal))
-
-    def tables(self, max_batch=1, reuse=False, branches=False):
-        plan = self.plan_branches(max_batch) if branches else None
-        if plan is not None and not any(b for b, _, _ in plan):
-            plan = None                                          # nothing to run side by side: one chain
-        self.branch_plan = plan
-        offsets, arena = self.plan_arena(max_batch, reuse, self.happens_before(plan) if plan is not None else None)
+    def tables(self, max_batch=1, reuse=False):
+        offsets, arena = self.plan_arena(max_batch, reuse)
         self.arena_bytes = arena
         ts = (fm_tensor * len(self.tensors))()
         for i, (h, w, c, f32) in enumerate(self.tensors):
@@ -691,11 +506,10 @@ class Graph:
             else:
                 L.res, L.res_coff = -1, 0
             L.res_mode = d['res_mode']
-            for key in ('cin', 'cout', 'k', 'stride', 'pad', 'act', 'hid', 'up', 'w_off', 'b_off', 'w2_off', 'b2_off', 'cin2'):
+            for key in ('cin', 'cout', 'k', 'stride', 'pad', 'act', 'hid', 'up', 'w_off', 'b_off', 'w2_off', 'b2_off'):
                 setattr(L, key, d[key])
             for j in range(4):
                 L.gate[j] = d['gates'][j] if j < len(d['gates']) else -1
-            L.branch, L.wait_for, L.signal = plan[i] if plan is not None else (0, -1, 0)
             ls[i] = L
         blob = bytes(self.blob) + b'\0' * 64
         return ts, ls, blob
@@ -707,13 +521,7 @@ class Graph:
             if d['op'] in (OP_CONV, OP_STEMCONV, OP_CONVS):
                 o = d['out']
                 total += 2 * d['k'] * d['k'] * d['ins'][0].c * d['cout'] * o.h * o.w * batch
-            elif d['op'] == OP_GATEDCONV:
-                o = d['out']
-                total += 2 * (d['cin'] + d['cin2']) * d['cout'] * o.h * o.w * batch
             elif d['op'] == OP_RESBLOCK:
                 o = d['out']
                 total += 2 * 10 * d['cin'] * d['hid'] * o.h * o.w * batch
-            elif d['op'] == OP_CSPSTAGE:
-                o, c, m = d['out'], d['cin'], d['hid']
-                total += 2 * (2 * c * c + c * m + 9 * m * c + c * c + 2 * c * d['cout']) * o.h * o.w * batch
         return total

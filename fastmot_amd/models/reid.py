@@ -97,17 +97,6 @@ def osnet_graph(model, weights, fuse_lightconv=True):
                 prev = g.lightconv_group(f'{name}.depth{i}', xs, [params[(t, i)] for t in ts], 'relu', gap_slot=True)
                 streams.append(prev.slice(0, mid))               # stream i+1 ends at depth i (group 0)
                 parts.append(g.last_gap_slot)
-            if chain and g.use_gatedconv and (cat is not None or x.c == cout):
-                # gate + gated sum + conv3 (+ downsample | identity shortcut) as ONE launch (gatedconv.hip): the block
-                # is conv1, the stream chains, this
-                if cat is not None:
-                    def tail_weights():
-                        wd, bd = fold_bn(weights.conv(name + '.down', cout, x.c, 1, bn=True))
-                        w3, b3 = fold_bn(weights.conv(name + '.conv3', cout, mid, 1, bn=True))
-                        return np.concatenate([w3, wd], axis=1), b3 + bd
-                    return g.gated_conv(name + '.gate', name + '.conv3', streams, hid, parts, cout, 'relu',
-                                        x2=cat.slice(mid, x.c), wb=tail_weights)
-                return g.gated_conv(name + '.gate', name + '.conv3', streams, hid, parts, cout, 'relu', res=x)
             x2 = g.gated_sum(name + '.gate', streams, hid, parts=parts,
                              dst=cat.slice(0, mid) if cat is not None else None)
         else:

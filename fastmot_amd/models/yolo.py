@@ -140,9 +140,6 @@ def yolov4_graph(model, weights):
 
     def csp(x, c_out, n_res, h, m):
         d = conv(x, c_out, 3, 2)
-        if g.use_cspstage and n_res == 1 and c_out == h and g.cspstage_supported(h, m) and merge_siblings and g.use_resblock:
-            # the whole stage behind its stride-2 conv in one launch (cspstage.hip): same six Darknet layers, same order
-            return g.cspstage([name() for _ in range(6)], d, m, c_out)
         cat = g.new(d.h, d.w, 2 * h)
         if merge_siblings:
             # the two 1x1 convs that read d (route branch A, second in the concat; residual branch) as ONE

@@ -50,9 +50,7 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
 /* tunables: "zero_copy_tracks" (default 2048; batches up to this many tracks / boxes exchange kernel
  * inputs and outputs through pinned device-mapped host memory instead of blit copies; 0 disables),
  * "host_lap_elems" (default 262144; LAP cost matrices up to this many elements are solved by the host
- * solver of the library, larger ones by the device kernels; 0 = always device), "conv1x1_stream" (default 0; 1: memory-bound stride-1 1x1
- * layers on large maps take the persistent streaming kernel of csrc/conv1x1.hip -- bit-identical, measured slower, kept for
- * the record; read when a network's graph is captured), "nms_path" (default 0: the fused sort + greedy
+ * solver of the library, larger ones by the device kernels; 0 = always device), "nms_path" (default 0: the fused sort + greedy
  * DIoU-NMS kernel for up to 4096 candidates per frame, the three-kernel sort / bit-matrix / scan path beyond; 1 = always
  * the latter), "use_graphs" (default 1;
  * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (diagnostic builds only, include/fastmot_hip_diag.h;
@@ -234,25 +232,13 @@ enum {
                           * launch (litechain.hip): stream s writes out channels [out_coff + s*cin, +cin);
                           * w_off / w2_off / b_off = the 10 parameter sets stacked in (stream, level) order,
                           * each laid out as for FM_OP_LITECONV; gate[s] = GAP partial slot of stream s       */
-    FM_OP_CSPSTAGE = 17, /* fused first CSP stage of CSPDarknet53 (cspstage.hip): in[0] = d (cin = 64 channels) ->
-                          * [b | A] = act(1x1 64->128) -> residual unit on b (1x1 64->hid, 3x3 hid->64, + b) -> c = act(1x1
-                          * 64->64) -> out = act(1x1 [c | A] 128 -> cout = 64).  w_off: the five matrices in MFMA
-                          * fragment order, concatenated in that order; b_off: their biases (float32) likewise  */
-    FM_OP_GATEDCONV = 18,/* tail of an OSNet block in one launch (gatedconv.hip): out = act(W . [x2 | x] + b (+ res)) with
-                          * x2 = FM_OP_GATED_SUM of the four streams in[0..3] (cin channels each, tile sums in gate[0..3]),
-                          * never stored.  res_mode FM_RES_CONCAT: tensor `res` holds the second K segment x (cin2
-                          * channels; a stage's first block: weights [W3 | Wd], bias b3 + bd); FM_RES_BEFORE_ACT: `res`
-                          * is the identity shortcut (cin2 = 0).  w_off: fp16 [ceil32(cout)][ceil64(ceil16(cin) +
-                          * ceil16(cin2))], columns [0, cin) over x2, [ceil16(cin), + cin2) over x, zero elsewhere; b_off:
-                          * f32 [ceil32(cout)]; w2_off: the gate MLP, fc1 [hid][cin] fp16 | b1 f32 | fc2 [cin][hid] fp16 |
-                          * b2 f32, every section 16 B aligned                                                     */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */
 };
 enum { FM_ACT_LINEAR = 0, FM_ACT_LEAKY = 1, FM_ACT_MISH = 2, FM_ACT_RELU = 3, FM_ACT_LOGISTIC = 4,
        FM_ACT_SWISH = 5 };
-enum { FM_RES_NONE = 0, FM_RES_AFTER_ACT = 1, FM_RES_BEFORE_ACT = 2, FM_RES_CONCAT = 3 /* FM_OP_GATEDCONV only */ };
+enum { FM_RES_NONE = 0, FM_RES_AFTER_ACT = 1, FM_RES_BEFORE_ACT = 2 };
 
 typedef struct fm_tensor {
     int32_t h, w, c;     /* per-sample geometry, c = channel stride (multiple of 8) */
@@ -274,13 +260,6 @@ typedef struct fm_layer {
                           * the [upsample] layer of yolo2onnx.py:806-836 folded into its producer */
     int32_t gate[4];
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob (16 B aligned) */
-    /* Two-branch schedule of the layer sequence (models/graph.py plan_branches; all zero / -1 = one chain): the layers
-     * of branch 1 run on a second stream beside branch 0 (e.g. a YOLO head's 3x3 + 1x1 beside the PAN path that
-     * continues from the same tensor), each branch in table order.  wait_for: index of a layer of the OTHER branch
-     * whose completion this layer waits for (-1: none; earlier waits of its branch cover the rest), signal: some layer
-     * of the other branch waits for this one.  Captured into the hipGraph as parallel paths. */
-    int32_t branch, wait_for, signal;
-    int32_t cin2;        /* FM_OP_GATEDCONV: channels of the second K segment (0: none) */
 } fm_layer;
 
 /* weights: CONV  w = fp16 [ceil32(cout)][ceil64(k*k*cin)] (K order kh,kw,cin), b = f32[ceil32(cout)]
@@ -496,8 +475,6 @@ int fm_track_predict_async(fm_ctx* ctx, int nT, const double* inside_tlbr, const
                            const int32_t* slots, const int32_t* ages, const int32_t* sorted_idx, double age_penalty,
                            double* tlbr_out, uint8_t* lost_out);
 int fm_track_predict_wait(fm_ctx* ctx, int* status_out, int* kalman_done_out);
-/* 1 if FM_OP_CSPSTAGE exists for c channels / a bottleneck of mid channels (the table builder asks) */
-int fm_cspstage_supported(int c, int mid);
 /* LDS bytes FM_OP_LITECHAIN needs for c channels on h x w maps (<= 65536 to be launchable): the layer-table
  * builder decides with the same formula whether an OSNet block can use the chain kernel (no device needed) */
 size_t fm_litechain_lds_bytes(int c, int w, int h);

@@ -282,34 +282,29 @@ def test_lightconv_fused(ctx, c, h, w, n):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
-def test_osnet_fused_and_arena_reuse_identical(ctx, monkeypatch):
-    """The production configuration (stream chains in one launch, gate + gated sum + conv3 + shortcut in one launch: 26
+def test_osnet_fused_and_arena_reuse_identical(ctx):
+    """The production configuration (stream chains in one launch, gate + gated sum in one launch, conv3 + shortcut: 32
     launches, activation arena shared between tensors with disjoint live ranges) against the layer-per-kernel graph (173
     launches, private buffers): arena reuse changes nothing bit for bit; the fused graph differs only by the summation
-    grouping of the gate's average pool.  Both block tails are covered: the default one (FM_OP_GATED_SUM + conv3 as two
-    launches, 32 in total) and the one-launch tail (FM_OP_GATEDCONV, FASTMOT_GATEDCONV=1: 26 launches), which feeds the
-    matrix cores the same fp16 operands."""
+    grouping of the gate's average pool."""
     class Small(ReID.get_model('OSNet025')):
         INPUT_SHAPE = (3, 128, 64)
     rng = np.random.default_rng(3)
     x = rng.normal(0, 1, (6, 128, 64, 3)).astype(np.float16)
     ctx.feat_configure(512)
     embs = {}
-    for fuse, reuse, tail in ((False, False, '1'), (True, False, '1'), (True, True, '1'), (True, True, '0')):
-        monkeypatch.setenv('FASTMOT_GATEDCONV', tail)
+    for fuse, reuse in ((False, False), (True, False), (True, True)):
         g, _ = Small.build_graph(RandomWeights(seed=5), fuse_lightconv=fuse)
-        assert len(g.layers) == ((26 if tail == '1' else 32) if fuse else 173)   # 50 with one launch per stream depth (next test)
+        assert len(g.layers) == (32 if fuse else 173)   # 50 with one launch per stream depth (next test)
         net = HipNet(ctx, NET_EXTRACTOR, g, 6, reuse_buffers=reuse)
         for _ in range(2):                      # second run: stale arena contents must not matter
             net.write(g.input, x)
             net.run(6)
-        embs[fuse, reuse, tail] = net.read_embeddings(6)
+        embs[fuse, reuse] = net.read_embeddings(6)
         net.close()
-    np.testing.assert_array_equal(embs[True, False, '1'], embs[True, True, '1'])
-    for tail in '01':
-        assert np.abs(embs[True, True, tail] - embs[False, False, '1']).max() < 2e-3
-        assert (np.sum(embs[True, True, tail] * embs[False, False, '1'], axis=1) > 0.9999).all()
-    assert np.abs(embs[True, True, '1'] - embs[True, True, '0']).max() < 1e-3
+    np.testing.assert_array_equal(embs[True, False], embs[True, True])
+    assert np.abs(embs[True, True] - embs[False, False]).max() < 2e-3
+    assert (np.sum(embs[True, True] * embs[False, False], axis=1) > 0.9999).all()
 
 
 @pytest.mark.parametrize('c,hid,h,w,n,k', [(16, 1, 64, 32, 3, 4), (24, 1, 32, 16, 5, 4), (32, 2, 16, 8, 2, 4),
@@ -493,81 +488,3 @@ def test_yolov4_small_input(ctx, monkeypatch, resblock):
     net.close()
 
 
-@pytest.mark.parametrize('cin,cout,h,w,n,act,extra', [
-    (64, 128, 76, 76, 1, 'mish', ''),          # CSP stage entry (merged siblings)
-    (64, 64, 96, 80, 1, 'mish', 'slice'),      # reads a channel slice, writes a concat slice
-    (128, 64, 70, 70, 1, 'mish', ''),          # ragged last tile (4900 pixels)
-    (128, 128, 64, 64, 2, 'leaky', ''),        # batch 2
-    (256, 128, 76, 76, 1, 'leaky', 'slice'),   # PAN lateral conv
-    (256, 256, 68, 68, 1, 'mish', ''),
-    (256, 255, 76, 76, 1, 'linear', 'f32'),    # 76 x 76 head: ragged cout, fp32 output
-    (128, 255, 72, 72, 1, 'logistic', 'f32'),  # NEW_COORDS head
-])
-def test_streaming_1x1_conv_equals_the_tiled_kernel(ctx, cin, cout, h, w, n, act, extra):
-    """conv1x1.hip (persistent workgroups, weights in registers, pixel tiles one ahead) against conv.hip on the same
-    layer: BIT-identical outputs (same MFMA order, same fp32 epilogue), and both against PyTorch."""
-    rng = np.random.default_rng(cin + cout + h)
-    x = rng.normal(0, 1, (n, h, w, cin + (64 if extra == 'slice' else 0))).astype(np.float16)
-    outs = []
-    for stream in (0, 1):
-        ctx.set_option('conv1x1_stream', stream)
-        g = Graph(RandomWeights(seed=cin + 3 * cout), (h, w), x.shape[-1])
-        src = g.input.slice(64, cin) if extra == 'slice' else g.input
-        dst = g.new(h, w, cout + 64).slice(64, cout) if extra == 'slice' else None
-        y = g.conv('c', src, cout, 1, 1, act, dst=dst, bn=extra != 'f32', f32_out=extra == 'f32')
-        net = HipNet(ctx, NET_DETECTOR, g, n)
-        for graphs in (1, 1):                       # eager validation + capture, then replay
-            net.write(g.input, x)
-            net.run(n)
-        outs.append(net.read(y, n))
-        if stream:
-            bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
-            close(outs[-1], nhwc(bufs[y.tid][:, y.coff:y.coff + cout]), what=f'1x1 {cin}->{cout}')
-        net.close()
-    ctx.set_option('conv1x1_stream', 0)
-    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
-    np.testing.assert_array_equal(outs[0], outs[1])
-
-
-class _MiniV4(YOLO):
-    NUM_CLASSES = 2
-    INPUT_SHAPE = (3, 96, 160)
-    LAYER_FACTORS = [8, 16, 32]
-    SCALES = [1.2, 1.1, 1.05]
-    ANCHORS = [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146], [142, 110, 192, 243, 459, 401]]
-
-
-def _csp_graphs(monkeypatch):
-    out = []
-    for mode in ('0', '1'):
-        monkeypatch.setenv('FASTMOT_CSPSTAGE', mode)
-        g, heads = _MiniV4.build_graph(RandomWeights(seed=11))
-        out.append((g, heads))
-    from fastmot_amd.models import graph as G
-    assert not any(d['op'] == G.OP_CSPSTAGE for d in out[0][0].layers)
-    assert sum(d['op'] == G.OP_CSPSTAGE for d in out[1][0].layers) == 1
-    assert len(out[0][0].layers) == len(out[1][0].layers) + 3          # four launches -> one
-    return out
-
-
-def test_fused_csp_stage_equals_the_four_launches(ctx, monkeypatch):
-    """cspstage.hip: the first CSP stage of CSPDarknet53 in one launch -- head tensors BIT-identical to the table with the
-    four separate launches (same MFMA order, same fp16 rounding points), on a map whose edge tiles are ragged
-    (48 x 80 pixels at the stage: 6 x 10 tiles), graph replay included; and the fused table against PyTorch."""
-    (g0, h0), (g1, h1) = _csp_graphs(monkeypatch)
-    _, H, W = _MiniV4.INPUT_SHAPE
-    x = np.random.default_rng(5).uniform(0, 1, (1, H, W, 3)).astype(np.float16)
-    outs = []
-    for g, heads in ((g0, h0), (g1, h1)):
-        net = HipNet(ctx, NET_DETECTOR, g, 1, reuse_buffers=True)
-        for _ in range(2):
-            net.write(g.input, x)
-            net.run(1)
-        outs.append([net.read(h, 1) for h in heads])
-        net.close()
-    for a, b in zip(*outs):
-        assert np.isfinite(a).all() and np.abs(a).max() > 0
-        np.testing.assert_array_equal(a, b)
-    bufs, _ = torch_ref.run_graph(g1, nchw(x.astype(np.float32)))
-    for h, got in zip(h1, outs[1]):
-        close(got, nhwc(bufs[h.tid][:, h.coff:h.coff + h.c]), what='head behind the fused CSP stage')

@@ -66,16 +66,6 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             if emulate_fp16_storage:
                 y = y.half().float()
             wr(d['out'], act_fn(F.conv2d(y, w2, b2, padding=1), d['act']) + xin)
-        elif op == G.OP_CSPSTAGE:
-            (w2, b2), (w3a, b3a), (w3b, b3b), (w4, b4), (w5, b5) = ((torch.from_numpy(w), torch.from_numpy(b)) for w, b in d['csp_ref'])
-            r16 = (lambda t: t.half().float()) if emulate_fp16_storage else (lambda t: t)
-            h = xin.shape[1]
-            t = r16(act_fn(F.conv2d(xin, w2, b2), d['act']))
-            b_, a_ = t[:, :h], t[:, h:]
-            r = r16(act_fn(F.conv2d(b_, w3a, b3a), d['act']))
-            bp = r16(act_fn(F.conv2d(r, w3b, b3b, padding=1), d['act']) + b_)
-            c = r16(act_fn(F.conv2d(bp, w4, b4), d['act']))
-            wr(d['out'], act_fn(F.conv2d(torch.cat([c, a_], 1), w5, b5), d['act']))
         elif op == G.OP_DWCONV3:
             w, b = params[idx]
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), padding=1, groups=xin.shape[1])
@@ -111,22 +101,6 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
                 hid = F.relu(xv.mean(dim=(2, 3)) @ w1.T + b1)
                 y = y + xv * torch.sigmoid(hid @ w2.T + b2)[:, :, None, None]
             wr(d['out'], y)
-        elif op == G.OP_GATEDCONV:
-            w1, b1, w2, b2 = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['gate_ref'])
-            y = 0
-            for v in d['ins']:
-                xv = rd(v)
-                hid = F.relu(xv.mean(dim=(2, 3)) @ w1.T + b1)
-                y = y + xv * torch.sigmoid(hid @ w2.T + b2)[:, :, None, None]
-            if emulate_fp16_storage:
-                y = y.half().float()
-            w, b = (torch.from_numpy(np.asarray(a, np.float32)) for a in d['conv_ref'])
-            if d['res_mode'] == G.RES_CONCAT:
-                y = torch.cat([y, rd(d['res'])], dim=1)
-            y = F.conv2d(y, w, b)
-            if d['res_mode'] == G.RES_BEFORE_ACT:
-                y = y + rd(d['res'])
-            wr(d['out'], act_fn(y, d['act']))
         elif op == G.OP_SPP:
             c = d['cout']
             for i, k in enumerate((13, 9, 5)):
