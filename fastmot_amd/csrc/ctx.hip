@@ -2,6 +2,7 @@
 // Replaces the buffer + stream plumbing of fastmot/utils/inference.py:7-125 (HostDeviceMem,
 // TRTInference) with plain HIP: one ctx per video stream, four HIP streams, pinned mirrors.
 #include "common.h"
+void convd_set_cfg(int code);             // convd.hip
 #include <sched.h>
 #include <cstring>
 #include <cstdlib>
@@ -23,6 +24,7 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "zero_copy_tracks")) ctx->opt_zero_copy_tracks = value;
     else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
     else if (!strcmp(key, "use_graphs")) ctx->opt_use_graphs = value;
+    else if (!strcmp(key, "convd_cfg")) convd_set_cfg(value);
     else if (!strcmp(key, "nms_path")) {
         ctx->opt_nms_general = value != 0;
     }

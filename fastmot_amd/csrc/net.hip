@@ -29,6 +29,7 @@ int launch_pool(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int
 int launch_upsample2(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, int N, int H,
                      int W, int C, hipStream_t s);
 int launch_conv_streamed(const ConvParams& p, hipStream_t s);
+int launch_convd(const ConvParams& p, hipStream_t s);
 bool resblock_supported(int C, int M);
 int launch_resblock(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, int out_coff, const f16* w1,
                     const float* b1, const f16* w2, const float* b2, int N, int H, int W, int C, int M, int act1,
@@ -144,7 +145,8 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
     f16* out = (f16*)net->bufs[L.out];
     switch (L.op) {
         case FM_OP_CONV:
-        case FM_OP_CONVS: {
+        case FM_OP_CONVS:
+        case FM_OP_CONVD: {
             ConvParams p{};
             p.in = in0; p.in_cs = ti.c; p.in_coff = L.in_coff[0];
             p.w = (const f16*)(net->weights + L.w_off);
@@ -167,6 +169,7 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             FM_CHECK_ARG((ti.h + 2 * L.pad - L.k) / L.stride + 1 == p.Ho);
             FM_CHECK_ARG(L.out_coff + p.cout_store <= to.c && L.in_coff[0] + L.cin <= ti.c);
             if (L.op == FM_OP_CONVS) return launch_conv_streamed(p, s);
+            if (L.op == FM_OP_CONVD) return launch_convd(p, s);
             return launch_conv(p, ws, net->ws_floats, s);
         }
         case FM_OP_DWCONV3:
@@ -391,6 +394,7 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
     switch (L.op) {
         case FM_OP_CONV:
         case FM_OP_CONVS:
+        case FM_OP_CONVD:
             *flops = 2.0 * L.k * L.k * L.cin * L.cout * pout;
             *bytes = pin * L.cin * 2 + pout * L.cout * (to.f32 ? 4 : 2) + (double)L.k * L.k * L.cin * L.cout * 2 +
                      (L.res_mode != FM_RES_NONE ? pout * L.cout * 2 : 0);
@@ -433,7 +437,7 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
     FM_CHECK_ARG(net != nullptr);
     double f = 0, b = 0;
     for (const fm_layer& L : net->layers)
-        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK) {
+        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK) {
             double lf, lb;
             layer_cost(net, L, batch, &lf, &lb);
             f += lf;
@@ -463,7 +467,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
             FM_HIP(hipEventSynchronize(e1));
             float ms = 0;
             FM_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_RESBLOCK) { tc += ms; ++nc; } else { to += ms; ++no; }
+            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK) { tc += ms; ++nc; } else { to += ms; ++no; }
         }
     FM_HIP(hipEventDestroy(e0));
     FM_HIP(hipEventDestroy(e1));

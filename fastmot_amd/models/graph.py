@@ -15,7 +15,8 @@ import numpy as np
 LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN) = range(17)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CONVD) = range(18)
+CONV_OPS = (OP_CONV, OP_CONVS, OP_CONVD)      # the three kernels behind Graph.conv (same fields, different weight layouts)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
@@ -131,6 +132,9 @@ class Graph:
         # convs with at most this many output pixels per sample and a long reduction take the streamed
         # kernel (K split inside the workgroup, convs.hip) instead of the LDS-tiled one + split-K reduce
         self.convs_max_pixels = int(os.environ.get('FASTMOT_CONVS_MAXP', '1444'))
+        # DMA-fed multi-accumulator kernel (convd.hip) for layers with cin % 64 == 0: 0 = never, 1 = instead of the
+        # LDS-tiled kernel, 2 = instead of the streamed kernel as well
+        self.convd_level = int(os.environ.get('FASTMOT_CONVD', '2'))
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -188,7 +192,18 @@ class Graph:
                         act=ACT[act], w_off=self._push(packed), b_off=self._push(bias32), name=name)
             self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
             return dst
-        if x.c == cin_pad and cin_pad % 64 == 0 and k * k * cin_pad >= 512 and ho * wo <= self.convs_max_pixels:
+        streamed = x.c == cin_pad and cin_pad % 64 == 0 and k * k * cin_pad >= 512 and ho * wo <= self.convs_max_pixels
+        if cin_pad % 64 == 0 and (k == 3 or (k == 1 and pad == 0)) and self.convd_level >= (2 if streamed else 1):
+            wk = np.zeros((ceil_to(cout, 32), k, k, cin_pad), np.float16)
+            wk[:cout, :, :, :x.c] = w16.transpose(0, 2, 3, 1)
+            bias = np.zeros(wk.shape[0], np.float32)
+            bias[:cout] = b
+            self._layer(op=OP_CONVD, ins=[x], out=dst, cin=cin_pad, cout=cout, k=k, stride=stride, pad=pad,
+                        act=ACT[act], up=up, w_off=self._push(self._pack_tile64(wk.reshape(wk.shape[0], -1))),
+                        b_off=self._push(bias), res=res, res_mode=res_mode if res is not None else RES_NONE, name=name)
+            self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
+            return dst
+        if streamed:
             wp = np.zeros((ceil_to(cout, 32), x.c, k, k), np.float16)
             wp[:cout] = w16
             bias = np.zeros(wp.shape[0], np.float32)
@@ -227,6 +242,19 @@ class Graph:
         assert cout % 32 == 0 and K % 16 == 0
         rows = w16.transpose(0, 2, 3, 1).reshape(cout // 32, 32, K // 16, 2, 8)
         return np.ascontiguousarray(rows.transpose(0, 2, 3, 1, 4))
+
+    @staticmethod
+    def _pack_tile64(wmat):
+        """[cout (% 32 == 0), K (% 64 == 0)] fp16, K order (kh, kw, cin) -> the LDS tile images of convd.hip:
+        [cout/32][K/64][32 rows][8 slots][8 halfs], slot s of row r = K chunk s ^ ((r / 2) % 8) of the row's K step
+        (the XOR swizzle that makes the kernel's ds_read_b128 fragment reads conflict-free; the DMA writes LDS
+        lane-linear, so the permutation has to be in the source)."""
+        cout, K = wmat.shape
+        assert cout % 32 == 0 and K % 64 == 0
+        rows = wmat.reshape(cout // 32, 32, K // 64, 8, 8).transpose(0, 2, 1, 3, 4)     # [blk][step][row][chunk][8]
+        r = np.arange(32)[:, None]
+        src = np.arange(8)[None, :] ^ ((r >> 1) & 7)                                    # chunk held by (row, slot)
+        return np.ascontiguousarray(rows[:, :, r, src, :])
 
     def resblock(self, name1, name2, x, mid, act='mish', dst=None, wb1=None, wb2=None, bn1=True, bn2=True):
         """Darknet residual unit in one launch (resblock.hip): x + act(conv3x3(act(conv1x1(x)))).
@@ -518,7 +546,7 @@ class Graph:
         """2*MAC over conv layers (the 'conv roofline' numerator)."""
         total = 0
         for d in self.layers:
-            if d['op'] in (OP_CONV, OP_STEMCONV, OP_CONVS):
+            if d['op'] in CONV_OPS + (OP_STEMCONV,):
                 o = d['out']
                 total += 2 * d['k'] * d['k'] * d['ins'][0].c * d['cout'] * o.h * o.w * batch
             elif d['op'] == OP_RESBLOCK:

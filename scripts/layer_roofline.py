@@ -44,14 +44,14 @@ for i, (d, (s, e, name)) in enumerate(zip(g.layers, rows)):
     o, x = d['out'], d['ins'][0]
     P = o.h * o.w
     op = d['op']
-    if op in (0, 12, 15):                      # conv (LDS-tiled / stem / streamed)
+    if op in (0, 12, 15, 17):                  # conv (LDS-tiled / stem / streamed / DMA-fed)
         K = d['k'] * d['k'] * d['cin']
         up = d.get('up') or 1
         Pc = P // (up * up)
         fl = 2.0 * K * d['cout'] * Pc
         by = (x.h * x.w * d['cin'] + P * d['cout'] * (2 if g.tensors[o.tid][3] else 1) + K * d['cout']) * 2
         shape = f"k{d['k']}s{d['stride']} {x.h}x{x.w}x{d['cin']} -> {o.h}x{o.w}x{d['cout']}"
-        kind = {0: 'conv', 12: 'stemconv', 15: 'convS'}[op]
+        kind = {0: 'conv', 12: 'stemconv', 15: 'convS', 17: 'convD'}[op]
     elif op == 14:                             # fused residual unit: 1x1 (c -> m) + 3x3 (m -> c) + shortcut
         w1, _, w2, _ = d['res_ref']
         m, c = w1.shape[0], w1.shape[1]

@@ -10,8 +10,8 @@ from fastmot_amd.models import YOLO, ReID
 
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ctx = get_context()
-if which == 0:
-    g, _ = YOLO.get_model('YOLOv4_608').build_graph(); batch = 1
+if which == 0:       # python scripts/trace_net.py 0 [YOLOv4_608 | YOLOv4CSP_640 | YOLOv4P6_1280]
+    g, _ = YOLO.get_model(sys.argv[2] if len(sys.argv) > 2 else 'YOLOv4_608').build_graph(); batch = 1
 else:
     ctx.feat_configure(512)
     g, _ = ReID.get_model('OSNet025').build_graph(); batch = int(sys.argv[2]) if len(sys.argv) > 2 else 50

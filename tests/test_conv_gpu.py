@@ -76,6 +76,7 @@ def test_streamed_conv(ctx, cin, cout, k, stride, act, h, w, n, extra):
     for maxp in (10 ** 6, 0):
         g = Graph(RandomWeights(seed=cin + 3 * cout + k), (h, w), cin)
         g.convs_max_pixels = maxp
+        g.convd_level = 0
         ho = (h + 2 * (k // 2) - k) // stride + 1
         wo = (w + 2 * (k // 2) - k) // stride + 1
         up = 2 if extra == 'up' else 1
@@ -472,7 +473,7 @@ def test_yolov4_small_input(ctx, monkeypatch, resblock):
     n_res = sum(d['op'] == 14 for d in g.layers)
     assert n_res == (19 if resblock == '1' else 0)
     # 110 conv layers of yolov4.cfg; the two sibling 1x1 convs of each of the 5 CSP stages run as one
-    assert sum(d['op'] in (0, 12, 15) for d in g.layers) + 2 * n_res == 110 - 5 and g.layers[0]['op'] == 12
+    assert sum(d['op'] in (0, 12, 15, 17) for d in g.layers) + 2 * n_res == 110 - 5 and g.layers[0]['op'] == 12
     net = HipNet(ctx, NET_DETECTOR, g, 1)
     rng = np.random.default_rng(22)
     x = rng.uniform(0, 1, (1, 96, 96, 3)).astype(np.float16)
@@ -488,3 +489,60 @@ def test_yolov4_small_input(ctx, monkeypatch, resblock):
     net.close()
 
 
+def _convd_code(bm, bn, kg, ns=0):
+    return bm | bn << 8 | kg << 16 | ns << 20
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,act,h,w,n,extra', [
+    (64, 128, 1, 1, 'mish', 76, 76, 1, ''),            # CSP stage entry
+    (64, 64, 1, 1, 'mish', 48, 40, 1, 'slice'),        # reads a channel slice, writes a concat slice
+    (128, 64, 1, 1, 'mish', 35, 35, 1, ''),            # ragged last pixel tile
+    (128, 128, 1, 1, 'leaky', 32, 32, 2, ''),          # batch 2
+    (256, 255, 1, 1, 'linear', 38, 38, 1, 'f32'),      # head: ragged cout, fp32 output
+    (128, 255, 1, 1, 'logistic', 20, 20, 1, 'f32'),    # NEW_COORDS head
+    (512, 256, 1, 1, 'leaky', 19, 19, 1, 'up'),        # fused nearest x2 upsample into a concat slice
+    (512, 512, 1, 1, 'mish', 19, 19, 1, 'res'),        # shortcut after the activation
+    (2048, 512, 1, 1, 'leaky', 19, 19, 1, ''),         # 32 K steps
+    (128, 256, 3, 1, 'leaky', 38, 38, 1, ''),          # 3x3, padding on every border
+    (64, 128, 3, 2, 'mish', 76, 76, 1, ''),            # stride-2 downsample
+    (256, 512, 3, 2, 'leaky', 38, 38, 1, ''),
+    (512, 1024, 3, 1, 'leaky', 19, 19, 1, ''),         # 72 K steps
+    (128, 64, 3, 1, 'relu', 7, 5, 3, 'res'),           # tiny maps, batch, shortcut
+    (64, 40, 3, 1, 'swish', 9, 9, 1, ''),              # cout padded to 64
+    (192, 96, 3, 1, 'relu', 16, 8, 4, 'resb'),         # cin = 3 * 64: a tap is three K steps; shortcut BEFORE the activation
+])
+@pytest.mark.parametrize('cfg', ['auto', (128, 128, 1), (128, 64, 2), (64, 128, 2, 2), (64, 64, 4), (64, 64, 1, 3)])
+def test_convd_conv(ctx, cin, cout, k, stride, act, h, w, n, extra, cfg):
+    """convd.hip (operands by DMA into an LDS ring, up to 2 x 2 accumulators per wave, K groups) against the LDS-tiled
+    kernel on the same layer and against PyTorch, under forced tile / K-group / ring configurations and the launcher's
+    own choice."""
+    rng = np.random.default_rng(cin + cout + h)
+    sl = extra == 'slice'
+    x = rng.normal(0, 1, (n, h, w, cin + (64 if sl else 0))).astype(np.float16)
+    outs = []
+    for level in (2, 0):
+        ctx.set_option('convd_cfg', 0 if cfg == 'auto' or not level else _convd_code(*cfg))
+        g = Graph(RandomWeights(seed=cin + 3 * cout + k), (h, w), x.shape[-1])
+        g.convd_level = level
+        g.convs_max_pixels = 0
+        src = g.input.slice(64, cin) if sl else g.input
+        ho = (h + 2 * (k // 2) - k) // stride + 1
+        wo = (w + 2 * (k // 2) - k) // stride + 1
+        up = 2 if extra == 'up' else 1
+        wide = g.new(ho * up, wo * up, cout + 64, f32=extra == 'f32')
+        res = g.conv('r', src, cout, 1, stride, 'linear') if extra in ('res', 'resb') else None
+        y = g.conv('c', src, cout, k, stride, act, dst=wide.slice(64, cout), res=res, up=up, f32_out=extra == 'f32',
+                   res_mode=RES_BEFORE_ACT if extra == 'resb' else 1, bn=extra != 'f32')
+        assert g.layers[-1]['op'] == (17 if level else 0)
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        for _ in range(2):                          # eager validation + capture, then a graph replay
+            net.write(g.input, x)
+            net.run(n)
+        outs.append(net.read(wide, n)[..., 64:64 + cout])
+        if level:
+            bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+            close(outs[-1], nhwc(bufs[wide.tid][:, 64:64 + cout]), what=f'convd {cin}->{cout} k{k}s{stride} {cfg}')
+        net.close()
+    ctx.set_option('convd_cfg', 0)
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    close(outs[0], outs[1], rel=1e-2, abs_=2e-3, what='convd vs tiled')

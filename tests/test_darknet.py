@@ -45,13 +45,13 @@ def test_lowering_mini_v4():
     # 18 convs (the first one on the stem kernel; the two sibling 1x1 convs of the CSP stage run as one),
     # SPP fused, shortcut + upsample folded into convs, every concat operand written in place:
     # 29 cfg sections -> 18 launches
-    assert ops[G.OP_CONV] + ops[G.OP_CONVS] + ops[G.OP_STEMCONV] == 17 and ops[G.OP_STEMCONV] == 1 and len(g.layers) == 18
-    merged = [d for d in g.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['name'] == '004_convolutional']
+    assert ops[G.OP_CONV] + ops[G.OP_CONVS] + ops[G.OP_CONVD] + ops[G.OP_STEMCONV] == 17 and ops[G.OP_STEMCONV] == 1 and len(g.layers) == 18
+    merged = [d for d in g.layers if d['op'] in G.CONV_OPS and d['name'] == '004_convolutional']
     assert len(merged) == 1 and merged[0]['cout'] == 32 and merged[0]['out'].coff == 0      # [b | A]: 16 + 16
     assert ops[G.OP_SPP] == 1 and ops[G.OP_MAXPOOL] == 0
     assert ops[G.OP_ADD] == 0 and ops[G.OP_UPSAMPLE2] == 0
-    assert sum(1 for d in g.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['up'] == 2) == 1
-    assert sum(1 for d in g.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['res'] is not None) == 1
+    assert sum(1 for d in g.layers if d['op'] in G.CONV_OPS and d['up'] == 2) == 1
+    assert sum(1 for d in g.layers if d['op'] in G.CONV_OPS and d['res'] is not None) == 1
     assert ops[G.OP_COPY] == 0
     assert meta['classes'] == 2 and meta['strides'] == [2, 4] and meta['scales'] == [1.2, 1.1]
     assert meta['anchors'] == [[12, 16, 19, 36, 40, 28], [36, 75, 76, 55, 72, 146]] and meta['new_coords'] is False
@@ -67,12 +67,12 @@ def test_lowering_mini_res(monkeypatch):
     res = [d for d in g.layers if d['op'] == G.OP_RESBLOCK]
     assert [d['hid'] for d in res] == [32, 64] and res[1]['out'].tid == g.layers[-1]['ins'][0].tid
     # (no sibling merge here: the concat slot below branch A is filled by a residual unit, not a plain 1x1)
-    assert sum(1 for d in g.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['cout'] == 128) == 0
+    assert sum(1 for d in g.layers if d['op'] in G.CONV_OPS and d['cout'] == 128) == 0
     monkeypatch.setenv('FASTMOT_RESBLOCK', '0')
     _, _, g0, _, _ = build('mini_res')
     ops0 = Counter(d['op'] for d in g0.layers)
     assert ops0[G.OP_RESBLOCK] == 0 and len(g0.layers) == 8
-    assert sum(1 for d in g0.layers if d['op'] in (G.OP_CONV, G.OP_CONVS) and d['res'] is not None) == 2
+    assert sum(1 for d in g0.layers if d['op'] in G.CONV_OPS and d['res'] is not None) == 2
 
 
 def test_full_yolov4_cfg_lowers_like_the_builtin_graph():

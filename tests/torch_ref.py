@@ -49,7 +49,7 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
     for idx, d in enumerate(graph.layers):
         op = d['op']
         xin = rd(d['ins'][0])
-        if op in (G.OP_CONV, G.OP_STEMCONV, G.OP_CONVS):
+        if op in G.CONV_OPS + (G.OP_STEMCONV,):
             w, b = params[idx]
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), stride=d['stride'], padding=d['pad'])
             if d['res_mode'] == G.RES_BEFORE_ACT:
