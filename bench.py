@@ -338,6 +338,86 @@ def pmc_traffic(n_conv_launches=None):
     return None
 
 
+class TorchCtl:
+    """torch.distributed as the harness communicator (FASTMOT_BENCH_TORCH=1 with backend nccl; gloo in the CPU test of
+    the harness): the same two calls as gallery.RcclComm -- barrier(), allgather_small(values) -> array [world, n]."""
+
+    def __init__(self, dist, torch, device=None):
+        self.dist, self.torch, self.device = dist, torch, device
+        self.world = dist.get_world_size()
+
+    def allgather_small(self, values):
+        v = self.torch.tensor(np.atleast_1d(np.asarray(values, np.float64)), device=self.device)
+        out = [self.torch.zeros_like(v) for _ in range(self.world)]
+        self.dist.all_gather(out, v)
+        return np.stack([t.cpu().numpy() for t in out])
+
+    def barrier(self):
+        if self.device is not None:
+            self.torch.cuda.synchronize()
+        self.dist.barrier()
+        if self.device is not None:
+            self.torch.cuda.synchronize()
+
+    def close(self):
+        pass
+
+
+class Harness:
+    """Control flow of the benchmark around the workload: untimed settle phase, fences, the timed region and the max over
+    ranks -- over a communicator `comm` (None for one process) with barrier() and allgather_small().  Every decision that
+    changes how many steps a rank runs is taken by ALL ranks in one collective, so that every rank issues the same
+    number of collectives (harness and gallery alike) whatever its own clock says (ADVICE r3, VERDICT r4 item 7;
+    tests/test_bench_harness.py runs it with two gloo processes whose step times differ)."""
+
+    def __init__(self, run, device_sync, comm=None, settle_min=SETTLE_MIN, settle_max=SETTLE_MAX,
+                 settle_check=SETTLE_CHECK, clock=time.perf_counter):
+        self.run, self.device_sync, self.comm, self.clock = run, device_sync, comm, clock
+        self.settle_min, self.settle_max, self.settle_check = settle_min, settle_max, settle_check
+
+    def fence(self):
+        self.device_sync()                 # hipDeviceSynchronize on this rank's GPU (all streams of the pipeline)
+        if self.comm is not None:
+            self.comm.barrier()
+
+    def all_ranks(self, flag):
+        """True iff `flag` holds on every rank (one small collective on the harness channel; N = 1: the flag)."""
+        if self.comm is None:
+            return bool(flag)
+        return bool(np.all(self.comm.allgather_small([1.0 if flag else 0.0]) > 0.5))
+
+    def max_over_ranks(self, x):
+        return float(x) if self.comm is None else float(self.comm.allgather_small([x]).max())
+
+    def timed(self, n, start, frames, prefetch):
+        self.fence()
+        t0 = self.clock()
+        net_ms = self.run(n, start, frames, prefetch)
+        self.fence()
+        return self.clock() - t0, net_ms
+
+    def settle(self, start, frames):
+        """Untimed settle phase before the warm-up the command line asks for: a fresh process runs its first few
+        hundred steps slower (GPU clocks ramping, hipGraphs instantiated, the prediction worker and the RANSAC pool
+        asleep), and a short `--steps 20 --warmup 5` run would time exactly that.  At least settle_min steps, then
+        until the last 20 step times lie within 3 % of their median, at most settle_max.  The decision to stop is
+        taken every settle_check steps and, with N > 1, by ALL ranks together: every rank runs the same number of
+        steps, hence the same number of gallery collectives (a rank that stopped on its own clock would leave the
+        others waiting in an exchange it never issues)."""
+        times = []
+        s = start
+        while s - start < self.settle_max:
+            t0 = self.clock()
+            self.run(1, s, frames, False)
+            times.append(self.clock() - t0)
+            s += 1
+            if s - start >= self.settle_min and (s - start - self.settle_min) % self.settle_check == 0:
+                last = np.array(times[-20:])
+                if self.all_ranks(np.all(np.abs(last - np.median(last)) <= 0.03 * np.median(last))):
+                    break
+        return s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -383,6 +463,7 @@ def main():
             import torch.distributed as dist
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
             dist.init_process_group('nccl', rank=rank, world_size=world)
+            ctl = TorchCtl(dist, torch, device='cuda')
         else:
             from fastmot_amd.gallery import RcclComm
             ctl = RcclComm(ctx, 64, channel=1)
@@ -414,67 +495,16 @@ def main():
             mot.step(frames[i], next_frame=nxt)
         return list(mot.detector.net_ms)
 
-    def fence():
-        ctx.synchronize()                  # hipDeviceSynchronize on this rank's GPU (all streams of the pipeline)
-        if ctl is not None:
-            ctl.barrier()
-        elif dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def timed(n, start, frames, prefetch):
-        fence()
-        t0 = time.perf_counter()
-        net_ms = run(n, start, frames, prefetch)
-        fence()
-        return time.perf_counter() - t0, net_ms
-
     frames = resident if args.resident else pinned
 
-    def all_ranks(flag):
-        """True iff `flag` holds on every rank (one small collective on the harness channel; N = 1: the flag)."""
-        if ctl is not None:
-            return bool(np.all(ctl.allgather_small([1.0 if flag else 0.0]) > 0.5))
-        if dist is not None:
-            t = torch.tensor([1.0 if flag else 0.0], device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t.item() > 0.5)
-        return bool(flag)
-
-    def settle(start):
-        """Untimed settle phase before the warm-up the command line asks for: a fresh process runs its first few
-        hundred steps slower (GPU clocks ramping, hipGraphs instantiated, the prediction worker and the RANSAC pool
-        asleep), and a short `--steps 20 --warmup 5` run would time exactly that.  At least SETTLE_MIN steps, then
-        until the last 20 step times lie within 3 % of their median, at most SETTLE_MAX.  The decision to stop is
-        taken every SETTLE_CHECK steps and, with N > 1, by ALL ranks together: every rank runs the same number of
-        steps, hence the same number of gallery collectives (a rank that stopped on its own clock would leave the
-        others waiting in an exchange it never issues -- ADVICE r3)."""
-        times = []
-        s = start
-        while s - start < SETTLE_MAX:
-            t0 = time.perf_counter()
-            run(1, s, frames, False)
-            times.append(time.perf_counter() - t0)
-            s += 1
-            if s - start >= SETTLE_MIN and (s - start - SETTLE_MIN) % SETTLE_CHECK == 0:
-                last = np.array(times[-20:])
-                if all_ranks(np.all(np.abs(last - np.median(last)) <= 0.03 * np.median(last))):
-                    break
-        return s
-
-    pos = settle(0)
+    hs = Harness(run, ctx.synchronize, comm=ctl)
+    pos = hs.settle(0, frames)
     settle_steps = pos
-    fence()                                # every rank enters warm-up and timed region at the same exchange index
+    hs.fence()                             # every rank enters warm-up and timed region at the same exchange index
     run(args.warmup, pos, frames, args.prefetch)
     pos += args.warmup
-    elapsed, net_ms = timed(args.steps, pos, frames, args.prefetch)
-    if ctl is not None:
-        elapsed = float(ctl.allgather_small([elapsed]).max())
-    elif dist is not None:
-        t = torch.tensor([elapsed], device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, net_ms = hs.timed(args.steps, pos, frames, args.prefetch)
+    elapsed = hs.max_over_ranks(elapsed)
     pos += args.steps
 
     variants = None
@@ -484,7 +514,7 @@ def main():
         for key, fr, pf in (('h2d_sequential_fps', pinned, False), ('resident_prefetch_fps', resident, True),
                             ('resident_sequential_fps', resident, False)):
             run(4, pos, fr, pf)
-            dt, _ = timed(nv, pos + 4, fr, pf)
+            dt, _ = hs.timed(nv, pos + 4, fr, pf)
             pos += nv + 4
             variants[key] = round(nv / dt, 2)
 
