@@ -38,6 +38,25 @@ namespace {
 
 int g_convd_cfg = 0;     // fm_ctx option "convd_cfg": bm | bn << 8 | kg << 16 | ns << 20 forces one configuration (A/B runs)
 
+// profiling build only (-DFM_CONVD_TIMING, scripts/convd_timing.py): cycle stamps of wave 0 of two workgroups, and
+// ablations (g_convd_abl bit 0: no DMA inside the K loop, bit 1: no fragment reads / MFMAs, bit 2: no output phase)
+#ifdef FM_CONVD_TIMING
+__device__ long long g_convd_stamps[2][264];
+int g_convd_abl = 0;
+// (stamps go to LDS behind the ring and leave at the end: a global store would count on vmcnt like the DMA does)
+#define CONVD_STAMP(i) if (stamp_slot >= 0 && (i) < 264) reinterpret_cast<long long*>(smem + stamp_off)[(i)] = __builtin_readcyclecounter();
+#define CONVD_ABL(bit) (abl & (bit))
+#define CONVD_EXTRA_PARAM , const int abl, const int stamp_off
+#define CONVD_EXTRA_ARG , g_convd_abl, (int)lds
+#define CONVD_EXTRA_LDS 4096
+#else
+#define CONVD_STAMP(i)
+#define CONVD_ABL(bit) false
+#define CONVD_EXTRA_PARAM
+#define CONVD_EXTRA_ARG
+#define CONVD_EXTRA_LDS 0
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -47,7 +66,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // TAPS: 0 = 1x1 conv without padding (no tap walk, no masks), 3 = 3x3 conv (any stride / padding)
 template <int WC, int WP, int MC, int MP, int KG, int TAPS>
-__global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, const int ns, const int nslots) {
+__global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, const int ns, const int nslots CONVD_EXTRA_PARAM) {
     static_assert(WC * WP == 4, "4 waves per K group");
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass has no buffer-resource type: it only needs the launch stub)
     constexpr int BM = WC * MC * 32, BN = WP * MP * 32;
@@ -80,6 +99,10 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
         }
     }
     const int c0 = tile_c * BM, p0 = tile_p * BN;
+#ifdef FM_CONVD_TIMING
+    const int stamp_slot = tid == 0 ? (blockIdx.x == 0 ? 0 : (blockIdx.x == 8 * 5 + 3 ? 1 : -1)) : -1;
+#endif
+    CONVD_STAMP(0)
 
     // ---- K range of this group
     const int nk = p.Kpad >> 6;
@@ -189,7 +212,9 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
     const unsigned boff = (unsigned)BM * 128u + (unsigned)(wp * MP * 32 + frow) * 128u;
 
     const int npro = min(ns - 1, nkg);
+    CONVD_STAMP(1)
     for (int s = 0; s < npro; ++s) issue();
+    CONVD_STAMP(2)
     int issued = npro, c_stage = 0;
     for (int it = 0; it < per; ++it) {
         // steps requested and not yet consumed (this iteration's included); everything but the oldest may stay in flight
@@ -197,13 +222,16 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
         if (rem >= 3) wait_vmcnt<2 * PPS>();
         else if (rem == 2) wait_vmcnt<PPS>();
         else wait_vmcnt<0>();
+        CONVD_STAMP(8 + 4 * it)
         __builtin_amdgcn_s_barrier();       // every wave's pieces of this step have landed; the previous step's slot is free
         asm volatile("" ::: "memory");
+        CONVD_STAMP(9 + 4 * it)
         if (issued < nkg) {
-            issue();
+            if (!CONVD_ABL(1)) issue();
             ++issued;
         }
-        if (it < nkg) {
+        CONVD_STAMP(10 + 4 * it)
+        if (it < nkg && !CONVD_ABL(2)) {
             const char* sa = ring + c_stage * SS;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -220,7 +248,9 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
             }
             c_stage = c_stage + 1 == nslots ? 0 : c_stage + 1;
         }
+        CONVD_STAMP(11 + 4 * it)
     }
+    CONVD_STAMP(3)
 
     // ---- epilogue.  LDS is reused: [0, BN * LDO * 4) the transposed fp32 tile, behind it the partial tiles of groups 1..
     float* so = reinterpret_cast<float*>(smem);
@@ -264,11 +294,12 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
                         make_float4(acc[mi][pi][4 * q + 0], acc[mi][pi][4 * q + 1], acc[mi][pi][4 * q + 2], acc[mi][pi][4 * q + 3]);
     }
     __syncthreads();
+    CONVD_STAMP(4)
     constexpr int CH = BM / 8;                       // 16 B chunks per pixel row of the tile
     constexpr int ROWS = T / CH;
     const int och = tid % CH, orow = tid / CH;
     const int co = c0 + och * 8;
-    if (co < p.cout_store) {
+    if (co < p.cout_store && !CONVD_ABL(4)) {
         const int hw_out = p.Ho * p.Wo;
         const float inv_hw = 1.f / (float)hw_out, inv_wo = 1.f / (float)p.Wo;
         float bias8[8];
@@ -314,6 +345,15 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
             }
         }
     }
+    CONVD_STAMP(5)
+#ifdef FM_CONVD_TIMING
+    if (stamp_slot >= 0) {
+        long long* st = reinterpret_cast<long long*>(smem + stamp_off);
+        st[6] = per;
+        st[7] = BM * 1000000 + BN * 1000 + KG * 10 + ns;
+        for (int i = 0; i < 264; ++i) g_convd_stamps[stamp_slot][i] = st[i];
+    }
+#endif
 #endif
 }
 
@@ -337,7 +377,7 @@ int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
     const size_t ring = (size_t)KG * nslots * SS;
     const size_t epi = (size_t)BN * (BM + 4) * 4 + (size_t)(KG - 1) * BM * BN * 4;
     const size_t lds = ring > epi ? ring : epi;
-    FM_CHECK_ARG(lds <= (size_t)LDS_MAX);
+    FM_CHECK_ARG(lds + CONVD_EXTRA_LDS <= (size_t)LDS_MAX);
     static bool configured = false;      // (one flag per instantiation)
     if (!configured) {
         FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convd_kernel<WC, WP, MC, MP, KG, TAPS>),
@@ -345,7 +385,7 @@ int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
         configured = true;
     }
     const int total = q.grid_p * q.grid_c;
-    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS>), dim3(((total + 7) / 8) * 8), dim3(256 * KG), lds, s, q, ns, nslots);
+    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS>), dim3(((total + 7) / 8) * 8), dim3(256 * KG), lds + CONVD_EXTRA_LDS, s, q, ns, nslots CONVD_EXTRA_ARG);
     FM_HIP(hipGetLastError());
     return 0;
 }
@@ -403,6 +443,15 @@ Cfg choose(const ConvParams& p) {
 }  // namespace
 
 void convd_set_cfg(int code) { g_convd_cfg = code; }
+
+#ifdef FM_CONVD_TIMING
+extern "C" int fm_debug_convd_stamps(long long* out528, int set_abl) {
+    FM_HIP(hipDeviceSynchronize());
+    FM_HIP(hipMemcpyFromSymbol(out528, HIP_SYMBOL(g_convd_stamps), sizeof(long long) * 528));
+    g_convd_abl = set_abl;
+    return 0;
+}
+#endif
 
 // p.w: tile-image weights (header); p.K = KH * KW * Cin with Cin % 64 == 0 (so Kpad == K)
 int launch_convd(const ConvParams& p, hipStream_t s) {
