@@ -57,6 +57,18 @@ int g_convd_abl = 0;
 #define CONVD_EXTRA_LDS 0
 #endif
 
+// Experimental structure variants (compile time, A/B builds through scripts/build_timing_lib.sh):
+//   FM_CONVD_ROLE 1: the workgroup gets as many LOADER waves as it has MFMA waves -- they own the DMA (address state,
+//                    issue, counted waits), the MFMA waves only read fragments and multiply; a loader's ~50-70 issue cycles
+//                    per 1 KB piece then overlap its SIMD partner's MFMAs instead of preceding them in one instruction stream
+//   FM_CONVD_ILV 1:  same waves, but the pieces of the next step are issued between the MFMA groups of a step
+#ifndef FM_CONVD_ROLE
+#define FM_CONVD_ROLE 0
+#endif
+#ifndef FM_CONVD_ILV
+#define FM_CONVD_ILV 0
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -66,7 +78,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // TAPS: 0 = 1x1 conv without padding (no tap walk, no masks), 3 = 3x3 conv (any stride / padding)
 template <int WC, int WP, int MC, int MP, int KG, int TAPS>
-__global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, const int ns, const int nslots CONVD_EXTRA_PARAM) {
+__global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CONVD_ROLE) ? 2 : 1) void convd_kernel(const ConvParams p, const int ns, const int nslots CONVD_EXTRA_PARAM) {
     static_assert(WC * WP == 4, "4 waves per K group");
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass has no buffer-resource type: it only needs the launch stub)
     constexpr int BM = WC * MC * 32, BN = WP * MP * 32;
@@ -74,12 +86,16 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
     constexpr int PPS = NPA + NPB;
     constexpr int SS = (BM + BN) * 128;             // bytes of one ring stage: [BM weight rows][BN pixel rows] x 128 B
     constexpr int LDO = BM + 4;
-    constexpr int T = 256 * KG;
+    constexpr int T = 256 * KG * (1 + FM_CONVD_ROLE);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int g = __builtin_amdgcn_readfirstlane(tid >> 8);           // K group
+    const int g = __builtin_amdgcn_readfirstlane((tid >> 8) % KG);    // K group
     const int w = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);     // wave inside the group
+    // (launch bounds: with one wave per SIMD hipcc put the accumulators into AGPRs and copied all of them to and from
+    // VGPRs around every K step's MFMAs -- 128 v_accvgpr moves per step; a budget of 256 registers keeps them in place)
+    const bool loader = FM_CONVD_ROLE ? __builtin_amdgcn_readfirstlane(tid >> 8) >= KG : true;
+    const bool mfma_wave = FM_CONVD_ROLE ? !loader : true;
     const int wc = w / WP, wp = w % WP;
 
     // ---- XCD-aware tile order (see conv.hip): XCD i gets the i-th contiguous chunk of an order in which the heavier
@@ -169,19 +185,26 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
     unsigned i_astep = (unsigned)s0 * 4096u;
     int i_stage = 0;
     char* const ring = smem + g * nslots * SS;
-    auto issue = [&]() {
+    // the PPS pieces of one K step in four parts (part q: pieces [q * PPS / 4, (q + 1) * PPS / 4) of the list A0.. B0..),
+    // so that the interleaved variant can place them between the MFMA groups; issue_advance() moves on to the next step
+    auto issue_part = [&](int q) {
         char* la = ring + i_stage * SS;
-#pragma unroll
-        for (int i = 0; i < NPA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (i * 4 + w) * 1024), 16, va, sa_blk[i] + i_astep, 0, 0);
         char* lb = la + BM * 128;
         const int t = i_kh * TAPS + i_kw;
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) {
-            unsigned vo = vb[i];
-            if constexpr (TAPS) vo = ((vm[i] >> t) & 1u) ? vo : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (w + 4 * i) * 1024), 16, vo, i_soff, 0, 0);
+        for (int e = 0; e < PPS; ++e) {
+            if (e * 4 / PPS != q) continue;
+            if (e < NPA) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (e * 4 + w) * 1024), 16, va, sa_blk[e] + i_astep, 0, 0);
+            } else {
+                const int i = e - NPA;
+                unsigned vo = vb[i];
+                if constexpr (TAPS) vo = ((vm[i] >> t) & 1u) ? vo : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (w + 4 * i) * 1024), 16, vo, i_soff, 0, 0);
+            }
         }
+    };
+    auto issue_advance = [&]() {
         i_astep += 4096u;
         i_stage = i_stage + 1 == nslots ? 0 : i_stage + 1;
         i_soff += 128u;
@@ -193,6 +216,11 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
                 i_soff = (unsigned)((i_kh * p.W + i_kw) * p.in_cs) * 2u;
             }
         }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_part(q);
+        issue_advance();
     };
 
     f32x16 acc[MC][MP];
@@ -213,25 +241,29 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
 
     const int npro = min(ns - 1, nkg);
     CONVD_STAMP(1)
-    for (int s = 0; s < npro; ++s) issue();
+    if (loader)
+        for (int s = 0; s < npro; ++s) issue();
     CONVD_STAMP(2)
     int issued = npro, c_stage = 0;
     for (int it = 0; it < per; ++it) {
-        // steps requested and not yet consumed (this iteration's included); everything but the oldest may stay in flight
-        const int rem = min(ns - 1, nkg - it);
-        if (rem >= 3) wait_vmcnt<2 * PPS>();
-        else if (rem == 2) wait_vmcnt<PPS>();
-        else wait_vmcnt<0>();
+        if (loader) {
+            // steps requested and not yet consumed (this iteration's included); everything but the oldest may stay in flight
+            const int rem = min(ns - 1, nkg - it);
+            if (rem >= 3) wait_vmcnt<2 * PPS>();
+            else if (rem == 2) wait_vmcnt<PPS>();
+            else wait_vmcnt<0>();
+        }
         CONVD_STAMP(8 + 4 * it)
         __builtin_amdgcn_s_barrier();       // every wave's pieces of this step have landed; the previous step's slot is free
         asm volatile("" ::: "memory");
         CONVD_STAMP(9 + 4 * it)
-        if (issued < nkg) {
+        const bool more = issued < nkg;
+        if (more) ++issued;
+        if (loader && more && !FM_CONVD_ILV) {
             if (!CONVD_ABL(1)) issue();
-            ++issued;
         }
         CONVD_STAMP(10 + 4 * it)
-        if (it < nkg && !CONVD_ABL(2)) {
+        if (mfma_wave && it < nkg && !CONVD_ABL(2)) {
             const char* sa = ring + c_stage * SS;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -240,6 +272,7 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
                 for (int mi = 0; mi < MC; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(sa + aoff + mi * 4096 + koff[j]);
 #pragma unroll
                 for (int pi = 0; pi < MP; ++pi) bf[pi] = *reinterpret_cast<const f16x8*>(sa + boff + pi * 4096 + koff[j]);
+                if (FM_CONVD_ILV && more && !CONVD_ABL(1)) issue_part(j);
 #pragma unroll
                 for (int mi = 0; mi < MC; ++mi)
 #pragma unroll
@@ -247,6 +280,9 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
                         acc[mi][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[pi], acc[mi][pi], 0, 0, 0);
             }
             c_stage = c_stage + 1 == nslots ? 0 : c_stage + 1;
+            if (FM_CONVD_ILV && more) issue_advance();
+        } else if (FM_CONVD_ILV && more) {     // (a group without a step of its own in this iteration still feeds its ring)
+            if (!CONVD_ABL(1)) issue();
         }
         CONVD_STAMP(11 + 4 * it)
     }
@@ -257,7 +293,7 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
     __syncthreads();                                 // every wave is done with the ring (no DMA is in flight any more)
     if constexpr (KG > 1) {
         float4* part = reinterpret_cast<float4*>(smem + BN * LDO * 4);
-        if (g > 0) {
+        if (mfma_wave && g > 0) {
 #pragma unroll
             for (int mi = 0; mi < MC; ++mi)
 #pragma unroll
@@ -268,7 +304,7 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
                             make_float4(acc[mi][pi][4 * q + 0], acc[mi][pi][4 * q + 1], acc[mi][pi][4 * q + 2], acc[mi][pi][4 * q + 3]);
         }
         __syncthreads();
-        if (g == 0) {
+        if (mfma_wave && g == 0) {
             for (int gg = 1; gg < KG; ++gg)          // fixed order: deterministic sums
 #pragma unroll
                 for (int mi = 0; mi < MC; ++mi)
@@ -282,7 +318,7 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
                         }
         }
     }
-    if (g == 0) {
+    if (mfma_wave && g == 0) {
         // D fragment: lane owns pixel lane % 32 and couts 8 q + 4 (lane / 32) + {0..3} of each 32 x 32 block
 #pragma unroll
         for (int pi = 0; pi < MP; ++pi)
@@ -305,31 +341,44 @@ __global__ __launch_bounds__(256 * KG) void convd_kernel(const ConvParams p, con
         float bias8[8];
         *reinterpret_cast<float4*>(&bias8[0]) = *reinterpret_cast<const float4*>(p.bias + co);
         *reinterpret_cast<float4*>(&bias8[4]) = *reinterpret_cast<const float4*>(p.bias + co + 4);
-        for (int row = orow; row < BN; row += ROWS) {
+        constexpr int NPASS = (BN + ROWS - 1) / ROWS;
+        // all passes' tile reads (and shortcut loads) are requested before the first activation: with one or two waves per
+        // SIMD a pass-by-pass loop paid the LDS / L2 latency once per pass (7.5 k cycles for a 128 x 128 tile)
+        float v[NPASS][8], r[NPASS][8];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = min(orow + ps * ROWS, BN - 1);
+            *reinterpret_cast<float4*>(&v[ps][0]) = *reinterpret_cast<const float4*>(&so[row * LDO + och * 8]);
+            *reinterpret_cast<float4*>(&v[ps][4]) = *reinterpret_cast<const float4*>(&so[row * LDO + och * 8 + 4]);
+        }
+        if (p.res_mode != RES_NONE) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int pix = min(p0 + orow + ps * ROWS, p.P - 1);
+                unpack8(*reinterpret_cast<const uint4*>(p.res + (size_t)pix * p.res_cs + p.res_coff + co), r[ps]);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = orow + ps * ROWS;
             const int pix = p0 + row;
-            if (pix >= p.P) break;
-            float v[8];
-            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&so[row * LDO + och * 8]);
-            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&so[row * LDO + och * 8 + 4]);
-            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (p.res_mode != RES_NONE)
-                unpack8(*reinterpret_cast<const uint4*>(p.res + (size_t)pix * p.res_cs + p.res_coff + co), r);
+            if (row >= BN || pix >= p.P) continue;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[e] += bias8[e];
-                if (p.res_mode == RES_BEFORE_ACT) v[e] += r[e];
+                v[ps][e] += bias8[e];
+                if (p.res_mode == RES_BEFORE_ACT) v[ps][e] += r[ps][e];
             }
-            apply_act_n<8>(v, p.act);
+            apply_act_n<8>(v[ps], p.act);
             if (p.res_mode == RES_AFTER_ACT) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                for (int e = 0; e < 8; ++e) v[ps][e] += r[ps][e];
             }
             if (p.out32) {
                 float* dst = p.out32 + (size_t)pix * p.out_cs + p.out_coff + co;
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                *reinterpret_cast<float4*>(dst) = make_float4(v[ps][0], v[ps][1], v[ps][2], v[ps][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[ps][4], v[ps][5], v[ps][6], v[ps][7]);
             } else {
-                const uint4 o = pack8(v);
+                const uint4 o = pack8(v[ps]);
                 if (p.up == 2) {   // fused nearest x2 upsample: replicate to the 2x2 block
                     const int nn = idiv_small(pix, hw_out, inv_hw), rem = pix - nn * hw_out;
                     const int ry = idiv_small(rem, p.Wo, inv_wo), rx = rem - ry * p.Wo;
@@ -385,7 +434,7 @@ int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
         configured = true;
     }
     const int total = q.grid_p * q.grid_c;
-    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS>), dim3(((total + 7) / 8) * 8), dim3(256 * KG), lds + CONVD_EXTRA_LDS, s, q, ns, nslots CONVD_EXTRA_ARG);
+    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS>), dim3(((total + 7) / 8) * 8), dim3(256 * KG * (1 + FM_CONVD_ROLE)), lds + CONVD_EXTRA_LDS, s, q, ns, nslots CONVD_EXTRA_ARG);
     FM_HIP(hipGetLastError());
     return 0;
 }
@@ -398,7 +447,7 @@ int launch_taps(const ConvParams& p, int ns, hipStream_t s) {
 
 template <int MC, int MP>
 int launch_kg(const ConvParams& p, const Cfg& c, hipStream_t s) {
-    if constexpr (MC * MP <= 2) {
+    if constexpr (MC * MP <= 2 && !FM_CONVD_ROLE) {      // (2 x 16 waves would exceed a workgroup)
         if (c.kg == 4) return launch_taps<2, 2, MC, MP, 4>(p, c.ns, s);
     }
     if (c.kg >= 2) return launch_taps<2, 2, MC, MP, 2>(p, c.ns, s);
