@@ -68,6 +68,11 @@ int g_convd_abl = 0;
 #ifndef FM_CONVD_ILV
 #define FM_CONVD_ILV 0
 #endif
+//   FM_CONVD_EPI 1:  outputs leave straight from the MFMA fragments (v_permlane32_swap pairs -> 16-byte stores) instead of
+//                    being transposed through LDS
+#ifndef FM_CONVD_EPI
+#define FM_CONVD_EPI 1
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -119,6 +124,9 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
     const int stamp_slot = tid == 0 ? (blockIdx.x == 0 ? 0 : (blockIdx.x == 8 * 5 + 3 ? 1 : -1)) : -1;
 #endif
     CONVD_STAMP(0)
+#ifdef FM_CONVD_TIMING
+    if (stamp_slot >= 0) reinterpret_cast<long long*>(smem + stamp_off)[262] = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock
+#endif
 
     // ---- K range of this group
     const int nk = p.Kpad >> 6;
@@ -288,11 +296,11 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
     }
     CONVD_STAMP(3)
 
-    // ---- epilogue.  LDS is reused: [0, BN * LDO * 4) the transposed fp32 tile, behind it the partial tiles of groups 1..
-    float* so = reinterpret_cast<float*>(smem);
-    __syncthreads();                                 // every wave is done with the ring (no DMA is in flight any more)
+    // ---- epilogue
+    // K groups: the partial tiles of groups 1.. meet group 0's in LDS (fragment layout, conflict-free float4 per lane)
     if constexpr (KG > 1) {
-        float4* part = reinterpret_cast<float4*>(smem + BN * LDO * 4);
+        __syncthreads();                             // every wave is done with the ring (no DMA is in flight any more)
+        float4* part = reinterpret_cast<float4*>(smem + (FM_CONVD_EPI ? 0 : BN * LDO * 4));
         if (mfma_wave && g > 0) {
 #pragma unroll
             for (int mi = 0; mi < MC; ++mi)
@@ -318,6 +326,94 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
                         }
         }
     }
+    CONVD_STAMP(4)
+#if FM_CONVD_EPI
+    // Straight from the MFMA D fragment.  A lane owns pixel lane % 32 and, per register quad q, couts 8 q + 4 (lane / 32)
+    // + {0..3} of a 32 x 32 block: bias, shortcut and activation are applied right there (one branch on the activation
+    // per block), the four fp16 results of quads q and q + 1 are exchanged between lanes l and l + 32
+    // (v_permlane32_swap) so that the lower lane holds couts 8 q .. 8 q + 7 and the upper one 8 (q + 1) .. + 7: one
+    // 16-byte store per lane, 32 contiguous bytes per pixel row and instruction -- no LDS round trip, no barrier.
+    if (mfma_wave && g == 0 && !CONVD_ABL(4)) {
+        const int hw_out = p.Ho * p.Wo;
+        const float inv_hw = 1.f / (float)hw_out, inv_wo = 1.f / (float)p.Wo;
+#pragma unroll
+        for (int pi = 0; pi < MP; ++pi) {
+            const int pix = p0 + (wp * MP + pi) * 32 + frow;
+            const bool pok = pix < p.P;
+            const int pc = min(pix, p.P - 1);
+            size_t orow_off;
+            if (p.up == 2) {
+                const int nn = idiv_small(pc, hw_out, inv_hw), rem = pc - nn * hw_out;
+                const int ry = idiv_small(rem, p.Wo, inv_wo), rx = rem - ry * p.Wo;
+                orow_off = (((size_t)nn * 2 * p.Ho + 2 * ry) * (2 * p.Wo) + 2 * rx) * p.out_cs + p.out_coff;
+            } else {
+                orow_off = (size_t)pc * p.out_cs + p.out_coff;
+            }
+#pragma unroll
+            for (int mi = 0; mi < MC; ++mi) {
+                const int cb = c0 + (wc * MC + mi) * 32;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cb + 8 * q + 4 * fh);
+                    v[4 * q + 0] = acc[mi][pi][4 * q + 0] + b4.x; v[4 * q + 1] = acc[mi][pi][4 * q + 1] + b4.y;
+                    v[4 * q + 2] = acc[mi][pi][4 * q + 2] + b4.z; v[4 * q + 3] = acc[mi][pi][4 * q + 3] + b4.w;
+                }
+                float r[16];
+                if (p.res_mode != RES_NONE) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co4 = min(cb + 8 * q + 4 * fh, p.cout_store - 4);       // (clamped lanes are never stored)
+                        const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)pc * p.res_cs + p.res_coff + co4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[4 * q + e] = (float)rv[e];
+                    }
+                    if (p.res_mode == RES_BEFORE_ACT) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] += r[e];
+                    }
+                }
+                apply_act_n<16>(v, p.act);
+                if (p.res_mode == RES_AFTER_ACT) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += r[e];
+                }
+                if (p.out32) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co4 = cb + 8 * q + 4 * fh;
+                        if (pok && co4 < p.cout_store)
+                            *reinterpret_cast<float4*>(p.out32 + orow_off + co4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        f16x4 lo, hi;                              // this lane's quads q and q + 1
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] = (f16)v[4 * q + e]; hi[e] = (f16)v[4 * q + 4 + e]; }
+                        uint2 a = *reinterpret_cast<const uint2*>(&lo), b = *reinterpret_cast<const uint2*>(&hi);
+                        auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+                        auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+                        const uint4 o = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        const int co8 = cb + 8 * (q + fh);
+                        if (pok && co8 < p.cout_store) {
+                            f16* dst = p.out + orow_off + co8;
+                            *reinterpret_cast<uint4*>(dst) = o;
+                            if (p.up == 2) {
+                                *reinterpret_cast<uint4*>(dst + p.out_cs) = o;
+                                *reinterpret_cast<uint4*>(dst + (size_t)2 * p.Wo * p.out_cs) = o;
+                                *reinterpret_cast<uint4*>(dst + (size_t)(2 * p.Wo + 1) * p.out_cs) = o;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#else
+    // Through LDS ([0, BN * LDO * 4): the transposed fp32 tile): every lane then owns 8 consecutive couts of a pixel row
+    float* so = reinterpret_cast<float*>(smem);
+    if constexpr (KG == 1) __syncthreads();          // every wave is done with the ring
     if (mfma_wave && g == 0) {
         // D fragment: lane owns pixel lane % 32 and couts 8 q + 4 (lane / 32) + {0..3} of each 32 x 32 block
 #pragma unroll
@@ -330,7 +426,6 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
                         make_float4(acc[mi][pi][4 * q + 0], acc[mi][pi][4 * q + 1], acc[mi][pi][4 * q + 2], acc[mi][pi][4 * q + 3]);
     }
     __syncthreads();
-    CONVD_STAMP(4)
     constexpr int CH = BM / 8;                       // 16 B chunks per pixel row of the tile
     constexpr int ROWS = T / CH;
     const int och = tid % CH, orow = tid / CH;
@@ -394,10 +489,12 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
             }
         }
     }
+#endif
     CONVD_STAMP(5)
 #ifdef FM_CONVD_TIMING
     if (stamp_slot >= 0) {
         long long* st = reinterpret_cast<long long*>(smem + stamp_off);
+        st[263] = __builtin_amdgcn_s_memrealtime();
         st[6] = per;
         st[7] = BM * 1000000 + BN * 1000 + KG * 10 + ns;
         for (int i = 0; i < 264; ++i) g_convd_stamps[stamp_slot][i] = st[i];
@@ -424,7 +521,7 @@ int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
     q.grid_z = 1;
     q.weight_major = (size_t)cout_pad * p.Kpad > (size_t)p.N * p.H * p.W * p.Cin ? 1 : 0;
     const size_t ring = (size_t)KG * nslots * SS;
-    const size_t epi = (size_t)BN * (BM + 4) * 4 + (size_t)(KG - 1) * BM * BN * 4;
+    const size_t epi = (FM_CONVD_EPI ? 0 : (size_t)BN * (BM + 4) * 4) + (size_t)(KG - 1) * BM * BN * 4;
     const size_t lds = ring > epi ? ring : epi;
     FM_CHECK_ARG(lds + CONVD_EXTRA_LDS <= (size_t)LDS_MAX);
     static bool configured = false;      // (one flag per instantiation)
@@ -447,7 +544,7 @@ int launch_taps(const ConvParams& p, int ns, hipStream_t s) {
 
 template <int MC, int MP>
 int launch_kg(const ConvParams& p, const Cfg& c, hipStream_t s) {
-    if constexpr (MC * MP <= 2 && !FM_CONVD_ROLE) {      // (2 x 16 waves would exceed a workgroup)
+    if constexpr (MC * MP == 1 && !FM_CONVD_ROLE) {      // (2 x 16 waves would exceed a workgroup; 2 accumulators spill at 128 VGPRs)
         if (c.kg == 4) return launch_taps<2, 2, MC, MP, 4>(p, c.ns, s);
     }
     if (c.kg >= 2) return launch_taps<2, 2, MC, MP, 2>(p, c.ns, s);
@@ -483,7 +580,7 @@ Cfg choose(const ConvParams& p) {
     const long nt = tiles(c.bm, c.bn);
     c.kg = 1;
     if (nk >= 8 && nt <= 512) c.kg = 2;
-    if (nk >= 32 && nt <= 128 && c.bm * c.bn <= 128 * 64) c.kg = 4;
+    if (nk >= 32 && nt <= 128 && c.bm * c.bn <= 64 * 64) c.kg = 4;
     while (c.kg > 1 && c.kg * 2 * (c.bm + c.bn) * 128 > LDS_MAX) c.kg >>= 1;
     c.ns = stages_for(c.bm, c.bn, c.kg, (nk + c.kg - 1) / c.kg);
     return c;

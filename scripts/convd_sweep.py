@@ -89,9 +89,27 @@ def measure(ctx, shape, level, maxp, cfg):
     return ev, rep, out, ops
 
 
+def kscan(ctx):
+    """Same map and couts, growing reduction: time = fixed + steps * slope per configuration (least squares)."""
+    for (k, stride, h, cout) in ((3, 1, 76, 256), (3, 1, 38, 512), (1, 1, 76, 256), (3, 1, 160, 128)):
+        print(f'## K scan: k{k}s{stride} {h}x{h}, cout {cout}', flush=True)
+        for label, cfg in [('tiled', None)] + [(f'{bm}x{bn} kg{kg}', code(bm, bn, kg)) for bm, bn, kg in
+                                               ((128, 128, 1), (128, 64, 1), (64, 64, 1), (128, 64, 2), (64, 64, 2))]:
+            xs, ys = [], []
+            for cin in (64, 128, 256, 512):
+                ev, rep, out, ops = measure(ctx, (cin, cout, k, stride, h, h), 0 if cfg is None else 2, 0, cfg or 0)
+                xs.append(k * k * cin // 64)
+                ys.append(ev)
+            slope, fixed = np.polyfit(xs, ys, 1)
+            print(f'   {label:<14} ' + '  '.join(f'{x} steps: {y:6.2f} us' for x, y in zip(xs, ys)) +
+                  f'   -> fixed {fixed:5.2f} us + {slope * 1e3:6.1f} ns / step', flush=True)
+
+
 def main():
-    names = SETS.get(sys.argv[1] if len(sys.argv) > 1 else 'all') or sys.argv[1].split(',')
     ctx = get_context()
+    if len(sys.argv) > 1 and sys.argv[1] == 'kscan':
+        return kscan(ctx)
+    names = SETS.get(sys.argv[1] if len(sys.argv) > 1 else 'all') or sys.argv[1].split(',')
     for name in names:
         shape = SHAPES[name]
         cin, cout, k, stride, h, w = shape

@@ -49,7 +49,9 @@ def main():
             for _ in range(3):
                 net.run(1)
             ctx.synchronize()
+            ev = float(np.mean(net.profile_layers(1, 20))) * 1e3
             st = stamps(ctx, 0)
+            print(f'   {tag:<22} HIP-event time of the launch {ev:.2f} us')
             for slot, name in ((0, 'wg 0'), (1, 'wg 43')):
                 s = st[slot]
                 if s[5] <= s[0]:
@@ -63,7 +65,7 @@ def main():
                 step = np.diff(it[:, 0])
                 print(f'   {tag:<22} {name:<6} cfg {int(s[7])} steps {per}: prologue {s[1] - s[0]} + first issues {s[2] - s[1]}'
                       f' | loop {s[3] - s[2]} ({(s[3] - s[2]) / max(per, 1):.0f} / step) | reduce+transpose {s[4] - s[3]} | output {s[5] - s[4]}'
-                      f' | total {s[5] - s[0]} cycles')
+                      f' | total {s[5] - s[0]} cycles in {(s[263] - s[262]) * 10} ns = {(s[5] - s[0]) / max((s[263] - s[262]) * 10, 1):.2f} GHz')
                 if per > 1:
                     print(f'      per step (median): wait {np.median(wait):.0f}  barrier {np.median(bar):.0f}  issue {np.median(iss):.0f}'
                           f'  reads+mfma {np.median(comp):.0f}  period {np.median(step):.0f};  first step: wait-for-first-data {it[0, 0] - s[2]}')
