@@ -57,23 +57,6 @@ int g_convd_abl = 0;
 #define CONVD_EXTRA_LDS 0
 #endif
 
-// Experimental structure variants (compile time, A/B builds through scripts/build_timing_lib.sh):
-//   FM_CONVD_ROLE 1: the workgroup gets as many LOADER waves as it has MFMA waves -- they own the DMA (address state,
-//                    issue, counted waits), the MFMA waves only read fragments and multiply; a loader's ~50-70 issue cycles
-//                    per 1 KB piece then overlap its SIMD partner's MFMAs instead of preceding them in one instruction stream
-//   FM_CONVD_ILV 1:  same waves, but the pieces of the next step are issued between the MFMA groups of a step
-#ifndef FM_CONVD_ROLE
-#define FM_CONVD_ROLE 0
-#endif
-#ifndef FM_CONVD_ILV
-#define FM_CONVD_ILV 0
-#endif
-//   FM_CONVD_EPI 1:  outputs leave straight from the MFMA fragments (v_permlane32_swap pairs -> 16-byte stores) instead of
-//                    being transposed through LDS
-#ifndef FM_CONVD_EPI
-#define FM_CONVD_EPI 1
-#endif
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -82,8 +65,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // TAPS: 0 = 1x1 conv without padding (no tap walk, no masks), 3 = 3x3 conv (any stride / padding)
-template <int WC, int WP, int MC, int MP, int KG, int TAPS>
-__global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CONVD_ROLE) ? 2 : 1) void convd_kernel(const ConvParams p, const int ns, const int nslots CONVD_EXTRA_PARAM) {
+// ROLE: 1 = the workgroup gets as many LOADER waves as it has MFMA waves.  The loaders own the DMA (address state, issue,
+//       counted waits), the MFMA waves only read fragments and multiply: a loader's ~50-70 issue cycles per 1 KB piece then
+//       overlap its SIMD partner's MFMAs instead of preceding them in the same instruction stream.
+template <int WC, int WP, int MC, int MP, int KG, int TAPS, int ROLE>
+__global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) void convd_kernel(const ConvParams p, const int ns, const int nslots CONVD_EXTRA_PARAM) {
     static_assert(WC * WP == 4, "4 waves per K group");
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass has no buffer-resource type: it only needs the launch stub)
     constexpr int BM = WC * MC * 32, BN = WP * MP * 32;
@@ -91,7 +77,7 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
     constexpr int PPS = NPA + NPB;
     constexpr int SS = (BM + BN) * 128;             // bytes of one ring stage: [BM weight rows][BN pixel rows] x 128 B
     constexpr int LDO = BM + 4;
-    constexpr int T = 256 * KG * (1 + FM_CONVD_ROLE);
+    constexpr int T = 256 * KG * (1 + ROLE);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,8 +85,8 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
     const int w = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);     // wave inside the group
     // (launch bounds: with one wave per SIMD hipcc put the accumulators into AGPRs and copied all of them to and from
     // VGPRs around every K step's MFMAs -- 128 v_accvgpr moves per step; a budget of 256 registers keeps them in place)
-    const bool loader = FM_CONVD_ROLE ? __builtin_amdgcn_readfirstlane(tid >> 8) >= KG : true;
-    const bool mfma_wave = FM_CONVD_ROLE ? !loader : true;
+    const bool loader = ROLE ? __builtin_amdgcn_readfirstlane(tid >> 8) >= KG : true;
+    const bool mfma_wave = ROLE ? !loader : true;
     const int wc = w / WP, wp = w % WP;
 
     // ---- XCD-aware tile order (see conv.hip): XCD i gets the i-th contiguous chunk of an order in which the heavier
@@ -193,26 +179,19 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
     unsigned i_astep = (unsigned)s0 * 4096u;
     int i_stage = 0;
     char* const ring = smem + g * nslots * SS;
-    // the PPS pieces of one K step in four parts (part q: pieces [q * PPS / 4, (q + 1) * PPS / 4) of the list A0.. B0..),
-    // so that the interleaved variant can place them between the MFMA groups; issue_advance() moves on to the next step
-    auto issue_part = [&](int q) {
+    auto issue = [&]() {
         char* la = ring + i_stage * SS;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (i * 4 + w) * 1024), 16, va, sa_blk[i] + i_astep, 0, 0);
         char* lb = la + BM * 128;
         const int t = i_kh * TAPS + i_kw;
 #pragma unroll
-        for (int e = 0; e < PPS; ++e) {
-            if (e * 4 / PPS != q) continue;
-            if (e < NPA) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (e * 4 + w) * 1024), 16, va, sa_blk[e] + i_astep, 0, 0);
-            } else {
-                const int i = e - NPA;
-                unsigned vo = vb[i];
-                if constexpr (TAPS) vo = ((vm[i] >> t) & 1u) ? vo : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (w + 4 * i) * 1024), 16, vo, i_soff, 0, 0);
-            }
+        for (int i = 0; i < NPB; ++i) {
+            unsigned vo = vb[i];
+            if constexpr (TAPS) vo = ((vm[i] >> t) & 1u) ? vo : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (w + 4 * i) * 1024), 16, vo, i_soff, 0, 0);
         }
-    };
-    auto issue_advance = [&]() {
         i_astep += 4096u;
         i_stage = i_stage + 1 == nslots ? 0 : i_stage + 1;
         i_soff += 128u;
@@ -224,11 +203,6 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
                 i_soff = (unsigned)((i_kh * p.W + i_kw) * p.in_cs) * 2u;
             }
         }
-    };
-    auto issue = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) issue_part(q);
-        issue_advance();
     };
 
     f32x16 acc[MC][MP];
@@ -265,10 +239,9 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
         __builtin_amdgcn_s_barrier();       // every wave's pieces of this step have landed; the previous step's slot is free
         asm volatile("" ::: "memory");
         CONVD_STAMP(9 + 4 * it)
-        const bool more = issued < nkg;
-        if (more) ++issued;
-        if (loader && more && !FM_CONVD_ILV) {
+        if (loader && issued < nkg) {
             if (!CONVD_ABL(1)) issue();
+            ++issued;
         }
         CONVD_STAMP(10 + 4 * it)
         if (mfma_wave && it < nkg && !CONVD_ABL(2)) {
@@ -280,7 +253,6 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
                 for (int mi = 0; mi < MC; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(sa + aoff + mi * 4096 + koff[j]);
 #pragma unroll
                 for (int pi = 0; pi < MP; ++pi) bf[pi] = *reinterpret_cast<const f16x8*>(sa + boff + pi * 4096 + koff[j]);
-                if (FM_CONVD_ILV && more && !CONVD_ABL(1)) issue_part(j);
 #pragma unroll
                 for (int mi = 0; mi < MC; ++mi)
 #pragma unroll
@@ -288,9 +260,6 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
                         acc[mi][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[pi], acc[mi][pi], 0, 0, 0);
             }
             c_stage = c_stage + 1 == nslots ? 0 : c_stage + 1;
-            if (FM_CONVD_ILV && more) issue_advance();
-        } else if (FM_CONVD_ILV && more) {     // (a group without a step of its own in this iteration still feeds its ring)
-            if (!CONVD_ABL(1)) issue();
         }
         CONVD_STAMP(11 + 4 * it)
     }
@@ -300,7 +269,7 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
     // K groups: the partial tiles of groups 1.. meet group 0's in LDS (fragment layout, conflict-free float4 per lane)
     if constexpr (KG > 1) {
         __syncthreads();                             // every wave is done with the ring (no DMA is in flight any more)
-        float4* part = reinterpret_cast<float4*>(smem + (FM_CONVD_EPI ? 0 : BN * LDO * 4));
+        float4* part = reinterpret_cast<float4*>(smem + BN * LDO * 4);
         if (mfma_wave && g > 0) {
 #pragma unroll
             for (int mi = 0; mi < MC; ++mi)
@@ -327,91 +296,11 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
         }
     }
     CONVD_STAMP(4)
-#if FM_CONVD_EPI
-    // Straight from the MFMA D fragment.  A lane owns pixel lane % 32 and, per register quad q, couts 8 q + 4 (lane / 32)
-    // + {0..3} of a 32 x 32 block: bias, shortcut and activation are applied right there (one branch on the activation
-    // per block), the four fp16 results of quads q and q + 1 are exchanged between lanes l and l + 32
-    // (v_permlane32_swap) so that the lower lane holds couts 8 q .. 8 q + 7 and the upper one 8 (q + 1) .. + 7: one
-    // 16-byte store per lane, 32 contiguous bytes per pixel row and instruction -- no LDS round trip, no barrier.
-    if (mfma_wave && g == 0 && !CONVD_ABL(4)) {
-        const int hw_out = p.Ho * p.Wo;
-        const float inv_hw = 1.f / (float)hw_out, inv_wo = 1.f / (float)p.Wo;
-#pragma unroll
-        for (int pi = 0; pi < MP; ++pi) {
-            const int pix = p0 + (wp * MP + pi) * 32 + frow;
-            const bool pok = pix < p.P;
-            const int pc = min(pix, p.P - 1);
-            size_t orow_off;
-            if (p.up == 2) {
-                const int nn = idiv_small(pc, hw_out, inv_hw), rem = pc - nn * hw_out;
-                const int ry = idiv_small(rem, p.Wo, inv_wo), rx = rem - ry * p.Wo;
-                orow_off = (((size_t)nn * 2 * p.Ho + 2 * ry) * (2 * p.Wo) + 2 * rx) * p.out_cs + p.out_coff;
-            } else {
-                orow_off = (size_t)pc * p.out_cs + p.out_coff;
-            }
-#pragma unroll
-            for (int mi = 0; mi < MC; ++mi) {
-                const int cb = c0 + (wc * MC + mi) * 32;
-                float v[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cb + 8 * q + 4 * fh);
-                    v[4 * q + 0] = acc[mi][pi][4 * q + 0] + b4.x; v[4 * q + 1] = acc[mi][pi][4 * q + 1] + b4.y;
-                    v[4 * q + 2] = acc[mi][pi][4 * q + 2] + b4.z; v[4 * q + 3] = acc[mi][pi][4 * q + 3] + b4.w;
-                }
-                float r[16];
-                if (p.res_mode != RES_NONE) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co4 = min(cb + 8 * q + 4 * fh, p.cout_store - 4);       // (clamped lanes are never stored)
-                        const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)pc * p.res_cs + p.res_coff + co4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) r[4 * q + e] = (float)rv[e];
-                    }
-                    if (p.res_mode == RES_BEFORE_ACT) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] += r[e];
-                    }
-                }
-                apply_act_n<16>(v, p.act);
-                if (p.res_mode == RES_AFTER_ACT) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] += r[e];
-                }
-                if (p.out32) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co4 = cb + 8 * q + 4 * fh;
-                        if (pok && co4 < p.cout_store)
-                            *reinterpret_cast<float4*>(p.out32 + orow_off + co4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; q += 2) {
-                        f16x4 lo, hi;                              // this lane's quads q and q + 1
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { lo[e] = (f16)v[4 * q + e]; hi[e] = (f16)v[4 * q + 4 + e]; }
-                        uint2 a = *reinterpret_cast<const uint2*>(&lo), b = *reinterpret_cast<const uint2*>(&hi);
-                        auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
-                        auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
-                        const uint4 o = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                        const int co8 = cb + 8 * (q + fh);
-                        if (pok && co8 < p.cout_store) {
-                            f16* dst = p.out + orow_off + co8;
-                            *reinterpret_cast<uint4*>(dst) = o;
-                            if (p.up == 2) {
-                                *reinterpret_cast<uint4*>(dst + p.out_cs) = o;
-                                *reinterpret_cast<uint4*>(dst + (size_t)2 * p.Wo * p.out_cs) = o;
-                                *reinterpret_cast<uint4*>(dst + (size_t)(2 * p.Wo + 1) * p.out_cs) = o;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-#else
-    // Through LDS ([0, BN * LDO * 4): the transposed fp32 tile): every lane then owns 8 consecutive couts of a pixel row
+    // Through LDS ([0, BN * LDO * 4): the transposed fp32 tile): every lane then owns 8 consecutive couts of a pixel row and
+    // outputs leave as 16-byte pieces of whole NHWC rows.  (Measured and rejected, profiles/r05_convd_kscan_*: stores straight
+    // from the MFMA fragments -- v_permlane32_swap pairs, 16 bytes per lane to 32 different rows per instruction, no barrier
+    // -- cost +0.8 us per launch on 128 x 128 tiles: the store path takes ~8 B/clk/CU either way, and the loader waves of a
+    // ROLE workgroup help with the row-wise form.)
     float* so = reinterpret_cast<float*>(smem);
     if constexpr (KG == 1) __syncthreads();          // every wave is done with the ring
     if (mfma_wave && g == 0) {
@@ -489,7 +378,6 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
             }
         }
     }
-#endif
     CONVD_STAMP(5)
 #ifdef FM_CONVD_TIMING
     if (stamp_slot >= 0) {
@@ -506,10 +394,10 @@ __global__ __launch_bounds__(256 * KG * (1 + FM_CONVD_ROLE), (KG == 1 && !FM_CON
 constexpr int LDS_MAX = 160 * 1024;
 
 struct Cfg {
-    int bm, bn, kg, ns;
+    int bm, bn, kg, ns, role;
 };
 
-template <int WC, int WP, int MC, int MP, int KG, int TAPS>
+template <int WC, int WP, int MC, int MP, int KG, int TAPS, int ROLE>
 int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
     constexpr int BM = WC * MC * 32, BN = WP * MP * 32, SS = (BM + BN) * 128;
     const int cout_pad = (p.Cout + 31) & ~31;
@@ -521,68 +409,69 @@ int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
     q.grid_z = 1;
     q.weight_major = (size_t)cout_pad * p.Kpad > (size_t)p.N * p.H * p.W * p.Cin ? 1 : 0;
     const size_t ring = (size_t)KG * nslots * SS;
-    const size_t epi = (FM_CONVD_EPI ? 0 : (size_t)BN * (BM + 4) * 4) + (size_t)(KG - 1) * BM * BN * 4;
+    const size_t epi = (size_t)BN * (BM + 4) * 4 + (size_t)(KG - 1) * BM * BN * 4;
     const size_t lds = ring > epi ? ring : epi;
     FM_CHECK_ARG(lds + CONVD_EXTRA_LDS <= (size_t)LDS_MAX);
     static bool configured = false;      // (one flag per instantiation)
     if (!configured) {
-        FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convd_kernel<WC, WP, MC, MP, KG, TAPS>),
+        FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
         configured = true;
     }
     const int total = q.grid_p * q.grid_c;
-    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS>), dim3(((total + 7) / 8) * 8), dim3(256 * KG * (1 + FM_CONVD_ROLE)), lds + CONVD_EXTRA_LDS, s, q, ns, nslots CONVD_EXTRA_ARG);
+    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE>), dim3(((total + 7) / 8) * 8), dim3(256 * KG * (1 + ROLE)),
+                       lds + CONVD_EXTRA_LDS, s, q, ns, nslots CONVD_EXTRA_ARG);
     FM_HIP(hipGetLastError());
     return 0;
 }
 
-template <int WC, int WP, int MC, int MP, int KG>
+template <int MC, int MP, int KG, int ROLE>
 int launch_taps(const ConvParams& p, int ns, hipStream_t s) {
-    if (p.KH == 1) return launch_inst<WC, WP, MC, MP, KG, 0>(p, ns, s);
-    return launch_inst<WC, WP, MC, MP, KG, 3>(p, ns, s);
+    if (p.KH == 1) return launch_inst<2, 2, MC, MP, KG, 0, ROLE>(p, ns, s);
+    return launch_inst<2, 2, MC, MP, KG, 3, ROLE>(p, ns, s);
 }
 
+// instances: tiles 128 x 128, 128 x 64, 64 x 64; 1 or 2 K groups with or without loader waves; 4 K groups (16 MFMA waves)
+// for the 64 x 64 tile only (two accumulators spill at the 128 registers a 1024-thread workgroup leaves a lane)
 template <int MC, int MP>
 int launch_kg(const ConvParams& p, const Cfg& c, hipStream_t s) {
-    if constexpr (MC * MP == 1 && !FM_CONVD_ROLE) {      // (2 x 16 waves would exceed a workgroup; 2 accumulators spill at 128 VGPRs)
-        if (c.kg == 4) return launch_taps<2, 2, MC, MP, 4>(p, c.ns, s);
+    if constexpr (MC * MP == 1) {
+        if (c.kg == 4) return launch_taps<MC, MP, 4, 0>(p, c.ns, s);
     }
-    if (c.kg >= 2) return launch_taps<2, 2, MC, MP, 2>(p, c.ns, s);
-    return launch_taps<2, 2, MC, MP, 1>(p, c.ns, s);
+    if (c.kg >= 2) return c.role ? launch_taps<MC, MP, 2, 1>(p, c.ns, s) : launch_taps<MC, MP, 2, 0>(p, c.ns, s);
+    return c.role ? launch_taps<MC, MP, 1, 1>(p, c.ns, s) : launch_taps<MC, MP, 1, 0>(p, c.ns, s);
 }
 
-// stage count: as deep as the K range of a group and the LDS allow (<= 4), at least 2
-int stages_for(int bm, int bn, int kg, int per) {
+// stage count: as deep as the K range of a group and `lds_budget` allow (<= 4), at least 2
+int stages_for(int bm, int bn, int kg, int per, int lds_budget) {
     const int ss = (bm + bn) * 128;
-    int ns = LDS_MAX / (kg * ss);
+    int ns = lds_budget / (kg * ss);
     ns = ns > 4 ? 4 : ns;
     ns = ns > per ? per : ns;
     return ns < 2 ? 2 : ns;
 }
 
-// Tile / K-group choice.  Batch 1 gives a layer 24 .. 1500 tiles of 64 x 64 for 256 CUs: prefer the largest tile that
-// still leaves ~one workgroup per CU, then add K groups (more wavefronts and bytes in flight per CU) where the K range
-// is long enough to feed them.
+// Tile / K-group / role choice, from the single-layer sweeps and K scans of round 5 (profiles/r05_convd_sweep_*.txt,
+// r05_convd_kscan_*.txt; every shape of YOLOv4 @ 608, -CSP @ 640 and -P6 @ 1280 with cin % 64 == 0):
+//   * the largest of 128 x 128, 128 x 64, 64 x 64 that still gives ~180 workgroups (0.7 per CU): the fill path and the
+//     store path (~8 B/clk/CU) both want every CU, the LDS read port wants the large register tile;
+//   * K ranges of one or two steps (1x1 convs on the large maps) are bound by their stores: 64 x 64 tiles, several small
+//     workgroups per CU at different phases, no loader waves (they would idle);
+//   * 128 x 128: one K group with loader waves; smaller tiles: two K groups with loader waves from 8 steps on;
+//   * ring depth 4 where one workgroup per CU is all the layer has, 2 (half the LDS) where a second workgroup can be
+//     resident beside it (more than 256 tiles).
 Cfg choose(const ConvParams& p) {
     const int cout_pad = (p.Cout + 31) & ~31, nk = p.Kpad >> 6;
     auto tiles = [&](int bm, int bn) { return (long)((p.P + bn - 1) / bn) * ((cout_pad + bm - 1) / bm); };
-    const bool m128 = cout_pad % 128 == 0 || cout_pad >= 512;
-    Cfg c{64, 64, 1, 2};
-    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    for (const auto& t : cand) {
-        if (t[0] == 128 && !m128) continue;
-        if (tiles(t[0], t[1]) >= 224 || (t[0] == 64 && t[1] == 64)) {
-            c.bm = t[0];
-            c.bn = t[1];
-            break;
-        }
+    Cfg c{64, 64, 1, 2, 0};
+    if (nk > 2) {
+        if (cout_pad % 128 == 0 && tiles(128, 128) >= 180) c = Cfg{128, 128, 1, 2, 1};
+        else if (cout_pad % 128 == 0 && tiles(128, 64) >= 180) c = Cfg{128, 64, 1, 2, 1};
+        else c.role = 1;
+        if (c.bm * c.bn < 128 * 128 && nk >= 8) c.kg = 2;
     }
     const long nt = tiles(c.bm, c.bn);
-    c.kg = 1;
-    if (nk >= 8 && nt <= 512) c.kg = 2;
-    if (nk >= 32 && nt <= 128 && c.bm * c.bn <= 64 * 64) c.kg = 4;
-    while (c.kg > 1 && c.kg * 2 * (c.bm + c.bn) * 128 > LDS_MAX) c.kg >>= 1;
-    c.ns = stages_for(c.bm, c.bn, c.kg, (nk + c.kg - 1) / c.kg);
+    c.ns = stages_for(c.bm, c.bn, c.kg, (nk + c.kg - 1) / c.kg, nt > 256 ? LDS_MAX / 2 : LDS_MAX);
     return c;
 }
 
@@ -610,17 +499,18 @@ int launch_convd(const ConvParams& p, hipStream_t s) {
     FM_CHECK_ARG(((long)p.N * p.H * p.W + (long)(p.KH + p.pad) * p.W + p.KW + p.pad) * p.in_cs * 2 < (1L << 31));
     FM_CHECK_ARG((long)((p.Cout + 31) & ~31) * p.Kpad * 2 < (1L << 31));
     Cfg c = choose(p);
-    if (g_convd_cfg) {
-        Cfg f{g_convd_cfg & 255, (g_convd_cfg >> 8) & 255, (g_convd_cfg >> 16) & 15, (g_convd_cfg >> 20) & 15};
+    if (g_convd_cfg) {      // forced: bm | bn << 8 | kg << 16 | ns << 20 | role << 24 (ns 0: as deep as LDS allows)
+        Cfg f{g_convd_cfg & 255, (g_convd_cfg >> 8) & 255, (g_convd_cfg >> 16) & 15, (g_convd_cfg >> 20) & 15, (g_convd_cfg >> 24) & 1};
         const int nk = p.Kpad >> 6;
         if (f.kg > nk) f.kg = nk >= 2 ? 2 : 1;
-        if (f.ns == 0) f.ns = stages_for(f.bm, f.bn, f.kg, (nk + f.kg - 1) / f.kg);
+        if (f.kg == 4 && (f.bm != 64 || f.bn != 64)) f.kg = 2;
+        if (f.kg == 4) f.role = 0;
+        if (f.ns == 0) f.ns = stages_for(f.bm, f.bn, f.kg, (nk + f.kg - 1) / f.kg, LDS_MAX);
         while (f.ns > 2 && (size_t)f.kg * f.ns * (f.bm + f.bn) * 128 > (size_t)LDS_MAX) --f.ns;
         if ((size_t)f.kg * 2 * (f.bm + f.bn) * 128 <= (size_t)LDS_MAX) c = f;
     }
     if (c.bm == 128 && c.bn == 128) return launch_kg<2, 2>(p, c, s);
     if (c.bm == 128 && c.bn == 64) return launch_kg<2, 1>(p, c, s);
-    if (c.bm == 64 && c.bn == 128) return launch_kg<1, 2>(p, c, s);
     if (c.bm == 64 && c.bn == 64) return launch_kg<1, 1>(p, c, s);
     fm_set_error("convd: no %d x %d tile", c.bm, c.bn);
     return FM_ERR_ARG;

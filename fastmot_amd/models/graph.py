@@ -132,9 +132,11 @@ class Graph:
         # convs with at most this many output pixels per sample and a long reduction take the streamed
         # kernel (K split inside the workgroup, convs.hip) instead of the LDS-tiled one + split-K reduce
         self.convs_max_pixels = int(os.environ.get('FASTMOT_CONVS_MAXP', '1444'))
-        # DMA-fed multi-accumulator kernel (convd.hip) for layers with cin % 64 == 0: 0 = never, 1 = instead of the
-        # LDS-tiled kernel, 2 = instead of the streamed kernel as well
-        self.convd_level = int(os.environ.get('FASTMOT_CONVD', '2'))
+        # DMA-fed multi-accumulator kernel (convd.hip) for 1x1 / 3x3 layers with cin % 64 == 0: 0 = never; 1 = where it
+        # measured faster (profiles/r05_convd_sweep_*.txt): instead of the LDS-tiled kernel everywhere, instead of the
+        # streamed kernel only for the stride-2 3x3 convs into a map of >= 1024 pixels (the streamed kernel keeps the
+        # 38 x 38 / 19 x 19 levels: 13.5 vs 14.1 us and 15.1 vs 19.4 us on their 3x3 layers); 2 = wherever it applies
+        self.convd_level = int(os.environ.get('FASTMOT_CONVD', '1'))
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -193,7 +195,9 @@ class Graph:
             self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
             return dst
         streamed = x.c == cin_pad and cin_pad % 64 == 0 and k * k * cin_pad >= 512 and ho * wo <= self.convs_max_pixels
-        if cin_pad % 64 == 0 and (k == 3 or (k == 1 and pad == 0)) and self.convd_level >= (2 if streamed else 1):
+        beats_streamed = k == 3 and stride == 2 and ho * wo >= 1024
+        if cin_pad % 64 == 0 and (k == 3 or (k == 1 and pad == 0)) and \
+                self.convd_level >= (1 if not streamed or beats_streamed else 2):
             wk = np.zeros((ceil_to(cout, 32), k, k, cin_pad), np.float16)
             wk[:cout, :, :, :x.c] = w16.transpose(0, 2, 3, 1)
             bias = np.zeros(wk.shape[0], np.float32)

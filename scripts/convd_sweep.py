@@ -1,6 +1,6 @@
 """A/B sweep of the conv kernels on single layers (round 5): for each layer shape, the LDS-tiled kernel (conv.hip), the
-streamed kernel (convs.hip) where it applies, and convd.hip under a list of forced (tile, K groups, stages)
-configurations.  Each measurement is a table of NREP layers of the same shape with DISTINCT weights reading one input
+streamed kernel (convs.hip) where it applies, and convd.hip under a list of forced (tile, K groups, stages, loader
+waves = 'L') configurations.  Each measurement is a table of NREP layers of the same shape with DISTINCT weights reading one input
 (so a layer's weights are not L2-resident from its previous run, as in the real network), timed two ways:
   ev  -- HIP events around every eager launch (fm_net_profile_layers), mean over layers and iterations;
   rep -- wall time of graph replays of the whole table / NREP (includes the ~1.5 us dependent-launch boundary).
@@ -48,15 +48,15 @@ SETS = {
 }
 
 
-def code(bm, bn, kg, ns=0):
-    return bm | bn << 8 | kg << 16 | ns << 20
+def code(bm, bn, kg, ns=0, role=0):
+    return bm | bn << 8 | kg << 16 | ns << 20 | role << 24
 
 
-CFGS = [('auto', 0)] + [(f'{bm}x{bn} kg{kg}' + (f' ns{ns}' if ns else ''), code(bm, bn, kg, ns))
-                        for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64))
-                        for kg in (1, 2, 4) if not (kg == 4 and bm * bn > 128 * 64)
-                        for ns in (0,)] + [('128x64 kg2 ns2', code(128, 64, 2, 2)), ('64x64 kg2 ns2', code(64, 64, 2, 2)),
-                                           ('128x128 kg1 ns2', code(128, 128, 1, 2)), ('128x128 kg1 ns3', code(128, 128, 1, 3))]
+CFGS = [('auto', 0)] + [(f'{bm}x{bn} kg{kg}' + (' L' if role else '') + (f' ns{ns}' if ns else ''), code(bm, bn, kg, ns, role))
+                        for bm, bn in ((128, 128), (128, 64), (64, 64))
+                        for kg in (1, 2, 4) if not (kg == 4 and bm * bn > 64 * 64)
+                        for role in (0, 1) if not (role and kg == 4)
+                        for ns in ((0, 2) if (bm, kg) in ((128, 1), (64, 2)) else (0,))]
 
 
 def measure(ctx, shape, level, maxp, cfg):
@@ -93,7 +93,7 @@ def kscan(ctx):
     """Same map and couts, growing reduction: time = fixed + steps * slope per configuration (least squares)."""
     for (k, stride, h, cout) in ((3, 1, 76, 256), (3, 1, 38, 512), (1, 1, 76, 256), (3, 1, 160, 128)):
         print(f'## K scan: k{k}s{stride} {h}x{h}, cout {cout}', flush=True)
-        for label, cfg in [('tiled', None)] + [(f'{bm}x{bn} kg{kg}', code(bm, bn, kg)) for bm, bn, kg in
+        for label, cfg in [('tiled', None)] + [(f'{bm}x{bn} kg{kg} L', code(bm, bn, kg, 0, 1)) for bm, bn, kg in
                                                ((128, 128, 1), (128, 64, 1), (64, 64, 1), (128, 64, 2), (64, 64, 2))]:
             xs, ys = [], []
             for cin in (64, 128, 256, 512):

@@ -17,13 +17,13 @@ from fastmot_amd.engine import HipNet, NET_DETECTOR
 from fastmot_amd.models.graph import Graph, RandomWeights
 
 CASES = [
-    # (cin, cout, k, stride, h, w), (bm, bn, kg, ns)
-    ((128, 256, 3, 1, 76, 76), (128, 128, 1, 4)),
-    ((128, 256, 3, 1, 76, 76), (128, 64, 2, 3)),
-    ((128, 256, 3, 1, 76, 76), (64, 64, 1, 4)),
-    ((256, 512, 3, 1, 38, 38), (64, 64, 2, 4)),
-    ((256, 256, 1, 1, 76, 76), (64, 64, 1, 4)),
-    ((128, 128, 3, 1, 160, 160), (128, 128, 2, 2)),
+    # (cin, cout, k, stride, h, w), (bm, bn, kg, ns, loader waves)
+    ((128, 256, 3, 1, 76, 76), (128, 128, 1, 4, 1)),
+    ((128, 256, 3, 1, 76, 76), (128, 64, 2, 3, 1)),
+    ((128, 256, 3, 1, 76, 76), (64, 64, 1, 4, 0)),
+    ((256, 512, 3, 1, 38, 38), (64, 64, 2, 4, 1)),
+    ((256, 256, 1, 1, 76, 76), (64, 64, 1, 4, 0)),
+    ((128, 128, 3, 1, 160, 160), (128, 128, 1, 4, 1)),
 ]
 
 
@@ -40,7 +40,7 @@ def main():
         g = Graph(RandomWeights(seed=1), (h, w), cin)
         g.convs_max_pixels = 0
         y = g.conv('c', g.input, cout, k, stride, 'leaky')
-        ctx.set_option('convd_cfg', cfg[0] | cfg[1] << 8 | cfg[2] << 16 | cfg[3] << 20)
+        ctx.set_option('convd_cfg', cfg[0] | cfg[1] << 8 | cfg[2] << 16 | cfg[3] << 20 | cfg[4] << 24)
         net = HipNet(ctx, NET_DETECTOR, g, 1)
         net.write(g.input, np.random.default_rng(0).normal(0, 1, (1, h, w, cin)).astype(np.float16))
         print(f'## k{k}s{stride} {h}x{w}x{cin} -> {cout}, forced {cfg}')

@@ -24,9 +24,16 @@ def test_table_builder_picks_the_dma_kernel_for_cin_multiple_of_64():
     y = g.conv('c', g.input, 32, 1)                     # 32 channels out ...
     g.conv('d', y, 64, 3)                               # ... so this one has cin = 32: LDS-tiled kernel
     g.conv('e', g.input, 64, 5)                         # 5 x 5: not a shape of the DMA kernel (here: the streamed one)
-    assert [d['op'] for d in g.layers] == [G.OP_CONVD, G.OP_CONVD, G.OP_CONVD, G.OP_CONV, G.OP_CONVS]
+    assert [d['op'] for d in g.layers] == [G.OP_CONVD, G.OP_CONVS, G.OP_CONVD, G.OP_CONV, G.OP_CONVS]   # (b: small map, long K)
+    g = Graph(RandomWeights(seed=0), (80, 80), 64)
+    g.conv('a', g.input, 64, 3)                         # 6400 pixels: no streamed kernel -> DMA kernel
+    g.conv('b', g.input, 64, 3, 2)                      # stride 2 into 1600 pixels: DMA kernel
+    y = g.conv('c', g.input, 64, 3, 2)
+    g.conv('d', y, 64, 3)                               # 1600 pixels, K = 576: DMA kernel (beyond convs_max_pixels)
+    g.conv('e', g.new(30, 30, 64), 64, 3)               # 900 pixels, K = 576: the streamed kernel keeps it
+    assert [d['op'] for d in g.layers] == [G.OP_CONVD] * 4 + [G.OP_CONVS]
     g = Graph(RandomWeights(seed=0), (20, 20), 64)
-    g.convd_level = 1                                   # keep the streamed kernel where it applies
+    g.convd_level = 2                                   # everything the DMA kernel can do
     g.conv('a', g.input, 64, 1)
     g.conv('b', g.input, 64, 3)
-    assert [d['op'] for d in g.layers] == [G.OP_CONVD, G.OP_CONVS]
+    assert [d['op'] for d in g.layers] == [G.OP_CONVD, G.OP_CONVD]
