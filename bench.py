@@ -324,15 +324,19 @@ def pmc_traffic(n_conv_launches=None):
     """(bytes per conv launch, source, stale) from the newest committed rocprofv3 PMC passes (profiles/*_pmc_conv.json,
     produced by scripts/collect_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of the detector network; FETCH_SIZE
     doubled per the gfx950 note of MI355X_MICROARCH.md).  PMC counters cannot be collected from inside this process,
-    hence the file; `stale` is True when the file counted another number of conv launches per frame than the network
+    hence the file; the 4th item carries the MFMA utilisation of the conv launches and their read amplification from
+    the same file when it has them; `stale` is True when the file counted another number of conv launches per frame than the network
     of this run has (the kernels changed since the passes were taken); None when no file is there."""
-    for name in ('r04_pmc_conv.json', 'r03_pmc_conv.json', 'r02_pmc_conv.json', 'r01_pmc_conv.json'):
+    for name in ('r05_pmc_conv.json', 'r04_pmc_conv.json', 'r03_pmc_conv.json', 'r02_pmc_conv.json', 'r01_pmc_conv.json'):
         try:
             with open(ROOT / 'profiles' / name) as f:
                 d = json.load(f)
             per_frame = d['launches'] / d['replays']
             stale = n_conv_launches is not None and abs(per_frame - n_conv_launches) > 0.5
-            return d['traffic_bytes_per_launch'], f'profiles/{name} (separate rocprofv3 --pmc passes)', bool(stale)
+            # (round 5: the same passes normalised per layer by scripts/layer_pmc.py -- MFMA busy cycles over duration x
+            # 2.4 GHz x 1024 SIMDs, 2 x FETCH_SIZE over the algorithmic read bytes)
+            extra = {k: d.get(k) for k in ('mfma_util', 'read_amplification')}
+            return d['traffic_bytes_per_launch'], f'profiles/{name} (separate rocprofv3 --pmc passes)', bool(stale), extra
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return None
@@ -574,6 +578,10 @@ def main():
                          # inside the process) but read from the committed rocprofv3 --pmc passes of the same network
                          'traffic': traffic[0] if traffic else None, 'traffic_source': traffic[1] if traffic else None,
                          'traffic_stale': traffic[2] if traffic else None,
+                         # matrix-pipe busy cycles / (duration x 2.4 GHz x 1024 SIMDs) and HBM-side reads / algorithmic
+                         # reads of the conv launches, from the same PMC passes (stand-alone replays of the network)
+                         'mfma_util': traffic[3].get('mfma_util') if traffic else None,
+                         'read_amplification': traffic[3].get('read_amplification') if traffic else None,
                          'flop_per_frame': flops, 'net_ms_per_frame': round(net_avg_ms, 4),
                          'avg_launch_us': round(net_avg_ms * 1e3 / n_launch, 3)},
         }

@@ -68,7 +68,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // ROLE: 1 = the workgroup gets as many LOADER waves as it has MFMA waves.  The loaders own the DMA (address state, issue,
 //       counted waits), the MFMA waves only read fragments and multiply: a loader's ~50-70 issue cycles per 1 KB piece then
 //       overlap its SIMD partner's MFMAs instead of preceding them in the same instruction stream.
-template <int WC, int WP, int MC, int MP, int KG, int TAPS, int ROLE>
+// SPB:  K steps per barrier (1 or 2).  With one 32 x 32 accumulator (or two) per wave a step is only 4 (8) MFMAs: the
+//       barrier, the counted wait and the latency of the first fragment reads then cost more than the multiplications;
+//       two steps per ring slot halve them (the ring holds nslots slots of SPB steps).
+template <int WC, int WP, int MC, int MP, int KG, int TAPS, int ROLE, int SPB>
 __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) void convd_kernel(const ConvParams p, const int ns, const int nslots CONVD_EXTRA_PARAM) {
     static_assert(WC * WP == 4, "4 waves per K group");
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass has no buffer-resource type: it only needs the launch stub)
@@ -177,32 +180,40 @@ __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) 
     }
     unsigned i_soff = (unsigned)((i_kh * p.W + i_kw) * p.in_cs + i_c0) * 2u;
     unsigned i_astep = (unsigned)s0 * 4096u;
-    int i_stage = 0;
-    char* const ring = smem + g * nslots * SS;
+    int i_stage = 0, i_step = 0;
+    char* const ring = smem + g * nslots * (SPB * SS);
+    // requests the SPB steps of the next ring slot.  A slot always receives SPB * PPS pieces, so that the counted waits
+    // stay exact: when the group's last slot has a step too few (odd K range), the last real step is fetched once more
+    // into the unused half (never multiplied).
     auto issue = [&]() {
-        char* la = ring + i_stage * SS;
 #pragma unroll
-        for (int i = 0; i < NPA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (i * 4 + w) * 1024), 16, va, sa_blk[i] + i_astep, 0, 0);
-        char* lb = la + BM * 128;
-        const int t = i_kh * TAPS + i_kw;
+        for (int u = 0; u < SPB; ++u) {
+            char* la = ring + (i_stage * SPB + u) * SS;
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) {
-            unsigned vo = vb[i];
-            if constexpr (TAPS) vo = ((vm[i] >> t) & 1u) ? vo : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (w + 4 * i) * 1024), 16, vo, i_soff, 0, 0);
-        }
-        i_astep += 4096u;
-        i_stage = i_stage + 1 == nslots ? 0 : i_stage + 1;
-        i_soff += 128u;
-        if constexpr (TAPS) {
-            i_c0 += 64;
-            if (i_c0 >= p.Cin) {
-                i_c0 = 0;
-                if (++i_kw == TAPS) { i_kw = 0; ++i_kh; }
-                i_soff = (unsigned)((i_kh * p.W + i_kw) * p.in_cs) * 2u;
+            for (int i = 0; i < NPA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (i * 4 + w) * 1024), 16, va, sa_blk[i] + i_astep, 0, 0);
+            char* lb = la + BM * 128;
+            const int t = i_kh * TAPS + i_kw;
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) {
+                unsigned vo = vb[i];
+                if constexpr (TAPS) vo = ((vm[i] >> t) & 1u) ? vo : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (w + 4 * i) * 1024), 16, vo, i_soff, 0, 0);
+            }
+            if (SPB > 1 && i_step + 1 >= nkg) continue;       // (the group's last step: stay on it)
+            ++i_step;
+            i_astep += 4096u;
+            i_soff += 128u;
+            if constexpr (TAPS) {
+                i_c0 += 64;
+                if (i_c0 >= p.Cin) {
+                    i_c0 = 0;
+                    if (++i_kw == TAPS) { i_kw = 0; ++i_kh; }
+                    i_soff = (unsigned)((i_kh * p.W + i_kw) * p.in_cs) * 2u;
+                }
             }
         }
+        i_stage = i_stage + 1 == nslots ? 0 : i_stage + 1;
     };
 
     f32x16 acc[MC][MP];
@@ -221,43 +232,48 @@ __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) 
     const unsigned aoff = (unsigned)(wc * MC * 32 + frow) * 128u;
     const unsigned boff = (unsigned)BM * 128u + (unsigned)(wp * MP * 32 + frow) * 128u;
 
-    const int npro = min(ns - 1, nkg);
+    const int psup = (per + SPB - 1) / SPB, nsup = (nkg + SPB - 1) / SPB;      // ring slots (SPB steps each) to walk / of this group
+    const int npro = min(ns - 1, nsup);
     CONVD_STAMP(1)
     if (loader)
         for (int s = 0; s < npro; ++s) issue();
     CONVD_STAMP(2)
     int issued = npro, c_stage = 0;
-    for (int it = 0; it < per; ++it) {
+    for (int it = 0; it < psup; ++it) {
         if (loader) {
-            // steps requested and not yet consumed (this iteration's included); everything but the oldest may stay in flight
-            const int rem = min(ns - 1, nkg - it);
-            if (rem >= 3) wait_vmcnt<2 * PPS>();
-            else if (rem == 2) wait_vmcnt<PPS>();
+            // slots requested and not yet consumed (this iteration's included); everything but the oldest may stay in flight
+            const int rem = min(ns - 1, nsup - it);
+            if (rem >= 3) wait_vmcnt<2 * SPB * PPS>();
+            else if (rem == 2) wait_vmcnt<SPB * PPS>();
             else wait_vmcnt<0>();
         }
         CONVD_STAMP(8 + 4 * it)
         __builtin_amdgcn_s_barrier();       // every wave's pieces of this step have landed; the previous step's slot is free
         asm volatile("" ::: "memory");
         CONVD_STAMP(9 + 4 * it)
-        if (loader && issued < nkg) {
+        if (loader && issued < nsup) {
             if (!CONVD_ABL(1)) issue();
             ++issued;
         }
         CONVD_STAMP(10 + 4 * it)
-        if (mfma_wave && it < nkg && !CONVD_ABL(2)) {
-            const char* sa = ring + c_stage * SS;
+        if (mfma_wave && it < nsup && !CONVD_ABL(2)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f16x8 af[MC], bf[MP];
+            for (int u = 0; u < SPB; ++u) {
+                if (SPB > 1 && it * SPB + u >= nkg) break;     // (odd K range: the last slot's second half is a repeat)
+                const char* sa = ring + (c_stage * SPB + u) * SS;
 #pragma unroll
-                for (int mi = 0; mi < MC; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(sa + aoff + mi * 4096 + koff[j]);
+                for (int j = 0; j < 4; ++j) {
+                    f16x8 af[MC], bf[MP];
 #pragma unroll
-                for (int pi = 0; pi < MP; ++pi) bf[pi] = *reinterpret_cast<const f16x8*>(sa + boff + pi * 4096 + koff[j]);
+                    for (int mi = 0; mi < MC; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(sa + aoff + mi * 4096 + koff[j]);
 #pragma unroll
-                for (int mi = 0; mi < MC; ++mi)
+                    for (int pi = 0; pi < MP; ++pi) bf[pi] = *reinterpret_cast<const f16x8*>(sa + boff + pi * 4096 + koff[j]);
 #pragma unroll
-                    for (int pi = 0; pi < MP; ++pi)
-                        acc[mi][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[pi], acc[mi][pi], 0, 0, 0);
+                    for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+                        for (int pi = 0; pi < MP; ++pi)
+                            acc[mi][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[pi], acc[mi][pi], 0, 0, 0);
+                }
             }
             c_stage = c_stage + 1 == nslots ? 0 : c_stage + 1;
         }
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) 
         long long* st = reinterpret_cast<long long*>(smem + stamp_off);
         st[263] = __builtin_amdgcn_s_memrealtime();
         st[6] = per;
-        st[7] = BM * 1000000 + BN * 1000 + KG * 10 + ns;
+        st[7] = BM * 1000000 + BN * 1000 + KG * 100 + SPB * 10 + ns;
         for (int i = 0; i < 264; ++i) g_convd_stamps[stamp_slot][i] = st[i];
     }
 #endif
@@ -394,14 +410,14 @@ __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) 
 constexpr int LDS_MAX = 160 * 1024;
 
 struct Cfg {
-    int bm, bn, kg, ns, role;
+    int bm, bn, kg, ns, role, spb;
 };
 
-template <int WC, int WP, int MC, int MP, int KG, int TAPS, int ROLE>
+template <int WC, int WP, int MC, int MP, int KG, int TAPS, int ROLE, int SPB>
 int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
-    constexpr int BM = WC * MC * 32, BN = WP * MP * 32, SS = (BM + BN) * 128;
+    constexpr int BM = WC * MC * 32, BN = WP * MP * 32, SS = (BM + BN) * 128 * SPB;      // one ring slot
     const int cout_pad = (p.Cout + 31) & ~31;
-    const int nk = p.Kpad >> 6, per = (nk + KG - 1) / KG;
+    const int nk = p.Kpad >> 6, per = ((nk + KG - 1) / KG + SPB - 1) / SPB;            // slots a K group walks
     const int nslots = ns < per ? ns : (per < 1 ? 1 : per);
     ConvParams q = p;
     q.grid_p = (p.P + BN - 1) / BN;
@@ -414,37 +430,46 @@ int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
     FM_CHECK_ARG(lds + CONVD_EXTRA_LDS <= (size_t)LDS_MAX);
     static bool configured = false;      // (one flag per instantiation)
     if (!configured) {
-        FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE>),
+        FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE, SPB>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
         configured = true;
     }
     const int total = q.grid_p * q.grid_c;
-    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE>), dim3(((total + 7) / 8) * 8), dim3(256 * KG * (1 + ROLE)),
+    hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE, SPB>), dim3(((total + 7) / 8) * 8), dim3(256 * KG * (1 + ROLE)),
                        lds + CONVD_EXTRA_LDS, s, q, ns, nslots CONVD_EXTRA_ARG);
     FM_HIP(hipGetLastError());
     return 0;
 }
 
-template <int MC, int MP, int KG, int ROLE>
+template <int MC, int MP, int KG, int ROLE, int SPB>
 int launch_taps(const ConvParams& p, int ns, hipStream_t s) {
-    if (p.KH == 1) return launch_inst<2, 2, MC, MP, KG, 0, ROLE>(p, ns, s);
-    return launch_inst<2, 2, MC, MP, KG, 3, ROLE>(p, ns, s);
+    if (p.KH == 1) return launch_inst<2, 2, MC, MP, KG, 0, ROLE, SPB>(p, ns, s);
+    return launch_inst<2, 2, MC, MP, KG, 3, ROLE, SPB>(p, ns, s);
 }
 
 // instances: tiles 128 x 128, 128 x 64, 64 x 64; 1 or 2 K groups with or without loader waves; 4 K groups (16 MFMA waves)
 // for the 64 x 64 tile only (two accumulators spill at the 128 registers a 1024-thread workgroup leaves a lane)
-template <int MC, int MP>
-int launch_kg(const ConvParams& p, const Cfg& c, hipStream_t s) {
-    if constexpr (MC * MP == 1) {
-        if (c.kg == 4) return launch_taps<MC, MP, 4, 0>(p, c.ns, s);
+template <int MC, int MP, int SPB>
+int launch_role(const ConvParams& p, const Cfg& c, hipStream_t s) {
+    if constexpr (MC * MP == 1 && SPB == 1) {
+        if (c.kg == 4) return launch_taps<MC, MP, 4, 0, 1>(p, c.ns, s);
     }
-    if (c.kg >= 2) return c.role ? launch_taps<MC, MP, 2, 1>(p, c.ns, s) : launch_taps<MC, MP, 2, 0>(p, c.ns, s);
-    return c.role ? launch_taps<MC, MP, 1, 1>(p, c.ns, s) : launch_taps<MC, MP, 1, 0>(p, c.ns, s);
+    if (c.kg >= 2) return c.role ? launch_taps<MC, MP, 2, 1, SPB>(p, c.ns, s) : launch_taps<MC, MP, 2, 0, SPB>(p, c.ns, s);
+    return c.role ? launch_taps<MC, MP, 1, 1, SPB>(p, c.ns, s) : launch_taps<MC, MP, 1, 0, SPB>(p, c.ns, s);
 }
 
-// stage count: as deep as the K range of a group and `lds_budget` allow (<= 4), at least 2
-int stages_for(int bm, int bn, int kg, int per, int lds_budget) {
-    const int ss = (bm + bn) * 128;
+// two steps per barrier only for the tiles with one or two accumulators per wave (the 2 x 2 tile has 16 MFMAs a step)
+template <int MC, int MP>
+int launch_kg(const ConvParams& p, const Cfg& c, hipStream_t s) {
+    if constexpr (MC * MP < 4) {
+        if (c.spb == 2) return launch_role<MC, MP, 2>(p, c, s);
+    }
+    return launch_role<MC, MP, 1>(p, c, s);
+}
+
+// ring slots: as many as the K range of a group (`per` slots of spb steps) and `lds_budget` allow (<= 4), at least 2
+int stages_for(int bm, int bn, int kg, int spb, int per, int lds_budget) {
+    const int ss = (bm + bn) * 128 * spb;
     int ns = lds_budget / (kg * ss);
     ns = ns > 4 ? 4 : ns;
     ns = ns > per ? per : ns;
@@ -463,15 +488,15 @@ int stages_for(int bm, int bn, int kg, int per, int lds_budget) {
 Cfg choose(const ConvParams& p) {
     const int cout_pad = (p.Cout + 31) & ~31, nk = p.Kpad >> 6;
     auto tiles = [&](int bm, int bn) { return (long)((p.P + bn - 1) / bn) * ((cout_pad + bm - 1) / bm); };
-    Cfg c{64, 64, 1, 2, 0};
+    Cfg c{64, 64, 1, 2, 0, 1};
     if (nk > 2) {
-        if (cout_pad % 128 == 0 && tiles(128, 128) >= 180) c = Cfg{128, 128, 1, 2, 1};
-        else if (cout_pad % 128 == 0 && tiles(128, 64) >= 180) c = Cfg{128, 64, 1, 2, 1};
+        if (cout_pad % 128 == 0 && tiles(128, 128) >= 180) c = Cfg{128, 128, 1, 2, 1, 1};
+        else if (cout_pad % 128 == 0 && tiles(128, 64) >= 180) c = Cfg{128, 64, 1, 2, 1, 1};
         else c.role = 1;
         if (c.bm * c.bn < 128 * 128 && nk >= 8) c.kg = 2;
     }
     const long nt = tiles(c.bm, c.bn);
-    c.ns = stages_for(c.bm, c.bn, c.kg, (nk + c.kg - 1) / c.kg, nt > 256 ? LDS_MAX / 2 : LDS_MAX);
+    c.ns = stages_for(c.bm, c.bn, c.kg, c.spb, ((nk + c.kg - 1) / c.kg + c.spb - 1) / c.spb, nt > 256 ? LDS_MAX / 2 : LDS_MAX);
     return c;
 }
 
@@ -499,15 +524,18 @@ int launch_convd(const ConvParams& p, hipStream_t s) {
     FM_CHECK_ARG(((long)p.N * p.H * p.W + (long)(p.KH + p.pad) * p.W + p.KW + p.pad) * p.in_cs * 2 < (1L << 31));
     FM_CHECK_ARG((long)((p.Cout + 31) & ~31) * p.Kpad * 2 < (1L << 31));
     Cfg c = choose(p);
-    if (g_convd_cfg) {      // forced: bm | bn << 8 | kg << 16 | ns << 20 | role << 24 (ns 0: as deep as LDS allows)
-        Cfg f{g_convd_cfg & 255, (g_convd_cfg >> 8) & 255, (g_convd_cfg >> 16) & 15, (g_convd_cfg >> 20) & 15, (g_convd_cfg >> 24) & 1};
+    if (g_convd_cfg) {      // forced: bm | bn << 8 | kg << 16 | ns << 20 | role << 24 | (spb == 2) << 25 (ns 0: as deep as LDS allows)
+        Cfg f{g_convd_cfg & 255, (g_convd_cfg >> 8) & 255, (g_convd_cfg >> 16) & 15, (g_convd_cfg >> 20) & 15, (g_convd_cfg >> 24) & 1,
+              1 + ((g_convd_cfg >> 25) & 1)};
         const int nk = p.Kpad >> 6;
         if (f.kg > nk) f.kg = nk >= 2 ? 2 : 1;
         if (f.kg == 4 && (f.bm != 64 || f.bn != 64)) f.kg = 2;
-        if (f.kg == 4) f.role = 0;
-        if (f.ns == 0) f.ns = stages_for(f.bm, f.bn, f.kg, (nk + f.kg - 1) / f.kg, LDS_MAX);
-        while (f.ns > 2 && (size_t)f.kg * f.ns * (f.bm + f.bn) * 128 > (size_t)LDS_MAX) --f.ns;
-        if ((size_t)f.kg * 2 * (f.bm + f.bn) * 128 <= (size_t)LDS_MAX) c = f;
+        if (f.bm * f.bn >= 128 * 128) f.spb = 1;
+        if (f.kg == 4) f.role = 0, f.spb = 1;
+        const int slot = (f.bm + f.bn) * 128 * f.spb;
+        if (f.ns == 0) f.ns = stages_for(f.bm, f.bn, f.kg, f.spb, ((nk + f.kg - 1) / f.kg + f.spb - 1) / f.spb, LDS_MAX);
+        while (f.ns > 2 && (size_t)f.kg * f.ns * slot > (size_t)LDS_MAX) --f.ns;
+        if ((size_t)f.kg * 2 * slot <= (size_t)LDS_MAX) c = f;
     }
     if (c.bm == 128 && c.bn == 128) return launch_kg<2, 2>(p, c, s);
     if (c.bm == 128 && c.bn == 64) return launch_kg<2, 1>(p, c, s);

@@ -208,7 +208,8 @@ def darknet_graph(cfg, weights, in_hw=None):
             return False
         a, b = conv_attrs(j - 2), conv_attrs(j - 1)
         return (a[:3] == (1, 1, 0) and b[:3] == (3, 1, 1) and a[3] == b[3] and shape[j - 3][0] == shape[j][0] and
-                Graph.resblock_supported(shape[j][0], shape[j - 2][0]))
+                Graph.resblock_supported(shape[j][0], shape[j - 2][0]) and
+                g.resblock_pays(shape[j][0], shape[j - 2][0], shape[j][1], shape[j][2]))
 
     def producer(j):
         """Layer index whose emitted op writes the tensor of layer j, or None if j is a view."""

@@ -237,6 +237,14 @@ class Graph:
     def resblock_supported(c, mid):
         return c in (64, 128, 256) and mid in (c, c // 2)
 
+    def resblock_pays(self, c, mid, h, w):
+        """The fused residual unit (resblock.hip) against its two convs on the DMA kernel (convd.hip, shortcut in the
+        3x3's epilogue): measured per shape in round 5 (profiles/r05_p6_layers_*.txt) -- at 80 x 80 x 256 (YOLOv4-P6) the
+        fused unit takes 41.5 us, the pair 6.7 + 18.5 us; at 160 x 160 x 128 25.4 against 7 + 16.5; on the maps of
+        YOLOv4 @ 608 / -CSP @ 640 (<= 0.8 M activations per unit) the fused unit wins (8.9 against ~13 us at
+        76 x 76 x 128).  Without the DMA kernel the fused unit always pays."""
+        return not (self.convd_level >= 1 and c >= 128 and mid % 64 == 0 and h * w * c >= 1500000)
+
     @staticmethod
     def _pack_frag(w16):
         """[cout, cin, k, k] -> MFMA A-fragment order [cout/32][K/16][lane][8], K order (kh, kw, cin),

@@ -152,7 +152,7 @@ def yolov4_graph(model, weights):
             conv(d, h, 1, dst=cat.slice(h, h))        # route branch A (second in the concat)
             b = conv(d, h, 1)
         for _ in range(n_res):
-            if g.use_resblock and g.resblock_supported(h, m):
+            if g.use_resblock and g.resblock_supported(h, m) and g.resblock_pays(h, m, b.h, b.w):
                 b = g.resblock(name(), name(), b, m)   # 1x1 + 3x3 + shortcut in one launch
                 continue
             t = conv(b, m, 1)

@@ -1,6 +1,6 @@
 """A/B sweep of the conv kernels on single layers (round 5): for each layer shape, the LDS-tiled kernel (conv.hip), the
 streamed kernel (convs.hip) where it applies, and convd.hip under a list of forced (tile, K groups, stages, loader
-waves = 'L') configurations.  Each measurement is a table of NREP layers of the same shape with DISTINCT weights reading one input
+waves = 'L', two steps per barrier = 'x2') configurations.  Each measurement is a table of NREP layers of the same shape with DISTINCT weights reading one input
 (so a layer's weights are not L2-resident from its previous run, as in the real network), timed two ways:
   ev  -- HIP events around every eager launch (fm_net_profile_layers), mean over layers and iterations;
   rep -- wall time of graph replays of the whole table / NREP (includes the ~1.5 us dependent-launch boundary).
@@ -48,15 +48,17 @@ SETS = {
 }
 
 
-def code(bm, bn, kg, ns=0, role=0):
-    return bm | bn << 8 | kg << 16 | ns << 20 | role << 24
+def code(bm, bn, kg, ns=0, role=0, spb=1):
+    return bm | bn << 8 | kg << 16 | ns << 20 | role << 24 | (spb - 1) << 25
 
 
-CFGS = [('auto', 0)] + [(f'{bm}x{bn} kg{kg}' + (' L' if role else '') + (f' ns{ns}' if ns else ''), code(bm, bn, kg, ns, role))
+CFGS = [('auto', 0)] + [(f'{bm}x{bn} kg{kg}' + (' L' if role else '') + (' x2' if spb == 2 else '') + (f' ns{ns}' if ns else ''),
+                         code(bm, bn, kg, ns, role, spb))
                         for bm, bn in ((128, 128), (128, 64), (64, 64))
                         for kg in (1, 2, 4) if not (kg == 4 and bm * bn > 64 * 64)
                         for role in (0, 1) if not (role and kg == 4)
-                        for ns in ((0, 2) if (bm, kg) in ((128, 1), (64, 2)) else (0,))]
+                        for spb in (1, 2) if not (spb == 2 and (bm * bn == 128 * 128 or kg == 4 or (bm == 128 and kg == 2)))
+                        for ns in ((0, 2) if (bm, kg, spb) in ((128, 1, 1), (64, 2, 1)) else (0,))]
 
 
 def measure(ctx, shape, level, maxp, cfg):

@@ -35,7 +35,14 @@ db = open_trace(sys.argv[1])
 model = sys.argv[2] if len(sys.argv) > 2 else 'YOLOv4_608'
 g, _ = YOLO.get_model(model).build_graph()
 n = len(g.layers)
-rows = db.execute("select start, end, name from kernels order by start").fetchall()[-n:]
+rows = []
+for s_, e_, name_ in db.execute("select start, end, name from kernels order by start").fetchall():
+    if 'splitk_reduce' in name_ and rows:      # the reduce launch of a split-K layer belongs to its conv's row (same layer)
+        ps, pe, pn = rows[-1]
+        rows[-1] = (ps, pe + (e_ - s_), pn)
+    else:
+        rows.append((s_, e_, name_))
+rows = rows[-n:]
 assert len(rows) == n
 print(f'# {model}: {n} launches per frame (last graph replay of the trace); peaks: 2.5 PFLOP/s dense fp16 MFMA, 8 TB/s HBM3E')
 print(f'{"#":>3} {"op":<10} {"shape":<44} {"GFLOP":>7} {"MB":>7} {"roof_us":>8} {"meas_us":>8} {"TFLOP/s":>8} {"GB/s":>7} {"bound":>5}')

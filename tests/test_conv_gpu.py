@@ -489,8 +489,8 @@ def test_yolov4_small_input(ctx, monkeypatch, resblock):
     net.close()
 
 
-def _convd_code(bm, bn, kg, ns=0, role=0):
-    return bm | bn << 8 | kg << 16 | ns << 20 | role << 24
+def _convd_code(bm, bn, kg, ns=0, role=0, spb=1):
+    return bm | bn << 8 | kg << 16 | ns << 20 | role << 24 | (spb - 1) << 25
 
 
 @pytest.mark.parametrize('cin,cout,k,stride,act,h,w,n,extra', [
@@ -512,11 +512,11 @@ def _convd_code(bm, bn, kg, ns=0, role=0):
     (192, 96, 3, 1, 'relu', 16, 8, 4, 'resb'),         # cin = 3 * 64: a tap is three K steps; shortcut BEFORE the activation
 ])
 @pytest.mark.parametrize('cfg', ['auto', (128, 128, 1, 0, 1), (128, 64, 2, 0, 1), (128, 64, 1, 2, 0), (64, 64, 4), (64, 64, 1, 3, 1),
-                                 (64, 64, 2, 0, 0), (128, 128, 2, 2, 1)])
+                                 (64, 64, 2, 0, 0), (128, 128, 2, 2, 1), (64, 64, 2, 2, 1, 2), (128, 64, 1, 3, 1, 2), (64, 64, 1, 0, 0, 2)])
 def test_convd_conv(ctx, cin, cout, k, stride, act, h, w, n, extra, cfg):
     """convd.hip (operands by DMA into an LDS ring, up to 2 x 2 accumulators per wave, K groups, loader waves) against the
-    LDS-tiled kernel on the same layer and against PyTorch, under forced (tile, K groups, ring depth, loader waves)
-    configurations and the launcher's own choice."""
+    LDS-tiled kernel on the same layer and against PyTorch, under forced (tile, K groups, ring depth, loader waves, steps per
+    barrier) configurations and the launcher's own choice."""
     rng = np.random.default_rng(cin + cout + h)
     sl = extra == 'slice'
     x = rng.normal(0, 1, (n, h, w, cin + (64 if sl else 0))).astype(np.float16)
