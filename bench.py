@@ -138,6 +138,11 @@ def cpu_leg(cfg, video, mot, budget_s=20.0):
 def _compiled_worker(args):
     """One host process = one independent video stream through the compiled CPU port (multi-core leg)."""
     cfg, seed, budget_s = args
+    if _AFFINITY_AT_START is not None:            # forked from a process get_context() has bound to the GPU's NUMA node
+        try:
+            os.sched_setaffinity(0, _AFFINITY_AT_START)
+        except OSError:
+            pass
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(1)
@@ -301,9 +306,14 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
     return out
 
 
+_AFFINITY_AT_START = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None
+
+
 def usable_cpus():
-    """Host cores this process may use: the affinity mask, capped by a cgroup-v2 CPU quota when there is one."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    """Host cores this process may use: the affinity mask it STARTED with (get_context() narrows the calling thread to the
+    GPU's NUMA node afterwards: the CPU baseline must not inherit that -- ADVICE r4), capped by a cgroup-v2 CPU quota
+    when there is one."""
+    n = len(_AFFINITY_AT_START) if _AFFINITY_AT_START is not None else (os.cpu_count() or 1)
     try:
         quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
         if quota != 'max':

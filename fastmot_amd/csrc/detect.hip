@@ -49,6 +49,7 @@ struct DetState {
     fm_det48* dets_host[NSLOT] = {nullptr, nullptr};
     int32_t* counters_host[NSLOT] = {nullptr, nullptr};
     hipEvent_t ev_done[NSLOT] = {nullptr, nullptr};
+    hipStream_t s_fallback = nullptr;          // redo of a pass the greedy kernel declined (collect): NOT s_up, see there
     hipEvent_t ev0[NSLOT] = {nullptr, nullptr}, ev1[NSLOT] = {nullptr, nullptr};   // bracket the network launches
     int wr = 0, rd = 0, pending = 0, last = -1;   // slot written next / collected next / passes in flight / last collected
     uint8_t* label_mask = nullptr;
@@ -64,6 +65,7 @@ void fm_det_free(DetState* d) {
     }
     for (void* p : {(void*)d->label_mask, (void*)d->rows_in})
         if (p) (void)hipFree(p);
+    if (d->s_fallback) (void)hipStreamDestroy(d->s_fallback);
     for (int i = 0; i < DetState::NSLOT; ++i) {
         if (d->dets_host[i]) (void)hipHostFree(d->dets_host[i]);
         if (d->counters_host[i]) (void)hipHostFree(d->counters_host[i]);
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
     }
     if (tid == 0) {
         counters[2] = base;
-        counters_host[0] = counters[0]; counters_host[1] = counters[1]; counters_host[2] = base; counters_host[3] = counters[3];
+        counters_host[0] = counters[0]; counters_host[1] = counters[1]; counters_host[2] = base; counters_host[3] = 0;   // (final: never "declined")
     }
 }
 
@@ -1025,7 +1027,11 @@ int collect(fm_ctx* ctx, DetState* d, hipStream_t s, fm_det48* out, int cap_out,
         // already, candidates untouched) goes through the general path now, and so do the following ones -- for good
         // beyond NG_KMAX candidates, otherwise until the greedy kernel is tried again GREEDY_RETRY passes later
         const int why = d->counters_host[slot][3];
-        hipStream_t sp = ctx->s_up;
+        // on a stream of its own: s_up may already hold the NEXT pass's post-processing, which waits for that pass's whole
+        // detector network (ev_dec) -- behind it this redo would stall for a network pass.  Every buffer it
+        // touches belongs to `slot`, whose earlier work is complete (ev_done above).
+        if (!d->s_fallback) FM_HIP(hipStreamCreateWithFlags(&d->s_fallback, hipStreamNonBlocking));
+        hipStream_t sp = d->s_fallback;
         int rc_g = enqueue_general_post(ctx, d, slot, sp, d->sorted_valid[slot]);
         if (rc_g) return rc_g;
         FM_HIP(hipStreamSynchronize(sp));

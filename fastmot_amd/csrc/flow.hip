@@ -1874,9 +1874,14 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
         off += (size_t)eig_tiles(c);
         crops[i] = c;
     }
-    if (off > f->eig_cap) {
-        fm_set_error("GFTT scratch too small (%zu > %zu tiles)", off, f->eig_cap);
-        return FM_ERR_STATE;
+    if (off > f->eig_cap) {     // many small crops (one tile at least each): grow like fm_flow_prepare does (stream idle: synchronised above)
+        FM_HIP(hipFree(f->eig));
+        f->eig = nullptr;
+        FM_HIP(hipFree(f->tile_stat));
+        f->tile_stat = nullptr;
+        FM_HIP(hipMalloc(&f->eig, sizeof(unsigned long long) * EIG_TPX * off * 2));
+        FM_HIP(hipMalloc(&f->tile_stat, sizeof(uint2) * off * 2));
+        f->eig_cap = off * 2;
     }
     const size_t o_crop = 0, o_md = sizeof(CropArgs) * n, o_box = (o_md + sizeof(int32_t) * n + 15) & ~size_t(15);
     const size_t in_bytes = o_box + sizeof(double) * 4 * n;

@@ -329,7 +329,16 @@ def darknet_cfg_from_onnx(model, descriptor):
     if not model.data_inputs or model.data_inputs[0][1] is None or len(model.data_inputs[0][1]) != 4:
         raise ValueError('ONNX model has no NCHW data input')
     in_name, (_, cin0, in_h, in_w) = model.data_inputs[0]
-    idx_of = lambda tensor: 0 if tensor == in_name else int(tensor[:3])          # 1-based section index of a tensor
+    if not all(isinstance(v, int) and v > 0 for v in (cin0, in_h, in_w)):
+        raise ValueError(f'ONNX input {in_name!r} has symbolic or unknown dimensions {model.data_inputs[0][1]}: '
+                         'scripts/yolo2onnx.py writes concrete ones, and the layer table needs them')
+
+    def idx_of(tensor):                       # 1-based section index of a tensor ('017_convolutional_lrelu' -> 17)
+        if tensor == in_name:
+            return 0
+        if not re.match(r'^\d{3}_', tensor):
+            raise ValueError(f'tensor {tensor!r} does not follow the yolo2onnx naming (three-digit section index first)')
+        return int(tensor[:3])
     by_idx = {}
     for nd in model.nodes:
         m = re.match(r'^(\d{3})_(convolutional|shortcut|route|upsample|maxpool)(.*)$', nd.name)

@@ -8,6 +8,7 @@ which is also what the reference's process-global `Track._count` requires (track
 """
 import atexit
 import os
+import platform
 
 from . import _lib
 
@@ -56,7 +57,9 @@ def bind_to_gpu_numa_node(device):
     for the same command line, the frames-resident variant unaffected).  Best effort and Linux only: without sysfs
     topology, on a single-node host, or with FASTMOT_NUMA_BIND=0 nothing is changed.  Returns what was found."""
     info = {'gpu_numa_node': None, 'bound': False}
-    try:
+    if hasattr(os, 'sched_getaffinity'):
+        info['affinity_before'] = sorted(os.sched_getaffinity(0))     # (what the embedding application had: bench.py hands
+    try:                                                                 # it back to the CPU baseline's worker processes)
         bdf = _lib.device_pci_bus_id(device)
         info['pci'] = bdf
         node = int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read())
@@ -72,6 +75,8 @@ def bind_to_gpu_numa_node(device):
             return info
         os.sched_setaffinity(0, allowed & local)
         try:                                     # memory policy: prefer the node as well (set_mempolicy, MPOL_PREFERRED)
+            if platform.machine() != 'x86_64':   # (raw syscall number 238 is x86-64's set_mempolicy only)
+                raise OSError('set_mempolicy by number: x86-64 only')
             import ctypes
             mask = ctypes.c_ulong(1 << node)
             libc = ctypes.CDLL(None, use_errno=True)
@@ -87,6 +92,8 @@ def bind_to_gpu_numa_node(device):
 def numa_node_of(array):
     """NUMA node of the first page of a host array (move_pages query); None when it cannot be told."""
     try:
+        if platform.machine() != 'x86_64':       # (raw syscall number 279 is x86-64's move_pages only)
+            return None
         import ctypes
         libc = ctypes.CDLL(None, use_errno=True)
         page = ctypes.c_void_p(array.ctypes.data & ~4095)
