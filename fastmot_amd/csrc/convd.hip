@@ -482,7 +482,8 @@ int stages_for(int bm, int bn, int kg, int spb, int per, int lds_budget) {
 //     store path (~8 B/clk/CU) both want every CU, the LDS read port wants the large register tile;
 //   * K ranges of one or two steps (1x1 convs on the large maps) are bound by their stores: 64 x 64 tiles, several small
 //     workgroups per CU at different phases, no loader waves (they would idle);
-//   * 128 x 128: one K group with loader waves; smaller tiles: two K groups with loader waves from 8 steps on;
+//   * 128 x 128: one K group with loader waves; 128 x 64: the same with two K steps per barrier from 8 steps on (12.5 vs
+//     13.2 us for two K groups on the 76 x 76 3x3 layers); 64 x 64: two K groups with loader waves from 8 steps on;
 //   * ring depth 4 where one workgroup per CU is all the layer has, 2 (half the LDS) where a second workgroup can be
 //     resident beside it (more than 256 tiles).
 Cfg choose(const ConvParams& p) {
@@ -491,9 +492,9 @@ Cfg choose(const ConvParams& p) {
     Cfg c{64, 64, 1, 2, 0, 1};
     if (nk > 2) {
         if (cout_pad % 128 == 0 && tiles(128, 128) >= 180) c = Cfg{128, 128, 1, 2, 1, 1};
-        else if (cout_pad % 128 == 0 && tiles(128, 64) >= 180) c = Cfg{128, 64, 1, 2, 1, 1};
+        else if (cout_pad % 128 == 0 && tiles(128, 64) >= 180) c = Cfg{128, 64, 1, 2, 1, nk >= 8 ? 2 : 1};
         else c.role = 1;
-        if (c.bm * c.bn < 128 * 128 && nk >= 8) c.kg = 2;
+        if (c.bm == 64 && nk >= 8) c.kg = 2;
     }
     const long nt = tiles(c.bm, c.bn);
     c.ns = stages_for(c.bm, c.bn, c.kg, c.spb, ((nk + c.kg - 1) / c.kg + c.spb - 1) / c.spb, nt > 256 ? LDS_MAX / 2 : LDS_MAX);

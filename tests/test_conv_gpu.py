@@ -493,7 +493,7 @@ def _convd_code(bm, bn, kg, ns=0, role=0, spb=1):
     return bm | bn << 8 | kg << 16 | ns << 20 | role << 24 | (spb - 1) << 25
 
 
-@pytest.mark.parametrize('cin,cout,k,stride,act,h,w,n,extra', [
+_CONVD_SHAPES = [
     (64, 128, 1, 1, 'mish', 76, 76, 1, ''),            # CSP stage entry
     (64, 64, 1, 1, 'mish', 48, 40, 1, 'slice'),        # reads a channel slice, writes a concat slice
     (128, 64, 1, 1, 'mish', 35, 35, 1, ''),            # ragged last pixel tile
@@ -504,15 +504,22 @@ def _convd_code(bm, bn, kg, ns=0, role=0, spb=1):
     (512, 512, 1, 1, 'mish', 19, 19, 1, 'res'),        # shortcut after the activation
     (2048, 512, 1, 1, 'leaky', 19, 19, 1, ''),         # 32 K steps
     (128, 256, 3, 1, 'leaky', 38, 38, 1, ''),          # 3x3, padding on every border
-    (64, 128, 3, 2, 'mish', 76, 76, 1, ''),            # stride-2 downsample
+    (64, 128, 3, 2, 'mish', 76, 76, 1, ''),            # stride-2 downsample, 9 K steps (odd: two steps per barrier repeat one)
     (256, 512, 3, 2, 'leaky', 38, 38, 1, ''),
     (512, 1024, 3, 1, 'leaky', 19, 19, 1, ''),         # 72 K steps
     (128, 64, 3, 1, 'relu', 7, 5, 3, 'res'),           # tiny maps, batch, shortcut
     (64, 40, 3, 1, 'swish', 9, 9, 1, ''),              # cout padded to 64
     (192, 96, 3, 1, 'relu', 16, 8, 4, 'resb'),         # cin = 3 * 64: a tap is three K steps; shortcut BEFORE the activation
-])
-@pytest.mark.parametrize('cfg', ['auto', (128, 128, 1, 0, 1), (128, 64, 2, 0, 1), (128, 64, 1, 2, 0), (64, 64, 4), (64, 64, 1, 3, 1),
-                                 (64, 64, 2, 0, 0), (128, 128, 2, 2, 1), (64, 64, 2, 2, 1, 2), (128, 64, 1, 3, 1, 2), (64, 64, 1, 0, 0, 2)])
+]
+# forced configurations (bm, bn, K groups, ring slots, loader waves, steps per barrier); every shape runs the launcher's own
+# choice and three of them (a different three per shape: every pairing of a shape class with a code path occurs)
+_CONVD_CFGS = [(128, 128, 1, 0, 1), (128, 64, 2, 0, 1), (128, 64, 1, 2, 0), (64, 64, 4), (64, 64, 1, 3, 1), (64, 64, 2, 0, 0),
+               (128, 128, 2, 2, 1), (64, 64, 2, 2, 1, 2), (128, 64, 1, 3, 1, 2), (64, 64, 1, 0, 0, 2)]
+_CONVD_CASES = [(*sh, cfg) for i, sh in enumerate(_CONVD_SHAPES)
+                for cfg in ['auto'] + [_CONVD_CFGS[(3 * i + j) % len(_CONVD_CFGS)] for j in range(3)]]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,act,h,w,n,extra,cfg', _CONVD_CASES)
 def test_convd_conv(ctx, cin, cout, k, stride, act, h, w, n, extra, cfg):
     """convd.hip (operands by DMA into an LDS ring, up to 2 x 2 accumulators per wave, K groups, loader waves) against the
     LDS-tiled kernel on the same layer and against PyTorch, under forced (tile, K groups, ring depth, loader waves, steps per
