@@ -3,6 +3,7 @@
 // TRTInference) with plain HIP: one ctx per video stream, four HIP streams, pinned mirrors.
 #include "common.h"
 void convd_set_cfg(int code);             // convd.hip
+void convd_set_ns_max(int n);
 #include <sched.h>
 #include <cstring>
 #include <cstdlib>
@@ -25,6 +26,7 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
     else if (!strcmp(key, "use_graphs")) ctx->opt_use_graphs = value;
     else if (!strcmp(key, "convd_cfg")) convd_set_cfg(value);
+    else if (!strcmp(key, "convd_ns_max")) convd_set_ns_max(value);
     else if (!strcmp(key, "nms_path")) {
         ctx->opt_nms_general = value != 0;
     }
@@ -122,6 +124,7 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     if (const char* e = getenv("FASTMOT_ZERO_COPY")) ctx->opt_zero_copy_tracks = atoi(e);
     if (const char* e = getenv("FASTMOT_HOST_LAP")) ctx->opt_host_lap_elems = atoi(e);
     if (const char* e = getenv("FASTMOT_GRAPHS")) ctx->opt_use_graphs = atoi(e);
+    if (const char* e = getenv("FASTMOT_CONVD_NS_MAX")) convd_set_ns_max(atoi(e));      // (A/B runs of whole pipelines)
     // the detector network is the long, throughput-oriented stream; tracker / KLT / ReID launches are
     // short and latency critical (the host waits on them), so they get the higher priority
     int prio_lo = 0, prio_hi = 0;

@@ -537,15 +537,27 @@ __device__ __forceinline__ float half_value(float v, int lane_in_half, int half_
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((half_base + lane_in_half) << 2, __builtin_bit_cast(int, v)));
 }
 
-template <int WINC>
+// PATCH (round 5): the iteration's samples of the NEW frame come from a 16 x 16 byte patch of the level
+// in LDS, filled once per (point, level) around the start position (+-5 px of travel inside a level; a window that
+// leaves the patch falls back to the global loads).  An iteration then waits for four ds_read_u8 (~100 cycles) instead
+// of four global byte loads (~500-700 cycles beside the networks); the values, and with them every result, are the same.
+// The patch is private to a half-wavefront: a wavefront's LDS operations execute in program order, no barrier is needed
+// (and none is possible: lanes leave early and the two halves diverge).
+constexpr int LK_PW = 16, LK_PR = 5;
+
+template <int WINC, bool PATCH>
 __global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
                                                                   float* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                                   float* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t patch_all[PATCH ? 8 * LK_PW * LK_PW : 16];
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int l = gidx & 63, g = l & 31, hb = l & 32;
     const int pt = (gidx >> 6) * 2 + (l >> 5);
     constexpr int win = WINC, NW = WINC * WINC;
     if (pt >= n || g >= NW) return;
+    uint8_t* const patch = patch_all + (PATCH ? ((threadIdx.x >> 5) & 7) * (LK_PW * LK_PW) : 0);
+    int sx0 = 0, sy0 = 0;                       // top-left corner of the patch in level coordinates
+    bool have_patch = false;
     const int wy = g / win, wx = g % win;
     const float half = (win - 1) * 0.5f;
     const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
@@ -565,11 +577,41 @@ __global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int 
         const int c0 = reflect101(bx + wx, w), c1 = reflect101(bx + wx + 1, w);
         return LK_DESCALE(lk_px(r0, c0) * iw00 + lk_px(r0, c1) * iw01 + lk_px(r1, c0) * iw10 + lk_px(r1, c1) * iw11, 14 - 5);
     };
+    // the same sample of the new frame J, from the patch when the (win + 1)^2 pixels of the window lie inside it
+    auto sample_j = [&](const uint8_t* img, int w, int h, int bx, int by, int iw00, int iw01, int iw10, int iw11) -> int {
+        if (PATCH && have_patch && bx >= sx0 && by >= sy0 && bx + win + 1 <= sx0 + LK_PW && by + win + 1 <= sy0 + LK_PW) {
+            const uint8_t* q = patch + (by - sy0 + wy) * LK_PW + (bx - sx0 + wx);
+            return LK_DESCALE((int)q[0] * iw00 + (int)q[1] * iw01 + (int)q[LK_PW] * iw10 + (int)q[LK_PW + 1] * iw11, 14 - 5);
+        }
+        return sample(img, w, h, bx, by, iw00, iw01, iw10, iw11);
+    };
+    // patch[r][c] = J[reflect101(y0 + r)][reflect101(x0 + c)]: 64 dwords, three per lane.  Inside the image a dword is two
+    // ALIGNED loads and a byte alignment; at the borders four byte loads with the reflection sample() applies.
+    auto fill_patch = [&](const uint8_t* img, int w, int h, int x0, int y0) {
+        sx0 = x0; sy0 = y0;
+        const bool inside = x0 >= 0 && x0 + LK_PW + 4 <= w;
+        for (int item = g; item < LK_PW * LK_PW / 4; item += NW) {
+            const int r = item >> 2, c = (item & 3) * 4;
+            const uint8_t* row = img + (size_t)reflect101(y0 + r, h) * w;
+            uint32_t v;
+            if (inside) {
+                const uintptr_t ad = reinterpret_cast<uintptr_t>(row) + (uintptr_t)(x0 + c);
+                const uint32_t* al = reinterpret_cast<const uint32_t*>(ad & ~uintptr_t(3));
+                v = __builtin_amdgcn_alignbyte(al[1], al[0], (uint32_t)(ad & 3));
+            } else {
+                v = (uint32_t)row[reflect101(x0 + c, w)] | (uint32_t)row[reflect101(x0 + c + 1, w)] << 8 |
+                    (uint32_t)row[reflect101(x0 + c + 2, w)] << 16 | (uint32_t)row[reflect101(x0 + c + 3, w)] << 24;
+            }
+            *reinterpret_cast<uint32_t*>(patch + r * LK_PW + c) = v;
+        }
+        have_patch = true;
+    };
     for (int level = a.levels - 1; level >= 0; --level) {
         const int w = a.w[level], h = a.h[level];
         const uint8_t* I = a.I[level];
         const uint8_t* J = a.J[level];
         const int16_t* D = a.D[level];
+        have_patch = false;
         const float sc = 1.f / (float)(1 << level);
         float ppx = px0 * sc, ppy = py0 * sc;
         if (level == a.levels - 1) { nx = ppx; ny = ppy; }
@@ -615,6 +657,10 @@ __global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int 
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
         float outx = nx + half, outy = ny + half;
+        if (PATCH) {
+            const int fx = (int)floorf(nx), fy = (int)floorf(ny);
+            if (fx >= -win && fx < w && fy >= -win && fy < h) fill_patch(J, w, h, fx - LK_PR, fy - LK_PR);
+        }
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
             if (inx < -win || inx >= w || iny < -win || iny >= h) {
@@ -622,7 +668,7 @@ __global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int 
                 break;
             }
             weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
-            const int diff = sample(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            const int diff = sample_j(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
             float b1, b2;
             {
                 const float v0 = (float)(diff * ixval), v1 = (float)(diff * iyval);
@@ -648,7 +694,7 @@ __global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int 
             const int inx = (int)floorf(ex), iny = (int)floorf(ey);
             if (inx < -win || inx >= w || iny < -win || iny >= h) { st = false; continue; }
             weights(ex - inx, ey - iny, iw00, iw01, iw10, iw11);
-            const int diff = sample(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            const int diff = sample_j(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
             const float v0 = fabsf((float)diff);
             float a0 = v0;
 #pragma unroll
@@ -2023,10 +2069,15 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
 #endif
                 const dim3 grid2((unsigned)((((size_t)n + 1) / 2 * 64 + threads - 1) / threads));     // two points per wavefront
                 fm_trace_mark(ctx, s, 40);
-                if (a.win == 5)
-                    hipLaunchKernelGGL(lk_pair_kernel<5>, grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                static const bool no_patch = getenv("FASTMOT_LK_PATCH") && atoi(getenv("FASTMOT_LK_PATCH")) == 0;   // (A/B runs)
+                if (a.win == 5 && !no_patch)
+                    hipLaunchKernelGGL((lk_pair_kernel<5, true>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                else if (a.win == 5)
+                    hipLaunchKernelGGL((lk_pair_kernel<5, false>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                else if (!no_patch)
+                    hipLaunchKernelGGL((lk_pair_kernel<3, true>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
                 else
-                    hipLaunchKernelGGL(lk_pair_kernel<3>, grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                    hipLaunchKernelGGL((lk_pair_kernel<3, false>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
                 fm_trace_mark(ctx, s, 41);
             }
         }
