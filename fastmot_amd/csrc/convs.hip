@@ -56,12 +56,15 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, half = lane >> 5;
     CONVS_STAMP(0)
-    // XCD-aware order (workgroup id % 8 = XCD): each XCD gets a contiguous run of the cout-group-major tile
-    // order, so a cout group's weights are fetched into few L2s
+    // XCD-aware order (workgroup id % 8 = XCD): each XCD gets a contiguous run of a tile order in which the LARGER operand's
+    // slice is private to it -- cout-group-major when the weights are (19 x 19 levels: a cout group's weights go to few
+    // L2s), pixel-tile-major when the input is (38 x 38 x 512 -> 256: round 5's per-layer PMC pass showed 12.2 MB of L2
+    // fills for 1.7 MB of operands, every XCD pulling the whole input)
     const int total = npt * ncg, per_xcd = (total + 7) >> 3;
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= total) return;
-    const int tile_c = logical / npt, tile_p = logical % npt;
+    const bool weight_major = (size_t)p.Cout * p.K >= (size_t)p.N * p.H * p.W * p.Cin;
+    const int tile_c = weight_major ? logical / npt : logical % ncg, tile_p = weight_major ? logical % npt : logical / ncg;
 
     // Pixel fragments.  The MFMA wants lane (pixel = lane % 32, k half) to hold 8 channels of ITS pixel; loaded
     // that way one instruction touches 32 cache lines for 1 KB (measured: these gathers cost more than twice
@@ -243,7 +246,16 @@ __global__ __launch_bounds__(NW * 64) void convs_halo_kernel(const ConvParams p,
     const int ntiles = tiles_x * tiles_y, total = ntiles * ncg, per_xcd = (total + 7) >> 3;
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= total) return;
-    const int tile_c = idiv_small(logical, ntiles, 1.f / (float)ntiles), tile_id = logical - tile_c * ntiles;
+    // (the same rule as convs_kernel: the larger operand's slice stays private to an XCD)
+    const bool weight_major = (size_t)p.Cout * p.K >= (size_t)p.H * p.W * p.Cin;
+    int tile_c, tile_id;
+    if (weight_major) {
+        tile_c = idiv_small(logical, ntiles, 1.f / (float)ntiles);
+        tile_id = logical - tile_c * ntiles;
+    } else {
+        tile_id = idiv_small(logical, ncg, 1.f / (float)ncg);
+        tile_c = logical - tile_id * ncg;
+    }
     const int tyi = idiv_small(tile_id, tiles_x, 1.f / (float)tiles_x);
     const int ty0 = tyi * TH, tx0 = (tile_id - tyi * tiles_x) * TW;
 
