@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NW * 64) void convs_kernel(const ConvParams p, int 
     const int total = npt * ncg, per_xcd = (total + 7) >> 3;
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= total) return;
-    const bool weight_major = (size_t)p.Cout * p.K >= (size_t)p.N * p.H * p.W * p.Cin;
+    const bool weight_major = p.weight_major != 0;      // (set by the launcher: weights >= input, or the order forced for an A/B run)
     const int tile_c = weight_major ? logical / npt : logical % ncg, tile_p = weight_major ? logical % npt : logical / ncg;
 
     // Pixel fragments.  The MFMA wants lane (pixel = lane % 32, k half) to hold 8 channels of ITS pixel; loaded
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void convs_halo_kernel(const ConvParams p,
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= total) return;
     // (the same rule as convs_kernel: the larger operand's slice stays private to an XCD)
-    const bool weight_major = (size_t)p.Cout * p.K >= (size_t)p.H * p.W * p.Cin;
+    const bool weight_major = p.weight_major != 0;
     int tile_c, tile_id;
     if (weight_major) {
         tile_c = idiv_small(logical, ntiles, 1.f / (float)ntiles);
@@ -431,7 +431,12 @@ extern "C" int fm_debug_convs_stamps(long long* out64) {
 #endif
 
 // p.w: fragment-order weights (see header); p.K = KH * KW * Cin with Cin % 64 == 0; p.Kpad unused
-int launch_conv_streamed(const ConvParams& p, hipStream_t s) {
+int launch_conv_streamed(const ConvParams& p_in, hipStream_t s) {
+    ConvParams p = p_in;
+    // XCD-aware tile order: the larger operand's slice private to an XCD (FASTMOT_CONVS_ORDER=0: always cout-major, the order
+    // of rounds 2-4, for A/B runs)
+    static const bool by_operand = !(getenv("FASTMOT_CONVS_ORDER") && atoi(getenv("FASTMOT_CONVS_ORDER")) == 0);
+    p.weight_major = !by_operand || (size_t)p.Cout * p.K >= (size_t)p.N * p.H * p.W * p.Cin ? 1 : 0;
     FM_CHECK_ARG(p.Cin % 64 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0 && p.K == p.KH * p.KW * p.Cin);
     FM_CHECK_ARG(p.out_cs % 4 == 0 && p.out_coff % 4 == 0 && p.cout_store % 4 == 0 && p.Cin <= 4096);
     FM_CHECK_ARG(p.res_mode == RES_NONE || (p.res_cs % 4 == 0 && p.res_coff % 4 == 0));
