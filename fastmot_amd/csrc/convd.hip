@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) 
         i_kh = tap / TAPS;
         i_kw = tap - i_kh * TAPS;
     }
+    const bool ragged = TAPS == 0 && (p.Cin & 63) != 0;
     unsigned i_soff = (unsigned)((i_kh * p.W + i_kw) * p.in_cs + i_c0) * 2u;
     unsigned i_astep = (unsigned)s0 * 4096u;
     int i_stage = 0, i_step = 0;
@@ -199,6 +200,9 @@ __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) 
             for (int i = 0; i < NPB; ++i) {
                 unsigned vo = vb[i];
                 if constexpr (TAPS) vo = ((vm[i] >> t) & 1u) ? vo : OOB;
+                // 1x1 with cin % 64 != 0 (OSNet's 16 .. 96-channel layers): the K range is padded to whole steps with
+                // zero weights; the chunks of a step that lie beyond the pixel's channels are not fetched (zeros)
+                else if (ragged) vo = (int)chunk < ((p.Cin - i_c0 + 7) >> 3) ? vo : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (w + 4 * i) * 1024), 16, vo, i_soff, 0, 0);
             }
             if (SPB > 1 && i_step + 1 >= nkg) continue;       // (the group's last step: stay on it)
@@ -212,6 +216,8 @@ __global__ __launch_bounds__(256 * KG * (1 + ROLE), (KG == 1 && !ROLE) ? 2 : 1) 
                     if (++i_kw == TAPS) { i_kw = 0; ++i_kh; }
                     i_soff = (unsigned)((i_kh * p.W + i_kw) * p.in_cs) * 2u;
                 }
+            } else {
+                i_c0 += 64;
             }
         }
         i_stage = i_stage + 1 == nslots ? 0 : i_stage + 1;
@@ -517,9 +523,11 @@ extern "C" int fm_debug_convd_stamps(long long* out528, int set_abl) {
 }
 #endif
 
-// p.w: tile-image weights (header); p.K = KH * KW * Cin with Cin % 64 == 0 (so Kpad == K)
+// p.w: tile-image weights (header); p.K = KH * KW * Cin; 3x3: Cin % 64 == 0 (Kpad == K); 1x1: Cin % 8 == 0, the image is
+// zero-padded to Kpad = ceil64(K)
 int launch_convd(const ConvParams& p, hipStream_t s) {
-    FM_CHECK_ARG(p.Cin % 64 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0 && p.K == p.KH * p.KW * p.Cin && p.Kpad == p.K);
+    FM_CHECK_ARG(p.in_cs % 8 == 0 && p.in_coff % 8 == 0 && p.K == p.KH * p.KW * p.Cin && p.Kpad == ((p.K + 63) & ~63));
+    FM_CHECK_ARG(p.KH == 1 ? p.Cin % 8 == 0 : p.Cin % 64 == 0);
     FM_CHECK_ARG(p.out_cs % 8 == 0 && p.out_coff % 8 == 0 && p.KH == p.KW && ((p.KH == 1 && p.pad == 0) || p.KH == 3));
     FM_CHECK_ARG(p.res_mode == RES_NONE || (p.res_cs % 8 == 0 && p.res_coff % 8 == 0));
     FM_CHECK_ARG(p.P < (1 << 22) && p.grid_p >= 0);

@@ -137,6 +137,7 @@ class Graph:
         # streamed kernel only for the stride-2 3x3 convs into a map of >= 1024 pixels (the streamed kernel keeps the
         # 38 x 38 / 19 x 19 levels: 13.5 vs 14.1 us and 15.1 vs 19.4 us on their 3x3 layers); 2 = wherever it applies
         self.convd_level = int(os.environ.get('FASTMOT_CONVD', '1'))
+        self.convd_min_cin1 = int(os.environ.get('FASTMOT_CONVD_MIN_CIN1', '16'))   # smallest cin of a 1x1 layer on it (A/B: 64)
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -196,14 +197,17 @@ class Graph:
             return dst
         streamed = x.c == cin_pad and cin_pad % 64 == 0 and k * k * cin_pad >= 512 and ho * wo <= self.convs_max_pixels
         beats_streamed = k == 3 and stride == 2 and ho * wo >= 1024
-        if cin_pad % 64 == 0 and (k == 3 or (k == 1 and pad == 0)) and \
+        # (1x1: any cin % 8 == 0 -- the K range is zero-padded to whole 64-deep steps; OSNet's 16 .. 96-channel pointwise convs)
+        if ((k == 3 and cin_pad % 64 == 0) or (k == 1 and pad == 0 and cin_pad >= self.convd_min_cin1)) and \
                 self.convd_level >= (1 if not streamed or beats_streamed else 2):
-            wk = np.zeros((ceil_to(cout, 32), k, k, cin_pad), np.float16)
-            wk[:cout, :, :, :x.c] = w16.transpose(0, 2, 3, 1)
+            wk4 = np.zeros((ceil_to(cout, 32), k, k, cin_pad), np.float16)
+            wk4[:cout, :, :, :x.c] = w16.transpose(0, 2, 3, 1)
+            wk = np.zeros((wk4.shape[0], ceil_to(k * k * cin_pad, 64)), np.float16)
+            wk[:, :k * k * cin_pad] = wk4.reshape(wk4.shape[0], -1)
             bias = np.zeros(wk.shape[0], np.float32)
             bias[:cout] = b
             self._layer(op=OP_CONVD, ins=[x], out=dst, cin=cin_pad, cout=cout, k=k, stride=stride, pad=pad,
-                        act=ACT[act], up=up, w_off=self._push(self._pack_tile64(wk.reshape(wk.shape[0], -1))),
+                        act=ACT[act], up=up, w_off=self._push(self._pack_tile64(wk)),
                         b_off=self._push(bias), res=res, res_mode=res_mode if res is not None else RES_NONE, name=name)
             self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
             return dst

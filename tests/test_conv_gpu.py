@@ -510,6 +510,9 @@ _CONVD_SHAPES = [
     (128, 64, 3, 1, 'relu', 7, 5, 3, 'res'),           # tiny maps, batch, shortcut
     (64, 40, 3, 1, 'swish', 9, 9, 1, ''),              # cout padded to 64
     (192, 96, 3, 1, 'relu', 16, 8, 4, 'resb'),         # cin = 3 * 64: a tap is three K steps; shortcut BEFORE the activation
+    (16, 64, 1, 1, 'relu', 64, 32, 5, ''),             # OSNet x0.25 pointwise convs: cin % 64 != 0 (K zero-padded to a step,
+    (96, 24, 1, 1, 'relu', 16, 8, 7, 'resb'),          #   chunks beyond the pixel's channels not fetched), batch
+    (24, 96, 1, 1, 'linear', 32, 16, 3, 'slice'),
 ]
 # forced configurations (bm, bn, K groups, ring slots, loader waves, steps per barrier); every shape runs the launcher's own
 # choice and three of them (a different three per shape: every pairing of a shape class with a code path occurs)
