@@ -129,10 +129,14 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     // short and latency critical (the host waits on them), so they get the higher priority
     int prio_lo = 0, prio_hi = 0;
     FM_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least, hi = greatest priority
+    // FASTMOT_STREAM_PRIO (A/B runs, round 5): 0 = as described above; 1 = detector network high as well; 2 = detector high,
+    // ReID network low
+    const int prio_mode = getenv("FASTMOT_STREAM_PRIO") ? atoi(getenv("FASTMOT_STREAM_PRIO")) : 0;
+    const int prio_det = prio_mode >= 1 ? prio_hi : prio_lo, prio_ext = prio_mode == 2 ? prio_lo : prio_hi;
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, prio_hi));
-    FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_lo));
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_det));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_up, hipStreamNonBlocking, prio_lo));
-    FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext, hipStreamNonBlocking, prio_hi));
+    FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext, hipStreamNonBlocking, prio_ext));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_in, hipEventDisableTiming));
     for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
         FM_HIP(hipStreamCreateWithPriority(&ctx->s_ext_x[i], hipStreamNonBlocking, prio_hi));

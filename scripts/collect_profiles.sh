@@ -4,12 +4,12 @@
 # -> gpurun_out/<tag>/: GPU test summary, bench lines (default command line, the driver's --steps 20 --warmup 5, configs 2
 #    and 4), rocprofv3 kernel stats of the bench command, per-layer roofline table of the detector, OSNet dispatch list,
 #    PMC traffic passes (separate rocprofv3 --pmc runs, MI355X_MICROARCH.md).  Copy what is to be judged into profiles/.
-TAG=${1:-r04}; QUICK=${2:-}
+TAG=${1:-r05}; QUICK=${2:-}
 export TMPDIR=/tmp FASTMOT_RANDOM_WEIGHTS=1
 R=$GRAFT_REPO_ROOT; [ -n "$R" ] || R=$(pwd)
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.txt; tail -3 $O/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q --durations=15 2>&1 | tail -30 > $O/pytest_gpu.txt; tail -3 $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-180 $O/bench_n1.json
 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_cmdline.json 2> $O/bench_driver.err; cut -c1-180 $O/bench_driver_cmdline.json
@@ -32,9 +32,18 @@ if [ -z "$QUICK" ]; then
 # stand-alone replays: per-layer roofline of the detector, dispatch list of the ReID network
 cd /tmp && rm -rf /tmp/tr_$TAG && rocprofv3 --kernel-trace -d /tmp/tr_$TAG -o t -- python $R/scripts/trace_net.py 0 > /dev/null 2>&1
 cd $R && python scripts/layer_roofline.py /tmp/tr_$TAG > $O/yolo_layer_roofline.txt 2>&1; tail -3 $O/yolo_layer_roofline.txt
+# the same for the detectors of configs [2] and [4], and for YOLOv4 @ 608 without the DMA-fed kernel (the A/B of DESIGN 4c)
+for m in YOLOv4P6_1280 YOLOv4CSP_640; do
+  cd /tmp && rm -rf /tmp/tr_${TAG}_$m && rocprofv3 --kernel-trace -d /tmp/tr_${TAG}_$m -o t -- python $R/scripts/trace_net.py 0 $m > /dev/null 2>&1
+  cd $R && python scripts/layer_roofline.py /tmp/tr_${TAG}_$m $m > $O/layers_$m.txt 2>&1; echo "$m: $(tail -2 $O/layers_$m.txt | head -1)"
+done
+for m in YOLOv4_608 YOLOv4P6_1280 YOLOv4CSP_640; do
+  cd /tmp && rm -rf /tmp/tr0_${TAG}_$m && FASTMOT_CONVD=0 rocprofv3 --kernel-trace -d /tmp/tr0_${TAG}_$m -o t -- python $R/scripts/trace_net.py 0 $m > /dev/null 2>&1
+  cd $R && FASTMOT_CONVD=0 python scripts/layer_roofline.py /tmp/tr0_${TAG}_$m $m > $O/layers_${m}_convd0.txt 2>&1; echo "$m without convd: $(tail -2 $O/layers_${m}_convd0.txt | head -1)"
+done
 cd /tmp && rm -rf /tmp/tro_$TAG && rocprofv3 --kernel-trace -d /tmp/tro_$TAG -o t -- python $R/scripts/trace_net.py 1 50 > /dev/null 2>&1
 cd $R && python scripts/rocpd_dispatches.py "$(find /tmp/tro_$TAG -name '*.db' | head -1)" 40 > $O/osnet_b50_dispatches.txt 2>&1; tail -3 $O/osnet_b50_dispatches.txt
 fi
 if [ -z "$QUICK" ]; then
-    bash scripts/collect_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_conv.json gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt gpurun_out/pmc_sq_yolo.txt $O/ 2>/dev/null; tail -3 $O/pmc.log | cut -c1-400
+    bash scripts/collect_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_conv.json gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt gpurun_out/pmc_sq_yolo.txt gpurun_out/pmc_layers.txt $O/ 2>/dev/null; tail -3 $O/pmc.log | cut -c1-400
 fi
