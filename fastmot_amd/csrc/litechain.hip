@@ -28,8 +28,8 @@ struct ChainGaps {
 // profiling build only (-DFM_LCH_TIMING, scripts/lch_timing.py): s_memtime stamps of workgroup (0, deepest stream)
 #ifdef FM_LCH_TIMING
 __device__ long long g_lch_stamps[32];
-#define LCH_STAMP(i) if (blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0) g_lch_stamps[i] = __builtin_readcyclecounter();
-#define LCH_WALL(i) if (blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0) g_lch_stamps[i] = wall_clock64();
+#define LCH_STAMP(i) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = __builtin_readcyclecounter();
+#define LCH_WALL(i) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = wall_clock64();
 #else
 #define LCH_STAMP(i)
 #define LCH_WALL(i)
@@ -63,17 +63,20 @@ __device__ __forceinline__ typename HalfVec<EPT>::T pack_n(const float* f) {
 // channels -- the pixel sequence of every channel, and with it the order of the gate's partial sums, is the same
 // for every SUB: results do not depend on the launch shape.
 template <int NT, int KS, int NTHR>
-__global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 3 : 1) void litechain_kernel(
+__global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void litechain_kernel(
     const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out, int out_cs, int out_coff_base,
     const f16* __restrict__ wpw_base, int kpad, const f16* __restrict__ wdw_base,
     const float* __restrict__ bias_base, int H, int W, int C, int th, int tw, int tiles_x, int tiles_y, int act,
-    ChainGaps gaps, int S, int ys_elems, int zb_elems) {
+    ChainGaps gaps, int S, int ys_elems, int zb_elems, int deep_first) {
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
     f16* ys = lds;                       // pointwise output of the current level (halo region)
     f16* zb = lds + ys_elems;            // depthwise output of the previous level = operand of this one
     f16* wd = zb + zb_elems;             // depthwise weights of ALL levels of this stream [D][9][C] ...
     float* bs = reinterpret_cast<float*>(wd + 4 * 9 * 32 * NT);   // ... and their biases [D][C]
-    const int stream = blockIdx.y, D = stream + 1, pset0 = stream * (stream + 1) / 2;
+    // blockIdx.y = 0 is the DEEPEST stream: workgroups are dispatched in (x, y) order, and a launch with more workgroups
+    // than the chip holds at once (400 x 4 against 256 CUs x 3) should start its four-level chains first and fill the
+    // tail with the one-level ones (longest-processing-time order), not the other way round.
+    const int stream = deep_first ? gridDim.y - 1 - blockIdx.y : blockIdx.y, D = stream + 1, pset0 = stream * (stream + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     const int tile = blockIdx.x % (tiles_x * tiles_y);
@@ -179,11 +182,14 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 3 : 1) void l
         const bool last = lvl == D - 1;
         const f16* wdl = wd + lvl * 9 * C;
         if (active) {
-            float b8[EPT], kf[9][EPT];                 // this thread's bias and depthwise taps of the level, as floats
+            // this thread's bias and depthwise taps of the level; the taps stay packed halfs (v_fma_mix_f32 extends both
+            // factors): 36 VGPRs less than float copies, which is what lets four workgroups share a CU
+            float b8[EPT];
+            hvec kh[9];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) b8[e] = bs[lvl * C + ch0 + e];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) unpack_n<EPT>(*reinterpret_cast<const hvec*>(&wdl[t * C + ch0]), kf[t]);
+            for (int t = 0; t < 9; ++t) kh[t] = *reinterpret_cast<const hvec*>(&wdl[t * C + ch0]);
             for (int pix = pl; pix < wz * hz; pix += lanes_px) {
                 const int oy = (int)(((unsigned)pix * rcp_wz) >> 16), ox = pix - oy * wz;
                 const int gy = ty0 - (hl - 1) + oy, gx = tx0 - (hl - 1) + ox;
@@ -200,7 +206,8 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 3 : 1) void l
                     for (int dx = 0; dx < 3; ++dx)
                         raw[dy * 3 + dx] = *reinterpret_cast<const hvec*>(yp + (dy * wp + dx) * S);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) fma_mix_n<EPT>(reinterpret_cast<const uint32_t*>(&raw[t]), kf[t], acc);
+                for (int t = 0; t < 9; ++t)
+                    fma_mix_nh<EPT>(reinterpret_cast<const uint32_t*>(&raw[t]), reinterpret_cast<const uint32_t*>(&kh[t]), acc);
                 apply_act_n<EPT>(acc, act);
                 hvec o = pack_n<EPT>(acc);
                 if (!last) {
@@ -253,11 +260,21 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 3 : 1) void l
 
 void liteconv_tiling(int C, int W, int H, int* th, int* tw, int* tiles_x, int* tiles_y);
 
+// Pixel stride of the LDS tiles, in halfs.  C + 8 where C / 8 is even keeps the 16-byte accesses of 32 consecutive pixels
+// off each other's banks; C = 16 goes unpadded: its 32-byte pixels are conflict-free for the 16-byte reads of both phases
+// (two-way only for phase A's 8-byte stores), and 35 KB instead of 51 KB per workgroup puts four of them on a CU where
+// the 64 x 32 stage of a 50-crop pass has 1600 to run.  (FASTMOT_LCH_PAD=1: A/B, the padded layout.)
+static int lds_stride(int C) {
+    static const int pad16 = getenv("FASTMOT_LCH_PAD") ? atoi(getenv("FASTMOT_LCH_PAD")) : 0;
+    if (C == 16 && !pad16) return 16;
+    return C + (((C >> 3) & 1) ? 0 : 8);
+}
+
 // LDS bytes of the chain kernel (graph.py mirrors this to decide whether a block can use it)
 size_t litechain_lds_bytes(int C, int W, int H) {
     int th, tw, tx, ty;
     liteconv_tiling(C, W, H, &th, &tw, &tx, &ty);
-    const int S = C + (((C >> 3) & 1) ? 0 : 8), nt = (C + 31) / 32;
+    const int S = lds_stride(C), nt = (C + 31) / 32;
     const size_t ys = (size_t)(th + 8) * (tw + 8) * S, zb = (size_t)(th + 6) * (tw + 6) * S;
     const size_t red = (size_t)(256 / (C / 8)) * C * 2;                  // phase-C floats, in halfs
     // + depthwise weights [4][9][32 nt] (halfs) and biases [4][32 nt] (floats) of the whole chain
@@ -276,7 +293,7 @@ int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     FM_CHECK_ARG(shmem <= 64 * 1024);
     int th, tw, tiles_x, tiles_y;
     liteconv_tiling(C, W, H, &th, &tw, &tiles_x, &tiles_y);
-    const int S = C + (((C >> 3) & 1) ? 0 : 8), nt = (C + 31) / 32, ks = (C + 15) / 16;
+    const int S = lds_stride(C), nt = (C + 31) / 32, ks = (C + 15) / 16;
     const size_t ys = (size_t)(th + 8) * (tw + 8) * S, red = (size_t)(256 / (C / 8)) * C * 2;
     const int ys_elems = (int)(ys > red ? ys : red), zb_elems = (th + 6) * (tw + 6) * S;
     ChainGaps gaps{};
@@ -284,11 +301,13 @@ int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     const long wgs = (long)N * tiles_x * tiles_y * 4;
     const dim3 grid((unsigned)(wgs / 4), 4);
     // few workgroups: wider ones (see the kernel)
-    const int nthr = wgs <= 384 ? 512 : 256;
+    static const long wide_max = getenv("FASTMOT_LCH_WIDE_MAX") ? atol(getenv("FASTMOT_LCH_WIDE_MAX")) : 384;   // A/B
+    const int nthr = wgs <= wide_max ? 512 : 256;
+    static const int deep_first = !(getenv("FASTMOT_LCH_ORDER") && atoi(getenv("FASTMOT_LCH_ORDER")) == 0);   // A/B
 #define LCH_LAUNCH_T(NT_, KS_, NTHR_)                                                                             \
     hipLaunchKernelGGL((litechain_kernel<NT_, KS_, NTHR_>), grid, dim3(NTHR_), shmem, s, in, in_cs, in_coff, out, \
                        out_cs, out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act, gaps, S,   \
-                       ys_elems, zb_elems)
+                       ys_elems, zb_elems, deep_first)
 #define LCH_LAUNCH(NT_, KS_)                                                                                      \
     {                                                                                                             \
         bool done_ = false;                                                                                       \

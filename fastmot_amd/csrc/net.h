@@ -82,6 +82,23 @@ __device__ __forceinline__ float fma_mix_h(uint32_t packed, float k, float acc) 
     else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(k), "v"(acc));
     return d;
 }
+// the same with the factor k a packed fp16 pair too (half of the registers of a float copy of the weights; a half
+// extends to the same float either way, so the FMA's result is the same bit pattern)
+template <int HI>
+__device__ __forceinline__ float fma_mix_hh(uint32_t packed, uint32_t kpacked, float acc) {
+    float d;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(packed), "v"(kpacked), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(packed), "v"(kpacked), "v"(acc));
+    return d;
+}
+template <int N>
+__device__ __forceinline__ void fma_mix_nh(const uint32_t* raw, const uint32_t* k, float* acc) {
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+        acc[e] = fma_mix_hh<0>(raw[e >> 1], k[e >> 1], acc[e]);
+        acc[e + 1] = fma_mix_hh<1>(raw[e >> 1], k[e >> 1], acc[e + 1]);
+    }
+}
 // acc[e] += (float)h[e] * k[e] for the N halfs packed in `raw` (N / 2 dwords)
 template <int N>
 __device__ __forceinline__ void fma_mix_n(const uint32_t* raw, const float* k, float* acc) {
