@@ -28,8 +28,8 @@ struct ChainGaps {
 // profiling build only (-DFM_LCH_TIMING, scripts/lch_timing.py): s_memtime stamps of workgroup (0, deepest stream)
 #ifdef FM_LCH_TIMING
 __device__ long long g_lch_stamps[32];
-#define LCH_STAMP(i) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = __builtin_readcyclecounter();
-#define LCH_WALL(i) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = wall_clock64();
+#define LCH_STAMP(i) if ((deep_first & 2) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = __builtin_readcyclecounter();
+#define LCH_WALL(i) if ((deep_first & 2) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = wall_clock64();
 #else
 #define LCH_STAMP(i)
 #define LCH_WALL(i)
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
     // blockIdx.y = 0 is the DEEPEST stream: workgroups are dispatched in (x, y) order, and a launch with more workgroups
     // than the chip holds at once (400 x 4 against 256 CUs x 3) should start its four-level chains first and fill the
     // tail with the one-level ones (longest-processing-time order), not the other way round.
-    const int stream = deep_first ? gridDim.y - 1 - blockIdx.y : blockIdx.y, D = stream + 1, pset0 = stream * (stream + 1) / 2;
+    const int stream = (deep_first & 1) ? gridDim.y - 1 - blockIdx.y : blockIdx.y, D = stream + 1, pset0 = stream * (stream + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     const int tile = blockIdx.x % (tiles_x * tiles_y);
@@ -135,7 +135,10 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
             // operand rows: the block input in HBM/L2 at level 0, the previous level's LDS tile afterwards (it
             // covers exactly this region and is zero outside the image).  (Requesting all of a wave's level-0
             // tiles up front was measured SLOWER: 54 -> 62 us for the 64 x 32 stage; the levels are bound by
-            // the depthwise phase, not by this round trip.)
+            // the depthwise phase, not by this round trip.  Round 5 staged the whole level-0 region into `ys` in
+            // one trip before the loop and ran level 0 in place from LDS: bit-identical, 383.2 / 381.3 -> 383.1 /
+            // 383.4 us per 50-crop pass, i.e. nothing -- the 7.7 k cycles of a workgroup's first phase are the
+            // cold start of a launch whose 1024 resident workgroups all miss at once, not these L2 hits.)
             const f16* src = lvl == 0 ? img + ((long)min(max(py, 0), H - 1) * W + min(max(px, 0), W - 1)) * in_cs
                                       : nullptr;
             f16x8 bfr[KS];
@@ -303,7 +306,14 @@ int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     // few workgroups: wider ones (see the kernel)
     static const long wide_max = getenv("FASTMOT_LCH_WIDE_MAX") ? atol(getenv("FASTMOT_LCH_WIDE_MAX")) : 384;   // A/B
     const int nthr = wgs <= wide_max ? 512 : 256;
-    static const int deep_first = !(getenv("FASTMOT_LCH_ORDER") && atoi(getenv("FASTMOT_LCH_ORDER")) == 0);   // A/B
+    static const int order = !(getenv("FASTMOT_LCH_ORDER") && atoi(getenv("FASTMOT_LCH_ORDER")) == 0);   // A/B
+    int deep_first = order;
+#ifdef FM_LCH_TIMING
+    // the stamps of the FASTMOT_LCH_TIMING_LAUNCH-th chain launch of every six (OSNet has six) are the ones kept
+    static int launches = 0;
+    static const int pick = getenv("FASTMOT_LCH_TIMING_LAUNCH") ? atoi(getenv("FASTMOT_LCH_TIMING_LAUNCH")) : 5;
+    if (launches++ % 6 == pick) deep_first |= 2;
+#endif
 #define LCH_LAUNCH_T(NT_, KS_, NTHR_)                                                                             \
     hipLaunchKernelGGL((litechain_kernel<NT_, KS_, NTHR_>), grid, dim3(NTHR_), shmem, s, in, in_cs, in_coff, out, \
                        out_cs, out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act, gaps, S,   \

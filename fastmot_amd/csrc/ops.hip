@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void gated_sum_part_kernel(GatedSumPartArgs a,
                                                              const f16* __restrict__ w2,
                                                              const float* __restrict__ b2,
                                                              f16* __restrict__ out, int out_cs, int out_coff) {
-    extern __shared__ float sm[];            // gap[4][C] | hidden[4][hid] | gate[4][C] | w1[hid][C] | w2[C][hid] | b1[hid] | b2[C]
+    extern __shared__ float sm[];            // gap[4][C] | hidden[4][hid] | gate[4][C] | w1[hid][C] | w2[C][hid] | b1[hid] | b2[C] | parts
     const int n = blockIdx.y, tid = threadIdx.x;
     float* gap = sm;
     float* hidden = gap + 4 * C;
@@ -384,15 +384,23 @@ __global__ __launch_bounds__(256) void gated_sum_part_kernel(GatedSumPartArgs a,
                 if (t < a.nstreams) first[t] = *reinterpret_cast<const uint4*>(a.in[t] + pix * a.in_cs[t] + a.in_coff[t] + cg * 8);
         }
     }
+    // the tile sums of the four streams: all of them requested at once by all threads and parked in LDS, then added per
+    // (stream, channel) in tile order -- the order a lone thread walking global memory used, one dependent round trip
+    // per tile (8-16 of them in a kernel that is otherwise four round trips long)
+    float* parts = sb2 + C;                  // [nstreams][tiles][C]
+    const int tc = tiles * C;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t >= a.nstreams) break;
-        const float* p = a.part[t] + (size_t)n * tiles * C;
-        for (int c = tid; c < C; c += 256) {
-            float s = 0.f;
-            for (int q = 0; q < tiles; ++q) s += p[q * C + c];
-            gap[t * C + c] = s / (float)HW;
-        }
+        const float* p = a.part[t] + (size_t)n * tc;
+        for (int i = tid; i < tc; i += 256) parts[t * tc + i] = p[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < a.nstreams * C; i += 256) {
+        const int t = i / C, c = i - t * C;
+        float s = 0.f;
+        for (int q = 0; q < tiles; ++q) s += parts[t * tc + q * C + c];
+        gap[i] = s / (float)HW;
     }
     __syncthreads();
     for (int i = tid; i < a.nstreams * hid; i += 256) {
@@ -576,7 +584,8 @@ int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const
             FM_CHECK_ARG(in_cs[t] % 8 == 0 && in_coff[t] % 8 == 0 && part[t]);
             a.in[t] = in[t]; a.in_cs[t] = in_cs[t]; a.in_coff[t] = in_coff[t]; a.part[t] = part[t];
         }
-        const size_t shmem = ((size_t)8 * C + 4 * hid + 2 * (size_t)hid * C + hid + C) * sizeof(float);
+        const size_t shmem = ((size_t)8 * C + 4 * hid + 2 * (size_t)hid * C + hid + C + (size_t)nstreams * tiles * C) * sizeof(float);
+        FM_CHECK_ARG(shmem <= 64 * 1024);
         const int pix = gs2_pix_default() > 0 ? gs2_pix_default() : (256 / (C / 8) > 64 ? 256 / (C / 8) : 64);
         hipLaunchKernelGGL(gated_sum_part_kernel, dim3((HW + pix - 1) / pix, N), dim3(256), shmem, s, a, HW,
                            C, hid, tiles, pix, w1, b1, w2, b2, out, out_cs, out_coff);

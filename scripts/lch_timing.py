@@ -20,7 +20,7 @@ for _ in range(3):
 st = (C.c_longlong * 32)()
 ctx.lib.fm_debug_lch_stamps(st)
 s = list(st)
-print('last litechain launch of the network (16 x 8 maps, C = 32), deepest stream, workgroup 0; cycles')
+print('litechain launch', _os.environ.get('FASTMOT_LCH_TIMING_LAUNCH', '5'), 'of the six of the network (0, 1: 64 x 32 maps, C = 16; 2, 3: 32 x 16, C = 24; 4, 5: 16 x 8, C = 32), batch', batch, '-- deepest stream, workgroup 0; cycles')
 print('wall (100 MHz ticks):', s[31] - s[30], '-> us', (s[31] - s[30]) / 100.0, ' cycles total', s[8] - s[0])
 prev = s[0]
 for lvl in range(4):
