@@ -36,7 +36,6 @@ int launch_convd(const ConvParams& p, hipStream_t s);
 
 namespace {
 
-int g_convd_ns_max = 0;  // fm_ctx option "convd_ns_max": cap of the ring depth the launcher chooses (0: none; A/B runs of the LDS footprint)
 int g_convd_cfg = 0;     // fm_ctx option "convd_cfg": bm | bn << 8 | kg << 16 | ns << 20 forces one configuration (A/B runs)
 
 // profiling build only (-DFM_CONVD_TIMING, scripts/convd_timing.py): cycle stamps of wave 0 of two workgroups, and
@@ -505,14 +504,12 @@ Cfg choose(const ConvParams& p) {
     }
     const long nt = tiles(c.bm, c.bn);
     c.ns = stages_for(c.bm, c.bn, c.kg, c.spb, ((nk + c.kg - 1) / c.kg + c.spb - 1) / c.spb, nt > 256 ? LDS_MAX / 2 : LDS_MAX);
-    if (g_convd_ns_max >= 2 && c.ns > g_convd_ns_max) c.ns = g_convd_ns_max;
     return c;
 }
 
 }  // namespace
 
 void convd_set_cfg(int code) { g_convd_cfg = code; }
-void convd_set_ns_max(int n) { g_convd_ns_max = n; }
 
 #ifdef FM_CONVD_TIMING
 extern "C" int fm_debug_convd_stamps(long long* out528, int set_abl) {

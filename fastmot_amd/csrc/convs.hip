@@ -433,10 +433,9 @@ extern "C" int fm_debug_convs_stamps(long long* out64) {
 // p.w: fragment-order weights (see header); p.K = KH * KW * Cin with Cin % 64 == 0; p.Kpad unused
 int launch_conv_streamed(const ConvParams& p_in, hipStream_t s) {
     ConvParams p = p_in;
-    // XCD-aware tile order: the larger operand's slice private to an XCD (FASTMOT_CONVS_ORDER=0: always cout-major, the order
-    // of rounds 2-4, for A/B runs)
-    static const bool by_operand = !(getenv("FASTMOT_CONVS_ORDER") && atoi(getenv("FASTMOT_CONVS_ORDER")) == 0);
-    p.weight_major = !by_operand || (size_t)p.Cout * p.K >= (size_t)p.N * p.H * p.W * p.Cin ? 1 : 0;
+    // XCD-aware tile order: the larger operand's slice private to an XCD (rounds 2-4: always the weights';
+    // profiles/r05_streamed_order_ab.txt)
+    p.weight_major = (size_t)p.Cout * p.K >= (size_t)p.N * p.H * p.W * p.Cin ? 1 : 0;
     FM_CHECK_ARG(p.Cin % 64 == 0 && p.in_cs % 8 == 0 && p.in_coff % 8 == 0 && p.K == p.KH * p.KW * p.Cin);
     FM_CHECK_ARG(p.out_cs % 4 == 0 && p.out_coff % 4 == 0 && p.cout_store % 4 == 0 && p.Cin <= 4096);
     FM_CHECK_ARG(p.res_mode == RES_NONE || (p.res_cs % 4 == 0 && p.res_coff % 4 == 0));

@@ -3,7 +3,6 @@
 // TRTInference) with plain HIP: one ctx per video stream, four HIP streams, pinned mirrors.
 #include "common.h"
 void convd_set_cfg(int code);             // convd.hip
-void convd_set_ns_max(int n);
 #include <sched.h>
 #include <cstring>
 #include <cstdlib>
@@ -26,7 +25,6 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "host_lap_elems")) ctx->opt_host_lap_elems = value;
     else if (!strcmp(key, "use_graphs")) ctx->opt_use_graphs = value;
     else if (!strcmp(key, "convd_cfg")) convd_set_cfg(value);
-    else if (!strcmp(key, "convd_ns_max")) convd_set_ns_max(value);
     else if (!strcmp(key, "nms_path")) {
         ctx->opt_nms_general = value != 0;
     }
@@ -124,15 +122,14 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     if (const char* e = getenv("FASTMOT_ZERO_COPY")) ctx->opt_zero_copy_tracks = atoi(e);
     if (const char* e = getenv("FASTMOT_HOST_LAP")) ctx->opt_host_lap_elems = atoi(e);
     if (const char* e = getenv("FASTMOT_GRAPHS")) ctx->opt_use_graphs = atoi(e);
-    if (const char* e = getenv("FASTMOT_CONVD_NS_MAX")) convd_set_ns_max(atoi(e));      // (A/B runs of whole pipelines)
     // the detector network is the long, throughput-oriented stream; tracker / KLT / ReID launches are
     // short and latency critical (the host waits on them), so they get the higher priority
     int prio_lo = 0, prio_hi = 0;
     FM_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least, hi = greatest priority
-    // FASTMOT_STREAM_PRIO (A/B runs, round 5): 0 = as described above; 1 = detector network high as well; 2 = detector high,
-    // ReID network low
-    const int prio_mode = getenv("FASTMOT_STREAM_PRIO") ? atoi(getenv("FASTMOT_STREAM_PRIO")) : 0;
-    const int prio_det = prio_mode >= 1 ? prio_hi : prio_lo, prio_ext = prio_mode == 2 ? prio_lo : prio_hi;
+    // (Round 5 measured the other assignments -- the levels are strict on this hardware: with the detector network high as
+    // well its pass takes 0.96 instead of 1.01 ms and the ReID network 0.90 instead of 0.47, 530 against 940 frames/s;
+    // profiles/r05_stream_priority_ab.txt.)
+    const int prio_det = prio_lo, prio_ext = prio_hi;
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, prio_hi));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_det, hipStreamNonBlocking, prio_det));
     FM_HIP(hipStreamCreateWithPriority(&ctx->s_up, hipStreamNonBlocking, prio_lo));

@@ -2069,15 +2069,12 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
 #endif
                 const dim3 grid2((unsigned)((((size_t)n + 1) / 2 * 64 + threads - 1) / threads));     // two points per wavefront
                 fm_trace_mark(ctx, s, 40);
-                static const bool no_patch = getenv("FASTMOT_LK_PATCH") && atoi(getenv("FASTMOT_LK_PATCH")) == 0;   // (A/B runs)
-                if (a.win == 5 && !no_patch)
+                // (PATCH = false, the global-load sampling of rounds 3-4, measured equal within the spread:
+                // profiles/r05_lk_patch_and_ring_depth_ab.txt)
+                if (a.win == 5)
                     hipLaunchKernelGGL((lk_pair_kernel<5, true>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
-                else if (a.win == 5)
-                    hipLaunchKernelGGL((lk_pair_kernel<5, false>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
-                else if (!no_patch)
-                    hipLaunchKernelGGL((lk_pair_kernel<3, true>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
                 else
-                    hipLaunchKernelGGL((lk_pair_kernel<3, false>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                    hipLaunchKernelGGL((lk_pair_kernel<3, true>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
                 fm_trace_mark(ctx, s, 41);
             }
         }

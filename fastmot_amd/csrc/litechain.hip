@@ -28,8 +28,8 @@ struct ChainGaps {
 // profiling build only (-DFM_LCH_TIMING, scripts/lch_timing.py): s_memtime stamps of workgroup (0, deepest stream)
 #ifdef FM_LCH_TIMING
 __device__ long long g_lch_stamps[32];
-#define LCH_STAMP(i) if ((deep_first & 2) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = __builtin_readcyclecounter();
-#define LCH_WALL(i) if ((deep_first & 2) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = wall_clock64();
+#define LCH_STAMP(i) if (record && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = __builtin_readcyclecounter();
+#define LCH_WALL(i) if (record && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_lch_stamps[i] = wall_clock64();
 #else
 #define LCH_STAMP(i)
 #define LCH_WALL(i)
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
     const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out, int out_cs, int out_coff_base,
     const f16* __restrict__ wpw_base, int kpad, const f16* __restrict__ wdw_base,
     const float* __restrict__ bias_base, int H, int W, int C, int th, int tw, int tiles_x, int tiles_y, int act,
-    ChainGaps gaps, int S, int ys_elems, int zb_elems, int deep_first) {
+    ChainGaps gaps, int S, int ys_elems, int zb_elems, int record) {
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
     f16* ys = lds;                       // pointwise output of the current level (halo region)
     f16* zb = lds + ys_elems;            // depthwise output of the previous level = operand of this one
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
     // blockIdx.y = 0 is the DEEPEST stream: workgroups are dispatched in (x, y) order, and a launch with more workgroups
     // than the chip holds at once (400 x 4 against 256 CUs x 3) should start its four-level chains first and fill the
     // tail with the one-level ones (longest-processing-time order), not the other way round.
-    const int stream = (deep_first & 1) ? gridDim.y - 1 - blockIdx.y : blockIdx.y, D = stream + 1, pset0 = stream * (stream + 1) / 2;
+    const int stream = gridDim.y - 1 - blockIdx.y, D = stream + 1, pset0 = stream * (stream + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     const int tile = blockIdx.x % (tiles_x * tiles_y);
@@ -266,10 +266,9 @@ void liteconv_tiling(int C, int W, int H, int* th, int* tw, int* tiles_x, int* t
 // Pixel stride of the LDS tiles, in halfs.  C + 8 where C / 8 is even keeps the 16-byte accesses of 32 consecutive pixels
 // off each other's banks; C = 16 goes unpadded: its 32-byte pixels are conflict-free for the 16-byte reads of both phases
 // (two-way only for phase A's 8-byte stores), and 35 KB instead of 51 KB per workgroup puts four of them on a CU where
-// the 64 x 32 stage of a 50-crop pass has 1600 to run.  (FASTMOT_LCH_PAD=1: A/B, the padded layout.)
+// the 64 x 32 stage of a 50-crop pass has 1600 to run.
 static int lds_stride(int C) {
-    static const int pad16 = getenv("FASTMOT_LCH_PAD") ? atoi(getenv("FASTMOT_LCH_PAD")) : 0;
-    if (C == 16 && !pad16) return 16;
+    if (C == 16) return 16;
     return C + (((C >> 3) & 1) ? 0 : 8);
 }
 
@@ -304,20 +303,18 @@ int launch_litechain(const f16* in, int in_cs, int in_coff, f16* out, int out_cs
     const long wgs = (long)N * tiles_x * tiles_y * 4;
     const dim3 grid((unsigned)(wgs / 4), 4);
     // few workgroups: wider ones (see the kernel)
-    static const long wide_max = getenv("FASTMOT_LCH_WIDE_MAX") ? atol(getenv("FASTMOT_LCH_WIDE_MAX")) : 384;   // A/B
-    const int nthr = wgs <= wide_max ? 512 : 256;
-    static const int order = !(getenv("FASTMOT_LCH_ORDER") && atoi(getenv("FASTMOT_LCH_ORDER")) == 0);   // A/B
-    int deep_first = order;
+    const int nthr = wgs <= 384 ? 512 : 256;     // (800: 396.7 vs 397.8 us per 50-crop pass, profiles/r05_osnet_launch_shapes_ab.txt)
+    int record = 0;                              // (profiling build: this launch keeps its stamps)
 #ifdef FM_LCH_TIMING
     // the stamps of the FASTMOT_LCH_TIMING_LAUNCH-th chain launch of every six (OSNet has six) are the ones kept
     static int launches = 0;
     static const int pick = getenv("FASTMOT_LCH_TIMING_LAUNCH") ? atoi(getenv("FASTMOT_LCH_TIMING_LAUNCH")) : 5;
-    if (launches++ % 6 == pick) deep_first |= 2;
+    if (launches++ % 6 == pick) record = 1;
 #endif
 #define LCH_LAUNCH_T(NT_, KS_, NTHR_)                                                                             \
     hipLaunchKernelGGL((litechain_kernel<NT_, KS_, NTHR_>), grid, dim3(NTHR_), shmem, s, in, in_cs, in_coff, out, \
                        out_cs, out_coff, wpw, kpad, wdw, bias, H, W, C, th, tw, tiles_x, tiles_y, act, gaps, S,   \
-                       ys_elems, zb_elems, deep_first)
+                       ys_elems, zb_elems, record)
 #define LCH_LAUNCH(NT_, KS_)                                                                                      \
     {                                                                                                             \
         bool done_ = false;                                                                                       \

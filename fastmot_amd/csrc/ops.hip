@@ -344,10 +344,6 @@ struct GatedSumPartArgs {
 // Pixels per workgroup: with 256 / (C / 8) (at least 64) every thread owns ONE (pixel, 8-channel group) item whose four
 // stream vectors are requested at kernel entry, under the gate MLP's three LDS round trips, and the launch has 2-4x the
 // workgroups (x0.25, 64 x 32 stage: 800 instead of 400); the per-workgroup MLP is a few hundred FMAs.
-static int gs2_pix_default() {
-    static const int v = getenv("FASTMOT_GS2_PIX") ? atoi(getenv("FASTMOT_GS2_PIX")) : 0;   // A/B: 256 = round 4's shape
-    return v;
-}
 __global__ __launch_bounds__(256) void gated_sum_part_kernel(GatedSumPartArgs a, int HW, int C, int hid, int tiles,
                                                              int GS2_PIX,
                                                              const f16* __restrict__ w1,
@@ -586,7 +582,7 @@ int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const
         }
         const size_t shmem = ((size_t)8 * C + 4 * hid + 2 * (size_t)hid * C + hid + C + (size_t)nstreams * tiles * C) * sizeof(float);
         FM_CHECK_ARG(shmem <= 64 * 1024);
-        const int pix = gs2_pix_default() > 0 ? gs2_pix_default() : (256 / (C / 8) > 64 ? 256 / (C / 8) : 64);
+        const int pix = 256 / (C / 8) > 64 ? 256 / (C / 8) : 64;
         hipLaunchKernelGGL(gated_sum_part_kernel, dim3((HW + pix - 1) / pix, N), dim3(256), shmem, s, a, HW,
                            C, hid, tiles, pix, w1, b1, w2, b2, out, out_cs, out_coff);
         FM_HIP(hipGetLastError());

@@ -137,7 +137,7 @@ class Graph:
         # streamed kernel only for the stride-2 3x3 convs into a map of >= 1024 pixels (the streamed kernel keeps the
         # 38 x 38 / 19 x 19 levels: 13.5 vs 14.1 us and 15.1 vs 19.4 us on their 3x3 layers); 2 = wherever it applies
         self.convd_level = int(os.environ.get('FASTMOT_CONVD', '1'))
-        self.convd_min_cin1 = int(os.environ.get('FASTMOT_CONVD_MIN_CIN1', '16'))   # smallest cin of a 1x1 layer on it (A/B: 64)
+        self.convd_min_cin1 = 16   # smallest cin of a 1x1 layer on it (64: profiles/r05_osnet_pointwise_on_convd_ab.txt)
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)

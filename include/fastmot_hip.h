@@ -54,7 +54,6 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
  * DIoU-NMS kernel for up to 4096 candidates per frame, the three-kernel sort / bit-matrix / scan path beyond; 1 = always
  * the latter), "convd_cfg" (default 0 = chosen per layer; bm | bn << 8 | kg << 16 | ns << 20 forces one tile /
  * K-group / ring configuration of FM_OP_CONVD for A/B measurements; read at every launch that is not a graph replay),
- * "convd_ns_max" (default 0 = none: cap of the ring depth FM_OP_CONVD chooses, i.e. of its LDS footprint; A/B measurements),
  * "use_graphs" (default 1;
  * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (diagnostic builds only, include/fastmot_hip_diag.h;
  * 0 is the only value the shipped library accepts).  Initial values can be set with the environment
