@@ -546,8 +546,8 @@ def test_convd_conv(ctx, cin, cout, k, stride, act, h, w, n, extra, cfg):
                    res_mode=RES_BEFORE_ACT if extra == 'resb' else 1, bn=extra != 'f32')
         assert g.layers[-1]['op'] == (17 if level else 0)
         net = HipNet(ctx, NET_DETECTOR, g, n)
-        for _ in range(2):                          # eager validation + capture, then a graph replay
-            net.write(g.input, x)
+        for xi in (x[:, ::-1].copy(), x):           # eager validation + capture, then a graph replay -- on another input, so
+            net.write(g.input, xi)                  # that a replay which did nothing could not pass on the first launch's output
             net.run(n)
         outs.append(net.read(wide, n)[..., 64:64 + cout])
         if level:
