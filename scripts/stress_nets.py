@@ -45,9 +45,15 @@ def run_yolo():
     return np.concatenate([ynet.read(h, 1).ravel() for h in heads])
 
 
+# (the victim's last feature map, not its embeddings: every OSNet graph of a context writes its head's output to the
+# context's ONE embedding bank at the row offset the extractor gives it -- a hammer OSNet launched by hand writes rows 0..49
+# like the victim, and round 5 first read "9 of 300 embeddings differ" off that shared buffer)
+_pre_head = go.layers[-1]['ins'][0]
+
+
 def run_osnet():
     onet.run(50)
-    return onet.read_embeddings(50).ravel()
+    return onet.read(_pre_head, 50).astype(np.float32).ravel()
 
 
 n = 50
@@ -73,7 +79,7 @@ def run_assoc():
     return np.concatenate([np.asarray(tlbr).ravel(), np.asarray(pw).ravel(), mean.ravel(), cov.ravel()])
 
 
-victims = (('yolov4 heads', run_yolo), ('osnet embeddings', run_osnet), ('kalman+pairwise', run_assoc))
+victims = (('yolov4 heads', run_yolo), ('osnet last feature map', run_osnet), ('kalman+pairwise', run_assoc))
 base = {name: fn() for name, fn in victims}
 for kind in ('liteconv', 'osnet', 'yolov4'):
     net, batch = hammer_net(kind)
@@ -91,6 +97,8 @@ for kind in ('liteconv', 'osnet', 'yolov4'):
     res = {}
     try:
         for name, fn in victims:
+            if kind == 'osnet' and name == 'kalman+pairwise':
+                continue            # (reads the embedding bank the hammer's head layer writes: not a victim of this hammer)
             bad, worst = 0, 0.
             for _ in range(N):
                 out = fn()
