@@ -63,7 +63,7 @@ __device__ __forceinline__ typename HalfVec<EPT>::T pack_n(const float* f) {
 // channels -- the pixel sequence of every channel, and with it the order of the gate's partial sums, is the same
 // for every SUB: results do not depend on the launch shape.
 template <int NT, int KS, int NTHR>
-__global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void litechain_kernel(
+__global__ __launch_bounds__(NTHR, NTHR != 256 ? 1 : NT * KS == 1 ? 4 : NT * KS == 2 ? 3 : 1) void litechain_kernel(
     const f16* __restrict__ in, int in_cs, int in_coff, f16* __restrict__ out, int out_cs, int out_coff_base,
     const f16* __restrict__ wpw_base, int kpad, const f16* __restrict__ wdw_base,
     const float* __restrict__ bias_base, int H, int W, int C, int th, int tw, int tiles_x, int tiles_y, int act,
@@ -121,16 +121,31 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
 
     for (int lvl = 0; lvl < D; ++lvl) {
         const int hl = D - lvl;                           // halo of this level's pointwise region
-        const int wp = tw + 2 * hl, hp = th + 2 * hl, npos = wp * hp;
+        // The region [X0, X1) x [Y0, Y1): the tile grown by the halo, CLIPPED to the image plus one ring of padding.  Nothing
+        // further out is ever needed -- it is zero at every level -- and for the tiles of OSNet's maps most of the halo
+        // lies out there: a 16 x 8 map is one tile (level 0: 18 x 10 positions instead of 24 x 16), the 32 x 16 and 64 x 32
+        // maps are two tiles wide (round 5: 1112 -> 720 pointwise and 856 -> 668 depthwise positions per depth-4 chain of
+        // the 16 x 8 stage; the values, and the order of the gate's sums, are unchanged).
+        const int X0 = max(tx0 - hl, -1), X1 = min(tx0 + tw + hl, W + 1);
+        const int Y0 = max(ty0 - hl, -1), Y1 = min(ty0 + th + hl, H + 1);
+        const int wp = X1 - X0, hp = Y1 - Y0, npos = wp * hp;
+        // the depthwise output region: the next level's pointwise region, or at the last level the tile itself (unclipped:
+        // its pixel enumeration is the order of the gate's partial sums, the same as in liteconv.hip)
+        const bool last = lvl == D - 1;
+        const int X0n = last ? tx0 : max(tx0 - hl + 1, -1), X1n = last ? tx0 + tw : min(tx0 + tw + hl - 1, W + 1);
+        const int Y0n = last ? ty0 : max(ty0 - hl + 1, -1), Y1n = last ? ty0 + th : min(ty0 + th + hl - 1, H + 1);
+        const int wz = X1n - X0n, hz = Y1n - Y0n;
+        const int ax = X0n - 1 - X0, ay = Y0n - 1 - Y0;   // top-left tap of output (0, 0) in this level's region (-1 only where
+                                                          // the output lies outside the image and reads nothing)
         // floor(i / d) = (i * ceil(2^16 / d)) >> 16 for i < 2048, d <= 32 (regions are at most 24 x 24)
-        const unsigned rcp_wp = (65536u + wp - 1) / wp, rcp_wz = (65536u + wp - 3) / (wp - 2);
+        const unsigned rcp_wp = (65536u + wp - 1) / wp, rcp_wz = (65536u + wz - 1) / wz;
 
         // ---- phase A
         const int mtiles = (npos + 31) / 32;
         for (int mt = wave; mt < mtiles; mt += NWAVES) {
             const int pos = mt * 32 + frow, posc = min(pos, npos - 1);
             const int prow = (int)(((unsigned)posc * rcp_wp) >> 16);
-            const int py = ty0 - hl + prow, px = tx0 - hl + (posc - prow * wp);
+            const int py = Y0 + prow, px = X0 + (posc - prow * wp);
             const bool inside = pos < npos && py >= 0 && py < H && px >= 0 && px < W;
             // operand rows: the block input in HBM/L2 at level 0, the previous level's LDS tile afterwards (it
             // covers exactly this region and is zero outside the image).  (Requesting all of a wave's level-0
@@ -181,8 +196,6 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
         }
 
         // ---- phase B
-        const int wz = wp - 2, hz = hp - 2;
-        const bool last = lvl == D - 1;
         const f16* wdl = wd + lvl * 9 * C;
         if (active) {
             // this thread's bias and depthwise taps of the level; the taps stay packed halfs (v_fma_mix_f32 extends both
@@ -195,13 +208,20 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
             for (int t = 0; t < 9; ++t) kh[t] = *reinterpret_cast<const hvec*>(&wdl[t * C + ch0]);
             for (int pix = pl; pix < wz * hz; pix += lanes_px) {
                 const int oy = (int)(((unsigned)pix * rcp_wz) >> 16), ox = pix - oy * wz;
-                const int gy = ty0 - (hl - 1) + oy, gx = tx0 - (hl - 1) + ox;
+                const int gy = Y0n + oy, gx = X0n + ox;
                 const bool in_img = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                if (last && !in_img) continue;
+                if (!in_img) {                              // outside the image: the next level's zero padding, nothing to read
+                    if (!last) {
+                        hvec zero;
+                        memset(&zero, 0, sizeof(zero));
+                        *reinterpret_cast<hvec*>(&zb[pix * S + ch0]) = zero;
+                    }
+                    continue;
+                }
                 float acc[EPT];
 #pragma unroll
                 for (int e = 0; e < EPT; ++e) acc[e] = b8[e];
-                const f16* yp = &ys[(oy * wp + ox) * S + ch0];
+                const f16* yp = &ys[((oy + ay) * wp + ox + ax) * S + ch0];
                 hvec raw[9];                                // all nine taps requested before the first FMA
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
@@ -214,7 +234,6 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && NT * KS <= 2) ? 4 : 1) void l
                 apply_act_n<EPT>(acc, act);
                 hvec o = pack_n<EPT>(acc);
                 if (!last) {
-                    if (!in_img) memset(&o, 0, sizeof(o));
                     *reinterpret_cast<hvec*>(&zb[pix * S + ch0]) = o;
                 } else {
                     *reinterpret_cast<hvec*>(dst + ((long)gy * W + gx) * out_cs + ch0) = o;
