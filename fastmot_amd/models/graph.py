@@ -243,7 +243,7 @@ class Graph:
 
     def resblock_pays(self, c, mid, h, w):
         """The fused residual unit (resblock.hip) against its two convs on the DMA kernel (convd.hip, shortcut in the
-        3x3's epilogue): measured per shape in round 5 (profiles/r05_p6_layers_*.txt) -- at 80 x 80 x 256 (YOLOv4-P6) the
+        3x3's epilogue): measured per shape in round 5 (profiles/r05_layers_YOLOv4P6_1280_convd*.txt and the sweeps r05_convd_sweep*.txt) -- at 80 x 80 x 256 (YOLOv4-P6) the
         fused unit takes 41.5 us, the pair 6.7 + 18.5 us; at 160 x 160 x 128 25.4 against 7 + 16.5; on the maps of
         YOLOv4 @ 608 / -CSP @ 640 (<= 0.8 M activations per unit) the fused unit wins (8.9 against ~13 us at
         76 x 76 x 128).  Without the DMA kernel the fused unit always pays."""
