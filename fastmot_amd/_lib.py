@@ -283,7 +283,10 @@ class HipContext:
         return out
 
     def assoc_prepare(self, metric, slots, trk_tlbr, trk_label, det_tlbr, det_label, det_occluded,
-                      trk_feat_f32=None):
+                      trk_feat_f32=None, after_extractor=False):
+        """All pairwise terms of this frame in one launch (fm_assoc_prepare2).  after_extractor: the embeddings are the
+        batch extract_async enqueued last and may still be in flight (ordered on the device).  Returns True when the
+        terms also reach page-locked host memory, i.e. `assoc_cascade` can run the whole cascade in one call."""
         s = _as(slots, np.int32)
         nT = len(s)
         tb = _as(trk_tlbr, np.float64).reshape(nT, 4)
@@ -294,8 +297,31 @@ class HipContext:
         do = _as(det_occluded, np.uint8)
         f32 = np.zeros(nT, np.uint8) if trk_feat_f32 is None else _as(trk_feat_f32, np.uint8)
         assert len(tl) == nT and len(dl) == nD and len(do) == nD and len(f32) == nT
-        check(self.lib.fm_assoc_prepare(self._ctx, C.c_int(metric), C.c_int(nT), _ptr(s), _ptr(tb),
-                                        _ptr(tl), C.c_int(nD), _ptr(db), _ptr(dl), _ptr(do), _ptr(f32)))
+        host = C.c_int(0)
+        check(self.lib.fm_assoc_prepare2(self._ctx, C.c_int(metric), C.c_int(nT), _ptr(s), _ptr(tb),
+                                         _ptr(tl), C.c_int(nD), _ptr(db), _ptr(dl), _ptr(do), _ptr(f32),
+                                         C.c_int(1 if after_extractor else 0), C.byref(host)))
+        return bool(host.value)
+
+    def cascade_pack(self, group_sizes, conf_rows, conf_active, unconf_rows, hist_rows, hist_labels, det_conf,
+                     motion_weight, max_assoc_cost, fill_val, max_iou_cost, conf_thresh, max_reid_cost):
+        """Packs the arguments of `assoc_cascade` (fm_cascade_in); everything here is known before the embeddings are."""
+        off = np.zeros(len(group_sizes) + 1, np.int32)
+        np.cumsum(group_sizes, out=off[1:])
+        arrs = (off, _as(conf_rows, np.int32), _as(conf_active, np.uint8), _as(unconf_rows, np.int32),
+                _as(hist_rows, np.int32), _as(hist_labels, np.int64), _as(det_conf, np.float64))
+        cin = CascadeIn(len(group_sizes), len(arrs[3]), len(arrs[4]), 0,
+                        *(a.__array_interface__['data'][0] for a in arrs),
+                        motion_weight, max_assoc_cost, fill_val, max_iou_cost, conf_thresh, max_reid_cost)
+        n_trk = len(arrs[1]) + len(arrs[3])
+        out = np.empty(CASCADE_HEADER + 3 * n_trk + 3 * len(arrs[6]), np.int32)
+        return cin, arrs, out
+
+    def assoc_cascade(self, pack):
+        """The association cascade in one call (fm_assoc_cascade); returns the output words as a list."""
+        cin, _, out = pack
+        check(self.lib.fm_assoc_cascade(self._ctx, C.byref(cin), _ptr(out), C.c_int(len(out))))
+        return out[:out[9]].tolist()
 
     def assoc_get_pairwise(self, nT, nD):
         feat = np.empty((nT, nD), np.float64)
@@ -344,6 +370,18 @@ class HipContext:
         check(self.lib.fm_greedy(self._ctx, _ptr(cm), C.c_int(nr), C.c_int(nc), C.c_double(max_cost),
                                  _ptr(m_rows), _ptr(m_cols), C.byref(n_match)))
         return m_rows[:n_match.value], m_cols[:n_match.value]
+
+
+CASCADE_HEADER = 16
+
+
+class CascadeIn(C.Structure):          # fm_cascade_in
+    _fields_ = [('n_groups', C.c_int32), ('n_unconf', C.c_int32), ('n_hist', C.c_int32), ('reserved', C.c_int32),
+                ('group_off', C.c_void_p), ('conf_rows', C.c_void_p), ('conf_active', C.c_void_p),
+                ('unconf_rows', C.c_void_p), ('hist_rows', C.c_void_p), ('hist_labels', C.c_void_p),
+                ('det_conf', C.c_void_p),
+                ('motion_weight', C.c_double), ('max_assoc_cost', C.c_double), ('fill_val', C.c_double),
+                ('max_iou_cost', C.c_double), ('conf_thresh', C.c_double), ('max_reid_cost', C.c_double)]
 
 
 METRIC_EUCLIDEAN = 0
@@ -469,10 +507,13 @@ def _bind_device_io(cls):
         check(self.lib.fm_detect_preprocess_only(self._ctx))
 
     def detect_sync(self, cap=4096):
-        out = np.zeros(cap, DET_DTYPE)
+        # (a staging array kept across calls: a fresh 196 KB np.zeros per frame cost ~10 us on the step's critical chain)
+        out = getattr(self, '_det_stage', None)
+        if out is None or len(out) < cap:
+            out = self._det_stage = np.zeros(cap, DET_DTYPE)
         n = C.c_int(0)
         check(self.lib.fm_detect_sync(self._ctx, _ptr(out), C.c_int(cap), C.byref(n)))
-        return out[:n.value].view(np.recarray)
+        return out[:n.value].copy().view(np.recarray)
 
     def filter_dets(self, rows, cap=8192):
         r = _as(rows, np.float32).reshape(-1, 7)

@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
     const float* __restrict__ favg, const int32_t* __restrict__ fcnt,
     const float* __restrict__ emb, KFConst kf, const uint8_t* __restrict__ row_f32,
     double* __restrict__ feat, double* __restrict__ maha, double* __restrict__ iou,
-    uint8_t* __restrict__ row_has_feat) {
+    uint8_t* __restrict__ row_has_feat, char* __restrict__ mirror) {
+    // mirror (may be null): the same four arrays at the same offsets in page-locked host memory -- the host cascade
+    // (fm_assoc_cascade) reads them there, no copy is enqueued
+    const size_t mat = (size_t)nT * nD;
+    double* const mfeat = reinterpret_cast<double*>(mirror);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sa = reinterpret_cast<float*>(smem);                         // [dim]
     double* sd = reinterpret_cast<double*>(smem + (size_t)dim * 4);     // L[16], pm[4], tb[4], area
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
         }
         sd[24] = box_area(trk_tlbr + (size_t)t * 4);
         row_has_feat[t] = cnt > 0 ? 1 : 0;
+        if (mirror) reinterpret_cast<uint8_t*>(mfeat + 3 * mat)[t] = cnt > 0 ? 1 : 0;
     }
     __syncthreads();
     for (int d = tid; d < nD; d += 256) {
@@ -140,8 +145,14 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
             for (int k = 0; k < i; ++k) s -= sd[i * 4 + k] * y[k];
             y[i] = s / sd[i * 4 + i];
         }
-        maha[(size_t)t * nD + d] = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
-        iou[(size_t)t * nD + d] = iou_dist_pair(sd + 20, sd[24], z);
+        const double md = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+        const double io = iou_dist_pair(sd + 20, sd[24], z);
+        maha[(size_t)t * nD + d] = md;
+        iou[(size_t)t * nD + d] = io;
+        if (mirror) {
+            mfeat[mat + (size_t)t * nD + d] = md;
+            mfeat[2 * mat + (size_t)t * nD + d] = io;
+        }
     }
     // feature distance: one wave per detection column (distance.py:47-87).  Accumulators are
     // f64; each term has the type the reference's operands give it: track feature f64 x embedding
@@ -188,10 +199,14 @@ __global__ __launch_bounds__(256) void pairwise_kernel(
                 if (metric == FM_METRIC_COSINE) v = 1. - acc0 / (sqrt(acc1) * sqrt(acc2));
                 else v = sqrt(acc0);
                 feat[(size_t)t * nD + d] = v;
+                if (mirror) mfeat[(size_t)t * nD + d] = v;
             }
         }
     } else {
-        for (int d = tid; d < nD; d += 256) feat[(size_t)t * nD + d] = 1.;
+        for (int d = tid; d < nD; d += 256) {
+            feat[(size_t)t * nD + d] = 1.;
+            if (mirror) mfeat[(size_t)t * nD + d] = 1.;
+        }
     }
 }
 
@@ -719,18 +734,25 @@ extern "C" int fm_iou_dist(fm_ctx* ctx, int na, const double* a, int nb, const d
 }
 
 
-extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* slots,
-                                const double* trk_tlbr, const int64_t* trk_label, int nD,
-                                const double* det_tlbr, const int64_t* det_label,
-                                const uint8_t* det_occluded, const uint8_t* trk_feat_f32) {
+// after_extractor: the embeddings are the batch fm_extract_async enqueued last -- the pairwise kernel is ordered behind
+// the ReID network's last launch ON THE DEVICE (ev_ext_net), so the call may be made while that network still runs.
+static int assoc_prepare_impl(fm_ctx* ctx, int metric, int nT, const int32_t* slots,
+                              const double* trk_tlbr, const int64_t* trk_label, int nD,
+                              const double* det_tlbr, const int64_t* det_label,
+                              const uint8_t* det_occluded, const uint8_t* trk_feat_f32, bool after_extractor) {
     FM_CHECK_ARG(ctx && nT >= 0 && nD >= 0 && ctx->kf_set);
     FM_CHECK_ARG(metric == FM_METRIC_EUCLIDEAN || metric == FM_METRIC_COSINE);
     ctx->as_nT = nT;
     ctx->as_nD = nD;
     ctx->as_metric = metric;
+    ctx->as_mirror = false;
     if (nT == 0 || nD == 0) return 0;
     FM_CHECK_ARG(slots && trk_tlbr && trk_label && det_tlbr && det_label && det_occluded && trk_feat_f32);
     FM_CHECK_ARG(nD <= ctx->emb_n);
+    if (after_extractor && !ctx->ext_net_recorded) {
+        fm_set_error("fm_assoc_prepare2(after_extractor): the embeddings on the device do not come from fm_extract_async");
+        return FM_ERR_STATE;
+    }
     for (int i = 0; i < nT; ++i) FM_CHECK_ARG(slots[i] >= 0 && slots[i] < ctx->slot_cap);
     std::vector<size_t> offs;
     int rc = upload(ctx, ctx->as_in,
@@ -744,17 +766,282 @@ extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* 
     if ((rc = ctx->as_pair.reserve(3 * mat + nT + 64))) return rc;
     char* in = ctx->as_in.dev<char>();
     char* pr = ctx->as_pair.dev<char>();
+    // small problems: the terms also go to the buffer's page-locked mirror, where the host cascade reads them
+    const bool mirror = FM_ZERO_COPY_TRACKS > 0 && (size_t)nT * nD <= (size_t)ctx->opt_host_lap_elems;
     const size_t shmem = (size_t)ctx->feat_dim * 4 + 32 * sizeof(double);
+    if (after_extractor) FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_ext_net, 0));
     fm_trace_mark(ctx, ctx->s_main, 54);
     hipLaunchKernelGGL(pairwise_kernel, dim3(nT), dim3(256), shmem, ctx->s_main, nT, nD, metric,
                        ctx->feat_dim, (const int32_t*)(in + offs[0]), (const double*)(in + offs[1]),
                        (const double*)(in + offs[3]), ctx->mean, ctx->cov, ctx->feat_avg, ctx->feat_cnt,
                        ctx->emb, ctx->kf, (const uint8_t*)(in + offs[6]), (double*)pr, (double*)(pr + mat),
                        (double*)(pr + 2 * mat),
-                       (uint8_t*)(pr + 3 * mat));
+                       (uint8_t*)(pr + 3 * mat), mirror ? ctx->as_pair.host<char>() : nullptr);
     FM_HIP(hipGetLastError());
     fm_trace_mark(ctx, ctx->s_main, 55);
+    if (mirror) FM_HIP(hipEventRecord(ctx->ev_pair, ctx->s_main));
+    ctx->as_mirror = mirror;
     return 0;
+}
+
+extern "C" int fm_assoc_prepare(fm_ctx* ctx, int metric, int nT, const int32_t* slots,
+                                const double* trk_tlbr, const int64_t* trk_label, int nD,
+                                const double* det_tlbr, const int64_t* det_label,
+                                const uint8_t* det_occluded, const uint8_t* trk_feat_f32) {
+    return assoc_prepare_impl(ctx, metric, nT, slots, trk_tlbr, trk_label, nD, det_tlbr, det_label, det_occluded,
+                              trk_feat_f32, false);
+}
+
+extern "C" int fm_assoc_prepare2(fm_ctx* ctx, int metric, int nT, const int32_t* slots,
+                                 const double* trk_tlbr, const int64_t* trk_label, int nD,
+                                 const double* det_tlbr, const int64_t* det_label,
+                                 const uint8_t* det_occluded, const uint8_t* trk_feat_f32, int after_extractor,
+                                 int* host_cascade) {
+    int rc = assoc_prepare_impl(ctx, metric, nT, slots, trk_tlbr, trk_label, nD, det_tlbr, det_label, det_occluded,
+                                trk_feat_f32, after_extractor != 0);
+    if (host_cascade) *host_cascade = (rc == 0 && ctx->as_mirror) ? 1 : 0;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// The association cascade of MultiTracker.update (tracker.py:198-248) in ONE call, on the host, for the problem sizes
+// whose assignment is solved on the host anyway (fm_lap_host: measured ~5x faster than one wavefront at every size,
+// profiles/r02_lap_crossover.txt).  The pairwise terms -- the arithmetic of the stage -- come from pairwise_kernel through
+// as_pair's page-locked mirror; what runs here is what stage_cost_kernel does per stage (a gather, one multiply-add and
+// the gates: the same IEEE doubles, this file is built with -ffp-contract=off for host and device), the solver, and the
+// reference's list bookkeeping between the stages, whose ORDER decides track IDs (utils/matching.py:58-70 with Numba's
+// set iteration order, utils/setorder.py).  Per-stage device launches + host wake-ups + Python round trips cost
+// ~25 us per stage on a GPU the two networks keep busy (profiles/r05_pipeline_trace.txt: 214 us between the embeddings
+// and the end of the step for 46 us of kernels); larger problems keep the per-stage device path (fm_assoc_stage).
+// ---------------------------------------------------------------------------------------
+namespace {
+
+// list(set(range(n)) - set(matched)) as Numba's integer set iterates it (fastmot_amd/utils/setorder.py)
+void unmatched_order(int n, const std::vector<uint8_t>& gone, std::vector<int>& out) {
+    out.clear();
+    for (int k = 0; k < n; ++k)
+        if (!gone[k]) out.push_back(k);
+    int size = 16;
+    while (size < 2 * n) size <<= 1;
+    const int min_entries = std::max(2 * (int)out.size(), 16);
+    if (4 * min_entries > size || size <= 16) return;
+    while ((size >> 1) >= min_entries) size >>= 1;
+    const int mask = size - 1;
+    if (out.empty() || out.back() <= mask) return;
+    std::vector<int> table(size, -1);
+    for (int k : out) {
+        unsigned index = k & mask, perturb = k;
+        int probes = 0;
+        for (; probes < 3; ++probes) {
+            if (table[index] < 0) break;
+            index = (index + 1) & mask;
+        }
+        if (probes == 3)
+            while (table[index] >= 0) {
+                perturb >>= 5;
+                index = (index * 5 + 1 + perturb) & mask;
+            }
+        table[index] = k;
+    }
+    out.clear();
+    for (int k : table)
+        if (k >= 0) out.push_back(k);
+}
+
+struct Pairwise {
+    const double *feat, *maha, *iou;
+    const uint8_t* has_feat;
+    const int64_t *tlab, *dlab;
+    const uint8_t* docc;
+    int nD;
+};
+
+// one linear-assignment stage (utils/matching.py:10-30,58-70): rows[] = pairwise rows, cols = detection ids.
+// matches: (index into rows[], detection id); u_rows: indices into rows[]; u_cols: detection ids.
+int lap_stage(fm_ctx* ctx, const Pairwise& P, int stage, const int32_t* rows, int nr, const std::vector<int>& cols,
+              double motion_weight, double max_cost, double fill_val, std::vector<double>& cost,
+              std::vector<std::pair<int, int>>& matches, std::vector<int>& u_rows, std::vector<int>& u_cols) {
+    const int nc = (int)cols.size();
+    matches.clear();
+    std::vector<uint8_t> rgone(nr, 0), cgone(nc, 0);
+    std::vector<int32_t> m_rows, m_cols;
+    std::vector<double> m_cost;
+    int n_match = 0;
+    if (nr > 0 && nc > 0) {
+        cost.resize((size_t)nr * nc);
+        const double norm_factor = 1. / CHI_SQ_INV_95, f_weight = 1. - motion_weight;
+        for (int i = 0; i < nr; ++i) {
+            const int t = rows[i];
+            for (int j = 0; j < nc; ++j) {
+                const int d = cols[j];
+                const size_t p = (size_t)t * P.nD + d;
+                const bool lab_bad = P.tlab[t] != P.dlab[d];
+                double c;
+                if (stage == FM_STAGE_MATCHING) {        // tracker.py:326-340 ; utils/matching.py:101-107
+                    const bool empty = (!P.has_feat[t]) || P.docc[d];
+                    const double f = empty ? fill_val : P.feat[p];
+                    const double md = P.maha[p];
+                    c = f_weight * f + (motion_weight * norm_factor) * md;
+                    if (md > CHI_SQ_INV_95) c = INF_COST;
+                    if (lab_bad || c > max_cost) c = INF_COST;
+                } else {                                 // tracker.py:351-352
+                    c = P.iou[p];
+                    if (lab_bad || c > max_cost) c = INF_COST;
+                }
+                cost[(size_t)i * nc + j] = c;
+            }
+        }
+        const int mn = nr < nc ? nr : nc;
+        m_rows.resize(mn); m_cols.resize(mn); m_cost.resize(mn);
+        int rc = run_lap(ctx, nullptr, nr, nc, m_rows.data(), m_cols.data(), &n_match, m_cost.data(), cost.data());
+        if (rc) return rc;
+        for (int k = 0; k < n_match; ++k) { rgone[m_rows[k]] = 1; cgone[m_cols[k]] = 1; }
+    }
+    std::vector<int> uc;
+    unmatched_order(nr, rgone, u_rows);
+    unmatched_order(nc, cgone, uc);
+    u_cols.clear();
+    for (int c : uc) u_cols.push_back(cols[c]);
+    for (int k = 0; k < n_match; ++k) {
+        if (m_cost[k] < INF_COST) matches.emplace_back(m_rows[k], cols[m_cols[k]]);
+        else { u_rows.push_back(m_rows[k]); u_cols.push_back(cols[m_cols[k]]); }
+    }
+    return 0;
+}
+
+}  // namespace
+
+static int cascade_run(const Pairwise& P, int nT, int nD, const fm_cascade_in* in, int32_t* out, int out_cap) {
+    fm_ctx* ctx = nullptr;          // (run_lap's host branch does not touch the context)
+    FM_CHECK_ARG(in && out && in->n_groups >= 0 && in->n_unconf >= 0 && in->n_hist >= 0 && nT > 0 && nD > 0);
+    FM_CHECK_ARG(in->group_off && in->det_conf);
+    const int n_conf = in->group_off[in->n_groups];
+    FM_CHECK_ARG(n_conf >= 0 && (n_conf == 0 || (in->conf_rows && in->conf_active)));
+    FM_CHECK_ARG(in->n_unconf == 0 || in->unconf_rows);
+    FM_CHECK_ARG(in->n_hist == 0 || (in->hist_rows && in->hist_labels));
+    for (int i = 0; i < n_conf; ++i) FM_CHECK_ARG(in->conf_rows[i] >= 0 && in->conf_rows[i] < nT);
+    for (int i = 0; i < in->n_unconf; ++i) FM_CHECK_ARG(in->unconf_rows[i] >= 0 && in->unconf_rows[i] < nT);
+    for (int i = 0; i < in->n_hist; ++i) FM_CHECK_ARG(in->hist_rows[i] >= 0 && in->hist_rows[i] < nT);
+    FM_CHECK_ARG(out_cap >= FM_CASCADE_HEADER + 3 * (n_conf + in->n_unconf) + 3 * nD);
+    std::vector<double> cost;
+    std::vector<std::pair<int, int>> m;
+    std::vector<int> u_rows, u_det(nD), nxt;
+    for (int d = 0; d < nD; ++d) u_det[d] = d;
+    int32_t* hdr = out;
+    int32_t* w = out + FM_CASCADE_HEADER;
+    // ---- 1st association: motion + embeddings, depth by depth (tracker.py:205-218)
+    std::vector<int> u1;          // indices into conf_rows
+    int n1 = 0;
+    for (int g = 0; g < in->n_groups; ++g) {
+        const int b = in->group_off[g], e = in->group_off[g + 1];
+        if (u_det.empty()) {
+            for (int i = b; i < n_conf; ++i) u1.push_back(i);
+            break;
+        }
+        if (e == b) continue;
+        int rc = lap_stage(ctx, P, FM_STAGE_MATCHING, in->conf_rows + b, e - b, u_det, in->motion_weight,
+                           in->max_assoc_cost, in->fill_val, cost, m, u_rows, nxt);
+        if (rc) return rc;
+        for (auto& mm : m) { *w++ = in->conf_rows[b + mm.first]; *w++ = mm.second; ++n1; }
+        for (int r : u_rows) u1.push_back(b + r);
+        u_det.swap(nxt);
+    }
+    // ---- 2nd association with IoU: the active ones among the unmatched (tracker.py:220-226)
+    std::vector<int32_t> act_rows;
+    std::vector<int> inact;
+    for (int i : u1) {
+        if (in->conf_active[i]) act_rows.push_back(in->conf_rows[i]);
+        else inact.push_back(in->conf_rows[i]);
+    }
+    int rc = lap_stage(ctx, P, FM_STAGE_IOU, act_rows.data(), (int)act_rows.size(), u_det, 0., in->max_iou_cost, 1., cost,
+                       m, u_rows, nxt);
+    if (rc) return rc;
+    const int n2 = (int)m.size();
+    for (auto& mm : m) { *w++ = act_rows[mm.first]; *w++ = mm.second; }
+    std::vector<int> u2;
+    for (int r : u_rows) u2.push_back(act_rows[r]);
+    u_det.swap(nxt);
+    // ---- 3rd association with unconfirmed tracks (tracker.py:228-231)
+    rc = lap_stage(ctx, P, FM_STAGE_IOU, in->unconf_rows, in->n_unconf, u_det, 0., in->max_iou_cost, 1., cost, m, u_rows, nxt);
+    if (rc) return rc;
+    const int n3 = (int)m.size();
+    for (auto& mm : m) { *w++ = in->unconf_rows[mm.first]; *w++ = mm.second; }
+    std::vector<int> u3;
+    for (int r : u_rows) u3.push_back(in->unconf_rows[r]);
+    u_det.swap(nxt);
+    for (int r : inact) *w++ = r;
+    for (int r : u2) *w++ = r;
+    for (int r : u3) *w++ = r;
+    // ---- reID with the track history (tracker.py:233-240,355-366; greedy: utils/matching.py:74-97)
+    std::vector<int> valid, invalid;
+    for (int d : u_det) {
+        if (!(in->det_conf[d] >= in->conf_thresh)) continue;
+        (P.docc[d] ? invalid : valid).push_back(d);
+    }
+    const int nh = in->n_hist, nv = (int)valid.size();
+    int n_reid = 0;
+    std::vector<uint8_t> taken(nv, 0);
+    if (nh > 0 && nv > 0) {
+        cost.resize((size_t)nh * nv);
+        for (int i = 0; i < nh; ++i)
+            for (int j = 0; j < nv; ++j) {
+                const int d = valid[j];
+                cost[(size_t)i * nv + j] = in->hist_labels[i] != P.dlab[d] ? INF_COST : P.feat[(size_t)in->hist_rows[i] * nD + d];
+            }
+        std::vector<uint8_t> ralive(nh, 1);
+        const int iters = nh < nv ? nh : nv;
+        for (int it = 0; it < iters; ++it) {
+            int bi = -1, bj = -1;
+            double bv = 0.;
+            for (int i = 0; i < nh; ++i) {           // np.argmin of the remaining sub-matrix: first minimum in row-major order
+                if (!ralive[i]) continue;
+                for (int j = 0; j < nv; ++j) {
+                    if (taken[j]) continue;
+                    const double c = cost[(size_t)i * nv + j];
+                    if (bi < 0 || c < bv) { bv = c; bi = i; bj = j; }
+                }
+            }
+            if (bi < 0 || !(bv <= in->max_reid_cost)) break;
+            *w++ = bi; *w++ = valid[bj];
+            ++n_reid;
+            ralive[bi] = 0;
+            taken[bj] = 1;
+        }
+    }
+    for (int d : invalid) *w++ = d;
+    int n_rest = 0;
+    for (int j = 0; j < nv; ++j)
+        if (!taken[j]) { *w++ = valid[j]; ++n_rest; }
+    hdr[0] = n1; hdr[1] = n2; hdr[2] = n3;
+    hdr[3] = (int)inact.size(); hdr[4] = (int)u2.size(); hdr[5] = (int)u3.size();
+    hdr[6] = n_reid; hdr[7] = (int)invalid.size(); hdr[8] = n_rest;
+    hdr[9] = (int)(w - out);
+    return 0;
+}
+
+extern "C" int fm_assoc_cascade(fm_ctx* ctx, const fm_cascade_in* in, int32_t* out, int out_cap) {
+    FM_CHECK_ARG(ctx);
+    const int nT = ctx->as_nT, nD = ctx->as_nD;
+    if (!ctx->as_mirror || nT == 0 || nD == 0) {
+        fm_set_error("fm_assoc_cascade: no host-side pairwise terms (fm_assoc_prepare2 on a small problem first)");
+        return FM_ERR_STATE;
+    }
+    FM_HIP(hipEventSynchronize(ctx->ev_pair));
+    const size_t mat = (size_t)nT * nD;
+    const double* pm = ctx->as_pair.host<double>();
+    const char* hin = ctx->as_in.host<char>();
+    Pairwise P{pm, pm + mat, pm + 2 * mat, reinterpret_cast<const uint8_t*>(pm + 3 * mat),
+               reinterpret_cast<const int64_t*>(hin + ctx->as_off[2]), reinterpret_cast<const int64_t*>(hin + ctx->as_off[4]),
+               reinterpret_cast<const uint8_t*>(hin + ctx->as_off[5]), nD};
+    return cascade_run(P, nT, nD, in, out, out_cap);
+}
+
+extern "C" int fm_cascade_host(int nT, int nD, const double* feat, const double* maha, const double* iou,
+                               const uint8_t* row_has_feat, const int64_t* trk_label, const int64_t* det_label,
+                               const uint8_t* det_occluded, const fm_cascade_in* in, int32_t* out, int out_cap) {
+    FM_CHECK_ARG(feat && maha && iou && row_has_feat && trk_label && det_label && det_occluded);
+    Pairwise P{feat, maha, iou, row_has_feat, trk_label, det_label, det_occluded, nD};
+    return cascade_run(P, nT, nD, in, out, out_cap);
 }
 
 extern "C" int fm_assoc_get_pairwise(fm_ctx* ctx, double* feat, double* maha, double* iou) {

@@ -109,6 +109,11 @@ struct fm_ctx {
     bool pyr_pending = false;
     hipEvent_t ev_prep = nullptr, ev_bg = nullptr;   // fork / join of the background-keypoint branch of fm_flow_prepare
     hipEvent_t ev_feat = nullptr;   // last reader of ctx->emb on s_main (fm_feat_update); s_ext waits on it
+    hipEvent_t ev_ext_net = nullptr;   // the ReID network's last launch of a batch on s_ext (embeddings complete on the device):
+                                       // fm_assoc_prepare2 orders the pairwise kernel behind it without the host
+    hipEvent_t ev_pair = nullptr;      // pairwise kernel of fm_assoc_prepare / fm_assoc_prepare2 done (its pinned mirror is complete)
+    bool ext_net_recorded = false;     // ev_ext_net belongs to the batch ctx->emb holds
+    bool as_mirror = false;            // the pairwise terms of this frame also lie in as_pair's pinned mirror (host cascade)
 
     // ---- device-resident track table
     int slot_cap = 0;

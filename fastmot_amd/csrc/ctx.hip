@@ -145,6 +145,8 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_bg, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_feat, hipEventDisableTiming));
+    FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_net, hipEventDisableTiming));
+    FM_HIP(hipEventCreateWithFlags(&ctx->ev_pair, hipEventDisableTiming));
     int rc = fm_ensure_slots(ctx, 1024);
     if (rc) return rc;
     *out = ctx;
@@ -176,7 +178,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
         b->release();
     for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_up, ctx->s_ext, ctx->s_flow, ctx->s_flow2})
         if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr, ctx->ev_prep, ctx->ev_bg})
+    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr, ctx->ev_prep, ctx->ev_bg, ctx->ev_ext_net, ctx->ev_pair})
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
         if (ctx->s_ext_x[i]) (void)hipStreamDestroy(ctx->s_ext_x[i]);
@@ -358,6 +360,7 @@ extern "C" int fm_emb_upload(fm_ctx* ctx, int n, const float* emb) {
     }
     FM_HIP(hipStreamSynchronize(ctx->s_main));
     fm_ext_invalidate_export(ctx);
+    ctx->ext_net_recorded = false;
     int rc = fm_emb_reserve(ctx, n);
     if (rc) return rc;
     if (n)

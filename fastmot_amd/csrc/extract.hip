@@ -142,6 +142,7 @@ static int export_embeddings(fm_ctx* ctx, ExtState* e, int n, hipStream_t s) {
 extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
     FM_CHECK_ARG(ctx && ctx->ext && ctx->ext_net && n >= 0 && ctx->frame_cur);
     ctx->emb_n = 0;
+    ctx->ext_net_recorded = false;
     int rc_exp = 0;
     if (ctx->ext) ctx->ext->exported_n = -1;
     if (n == 0) return 0;
@@ -203,6 +204,8 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
             }
             off += b;
         }
+        FM_HIP(hipEventRecord(ctx->ev_ext_net, s));
+        ctx->ext_net_recorded = true;
         if ((rc_exp = export_embeddings(ctx, e, n, s))) return rc_exp;
         fm_trace_mark(ctx, s, 33);
         ctx->emb_n = n;
@@ -221,6 +224,8 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
         if (rc) return rc;
     }
     fm_trace_mark(ctx, s, 35);
+    FM_HIP(hipEventRecord(ctx->ev_ext_net, s));
+    ctx->ext_net_recorded = true;
     if ((rc_exp = export_embeddings(ctx, e, n, s))) return rc_exp;
     fm_trace_mark(ctx, s, 33);
     ctx->emb_n = n;

@@ -183,7 +183,13 @@ class MOT:
                     # packed launch arguments) runs while the ReID network is still busy: it only needs the Kalman
                     # step, i.e. the KLT thread, to have finished
                     flow_done.result()
-                    pre = self.tracker.update_begin(detections)
+                    # exactly one extractor holds all of this frame's boxes (always so with one class; with several,
+                    # whenever _split_bboxes_by_cls hands every box to the first): the pairwise-cost kernel of the
+                    # association is enqueued now, behind the ReID network on the device (tracker.update_begin)
+                    busy = [e for e in self.extractors if getattr(e, 'last_num_features', 0)]
+                    in_flight = len(busy) == 1 and busy[0].last_num_features == len(detections) and \
+                        getattr(busy[0], '_pending', False)
+                    pre = self.tracker.update_begin(detections, embeddings_in_flight=in_flight)
                     if len(self.extractors) == 1:
                         embeddings = self.extractors[0].postprocess()
                     else:

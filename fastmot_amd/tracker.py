@@ -14,6 +14,7 @@ from types import SimpleNamespace
 from collections import OrderedDict
 import itertools
 import logging
+import os
 
 import numpy as np
 
@@ -28,6 +29,9 @@ from .utils.setorder import unmatched_order
 LOGGER = logging.getLogger(__name__)
 
 _METRICS = {'EUCLIDEAN': _lib.METRIC_EUCLIDEAN, 'COSINE': _lib.METRIC_COSINE}
+# 0: every association stage through fm_assoc_stage (launch + wait per stage), nothing enqueued ahead of the embeddings --
+# the path of round 5, kept for the A/B and for the tests that compare the two
+_HOST_CASCADE = os.environ.get('FASTMOT_HOST_CASCADE', '1') != '0'
 
 
 def _frame_rect(size):
@@ -254,11 +258,16 @@ class MultiTracker:
         occluded = self.ctx.find_occluded(det_tlbr, self.occlusion_thresh)
         self._prepared = (detections, det_tlbr, det_label, det_conf, occluded)
 
-    def update_begin(self, detections):
+    def update_begin(self, detections, embeddings_in_flight=False):
         """The part of `update` that needs no embeddings: track grouping, the row order of the cost matrices and
         the packed arguments of the pairwise-cost launch.  MOT.step calls it while the ReID network is still
         running (after the Kalman step has finished) and hands the result to `update`; nothing may touch the
-        tracks in between."""
+        tracks in between.
+
+        embeddings_in_flight: the embeddings of exactly these detections are being computed by
+        FeatureExtractor.extract_async on this context.  The pairwise-cost kernel is then enqueued right here, ordered
+        behind the ReID network on the device (fm_assoc_prepare2), and the arguments of the one-call cascade are packed,
+        so that `update` finds the cost terms in page-locked memory a kernel's length after the embeddings."""
         if self._prepared is None or self._prepared[0] is not detections:
             self.prepare_detections(detections)
         _, det_tlbr, det_label, det_conf, occluded_det_mask = self._prepared
@@ -277,9 +286,50 @@ class MultiTracker:
                           np.array([t.tlbr for t in row_tracks] + [np.zeros(4)] * len(foreign)),
                           [t.label for t in row_tracks] + [e['label'] for e in foreign])
             trk_feat_f32 = [t not in self.tracks for t in row_ids] + [True] * len(foreign)
-        return dict(detections=detections, det=(det_tlbr, det_label, det_conf, occluded_det_mask), groups=groups,
-                    hist_ids=hist_ids, row_ids=row_ids, row_of=row_of, foreign=foreign, assoc_args=assoc_args,
-                    trk_feat_f32=trk_feat_f32)
+        pre = dict(detections=detections, det=(det_tlbr, det_label, det_conf, occluded_det_mask), groups=groups,
+                   hist_ids=hist_ids, row_ids=row_ids, row_of=row_of, foreign=foreign, assoc_args=assoc_args,
+                   trk_feat_f32=trk_feat_f32, armed=False, cascade=None)
+        if embeddings_in_flight and assoc_args is not None and _HOST_CASCADE:
+            pre['armed'] = True
+            if self.ctx.assoc_prepare(self._metric_id, *assoc_args, det_tlbr, det_label, occluded_det_mask,
+                                      trk_feat_f32=trk_feat_f32, after_extractor=True):
+                pre['cascade'] = self._cascade_pack(pre)
+        return pre
+
+    def _cascade_pack(self, pre):
+        """Arguments of the one-call cascade (ctx.assoc_cascade): the groups of `_group_tracks_by_depth` as rows of the
+        pairwise matrices, Track.active of the confirmed tracks (tracker.py:220-221), the history rows with the labels
+        tracker.py:364 gives them (quirk Q4: the first n of ALL history tracks), the thresholds."""
+        confirmed_by_depth, unconfirmed = pre['groups']
+        row_of, hist_ids, foreign = pre['row_of'], pre['hist_ids'], pre['foreign']
+        tracks = self.tracks
+        flat = list(itertools.chain.from_iterable(confirmed_by_depth))
+        n_rows = len(pre['row_ids'])
+        hist_labels = list(itertools.islice((t.label for t in self.hist_tracks.values()), len(hist_ids)))
+        return self.ctx.cascade_pack(
+            [len(g) for g in confirmed_by_depth], [row_of[t] for t in flat], [tracks[t].active for t in flat],
+            [row_of[t] for t in unconfirmed],
+            [row_of[t] for t in hist_ids] + list(range(n_rows, n_rows + len(foreign))),
+            hist_labels + [e['label'] for e in foreign], pre['det'][2],
+            self.motion_weight, self.max_assoc_cost, min(self.max_assoc_cost + 0.1, 1.), 1. - self.iou_thresh,
+            self.conf_thresh, self.max_reid_cost)
+
+    def _cascade_host(self, pre):
+        """The cascade of `update` in one library call (fm_assoc_cascade) -> the lists `_cascade_stages` returns."""
+        w = self.ctx.assoc_cascade(pre['cascade'])
+        n1, n2, n3, nu1, nu2, nu3, n_reid, n_inv, n_rest = w[:9]
+        row_ids, hist_ids, foreign = pre['row_ids'], pre['hist_ids'], pre['foreign']
+        p = _lib.CASCADE_HEADER
+        q = p + 2 * (n1 + n2 + n3)
+        matches = [(row_ids[r], d) for r, d in zip(w[p:q:2], w[p + 1:q:2])]
+        p, q = q, q + nu1 + nu2 + nu3
+        u_trk_ids = [row_ids[r] for r in w[p:q]]
+        p, q = q, q + 2 * n_reid
+        n_hist = len(hist_ids)
+        reid = list(zip(w[p:q:2], w[p + 1:q:2]))
+        reid_matches = [(hist_ids[r], d) for r, d in reid if r < n_hist]
+        foreign_matches = [(foreign[r - n_hist], d) for r, d in reid if r >= n_hist]
+        return matches, u_trk_ids, reid_matches, foreign_matches, w[q:q + n_inv + n_rest]
 
     def update(self, frame_id, detections, embeddings, pre=None):
         """Associates detections to tracklets based on motion and feature embeddings
@@ -297,63 +347,30 @@ class MultiTracker:
         hist_ids, row_ids, row_of, foreign = pre['hist_ids'], pre['row_ids'], pre['row_of'], pre['foreign']
 
         # ---- device: embeddings + every pairwise term of this frame in one launch
+        host_cascade = False
         if n_det > 0:
-            if embeddings is ctx.device_emb_host and embeddings is not None:
-                ctx.emb_use_device(n_det)
+            on_device = embeddings is ctx.device_emb_host and embeddings is not None
+            if pre['armed'] and on_device:
+                host_cascade = pre['cascade'] is not None          # enqueued by update_begin behind the ReID network
             else:
-                ctx.emb_upload(embeddings)
-                ctx.device_emb_host = None
-            if row_ids or foreign:
-                ctx.assoc_prepare(self._metric_id, *pre['assoc_args'], det_tlbr, det_label, occluded_det_mask,
-                                  trk_feat_f32=pre['trk_feat_f32'])
+                if pre['armed']:
+                    ctx.synchronize()                              # (the early launch read other embeddings: redo)
+                if on_device:
+                    ctx.emb_use_device(n_det)
+                else:
+                    ctx.emb_upload(embeddings)
+                    ctx.device_emb_host = None
+                if row_ids or foreign:
+                    host_cascade = ctx.assoc_prepare(self._metric_id, *pre['assoc_args'], det_tlbr, det_label,
+                                                     occluded_det_mask, trk_feat_f32=pre['trk_feat_f32'])
+                    host_cascade = host_cascade and _HOST_CASCADE
+                    if host_cascade:
+                        pre['cascade'] = self._cascade_pack(pre)
 
-        # ---- 1st association: motion + embeddings, tracks with small age are prioritized
-        fill_val = min(self.max_assoc_cost + 0.1, 1.)
-        matches1 = []
-        u_trk_ids1 = []
-        u_det_ids = list(range(n_det))
-        for depth, trk_ids in enumerate(confirmed_by_depth):
-            if len(u_det_ids) == 0:
-                u_trk_ids1.extend(itertools.chain.from_iterable(confirmed_by_depth[depth:]))
-                break
-            if len(trk_ids) == 0:
-                continue
-            matches, u_trk_ids, u_det_ids = self._linear_assignment(
-                _lib.STAGE_MATCHING, trk_ids, u_det_ids, row_of, motion_weight=self.motion_weight,
-                max_cost=self.max_assoc_cost, fill_val=fill_val)
-            matches1 += matches
-            u_trk_ids1 += u_trk_ids
-
-        # ---- 2nd association with IoU
-        active = [trk_id for trk_id in u_trk_ids1 if self.tracks[trk_id].active]
-        u_trk_ids1 = [trk_id for trk_id in u_trk_ids1 if not self.tracks[trk_id].active]
-        matches2, u_trk_ids2, u_det_ids = self._linear_assignment(
-            _lib.STAGE_IOU, active, u_det_ids, row_of, max_cost=1. - self.iou_thresh)
-
-        # ---- 3rd association with unconfirmed tracks
-        matches3, u_trk_ids3, u_det_ids = self._linear_assignment(
-            _lib.STAGE_IOU, unconfirmed, u_det_ids, row_of, max_cost=1. - self.iou_thresh)
-
-        # ---- reID with track history
-        u_det_ids = [det_id for det_id in u_det_ids if det_conf[det_id] >= self.conf_thresh]
-        valid_u_det_ids = [det_id for det_id in u_det_ids if not occluded_det_mask[det_id]]
-        invalid_u_det_ids = [det_id for det_id in u_det_ids if occluded_det_mask[det_id]]
-
-        n_hist = len(hist_ids)
-        # quirk Q4 (tracker.py:364): labels come from the first n_hist of ALL history tracks
-        hist_labels = list(itertools.islice((t.label for t in self.hist_tracks.values()), n_hist))
-        n_rows = len(row_ids)
-        m_rows, m_cols, _ = self._solve(_lib.STAGE_REID, _lib.SOLVER_GREEDY, hist_ids,
-                                        [row_of[t] for t in hist_ids] + list(range(n_rows, n_rows + len(foreign))),
-                                        valid_u_det_ids, valid_u_det_ids, max_cost=self.max_reid_cost,
-                                        row_labels=hist_labels + [e['label'] for e in foreign])
-        reid_matches = [(hist_ids[r], valid_u_det_ids[c]) for r, c in zip(m_rows, m_cols) if r < n_hist]
-        foreign_matches = [(foreign[r - n_hist], valid_u_det_ids[c]) for r, c in zip(m_rows, m_cols) if r >= n_hist]
-        taken = set(m_cols)
-        reid_u_det_ids = [det_id for c, det_id in enumerate(valid_u_det_ids) if c not in taken]
-
-        matches = itertools.chain(matches1, matches2, matches3)
-        u_trk_ids = itertools.chain(u_trk_ids1, u_trk_ids2, u_trk_ids3)
+        if host_cascade:
+            matches, u_trk_ids, reid_matches, foreign_matches, new_det_ids = self._cascade_host(pre)
+        else:
+            matches, u_trk_ids, reid_matches, foreign_matches, new_det_ids = self._cascade_stages(pre, n_det)
 
         # rectify matches that may cause duplicate tracks
         matches, u_trk_ids = self._rectify_matches(matches, u_trk_ids, det_tlbr)
@@ -414,7 +431,6 @@ class MultiTracker:
                 self._mark_lost(trk_id)
 
         # ---- start new tracks (one create launch), IDs in the reference's order
-        new_det_ids = list(itertools.chain(invalid_u_det_ids, reid_u_det_ids))
         self._new_tracks(frame_id, [det_tlbr[d] for d in new_det_ids],
                          [int(det_label[d]) for d in new_det_ids])
 
@@ -431,6 +447,63 @@ class MultiTracker:
             ctx.feat_update([trk.slot], [det_id])
             trk.avg_feat.count += 1
             trk.hits = self.confirm_hits
+
+    def _cascade_stages(self, pre, n_det):
+        """The association cascade stage by stage on the device (fm_assoc_stage: cost gather + gate kernel, LAP /
+        greedy kernel or the host solver per stage) -- the path of problems too large for the one-call host cascade,
+        and of `host_lap_elems = 0`.  Returns matches, unmatched track ids, re-identified (history id, detection)
+        pairs, foreign-gallery matches and the detections that start new tracks, in the reference's order."""
+        det_tlbr, det_label, det_conf, occluded_det_mask = pre['det']
+        confirmed_by_depth, unconfirmed = pre['groups']
+        hist_ids, row_ids, row_of, foreign = pre['hist_ids'], pre['row_ids'], pre['row_of'], pre['foreign']
+        # ---- 1st association: motion + embeddings, tracks with small age are prioritized
+        fill_val = min(self.max_assoc_cost + 0.1, 1.)
+        matches1 = []
+        u_trk_ids1 = []
+        u_det_ids = list(range(n_det))
+        for depth, trk_ids in enumerate(confirmed_by_depth):
+            if len(u_det_ids) == 0:
+                u_trk_ids1.extend(itertools.chain.from_iterable(confirmed_by_depth[depth:]))
+                break
+            if len(trk_ids) == 0:
+                continue
+            matches, u_trk_ids, u_det_ids = self._linear_assignment(
+                _lib.STAGE_MATCHING, trk_ids, u_det_ids, row_of, motion_weight=self.motion_weight,
+                max_cost=self.max_assoc_cost, fill_val=fill_val)
+            matches1 += matches
+            u_trk_ids1 += u_trk_ids
+
+        # ---- 2nd association with IoU
+        active = [trk_id for trk_id in u_trk_ids1 if self.tracks[trk_id].active]
+        u_trk_ids1 = [trk_id for trk_id in u_trk_ids1 if not self.tracks[trk_id].active]
+        matches2, u_trk_ids2, u_det_ids = self._linear_assignment(
+            _lib.STAGE_IOU, active, u_det_ids, row_of, max_cost=1. - self.iou_thresh)
+
+        # ---- 3rd association with unconfirmed tracks
+        matches3, u_trk_ids3, u_det_ids = self._linear_assignment(
+            _lib.STAGE_IOU, unconfirmed, u_det_ids, row_of, max_cost=1. - self.iou_thresh)
+
+        # ---- reID with track history
+        u_det_ids = [det_id for det_id in u_det_ids if det_conf[det_id] >= self.conf_thresh]
+        valid_u_det_ids = [det_id for det_id in u_det_ids if not occluded_det_mask[det_id]]
+        invalid_u_det_ids = [det_id for det_id in u_det_ids if occluded_det_mask[det_id]]
+
+        n_hist = len(hist_ids)
+        # quirk Q4 (tracker.py:364): labels come from the first n_hist of ALL history tracks
+        hist_labels = list(itertools.islice((t.label for t in self.hist_tracks.values()), n_hist))
+        n_rows = len(row_ids)
+        m_rows, m_cols, _ = self._solve(_lib.STAGE_REID, _lib.SOLVER_GREEDY, hist_ids,
+                                        [row_of[t] for t in hist_ids] + list(range(n_rows, n_rows + len(foreign))),
+                                        valid_u_det_ids, valid_u_det_ids, max_cost=self.max_reid_cost,
+                                        row_labels=hist_labels + [e['label'] for e in foreign])
+        reid_matches = [(hist_ids[r], valid_u_det_ids[c]) for r, c in zip(m_rows, m_cols) if r < n_hist]
+        foreign_matches = [(foreign[r - n_hist], valid_u_det_ids[c]) for r, c in zip(m_rows, m_cols) if r >= n_hist]
+        taken = set(m_cols)
+        reid_u_det_ids = [det_id for c, det_id in enumerate(valid_u_det_ids) if c not in taken]
+
+        matches = list(itertools.chain(matches1, matches2, matches3))
+        u_trk_ids = list(itertools.chain(u_trk_ids1, u_trk_ids2, u_trk_ids3))
+        return matches, u_trk_ids, reid_matches, foreign_matches, list(itertools.chain(invalid_u_det_ids, reid_u_det_ids))
 
     def _exchange_gallery(self, hist_ids):
         """Hands the local history {id, label, count, avg feature} to the gallery exchange (an asynchronous RCCL

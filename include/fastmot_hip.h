@@ -180,6 +180,50 @@ int fm_assoc_stage(fm_ctx* ctx, int stage, int solver,
                    int32_t* m_rows, int32_t* m_cols, uint8_t* match_gated, int* n_match,
                    double* cost_out);
 
+/* fm_assoc_prepare with two additions.  after_extractor = 1: the embeddings are the batch fm_extract_async is still
+ * computing -- the pairwise kernel is ordered behind the ReID network's last launch on the device, so
+ * MultiTracker.update_begin can enqueue it while that network runs and the terms are complete a kernel's length after
+ * the embeddings (no host wake-up in between).  *host_cascade = 1 when the problem is small enough (nT * nD <=
+ * host_lap_elems, zero_copy_tracks > 0) for the terms to be written to page-locked host memory as well, where
+ * fm_assoc_cascade reads them. */
+int fm_assoc_prepare2(fm_ctx* ctx, int metric,
+                      int nT, const int32_t* slots, const double* trk_tlbr, const int64_t* trk_label,
+                      int nD, const double* det_tlbr, const int64_t* det_label,
+                      const uint8_t* det_occluded, const uint8_t* trk_feat_f32, int after_extractor, int* host_cascade);
+
+/* The association cascade of MultiTracker.update (tracker.py:198-248) in one call, for problems whose assignment is
+ * solved on the host anyway (host_lap_elems; after fm_assoc_prepare2 reported host_cascade): the three
+ * linear-assignment stages -- _matching_cost depth by depth (tracker.py:205-218,314-341), _iou_cost for the remaining
+ * active and then for the unconfirmed tracks (:220-231,343-353) -- with the unmatched lists in the order of
+ * utils/matching.py:58-70 under Numba's set iteration, the confidence / occlusion split of the remaining detections
+ * (:233-235) and the greedy re-identification against the history (:236-240,355-366, utils/matching.py:74-97).
+ * Rows are indices into the fm_assoc_prepare arrays.  `out` (int32, capacity out_cap >= FM_CASCADE_HEADER +
+ * 3 * (n_conf + n_unconf) + 3 * nD): header [n1, n2, n3, nu1, nu2, nu3, n_reid, n_invalid, n_rest, used], then
+ * (row, det) pairs of the three stages, the unmatched rows of the three stages (stage 1: its inactive tracks, :221),
+ * (index into hist_rows, det) pairs of the re-identification, the occluded unmatched detections, the others. */
+#define FM_CASCADE_HEADER 16
+typedef struct fm_cascade_in {
+    int32_t n_groups;              /* depth groups of the confirmed tracks (tracker.py:219-233: age // 2) */
+    int32_t n_unconf, n_hist;
+    int32_t reserved;
+    const int32_t* group_off;      /* [n_groups + 1] offsets into conf_rows */
+    const int32_t* conf_rows;      /* rows of the confirmed tracks, group by group */
+    const uint8_t* conf_active;    /* Track.active of each of them */
+    const int32_t* unconf_rows;
+    const int32_t* hist_rows;      /* history rows (then foreign gallery rows) */
+    const int64_t* hist_labels;    /* labels used for them (tracker.py:364 takes the first n of ALL history tracks) */
+    const double* det_conf;        /* [nD] */
+    double motion_weight, max_assoc_cost, fill_val, max_iou_cost, conf_thresh, max_reid_cost;
+} fm_cascade_in;
+int fm_assoc_cascade(fm_ctx* ctx, const fm_cascade_in* in, int32_t* out, int out_cap);
+/* The host half of fm_assoc_cascade on caller-provided pairwise terms ([nT][nD] f64 each; row_has_feat, labels and the
+ * occlusion mask as fm_assoc_prepare takes them): no context, no device -- what the CPU test suite checks against the
+ * oracle's restatement of utils/matching.py (tests/test_cascade_host.py).  Not a fallback: the terms themselves only
+ * ever come from pairwise_kernel. */
+int fm_cascade_host(int nT, int nD, const double* feat, const double* maha, const double* iou,
+                    const uint8_t* row_has_feat, const int64_t* trk_label, const int64_t* det_label,
+                    const uint8_t* det_occluded, const fm_cascade_in* in, int32_t* out, int out_cap);
+
 /* Stand-alone solvers on a host cost matrix [nr][nc] f64 (device kernels; used by
  * _rectify_matches' greedy_match, tracker.py:384, and by the parity tests). */
 int fm_lap(fm_ctx* ctx, const double* cost, int nr, int nc,
