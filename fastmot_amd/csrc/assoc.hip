@@ -754,33 +754,43 @@ static int assoc_prepare_impl(fm_ctx* ctx, int metric, int nT, const int32_t* sl
         return FM_ERR_STATE;
     }
     for (int i = 0; i < nT; ++i) FM_CHECK_ARG(slots[i] >= 0 && slots[i] < ctx->slot_cap);
+    // small problems: the terms also go to the buffer's page-locked mirror, where the host cascade reads them
+    const bool mirror = FM_ZERO_COPY_TRACKS > 0 && (size_t)nT * nD <= (size_t)ctx->opt_host_lap_elems;
+    // An early launch goes onto the ReID stream itself, behind the network in stream order, and reads its (few KB of)
+    // inputs from the page-locked staging buffer: no cross-stream wait is parked anywhere.  Round 6 first enqueued it on
+    // s_main behind hipStreamWaitEvent(ev_ext_net); with one more stream in the context that pending barrier packet made
+    // every dependent launch of the streams sharing its hardware queue slower (ReID stage 0.54 -> 0.75 ms,
+    // profiles/r06_schedule_patch_retest_ab.txt).  Only small problems launch early: the stage kernels of the large
+    // ones run on s_main and order behind the event as before.
+    const bool early = after_extractor && mirror;
+    hipStream_t st = early ? ctx->s_ext : ctx->s_main;
     std::vector<size_t> offs;
+    char* in = nullptr;
     int rc = upload(ctx, ctx->as_in,
                     {{slots, sizeof(int32_t) * nT}, {trk_tlbr, sizeof(double) * 4 * nT},
                      {trk_label, sizeof(int64_t) * nT}, {det_tlbr, sizeof(double) * 4 * nD},
                      {det_label, sizeof(int64_t) * nD}, {det_occluded, (size_t)nD},
-                     {trk_feat_f32, (size_t)nT}}, offs);
+                     {trk_feat_f32, (size_t)nT}}, offs, &in, early);
     if (rc) return rc;
     for (int i = 0; i < 6; ++i) ctx->as_off[i] = offs[i];
     const size_t mat = sizeof(double) * (size_t)nT * nD;
     if ((rc = ctx->as_pair.reserve(3 * mat + nT + 64))) return rc;
-    char* in = ctx->as_in.dev<char>();
     char* pr = ctx->as_pair.dev<char>();
-    // small problems: the terms also go to the buffer's page-locked mirror, where the host cascade reads them
-    const bool mirror = FM_ZERO_COPY_TRACKS > 0 && (size_t)nT * nD <= (size_t)ctx->opt_host_lap_elems;
     const size_t shmem = (size_t)ctx->feat_dim * 4 + 32 * sizeof(double);
-    if (after_extractor) FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_ext_net, 0));
-    fm_trace_mark(ctx, ctx->s_main, 54);
-    hipLaunchKernelGGL(pairwise_kernel, dim3(nT), dim3(256), shmem, ctx->s_main, nT, nD, metric,
+    if (after_extractor && !early) FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_ext_net, 0));
+    fm_trace_mark(ctx, st, 54);
+    hipLaunchKernelGGL(pairwise_kernel, dim3(nT), dim3(256), shmem, st, nT, nD, metric,
                        ctx->feat_dim, (const int32_t*)(in + offs[0]), (const double*)(in + offs[1]),
                        (const double*)(in + offs[3]), ctx->mean, ctx->cov, ctx->feat_avg, ctx->feat_cnt,
                        ctx->emb, ctx->kf, (const uint8_t*)(in + offs[6]), (double*)pr, (double*)(pr + mat),
                        (double*)(pr + 2 * mat),
                        (uint8_t*)(pr + 3 * mat), mirror ? ctx->as_pair.host<char>() : nullptr);
     FM_HIP(hipGetLastError());
-    fm_trace_mark(ctx, ctx->s_main, 55);
-    if (mirror) FM_HIP(hipEventRecord(ctx->ev_pair, ctx->s_main));
+    fm_trace_mark(ctx, st, 55);
+    if (mirror) FM_HIP(hipEventRecord(ctx->ev_pair, st));
     ctx->as_mirror = mirror;
+    ctx->as_in_device = !early;
+    ctx->as_in_bytes = offs[6] + (size_t)nT;
     return 0;
 }
 
@@ -1049,6 +1059,7 @@ extern "C" int fm_assoc_get_pairwise(fm_ctx* ctx, double* feat, double* maha, do
     const size_t mat = sizeof(double) * (size_t)ctx->as_nT * ctx->as_nD;
     if (mat == 0) return 0;
     FM_HIP(hipStreamSynchronize(ctx->s_main));
+    if (!ctx->as_in_device) FM_HIP(hipStreamSynchronize(ctx->s_ext));   // (an early launch ran there)
     char* pr = ctx->as_pair.dev<char>();
     if (feat) FM_HIP(hipMemcpy(feat, pr, mat, hipMemcpyDeviceToHost));
     if (maha) FM_HIP(hipMemcpy(maha, pr + mat, mat, hipMemcpyDeviceToHost));
@@ -1088,6 +1099,13 @@ extern "C" int fm_assoc_stage(fm_ctx* ctx, int stage, int solver, int nr, const 
     const bool host_lap = solver == 0 && FM_ZERO_COPY_TRACKS > 0 && (size_t)nr * nc <= (size_t)ctx->opt_host_lap_elems;
     double* cost_dst = host_lap ? ctx->as_cost.host<double>() : ctx->as_cost.dev<double>();
     const size_t mat = sizeof(double) * (size_t)nT * nD;
+    if (!ctx->as_in_device) {
+        // the terms came from an early launch on the ReID stream (fm_assoc_prepare2): its inputs were read from the staging
+        // buffer -- the labels / occlusion flags go to the device now, and this stream orders behind that launch
+        FM_HIP(hipMemcpyAsync(ctx->as_in.d, ctx->as_in.h, ctx->as_in_bytes, hipMemcpyHostToDevice, ctx->s_main));
+        FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_pair, 0));
+        ctx->as_in_device = true;
+    }
     char* in = ctx->as_in.dev<char>();
     char* pr = ctx->as_pair.dev<char>();
     fm_trace_mark(ctx, ctx->s_main, 56);

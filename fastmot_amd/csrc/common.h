@@ -111,8 +111,11 @@ struct fm_ctx {
     hipEvent_t ev_feat = nullptr;   // last reader of ctx->emb on s_main (fm_feat_update); s_ext waits on it
     hipEvent_t ev_ext_net = nullptr;   // the ReID network's last launch of a batch on s_ext (embeddings complete on the device):
                                        // fm_assoc_prepare2 orders the pairwise kernel behind it without the host
+    hipEvent_t ev_ext_done = nullptr;  // embeddings exported to page-locked memory (fm_extract_sync waits for this, not for the stream)
     hipEvent_t ev_pair = nullptr;      // pairwise kernel of fm_assoc_prepare / fm_assoc_prepare2 done (its pinned mirror is complete)
     bool ext_net_recorded = false;     // ev_ext_net belongs to the batch ctx->emb holds
+    size_t as_in_bytes = 0;
+    bool as_in_device = true;          // as_in's device copy holds this frame's inputs (not for an early launch: fm_assoc_stage refuses)
     bool as_mirror = false;            // the pairwise terms of this frame also lie in as_pair's pinned mirror (host cascade)
 
     // ---- device-resident track table

@@ -30,6 +30,7 @@
 // Roofline per layer: max(2 K Cout P / 2.5 PFLOP/s, (in + out + weights) * 2 B / 8 TB/s); per workgroup the L2 -> LDS
 // fill path (~64 B/clk/CU) bounds a tile at (BM + BN) * K * 2 B / 64 cycles.
 #include "net.h"
+#include <atomic>
 #include <cstdlib>
 
 int launch_convd(const ConvParams& p, hipStream_t s);
@@ -434,11 +435,15 @@ int launch_inst(const ConvParams& p, int ns, hipStream_t s) {
     const size_t epi = (size_t)BN * (BM + 4) * 4 + (size_t)(KG - 1) * BM * BN * 4;
     const size_t lds = ring > epi ? ring : epi;
     FM_CHECK_ARG(lds + CONVD_EXTRA_LDS <= (size_t)LDS_MAX);
-    static bool configured = false;      // (one flag per instantiation)
-    if (!configured) {
+    // the opt-in to more than 64 KB of dynamic LDS belongs to (device, instantiation): one flag each (a process may hold
+    // contexts on several GPUs; set from any of their threads -- setting it twice is harmless, the flag only saves the call)
+    static std::atomic<unsigned long long> configured{0};
+    int dev = 0;
+    FM_HIP(hipGetDevice(&dev));
+    if (dev >= 64 || !(configured.load(std::memory_order_relaxed) >> dev & 1)) {
         FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE, SPB>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-        configured = true;
+        if (dev < 64) configured.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
     const int total = q.grid_p * q.grid_c;
     hipLaunchKernelGGL((convd_kernel<WC, WP, MC, MP, KG, TAPS, ROLE, SPB>), dim3(((total + 7) / 8) * 8), dim3(256 * KG * (1 + ROLE)),
@@ -541,6 +546,7 @@ int launch_convd(const ConvParams& p, hipStream_t s) {
         if (f.kg == 4 && (f.bm != 64 || f.bn != 64)) f.kg = 2;
         if (f.bm * f.bn >= 128 * 128) f.spb = 1;
         if (f.kg == 4) f.role = 0, f.spb = 1;
+        if (f.ns == 1) f.ns = 2;          // (a ring of one slot would be read while its DMA is in flight)
         const int slot = (f.bm + f.bn) * 128 * f.spb;
         if (f.ns == 0) f.ns = stages_for(f.bm, f.bn, f.kg, f.spb, ((nk + f.kg - 1) / f.kg + f.spb - 1) / f.spb, LDS_MAX);
         while (f.ns > 2 && (size_t)f.kg * f.ns * slot > (size_t)LDS_MAX) --f.ns;

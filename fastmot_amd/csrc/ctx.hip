@@ -147,6 +147,7 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_feat, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_net, hipEventDisableTiming));
     FM_HIP(hipEventCreateWithFlags(&ctx->ev_pair, hipEventDisableTiming));
+    FM_HIP(hipEventCreateWithFlags(&ctx->ev_ext_done, hipEventDisableTiming));
     int rc = fm_ensure_slots(ctx, 1024);
     if (rc) return rc;
     *out = ctx;
@@ -178,7 +179,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
         b->release();
     for (hipStream_t s : {ctx->s_main, ctx->s_det, ctx->s_up, ctx->s_ext, ctx->s_flow, ctx->s_flow2})
         if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr, ctx->ev_prep, ctx->ev_bg, ctx->ev_ext_net, ctx->ev_pair})
+    for (hipEvent_t e : {ctx->ev_feat, ctx->ev_ext_in, ctx->ev_pyr, ctx->ev_prep, ctx->ev_bg, ctx->ev_ext_net, ctx->ev_pair, ctx->ev_ext_done})
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < FM_MAX_EXTRA_EXTRACTORS; ++i) {
         if (ctx->s_ext_x[i]) (void)hipStreamDestroy(ctx->s_ext_x[i]);

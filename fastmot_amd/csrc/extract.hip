@@ -136,6 +136,8 @@ static int export_embeddings(fm_ctx* ctx, ExtState* e, int n, hipStream_t s) {
                        (const float4*)ctx->emb, (float4*)e->emb_out.h, n4);
     FM_HIP(hipGetLastError());
     e->exported_n = n;
+    // what fm_extract_sync waits for: the stream may go on with work of the association (the early pairwise launch)
+    FM_HIP(hipEventRecord(ctx->ev_ext_done, s));
     return 0;
 }
 
@@ -246,8 +248,10 @@ extern "C" int fm_extract_sync(fm_ctx* ctx, int n, float* emb) {
         int rc = ctx->ext->emb_out.reserve(bytes);
         if (rc) return rc;
         FM_HIP(hipMemcpyAsync(ctx->ext->emb_out.h, ctx->emb, bytes, hipMemcpyDeviceToHost, ctx->s_ext));
+        FM_HIP(hipStreamSynchronize(ctx->s_ext));
+    } else {
+        FM_HIP(hipEventSynchronize(ctx->ev_ext_done));   // the export kernel's rows are in page-locked memory
     }
-    FM_HIP(hipStreamSynchronize(ctx->s_ext));
     memcpy(emb, ctx->ext->emb_out.h, bytes);
     return 0;
 }

@@ -1921,6 +1921,7 @@ extern "C" int fm_flow_detect(fm_ctx* ctx, int n, const int32_t* track_idx, cons
         crops[i] = c;
     }
     if (off > f->eig_cap) {     // many small crops (one tile at least each): grow like fm_flow_prepare does (stream idle: synchronised above)
+        f->eig_cap = 0;         // (a failing allocation below must not leave a capacity behind null pointers)
         FM_HIP(hipFree(f->eig));
         f->eig = nullptr;
         FM_HIP(hipFree(f->tile_stat));
@@ -2179,6 +2180,7 @@ extern "C" int fm_flow_prepare(fm_ctx* ctx, int nT, const double* inside_tlbr, c
         FM_HIP(hipStreamSynchronize(s));
     g_flow_sub[1] += fm_now_ms() - tp0; tp0 = fm_now_ms();
     if (eig_total > f->eig_cap) {
+        f->eig_cap = 0;
         FM_HIP(hipFree(f->eig));
         f->eig = nullptr;
         FM_HIP(hipFree(f->tile_stat));

@@ -3,6 +3,7 @@
 // definition summarised in SURVEY.md appendix A (LightConv3x3, channel gate, pooling, head).
 // All of these are HBM/L2-bandwidth bound: one pass, 16-byte coalesced accesses, no re-reads.
 #include "net.h"
+#include <atomic>
 
 namespace {
 
@@ -573,6 +574,10 @@ int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const
                      int out_cs, int out_coff, const float* const* part, int tiles, hipStream_t s) {
     FM_CHECK_ARG(nstreams >= 1 && nstreams <= 4 && C % 8 == 0 && C / 8 <= GS_THREADS && out_cs % 8 == 0 &&
                  out_coff % 8 == 0 && hid >= 1);
+    // the tile sums of all streams are staged in LDS (round 5): shapes whose sums do not fit take the kernel that
+    // reduces the maps itself (same gate; the order of its fp32 sums differs)
+    const size_t part_lds = ((size_t)8 * C + 4 * hid + 2 * (size_t)hid * C + hid + C + (size_t)nstreams * tiles * C) * sizeof(float);
+    if (part && part_lds > 150 * 1024) part = nullptr;
     if (part) {
         GatedSumPartArgs a{};
         a.nstreams = nstreams;
@@ -580,8 +585,17 @@ int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const
             FM_CHECK_ARG(in_cs[t] % 8 == 0 && in_coff[t] % 8 == 0 && part[t]);
             a.in[t] = in[t]; a.in_cs[t] = in_cs[t]; a.in_coff[t] = in_coff[t]; a.part[t] = part[t];
         }
-        const size_t shmem = ((size_t)8 * C + 4 * hid + 2 * (size_t)hid * C + hid + C + (size_t)nstreams * tiles * C) * sizeof(float);
-        FM_CHECK_ARG(shmem <= 64 * 1024);
+        const size_t shmem = part_lds;
+        if (shmem > 64 * 1024) {          // opt-in per device (GATE_SLOT_TILES = 32 tiles x 128 channels x 4 streams is 64 KB + the MLP)
+            static std::atomic<unsigned long long> configured{0};
+            int dev = 0;
+            FM_HIP(hipGetDevice(&dev));
+            if (dev >= 64 || !(configured.load(std::memory_order_relaxed) >> dev & 1)) {
+                FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gated_sum_part_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                if (dev < 64) configured.fetch_or(1ull << dev, std::memory_order_relaxed);
+            }
+        }
         const int pix = 256 / (C / 8) > 64 ? 256 / (C / 8) : 64;
         hipLaunchKernelGGL(gated_sum_part_kernel, dim3((HW + pix - 1) / pix, N), dim3(256), shmem, s, a, HW,
                            C, hid, tiles, pix, w1, b1, w2, b2, out, out_cs, out_coff);

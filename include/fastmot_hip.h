@@ -52,8 +52,9 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
  * "host_lap_elems" (default 262144; LAP cost matrices up to this many elements are solved by the host
  * solver of the library, larger ones by the device kernels; 0 = always device), "nms_path" (default 0: the fused sort + greedy
  * DIoU-NMS kernel for up to 4096 candidates per frame, the three-kernel sort / bit-matrix / scan path beyond; 1 = always
- * the latter), "convd_cfg" (default 0 = chosen per layer; bm | bn << 8 | kg << 16 | ns << 20 forces one tile /
- * K-group / ring configuration of FM_OP_CONVD for A/B measurements; read at every launch that is not a graph replay),
+ * the latter), "convd_cfg" (default 0 = chosen per layer; bm | bn << 8 | kg << 16 | ns << 20 | role << 24 | (spb == 2) << 25 forces
+ * one tile / K-group / ring depth (0 = as deep as LDS allows, otherwise >= 2) / loader-wave / steps-per-barrier configuration
+ * of FM_OP_CONVD for A/B measurements; read at every launch that is not a graph replay),
  * "use_graphs" (default 1;
  * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (diagnostic builds only, include/fastmot_hip_diag.h;
  * 0 is the only value the shipped library accepts).  Initial values can be set with the environment
@@ -280,9 +281,10 @@ enum {
                           * each laid out as for FM_OP_LITECONV; gate[s] = GAP partial slot of stream s       */
     FM_OP_CONVD = 17,    /* FM_OP_CONV with both operands moved global -> LDS by the DMA path and up to 2 x 2 MFMA accumulators
                           * per wavefront, K optionally split across wave groups of the workgroup (convd.hip).  Same fields
-                          * and semantics as FM_OP_CONV; cin % 64 == 0; weights as LDS tile images:
-                          * [ceil32(cout)/32][k*k*cin/64][32 rows][8 slots][8 halfs], K order (kh, kw, cin), slot s of row r
-                          * holding K chunk s ^ ((r / 2) % 8) of that row's 64-wide K step                          */
+                          * and semantics as FM_OP_CONV; 3x3: cin % 64 == 0; 1x1: cin % 8 == 0 and cin >= 16 (ragged K: the
+                          * image is zero-padded to ceil64(K), chunks of a step beyond cin are not fetched); weights as LDS
+                          * tile images: [ceil32(cout)/32][ceil64(k*k*cin)/64][32 rows][8 slots][8 halfs], K order (kh, kw, cin),
+                          * slot s of row r holding K chunk s ^ ((r / 2) % 8) of that row's 64-wide K step              */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

@@ -66,12 +66,6 @@ for i, (d, (s, e, name)) in enumerate(zip(g.layers, rows)):
         by = (2 * P * c + c * m + 9 * m * c) * 2
         shape = f"{o.h}x{o.w}x{c} (mid {m})"
         kind = 'resblock'
-    elif op == 17:                             # fused CSP stage: five convs, d in / stage output out
-        c, m = d['cin'], d['hid']
-        fl = 2.0 * P * (2 * c * c + c * m + 9 * m * c + c * c + 2 * c * d['cout'])
-        by = (P * c + P * d['cout'] + 2 * c * c + c * m + 9 * m * c + c * c + 2 * c * d['cout']) * 2
-        shape = f"{o.h}x{o.w}x{c} (mid {m}) csp stage"
-        kind = 'cspstage'
     else:                                      # SPP etc.
         fl = 0.
         by = (x.h * x.w * x.c + P * o.c) * 2
