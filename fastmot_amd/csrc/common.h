@@ -94,6 +94,8 @@ struct fm_ctx {
     int opt_host_lap_elems = 262144;   // FASTMOT_HOST_LAP: cost matrices up to this size use lap_host.hip (measured: the
                                        // host solver is ~5x faster at every size up to 400 x 400, profiles/r02_lap_crossover.txt)
     int opt_use_graphs = 1;            // FASTMOT_GRAPHS: 0 = launch network layers one by one (no hipGraph)
+    int opt_fused_input = 1;           // "fused_input" / FASTMOT_FUSED_INPUT: the networks' stem convolutions compute their input pixels from the
+                                       // frame themselves (pixel_source.h); 0 = front-end kernel + input tensor (tests compare the two, A/B)
     int opt_nms_general = 0;           // "nms_path" = 1: always the three-kernel sort / bit matrix / scan path (tests, A/B)
     int opt_lk_variant = 0;            // "lk_variant": diagnostic variants of the LK kernel (flow.hip lk_diag_kernel)
     void* predict_worker = nullptr;    // native KLT + Kalman worker thread of this context (flow_estimate.hip)

@@ -28,6 +28,7 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "nms_path")) {
         ctx->opt_nms_general = value != 0;
     }
+    else if (!strcmp(key, "fused_input")) ctx->opt_fused_input = value != 0;
     else if (!strcmp(key, "lk_variant")) {
 #ifndef FM_DIAG
         if (value != 0) {
@@ -122,6 +123,7 @@ extern "C" int fm_ctx_create(int device, fm_ctx** out) {
     if (const char* e = getenv("FASTMOT_ZERO_COPY")) ctx->opt_zero_copy_tracks = atoi(e);
     if (const char* e = getenv("FASTMOT_HOST_LAP")) ctx->opt_host_lap_elems = atoi(e);
     if (const char* e = getenv("FASTMOT_GRAPHS")) ctx->opt_use_graphs = atoi(e);
+    if (const char* e = getenv("FASTMOT_FUSED_INPUT")) ctx->opt_fused_input = atoi(e) != 0;
     // the detector network is the long, throughput-oriented stream; tracker / KLT / ReID launches are
     // short and latency critical (the host waits on them), so they get the higher priority
     int prio_lo = 0, prio_hi = 0;

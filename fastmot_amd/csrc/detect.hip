@@ -18,7 +18,7 @@
 // them (areas f32, box corners / IoU / DIoU f64); rounding half-to-even.
 // Roofline: HBM bound -- reads (5+C)*A*sum(HW)*4 B of head tensors (7.7 MB @608/80 classes),
 // frame 6.2 MB in, 608*608*8*2 B out.
-#include "net.h"
+#include "pixel_source.h"
 #include <cmath>
 #include <mutex>
 #include <utility>
@@ -92,30 +92,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ frame, int fw, int
     if (counters && x < 4 && y == 0) counters[x] = 0;
     if (x >= in_w || y >= in_h) return;
     float rgb[3];
-    const int rx = x - roi_x, ry = y - roi_y;
-    if (rx < 0 || ry < 0 || rx >= roi_w || ry >= roi_h) {
-        rgb[0] = rgb[1] = rgb[2] = 0.5f;
-    } else {
-        const double zy = (double)fh / roi_h, zx = (double)fw / roi_w;
-        const double sy = ry * zy + (zy - 1.) / 2., sx = rx * zx + (zx - 1.) / 2.;
-        const double fy = floor(sy), fx = floor(sx);
-        const double wy = sy - fy, wx = sx - fx;
-        int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-        y0 = min(max(y0, 0), fh - 1); y1 = min(max(y1, 0), fh - 1);
-        x0 = min(max(x0, 0), fw - 1); x1 = min(max(x1, 0), fw - 1);
-        const uint8_t* p00 = frame + ((size_t)y0 * fw + x0) * 3;
-        const uint8_t* p01 = frame + ((size_t)y0 * fw + x1) * 3;
-        const uint8_t* p10 = frame + ((size_t)y1 * fw + x0) * 3;
-        const uint8_t* p11 = frame + ((size_t)y1 * fw + x1) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double top = (1. - wx) * p00[c] + wx * p01[c];
-            const double bot = (1. - wx) * p10[c] + wx * p11[c];
-            const double v = rint((1. - wy) * top + wy * bot);
-            const double u8 = fmin(fmax(v, 0.), 255.);
-            rgb[2 - c] = (float)(u8 * (1. / 255.));      // BGR -> RGB
-        }
-    }
+    det_input_pixel(frame, fw, fh, x, y, roi_x, roi_y, roi_w, roi_h, rgb);      // (pixel_source.h: shared with the fused stem)
     f16x8 o;
     o[0] = (f16)rgb[0]; o[1] = (f16)rgb[1]; o[2] = (f16)rgb[2];
 #pragma unroll
@@ -1316,10 +1293,29 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     int rc = acquire_slot(d, s);
     if (rc) return rc;
     fm_trace_mark(ctx, s, 14);
-    if ((rc = enqueue_preprocess(ctx, d, net, frame))) return rc;
-    FM_HIP(hipEventRecord(d->ev0[d->wr], s));
-    fm_trace_mark(ctx, s, 11);
-    if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
+    // Round 6: when the network begins with a stem convolution over its input tensor, that convolution computes the
+    // resized / normalised pixels itself while it stages its patch (stemconv.hip, pixel_source.h): the preprocess launch
+    // (15 us inside the pipeline, between two passes of the stream whose period is the step) and the input tensor's
+    // write + read disappear.  Same functions, same values (tests/test_detect_gpu.py compares the head tensors).
+    const bool fused = ctx->opt_fused_input && fm_net_stem_fusable(net, c.input_tensor);
+    if (fused) {
+        FM_HIP(hipEventRecord(d->ev0[d->wr], s));
+        fm_trace_mark(ctx, s, 11);
+        StemSrc src{};
+        src.kind = 1; src.frame = frame; src.fw = ctx->frame_w; src.fh = ctx->frame_h;
+        src.roi_x = c.roi_x; src.roi_y = c.roi_y; src.roi_w = c.roi_w; src.roi_h = c.roi_h;
+        src.zero4 = filter_args(d, d->wr).counters;
+        if ((rc = fm_net_run_stem_from(ctx, net, src, 1))) return rc;
+        net->first = 1;
+        rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1);
+        net->first = 0;
+        if (rc) return rc;
+    } else {
+        if ((rc = enqueue_preprocess(ctx, d, net, frame))) return rc;
+        FM_HIP(hipEventRecord(d->ev0[d->wr], s));
+        fm_trace_mark(ctx, s, 11);
+        if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
+    }
     FM_HIP(hipEventRecord(d->ev1[d->wr], s));
     fm_trace_mark(ctx, s, 12);
     FilterArgs fa = filter_args(d, d->wr);      // (counters were zeroed by this frame's preprocess kernel)

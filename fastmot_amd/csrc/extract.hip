@@ -12,7 +12,7 @@
 // Parity for this stage is pinned only against the restatement in oracle/cv_oracle.py (OpenCV is
 // not available to run; SURVEY.md section 8c "parity unpinned").
 // Roofline: HBM bound; per crop reads <= w*h*3 B of frame, writes 256*128*8*2 B = 512 KB.
-#include "net.h"
+#include "pixel_source.h"
 #include <cmath>
 
 struct ExtState {
@@ -46,65 +46,14 @@ __global__ __launch_bounds__(256) void export_kernel(const float4* __restrict__ 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) dst[i] = src[i];
 }
 
-struct Coef { int s; short a0, a1; };
-
-// OpenCV resize coordinate + coefficient computation for one output index
-__device__ __forceinline__ Coef lin_coef(int d, double scale, int ssize) {
-    float f = (float)((d + 0.5) * scale - 0.5);
-    int s = (int)floorf(f);
-    f -= s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
-    Coef c;
-    c.s = s;
-    // saturate_cast<short>(v * 2048) with cvRound (round half to even)
-    c.a0 = (short)__float2int_rn((1.f - f) * 2048.f);
-    c.a1 = (short)__float2int_rn(f * 2048.f);
-    return c;
-}
-
 __global__ void crop_resize_kernel(const uint8_t* __restrict__ frame, int fw, int fh,
                                    const double* __restrict__ boxes, int n, f16* __restrict__ out,
                                    int ow, int oh, int cs) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
     if (x >= ow) return;
-    const double* bx = boxes + (size_t)b * 4;
-    // multi_crop: astype(int) truncation, maximum(., 0), inclusive bottom-right, numpy slice clamp
-    int x1 = max((int)bx[0], 0), y1 = max((int)bx[1], 0);
-    int x2 = max((int)bx[2], 0), y2 = max((int)bx[3], 0);
-    x2 = min(x2 + 1, fw); y2 = min(y2 + 1, fh);
-    const int cw = x2 - x1, ch = y2 - y1;
     f16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (f16)0.f;
-    if (cw > 0 && ch > 0) {
-        const Coef cx = lin_coef(x, (double)cw / ow, cw);
-        const Coef cy = lin_coef(y, (double)ch / oh, ch);
-        const int sx1 = min(cx.s + 1, cw - 1), sy1 = min(cy.s + 1, ch - 1);
-        const uint8_t* r0 = frame + ((size_t)(y1 + cy.s) * fw + x1) * 3;
-        const uint8_t* r1 = frame + ((size_t)(y1 + sy1) * fw + x1) * 3;
-        const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
-        // cv::resize routes INTER_LINEAR with an exact 2x decimation in both axes to INTER_AREA (resize.cpp:
-        // `is_area_fast && iscale_x == 2 && iscale_y == 2`): rounded mean of the 2x2 block
-        const bool area2 = cw == 2 * ow && ch == 2 * oh;
-        const uint8_t* q0 = frame + ((size_t)(y1 + 2 * y) * fw + x1 + 2 * x) * 3;
-        const uint8_t* q1 = q0 + (size_t)fw * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            int u8;
-            if (area2) {
-                u8 = (q0[c] + q0[3 + c] + q1[c] + q1[3 + c] + 2) >> 2;
-            } else {
-                const int S0 = r0[cx.s * 3 + c] * cx.a0 + r0[sx1 * 3 + c] * cx.a1;
-                const int S1 = r1[cx.s * 3 + c] * cx.a0 + r1[sx1 * 3 + c] * cx.a1;
-                const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
-                u8 = min(max(v, 0), 255);
-            }
-            const int rc = 2 - c;    // BGR -> RGB
-            o[rc] = (f16)(float)(((double)u8 / 255. - mean[rc]) / stdv[rc]);
-        }
-    }
+    crop_input_pixel(frame, fw, fh, boxes + (size_t)b * 4, x, y, ow, oh, o);     // (pixel_source.h: shared with the fused stem)
     *reinterpret_cast<f16x8*>(out + (((size_t)b * oh + y) * ow + x) * cs) = o;
 }
 
@@ -138,6 +87,28 @@ static int export_embeddings(fm_ctx* ctx, ExtState* e, int n, hipStream_t s) {
     e->exported_n = n;
     // what fm_extract_sync waits for: the stream may go on with work of the association (the early pairwise launch)
     FM_HIP(hipEventRecord(ctx->ev_ext_done, s));
+    return 0;
+}
+
+// crops [off, off + b) of the uploaded boxes -> the network's first activation.  Round 6: when the network begins with
+// a stem convolution over its input tensor, that convolution computes crop -> resize -> normalise itself while it stages
+// its patch (stemconv.hip, pixel_source.h; sets ni->first = 1 for the fm_net_run that follows): the crop launch and the
+// input tensor -- 26 MB written and read back per 50 crops -- disappear.  Otherwise crop_resize_kernel fills the tensor.
+static int front_end(fm_ctx* ctx, ExtState* e, NetState* ni, hipStream_t si, int off, int b, int cs) {
+    ni->first = 0;
+    if (ctx->opt_fused_input && fm_net_stem_fusable(ni, e->input_tensor)) {
+        StemSrc src{};
+        src.kind = 2; src.frame = ctx->frame_cur; src.fw = ctx->frame_w; src.fh = ctx->frame_h;
+        src.boxes = e->boxes + (size_t)off * 4;
+        int rc = fm_net_run_stem_from(ctx, ni, src, b);
+        if (rc) return rc;
+        ni->first = 1;
+        return 0;
+    }
+    hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, b), dim3(128), 0, si,
+                       ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes + (size_t)off * 4, b,
+                       (f16*)ni->bufs[e->input_tensor], e->in_w, e->in_h, cs);
+    FM_HIP(hipGetLastError());
     return 0;
 }
 
@@ -192,13 +163,12 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
             hipStream_t si = i == 0 ? s : ctx->s_ext_x[i - 1];
             FM_CHECK_ARG(b <= ni->max_batch);
             if (i) FM_HIP(hipStreamWaitEvent(si, ctx->ev_ext_in, 0));
-            hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, b), dim3(128), 0, si,
-                               ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes + (size_t)off * 4, b,
-                               (f16*)ni->bufs[e->input_tensor], e->in_w, e->in_h, t.c);
-            FM_HIP(hipGetLastError());
+            int rc = front_end(ctx, e, ni, si, off, b, t.c);
+            if (rc) return rc;
             ni->emb_offset = off;
-            const int rc = fm_net_run_internal(ctx, i == 0 ? FM_NET_EXTRACTOR : FM_NET_EXTRACTOR_B + i - 1, b);
+            rc = fm_net_run_internal(ctx, i == 0 ? FM_NET_EXTRACTOR : FM_NET_EXTRACTOR_B + i - 1, b);
             ni->emb_offset = 0;
+            ni->first = 0;
             if (rc) return rc;
             if (i) {                                            // everything downstream orders after s_ext only
                 FM_HIP(hipEventRecord(ctx->ev_ext_x_done[i - 1], si));
@@ -215,14 +185,13 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
     }
     for (int off = 0; off < n; off += net->max_batch) {
         const int b = n - off < net->max_batch ? n - off : net->max_batch;
-        hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, b), dim3(128), 0, s,
-                           ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes + (size_t)off * 4, b,
-                           (f16*)net->bufs[e->input_tensor], e->in_w, e->in_h, t.c);
-        FM_HIP(hipGetLastError());
+        int rc = front_end(ctx, e, net, s, off, b, t.c);
+        if (rc) return rc;
         fm_trace_mark(ctx, s, 34);
         net->emb_offset = off;
-        int rc = fm_net_run_internal(ctx, FM_NET_EXTRACTOR, b);
+        rc = fm_net_run_internal(ctx, FM_NET_EXTRACTOR, b);
         net->emb_offset = 0;
+        net->first = 0;
         if (rc) return rc;
     }
     fm_trace_mark(ctx, s, 35);
@@ -261,6 +230,15 @@ extern "C" int fm_extract_read_input(fm_ctx* ctx, int n, float* out) {
     ExtState* e = ctx->ext;
     NetState* net = ctx->ext_net;
     const fm_tensor& t = net->tensors[e->input_tensor];
+    if (ctx->opt_fused_input && fm_net_stem_fusable(net, e->input_tensor)) {
+        // the fused stem never wrote the tensor: fill it now with the front-end kernel (same pixel function) from the
+        // boxes of the last fm_extract_async, which are still on the device
+        FM_CHECK_ARG(ctx->frame_cur && n <= e->cap);
+        hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, n), dim3(128), 0, ctx->s_ext,
+                           ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes, n, (f16*)net->bufs[e->input_tensor],
+                           e->in_w, e->in_h, t.c);
+        FM_HIP(hipGetLastError());
+    }
     FM_HIP(hipStreamSynchronize(ctx->s_ext));
     std::vector<f16> tmp((size_t)n * t.h * t.w * t.c);
     FM_HIP(hipMemcpy(tmp.data(), net->bufs[e->input_tensor], tmp.size() * 2, hipMemcpyDeviceToHost));

@@ -46,6 +46,7 @@ struct NetState {
     bool use_graphs = true;
     int emb_offset = 0;   // row offset of FM_OP_HEAD outputs in ctx->emb (batched extraction)
     int batch_offset = 0; // sample offset into the input tensor for chunked runs
+    int first = 0;        // first layer fm_net_run executes: 1 when the caller has run layer 0 itself (fm_net_run_stem_from)
 };
 
 NetState* fm_net_get(fm_ctx* ctx, int which);

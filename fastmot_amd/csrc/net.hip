@@ -2,7 +2,7 @@
 // Replaces TRTInference (fastmot/utils/inference.py:39-125): buffers are allocated once, a run
 // enqueues every layer on the network's own HIP stream; nothing synchronises until the caller
 // asks for results (detect_async/postprocess protocol of fastmot/detector.py:26-42).
-#include "net.h"
+#include "pixel_source.h"
 #include <memory>
 
 int launch_dwconv3(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
@@ -306,11 +306,43 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
 // gate kernels index gate[n*C + c] with C = the gated channel count; buffers are spaced by
 // max_batch*gate_c so any C <= gate_c fits.
 static int run_layers_eager(fm_ctx* ctx, NetState* net, int batch) {
-    for (const fm_layer& L : net->layers) {
-        int rc = run_layer(ctx, net, L, batch);
+    for (size_t i = (size_t)net->first; i < net->layers.size(); ++i) {
+        int rc = run_layer(ctx, net, net->layers[i], batch);
         if (rc) return rc;
     }
     return 0;
+}
+
+// Layer 0 is a stem convolution over the network's input tensor (and nothing else reads that tensor): the detector /
+// extractor front ends can then let the stem compute its input pixels from the frame itself (pixel_source.h).
+bool fm_net_stem_fusable(const NetState* net, int input_tensor) {
+    if (!net || net->layers.empty()) return false;
+    const fm_layer& L = net->layers[0];
+    if (L.op != FM_OP_STEMCONV || L.n_in != 1 || L.in[0] != input_tensor || L.in_coff[0] != 0) return false;
+    for (size_t i = 1; i < net->layers.size(); ++i) {
+        const fm_layer& M = net->layers[i];
+        for (int k = 0; k < M.n_in; ++k)
+            if (M.in[k] == input_tensor) return false;
+        if (M.res_mode != FM_RES_NONE && M.res == input_tensor) return false;
+        if (M.out == input_tensor) return false;
+    }
+    return true;
+}
+
+// Layer 0 of `net` on `src` instead of the input tensor, launched eagerly on the network's stream (its arguments -- the
+// frame, the boxes -- change from call to call: not part of the captured graph); fm_net_run then starts at layer 1
+// (net->first, which the caller sets around its fm_net_run call).
+int fm_net_run_stem_from(fm_ctx* ctx, NetState* net, const StemSrc& src, int batch) {
+    FM_CHECK_ARG(ctx && net && !net->layers.empty() && batch >= 1 && batch <= net->max_batch);
+    const fm_layer& L = net->layers[0];
+    FM_CHECK_ARG(L.op == FM_OP_STEMCONV);
+    const fm_tensor& ti = net->tensors[L.in[0]];
+    const fm_tensor& to = net->tensors[L.out];
+    FM_CHECK_ARG(!to.f32 && (ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h &&
+                 (ti.w + 2 * L.pad - L.k) / L.stride + 1 == to.w && L.out_coff + ((L.cout + 7) & ~7) <= to.c);
+    return launch_stemconv_src(src, (const f16*)net->bufs[L.in[0]], ti.c, 0, (f16*)net->bufs[L.out], to.c, L.out_coff,
+                               (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off), batch, ti.h,
+                               ti.w, to.h, to.w, L.k, L.stride, L.pad, L.cout, L.act, net->stream);
 }
 
 // The layer sequence of one (batch, embedding offset) is captured once into a hipGraph and
@@ -322,7 +354,7 @@ extern "C" int fm_net_run(fm_ctx* ctx, int which, int batch) {
     FM_CHECK_ARG(net != nullptr && batch >= 0 && batch <= net->max_batch);
     if (batch == 0) return 0;
     if (!net->use_graphs || !ctx->opt_use_graphs) return run_layers_eager(ctx, net, batch);
-    const long key = ((long)batch << 32) | (unsigned)net->emb_offset;
+    const long key = (((long)batch << 32) | (unsigned)net->emb_offset) ^ ((long)net->first << 60);
     for (auto& g : net->graphs)
         if (g.first == key) {
             FM_HIP(hipGraphLaunch(g.second, net->stream));

@@ -8,14 +8,20 @@
 // and builds the MFMA B operand from it: 8 consecutive K = 2 taps x 4 channels = one ds_read2_b64.
 //   D[cout][pixel] = sum_k W[cout][k] X[pixel][k],  k = (kh, kw, c4), K = k*k*4 padded to 16
 // A (weights, [32][KP] fp16) lives in registers for the whole workgroup.
-#include "net.h"
+#include "pixel_source.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KS, int STRIDE>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
+// SRC: where the patch comes from (pixel_source.h StemSrc): 0 the fp16 NHWC tensor `in`; 1 the detector's letterboxed
+// resize of the u8 frame, 2 the extractor's crops -- computed on the fly with the front-end kernels' own functions, so
+// the network input tensor is neither written nor read and the front-end launch disappears (round 6: the detector's
+// preprocess kernel was 15 us between two passes of the detector stream, whose period is the step; the crop kernel
+// wrote and the stem re-read 26 MB per 50 crops).  A patch position is computed by every tile it lies in (1.27x / 1.34x
+// of the pixels).
+template <int KS, int STRIDE, int SRC>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const StemSrc src, const f16* __restrict__ in, int in_cs, int in_coff,
                                                         f16* __restrict__ out, int out_cs, int out_coff,
                                                         const f16* __restrict__ w, const float* __restrict__ bias,
                                                         int H, int W, int Ho, int Wo, int pad, int act,
@@ -29,10 +35,27 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const f16* __restrict__ 
     const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16;
     const long n = blockIdx.z;
     const f16* img = in + n * (long)H * W * in_cs + in_coff;
+    if (SRC != 0 && src.zero4 && tid < 4 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) src.zero4[tid] = 0;
     for (int i = tid; i < PH * PW; i += 256) {
         const int iy = oy0 * STRIDE - pad + i / PW, ix = ox0 * STRIDE - pad + i % PW;
         uint2 v = make_uint2(0u, 0u);
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint2*>(img + ((long)iy * W + ix) * in_cs);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            if constexpr (SRC == 0) {
+                v = *reinterpret_cast<const uint2*>(img + ((long)iy * W + ix) * in_cs);
+            } else if constexpr (SRC == 1) {
+                float rgb[3];
+                det_input_pixel(src.frame, src.fw, src.fh, ix, iy, src.roi_x, src.roi_y, src.roi_w, src.roi_h, rgb);
+                union { f16 h[4]; uint2 u; } pk;
+                pk.h[0] = (f16)rgb[0]; pk.h[1] = (f16)rgb[1]; pk.h[2] = (f16)rgb[2]; pk.h[3] = (f16)0.f;
+                v = pk.u;
+            } else {
+                f16x8 o;
+                crop_input_pixel(src.frame, src.fw, src.fh, src.boxes + n * 4, ix, iy, W, H, o);
+                union { f16 h[4]; uint2 u; } pk;
+                pk.h[0] = o[0]; pk.h[1] = o[1]; pk.h[2] = o[2]; pk.h[3] = o[3];
+                v = pk.u;
+            }
+        }
         patch[i] = v;
     }
     const int frow = lane & 31, fh = lane >> 5;
@@ -83,21 +106,20 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const f16* __restrict__ 
 
 }  // namespace
 
-// w: fp16 [32][ceil16(k*k*4)], K order (kh, kw, c) with c < 4; bias f32[32]
-int launch_stemconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
-                    const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad, int cout,
-                    int act, hipStream_t s) {
-    FM_CHECK_ARG(cout >= 1 && cout <= 32 && in_cs % 4 == 0 && in_coff % 4 == 0 && out_cs % 4 == 0 && out_coff % 4 == 0);
+template <int SRC>
+static int launch_stem_kind(const StemSrc& src, const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff,
+                            const f16* w, const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad,
+                            int cout, int act, hipStream_t s) {
     const dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, N), block(256);
     const int cs = (cout + 7) & ~7;
     if (k == 3 && stride == 1)
-        hipLaunchKernelGGL((stem_conv_kernel<3, 1>), grid, block, 0, s, in, in_cs, in_coff, out, out_cs, out_coff, w,
+        hipLaunchKernelGGL((stem_conv_kernel<3, 1, SRC>), grid, block, 0, s, src, in, in_cs, in_coff, out, out_cs, out_coff, w,
                            bias, H, W, Ho, Wo, pad, act, cs);
     else if (k == 3 && stride == 2)
-        hipLaunchKernelGGL((stem_conv_kernel<3, 2>), grid, block, 0, s, in, in_cs, in_coff, out, out_cs, out_coff, w,
+        hipLaunchKernelGGL((stem_conv_kernel<3, 2, SRC>), grid, block, 0, s, src, in, in_cs, in_coff, out, out_cs, out_coff, w,
                            bias, H, W, Ho, Wo, pad, act, cs);
     else if (k == 7 && stride == 2)
-        hipLaunchKernelGGL((stem_conv_kernel<7, 2>), grid, block, 0, s, in, in_cs, in_coff, out, out_cs, out_coff, w,
+        hipLaunchKernelGGL((stem_conv_kernel<7, 2, SRC>), grid, block, 0, s, src, in, in_cs, in_coff, out, out_cs, out_coff, w,
                            bias, H, W, Ho, Wo, pad, act, cs);
     else {
         fm_set_error("stem conv: unsupported k=%d stride=%d", k, stride);
@@ -105,4 +127,22 @@ int launch_stemconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs,
     }
     FM_HIP(hipGetLastError());
     return 0;
+}
+
+// w: fp16 [32][ceil16(k*k*4)], K order (kh, kw, c) with c < 4; bias f32[32]
+int launch_stemconv_src(const StemSrc& src, const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff,
+                        const f16* w, const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad,
+                        int cout, int act, hipStream_t s) {
+    FM_CHECK_ARG(cout >= 1 && cout <= 32 && in_cs % 4 == 0 && in_coff % 4 == 0 && out_cs % 4 == 0 && out_coff % 4 == 0);
+    FM_CHECK_ARG(src.kind == 0 || (src.frame && src.fw > 0 && src.fh > 0 && (src.kind == 1 || (src.kind == 2 && src.boxes))));
+    if (src.kind == 1) return launch_stem_kind<1>(src, in, in_cs, in_coff, out, out_cs, out_coff, w, bias, N, H, W, Ho, Wo, k, stride, pad, cout, act, s);
+    if (src.kind == 2) return launch_stem_kind<2>(src, in, in_cs, in_coff, out, out_cs, out_coff, w, bias, N, H, W, Ho, Wo, k, stride, pad, cout, act, s);
+    return launch_stem_kind<0>(src, in, in_cs, in_coff, out, out_cs, out_coff, w, bias, N, H, W, Ho, Wo, k, stride, pad, cout, act, s);
+}
+
+int launch_stemconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
+                    const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad, int cout,
+                    int act, hipStream_t s) {
+    return launch_stemconv_src(StemSrc{}, in, in_cs, in_coff, out, out_cs, out_coff, w, bias, N, H, W, Ho, Wo, k, stride, pad,
+                               cout, act, s);
 }

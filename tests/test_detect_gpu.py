@@ -250,3 +250,59 @@ def test_reid_split_batches_identical(ctx):
     for n in (33, 32, 9, 7, 1):
         np.testing.assert_array_equal(embs[2, n], embs[1, n])
         np.testing.assert_array_equal(embs[4, n], embs[1, n])
+
+
+@pytest.mark.parametrize('model', ['TinyYOLO', 'TinyLetterbox', 'YOLOv4_608'])
+def test_fused_input_stem_equals_preprocess_kernel(ctx, model):
+    """Round 6: the detector's stem convolution computes the resized / normalised input pixels itself (fm_ctx option
+    "fused_input", default 1; stemconv.hip + pixel_source.h) instead of reading the tensor preprocess_kernel wrote.
+    Same pixel function on both paths: every head tensor and the detections are equal bit for bit."""
+    size = (1920, 1080) if model == 'YOLOv4_608' else (320, 180)
+    det = YOLODetector(size, (0, 1, 2), model=model, conf_thresh=0.1, nms_thresh=0.5, weights=RandomWeights(seed=4),
+                       max_candidates=65536, reuse_buffers=False)
+    frame = synthetic_frame(*size, seed=11)
+    outs = {}
+    try:
+        for fused in (1, 0, 1):
+            ctx.set_option('fused_input', fused)
+            dets = det(frame)
+            heads = [det.backend.read(h, 1).copy() for h in det.heads]
+            stem = det.backend.read(det.graph.layers[0]['out'], 1).copy()
+            outs.setdefault(fused, []).append((dets, heads, stem))
+    finally:
+        ctx.set_option('fused_input', 1)
+    assert det.graph.layers[0]['op'] == 12                      # FM_OP_STEMCONV: the fused path really is in use
+    for dets, heads, stem in outs[1][1:] + outs[0]:
+        ref = outs[1][0]
+        np.testing.assert_array_equal(stem, ref[2])
+        for a, b in zip(heads, ref[1]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(dets.tlbr, ref[0].tlbr)
+        np.testing.assert_array_equal(dets.conf, ref[0].conf)
+
+
+@pytest.mark.parametrize('model,n', [('OSNet025', 5), ('OSNet025', 19), ('OSNet10', 5)])
+def test_fused_input_stem_equals_crop_kernel(ctx, model, n):
+    """The same for the ReID network: crop -> resize -> normalise inside OSNet's 7x7 stem (chunked batches included:
+    n > batch_size) against crop_resize_kernel + input tensor -- embeddings equal bit for bit."""
+    size = (640, 360)
+    frame = synthetic_frame(*size, seed=2)
+    ext = FeatureExtractor(model, batch_size=8, weights=RandomWeights(seed=3), size=size)
+    rng = np.random.default_rng(n)
+    tl = rng.uniform([-20, -20], [560, 250], (n, 2))
+    boxes = np.concatenate([tl, tl + rng.uniform([8, 16], [140, 300], (n, 2))], axis=1)
+    embs = {}
+    try:
+        for fused in (1, 0):
+            ctx.set_option('fused_input', fused)
+            ext.extract_async(frame, boxes)
+            embs[fused] = ext.postprocess().copy()
+    finally:
+        ctx.set_option('fused_input', 1)
+    # (OSNet-x1.0's first conv has 64 output channels: not a stem-kernel layer, both settings take the crop kernel)
+    assert (ext.graph.layers[0]['op'] == 12) == (model == 'OSNet025')
+    np.testing.assert_array_equal(embs[1], embs[0])
+    if n <= 8:
+        inp = ctx.extract_read_input(n, 128, 256)            # (refilled by the front-end kernel on the fused path)
+        exp = cv_oracle.reid_preprocess(frame, boxes).transpose(0, 2, 3, 1)
+        np.testing.assert_allclose(inp, exp, rtol=0, atol=2.5e-3)
