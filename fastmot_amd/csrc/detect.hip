@@ -1062,11 +1062,11 @@ extern "C" int fm_frame_configure(fm_ctx* ctx, int width, int height, int ring_s
     ctx->frame_own = ctx->frame_own2 = ctx->frame_ring = ctx->frame_pinned = ctx->frame_pinned2 = nullptr;
     ctx->frame_next = nullptr;
     const size_t bytes = (size_t)width * height * 3;
-    FM_HIP(hipMalloc(&ctx->frame_own, bytes));
-    FM_HIP(hipMalloc(&ctx->frame_own2, bytes));
+    FM_HIP(hipMalloc(&ctx->frame_own, bytes + FM_FRAME_SLACK));        // (pixel_source.h load_px2 reads 8 bytes at a pixel)
+    FM_HIP(hipMalloc(&ctx->frame_own2, bytes + FM_FRAME_SLACK));
     FM_HIP(hipHostMalloc(&ctx->frame_pinned, bytes, hipHostMallocDefault));
     FM_HIP(hipHostMalloc(&ctx->frame_pinned2, bytes, hipHostMallocDefault));
-    if (ring_size > 0) FM_HIP(hipMalloc(&ctx->frame_ring, bytes * ring_size));
+    if (ring_size > 0) FM_HIP(hipMalloc(&ctx->frame_ring, bytes * ring_size + FM_FRAME_SLACK));
     ctx->frame_w = width;
     ctx->frame_h = height;
     ctx->ring_size = ring_size;
@@ -1306,6 +1306,7 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
         src.roi_x = c.roi_x; src.roi_y = c.roi_y; src.roi_w = c.roi_w; src.roi_h = c.roi_h;
         src.zero4 = filter_args(d, d->wr).counters;
         if ((rc = fm_net_run_stem_from(ctx, net, src, 1))) return rc;
+        fm_trace_mark(ctx, s, 15);
         net->first = 1;
         rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1);
         net->first = 0;

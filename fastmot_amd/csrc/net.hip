@@ -247,6 +247,11 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             return launch_stemconv(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
                                    (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                    B, ti.h, ti.w, to.h, to.w, L.k, L.stride, L.pad, L.cout, L.act, s);
+        case FM_OP_STEM2:
+            FM_CHECK_ARG(!to.f32 && L.hid == 32 && stem2_supported(L.hid, L.cout) && L.in_coff[0] == 0 && L.out_coff + L.cout <= to.c);
+            return launch_stem2(StemSrc{}, in0, ti.c, out, to.c, L.out_coff, (const f16*)(net->weights + L.w_off),
+                                (const float*)(net->weights + L.b_off), (const f16*)(net->weights + L.w2_off),
+                                (const float*)(net->weights + L.b2_off), B, ti.h, ti.w, to.h, to.w, L.cout, L.gate[0], L.act, s);
         case FM_OP_SPP:
             FM_CHECK_ARG(to.h == ti.h && to.w == ti.w && L.out_coff + 3 * L.cin <= to.c);
             return launch_spp(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, s);
@@ -318,7 +323,7 @@ static int run_layers_eager(fm_ctx* ctx, NetState* net, int batch) {
 bool fm_net_stem_fusable(const NetState* net, int input_tensor) {
     if (!net || net->layers.empty()) return false;
     const fm_layer& L = net->layers[0];
-    if (L.op != FM_OP_STEMCONV || L.n_in != 1 || L.in[0] != input_tensor || L.in_coff[0] != 0) return false;
+    if ((L.op != FM_OP_STEMCONV && L.op != FM_OP_STEM2) || L.n_in != 1 || L.in[0] != input_tensor || L.in_coff[0] != 0) return false;
     for (size_t i = 1; i < net->layers.size(); ++i) {
         const fm_layer& M = net->layers[i];
         for (int k = 0; k < M.n_in; ++k)
@@ -335,9 +340,16 @@ bool fm_net_stem_fusable(const NetState* net, int input_tensor) {
 int fm_net_run_stem_from(fm_ctx* ctx, NetState* net, const StemSrc& src, int batch) {
     FM_CHECK_ARG(ctx && net && !net->layers.empty() && batch >= 1 && batch <= net->max_batch);
     const fm_layer& L = net->layers[0];
-    FM_CHECK_ARG(L.op == FM_OP_STEMCONV);
+    FM_CHECK_ARG(L.op == FM_OP_STEMCONV || L.op == FM_OP_STEM2);
     const fm_tensor& ti = net->tensors[L.in[0]];
     const fm_tensor& to = net->tensors[L.out];
+    if (L.op == FM_OP_STEM2) {
+        FM_CHECK_ARG(src.kind != 2 && !to.f32 && L.hid == 32 && stem2_supported(L.hid, L.cout) && L.out_coff + L.cout <= to.c);
+        return launch_stem2(src, (const f16*)net->bufs[L.in[0]], ti.c, (f16*)net->bufs[L.out], to.c, L.out_coff,
+                            (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                            (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off), batch, ti.h, ti.w,
+                            to.h, to.w, L.cout, L.gate[0], L.act, net->stream);
+    }
     FM_CHECK_ARG(!to.f32 && (ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h &&
                  (ti.w + 2 * L.pad - L.k) / L.stride + 1 == to.w && L.out_coff + ((L.cout + 7) & ~7) <= to.c);
     return launch_stemconv_src(src, (const f16*)net->bufs[L.in[0]], ti.c, 0, (f16*)net->bufs[L.out], to.c, L.out_coff,
@@ -448,6 +460,10 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *flops = 2.0 * L.k * L.k * 3 * L.cout * pout;
             *bytes = pin * 8 + pout * L.cout * 2;
             break;
+        case FM_OP_STEM2:       // both convs' FLOPs; the bytes of the fused pair: input in, second conv's output out, weights
+            *flops = 2.0 * 9 * 3 * L.hid * pin + 2.0 * 9 * L.hid * L.cout * pout;
+            *bytes = pin * 8 + pout * L.cout * 2 + 9.0 * L.hid * L.cout * 2;
+            break;
         case FM_OP_RESBLOCK:
             *flops = 2.0 * 10 * L.cin * L.hid * pout;
             *bytes = (pin + pout) * L.cin * 2 + 10.0 * L.cin * L.hid * 2;
@@ -474,6 +490,14 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
             layer_cost(net, L, batch, &lf, &lb);
             f += lf;
             b += lb;
+        } else if (L.op == FM_OP_STEM2) {
+            // the pair's second conv as the stand-alone layer it replaces (the stem itself was never part of this sum): the
+            // algorithmic work of a network does not change with the fusions of its layer table
+            const fm_tensor& ti = net->tensors[L.in[0]];
+            const fm_tensor& to = net->tensors[L.out];
+            const double pmid = (double)batch * ti.h * ti.w, pout = (double)batch * to.h * to.w;
+            f += 2.0 * 9 * L.hid * L.cout * pout;
+            b += pmid * L.hid * 2 + pout * L.cout * 2 + 9.0 * L.hid * L.cout * 2;
         }
     *flops = f;
     *bytes = b;
@@ -499,7 +523,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
             FM_HIP(hipEventSynchronize(e1));
             float ms = 0;
             FM_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK) { tc += ms; ++nc; } else { to += ms; ++no; }
+            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK || L.op == FM_OP_STEM2) { tc += ms; ++nc; } else { to += ms; ++no; }
         }
     FM_HIP(hipEventDestroy(e0));
     FM_HIP(hipEventDestroy(e1));

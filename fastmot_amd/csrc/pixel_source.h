@@ -9,13 +9,20 @@
 // clamp (cupyx zoom mode='opencv', grid_mode=True: src = (dst + 0.5) * (in/out) - 0.5; affine_transform order=1,
 // mode='nearest'), rounded to uint8 (rint), BGR -> RGB, * 1/255 (fp32), fp16.  Outside the letterbox ROI: 0.5.
 // (x, y): pixel of the network input.  Returns the three channels as floats already rounded through u8.
+// two neighbouring BGR pixels = 6 consecutive bytes as ONE (unaligned) 8-byte load instead of six byte loads: the resize
+// functions below are bound by their dependent trips to memory (round 6: the stem computing its own input took 31 us inside
+// the pipeline).  Reads up to 7 bytes past a pixel: frame buffers are allocated with FM_FRAME_SLACK spare bytes.
+#define FM_FRAME_SLACK 16
+typedef uint64_t fm_u64_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint64_t load_px2(const uint8_t* p) { return *reinterpret_cast<const fm_u64_unaligned*>(p); }
+
 __device__ __forceinline__ void det_input_pixel(const uint8_t* __restrict__ frame, int fw, int fh, int x, int y,
                                                 int roi_x, int roi_y, int roi_w, int roi_h, float rgb[3]) {
-    const int rx = x - roi_x, ry = y - roi_y;
-    if (rx < 0 || ry < 0 || rx >= roi_w || ry >= roi_h) {
-        rgb[0] = rgb[1] = rgb[2] = 0.5f;
-        return;
-    }
+    // (branch-free: positions outside the letterbox ROI compute a clamped one and select 0.5 at the end, so that a caller's
+    // unrolled loop can have all its loads in flight at once)
+    const int rx0 = x - roi_x, ry0 = y - roi_y;
+    const bool in_roi = !(rx0 < 0 || ry0 < 0 || rx0 >= roi_w || ry0 >= roi_h);
+    const int rx = min(max(rx0, 0), roi_w - 1), ry = min(max(ry0, 0), roi_h - 1);
     const double zy = (double)fh / roi_h, zx = (double)fw / roi_w;
     const double sy = ry * zy + (zy - 1.) / 2., sx = rx * zx + (zx - 1.) / 2.;
     const double fy = floor(sy), fx = floor(sx);
@@ -23,17 +30,18 @@ __device__ __forceinline__ void det_input_pixel(const uint8_t* __restrict__ fram
     int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
     y0 = min(max(y0, 0), fh - 1); y1 = min(max(y1, 0), fh - 1);
     x0 = min(max(x0, 0), fw - 1); x1 = min(max(x1, 0), fw - 1);
-    const uint8_t* p00 = frame + ((size_t)y0 * fw + x0) * 3;
-    const uint8_t* p01 = frame + ((size_t)y0 * fw + x1) * 3;
-    const uint8_t* p10 = frame + ((size_t)y1 * fw + x0) * 3;
-    const uint8_t* p11 = frame + ((size_t)y1 * fw + x1) * 3;
+    // (after the clamps x1 is x0 + 1 or x0)
+    const uint64_t q0 = load_px2(frame + ((size_t)y0 * fw + x0) * 3), q1 = load_px2(frame + ((size_t)y1 * fw + x0) * 3);
+    const int sh = x1 == x0 ? 0 : 24;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double top = (1. - wx) * p00[c] + wx * p01[c];
-        const double bot = (1. - wx) * p10[c] + wx * p11[c];
+        const int p00 = (int)((q0 >> (8 * c)) & 255), p01 = (int)((q0 >> (sh + 8 * c)) & 255);
+        const int p10 = (int)((q1 >> (8 * c)) & 255), p11 = (int)((q1 >> (sh + 8 * c)) & 255);
+        const double top = (1. - wx) * p00 + wx * p01;
+        const double bot = (1. - wx) * p10 + wx * p11;
         const double v = rint((1. - wy) * top + wy * bot);
         const double u8 = fmin(fmax(v, 0.), 255.);
-        rgb[2 - c] = (float)(u8 * (1. / 255.));      // BGR -> RGB
+        rgb[2 - c] = in_roi ? (float)(u8 * (1. / 255.)) : 0.5f;      // BGR -> RGB
     }
 }
 
@@ -70,20 +78,23 @@ __device__ __forceinline__ void crop_input_pixel(const uint8_t* __restrict__ fra
         const ResizeCoef cx = lin_coef(x, (double)cw / ow, cw);
         const ResizeCoef cy = lin_coef(y, (double)ch / oh, ch);
         const int sx1 = min(cx.s + 1, cw - 1), sy1 = min(cy.s + 1, ch - 1);
-        const uint8_t* r0 = frame + ((size_t)(y1 + cy.s) * fw + x1) * 3;
-        const uint8_t* r1 = frame + ((size_t)(y1 + sy1) * fw + x1) * 3;
         const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
         const bool area2 = cw == 2 * ow && ch == 2 * oh;
-        const uint8_t* q0 = frame + ((size_t)(y1 + 2 * y) * fw + x1 + 2 * x) * 3;
-        const uint8_t* q1 = q0 + (size_t)fw * 3;
+        // both branches read two neighbouring pixels of two rows: one 8-byte load per row (load_px2)
+        const int ax = area2 ? 2 * x : cx.s, ay0 = area2 ? 2 * y : cy.s, ay1 = area2 ? 2 * y + 1 : sy1;
+        const uint64_t q0 = load_px2(frame + ((size_t)(y1 + ay0) * fw + x1 + ax) * 3);
+        const uint64_t q1 = load_px2(frame + ((size_t)(y1 + ay1) * fw + x1 + ax) * 3);
+        const int sh = (area2 || sx1 != cx.s) ? 24 : 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            const int a0 = (int)((q0 >> (8 * c)) & 255), a1 = (int)((q0 >> (sh + 8 * c)) & 255);
+            const int b0 = (int)((q1 >> (8 * c)) & 255), b1 = (int)((q1 >> (sh + 8 * c)) & 255);
             int u8;
             if (area2) {
-                u8 = (q0[c] + q0[3 + c] + q1[c] + q1[3 + c] + 2) >> 2;
+                u8 = (a0 + a1 + b0 + b1 + 2) >> 2;
             } else {
-                const int S0 = r0[cx.s * 3 + c] * cx.a0 + r0[sx1 * 3 + c] * cx.a1;
-                const int S1 = r1[cx.s * 3 + c] * cx.a0 + r1[sx1 * 3 + c] * cx.a1;
+                const int S0 = a0 * cx.a0 + a1 * cx.a1;
+                const int S1 = b0 * cx.a0 + b1 * cx.a1;
                 const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
                 u8 = min(max(v, 0), 255);
             }
@@ -107,6 +118,10 @@ struct StemSrc {
 int launch_stemconv_src(const StemSrc& src, const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff,
                         const f16* w, const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad,
                         int cout, int act, hipStream_t s);
+int launch_stem2(const StemSrc& src, const f16* in, int in_cs, f16* out, int out_cs, int out_coff, const f16* w1,
+                 const float* b1, const f16* w2, const float* b2, int N, int H, int W, int Ho, int Wo, int cout, int act1,
+                 int act2, hipStream_t s);
+bool stem2_supported(int mid, int cout);
 // runs layer 0 of `net` -- a stem convolution over the network's input tensor -- on `src` instead of that tensor
 bool fm_net_stem_fusable(const NetState* net, int input_tensor);
 int fm_net_run_stem_from(fm_ctx* ctx, NetState* net, const StemSrc& src, int batch);

@@ -36,27 +36,33 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemSrc src, const
     const long n = blockIdx.z;
     const f16* img = in + n * (long)H * W * in_cs + in_coff;
     if (SRC != 0 && src.zero4 && tid < 4 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) src.zero4[tid] = 0;
-    for (int i = tid; i < PH * PW; i += 256) {
-        const int iy = oy0 * STRIDE - pad + i / PW, ix = ox0 * STRIDE - pad + i % PW;
-        uint2 v = make_uint2(0u, 0u);
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            if constexpr (SRC == 0) {
-                v = *reinterpret_cast<const uint2*>(img + ((long)iy * W + ix) * in_cs);
-            } else if constexpr (SRC == 1) {
-                float rgb[3];
-                det_input_pixel(src.frame, src.fw, src.fh, ix, iy, src.roi_x, src.roi_y, src.roi_w, src.roi_h, rgb);
-                union { f16 h[4]; uint2 u; } pk;
-                pk.h[0] = (f16)rgb[0]; pk.h[1] = (f16)rgb[1]; pk.h[2] = (f16)rgb[2]; pk.h[3] = (f16)0.f;
-                v = pk.u;
-            } else {
-                f16x8 o;
-                crop_input_pixel(src.frame, src.fw, src.fh, src.boxes + n * 4, ix, iy, W, H, o);
-                union { f16 h[4]; uint2 u; } pk;
-                pk.h[0] = o[0]; pk.h[1] = o[1]; pk.h[2] = o[2]; pk.h[3] = o[3];
-                v = pk.u;
-            }
+    // (unrolled, loads unconditional on clamped coordinates, zeroing afterwards: all trips to memory of a thread's patch
+    // positions are in flight together -- a load inside a divergent branch waits on the spot)
+    constexpr int NIT = (PH * PW + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256, ic = min(i, PH * PW - 1);
+        const int iy = oy0 * STRIDE - pad + ic / PW, ix = ox0 * STRIDE - pad + ic % PW;
+        const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+        uint2 v;
+        if constexpr (SRC == 0) {
+            v = *reinterpret_cast<const uint2*>(img + ((long)cy * W + cx) * in_cs);
+        } else if constexpr (SRC == 1) {
+            float rgb[3];
+            det_input_pixel(src.frame, src.fw, src.fh, cx, cy, src.roi_x, src.roi_y, src.roi_w, src.roi_h, rgb);
+            union { f16 h[4]; uint2 u; } pk;
+            pk.h[0] = (f16)rgb[0]; pk.h[1] = (f16)rgb[1]; pk.h[2] = (f16)rgb[2]; pk.h[3] = (f16)0.f;
+            v = pk.u;
+        } else {
+            f16x8 o;
+            crop_input_pixel(src.frame, src.fw, src.fh, src.boxes + n * 4, cx, cy, W, H, o);
+            union { f16 h[4]; uint2 u; } pk;
+            pk.h[0] = o[0]; pk.h[1] = o[1]; pk.h[2] = o[2]; pk.h[3] = o[3];
+            v = pk.u;
         }
-        patch[i] = v;
+        if (!inside) v = make_uint2(0u, 0u);
+        if (i < PH * PW) patch[i] = v;
     }
     const int frow = lane & 31, fh = lane >> 5;
     f16x8 afr[NKS];

@@ -15,7 +15,7 @@ import numpy as np
 LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CONVD) = range(18)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CONVD, OP_STEM2) = range(19)
 CONV_OPS = (OP_CONV, OP_CONVS, OP_CONVD)      # the three kernels behind Graph.conv (same fields, different weight layouts)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
@@ -138,6 +138,8 @@ class Graph:
         # 38 x 38 / 19 x 19 levels: 13.5 vs 14.1 us and 15.1 vs 19.4 us on their 3x3 layers); 2 = wherever it applies
         self.convd_level = int(os.environ.get('FASTMOT_CONVD', '1'))
         self.convd_min_cin1 = 16   # smallest cin of a 1x1 layer on it (64: profiles/r05_osnet_pointwise_on_convd_ab.txt)
+        # the stem (3 -> 32, 3x3 s1) and the stride-2 3x3 conv behind it as one launch (stem2.hip, FM_OP_STEM2)
+        self.use_stem2 = os.environ.get('FASTMOT_STEM2', '1') != '0' 
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -181,6 +183,22 @@ class Graph:
         if not bias:
             b = np.zeros_like(b)
         w16 = w.astype(np.float16)
+        if self._stem2_applies(x, cout, k, stride, pad, res, f32_out, up):
+            # second layer of the network, a 3x3 stride-2 conv over the whole output of the stem layer: both as ONE launch
+            # (stem2.hip) -- the 32-channel full-resolution tensor between them (27 MB at 608 x 608) is never stored.  The
+            # stem's layer entry is replaced; finish() checks that nothing else wanted its output.
+            stem = self.layers.pop()
+            _, w1ref, b1ref = self.conv_params.pop()
+            wp = np.zeros((ceil_to(cout, 32), x.c, 3, 3), np.float16)
+            wp[:cout] = w16
+            bias2 = np.zeros(wp.shape[0], np.float32)
+            bias2[:cout] = b
+            self._stem2_dropped = x.tid
+            self._layer(op=OP_STEM2, ins=stem['ins'], out=dst, cin=stem['cin'], cout=cout, k=3, stride=2, pad=1, act=ACT[act],
+                        hid=32, gates=[stem['act']], w_off=stem['w_off'], b_off=stem['b_off'],
+                        w2_off=self._push(self._pack_frag(wp)), b2_off=self._push(bias2), name=name,
+                        stem2_ref=(w1ref, b1ref, stem['act'], w16.astype(np.float32), b))
+            return dst
         if (self.use_stem and x.c <= 4 and x.coff == 0 and cout <= 32 and (k, stride) in ((3, 1), (3, 2), (7, 2))
                 and res is None and not f32_out and up == 1):
             # stem layer: input patch staged in LDS instead of 16 B gathers per tap (stemconv.hip)
@@ -236,6 +254,26 @@ class Graph:
                           res=res, res_mode=res_mode if res is not None else RES_NONE, name=name)
         self.conv_params.append((len(self.layers) - 1, w16.astype(np.float32), b))
         return dst
+
+    def _stem2_applies(self, x, cout, k, stride, pad, res, f32_out, up):
+        if not (self.use_stem2 and len(self.layers) == 1 and k == 3 and stride == 2 and pad == 1 and res is None and
+                not f32_out and up == 1 and cout in (64, 128)):
+            return False
+        stem = self.layers[0]
+        return (stem['op'] == OP_STEMCONV and stem['k'] == 3 and stem['stride'] == 1 and stem['pad'] == 1 and
+                stem['cout'] == 32 and stem['ins'][0].tid == self.input.tid and stem['out'].tid == x.tid and x.coff == 0 and
+                x.c == 32 and x.tid != self.input.tid and x.tid not in [v.tid for v in self.outputs])
+
+    def check_fusions(self):
+        """A fused stem pair dropped the stem's output tensor: no later layer may read it (a cfg that routes from layer 0
+        has to be built with FASTMOT_STEM2=0 / use_stem2 = False)."""
+        t = getattr(self, '_stem2_dropped', None)
+        if t is None:
+            return
+        for d in self.layers:
+            used = [v.tid for v in d['ins']] + ([d['res'].tid] if d['res'] is not None else [])
+            if t in used or t in [v.tid for v in self.outputs]:
+                raise ValueError('the stem\'s output is read by another layer: build this network with use_stem2 = False')
 
     @staticmethod
     def resblock_supported(c, mid):
@@ -531,6 +569,7 @@ class Graph:
         return offsets, total
 
     def tables(self, max_batch=1, reuse=False):
+        self.check_fusions()
         offsets, arena = self.plan_arena(max_batch, reuse)
         self.arena_bytes = arena
         ts = (fm_tensor * len(self.tensors))()
@@ -568,4 +607,7 @@ class Graph:
             elif d['op'] == OP_RESBLOCK:
                 o = d['out']
                 total += 2 * 10 * d['cin'] * d['hid'] * o.h * o.w * batch
+            elif d['op'] == OP_STEM2:
+                o, i = d['out'], d['ins'][0]
+                total += (2 * 9 * i.c * d['hid'] * i.h * i.w + 2 * 9 * d['hid'] * d['cout'] * o.h * o.w) * batch
         return total

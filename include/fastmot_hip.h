@@ -285,6 +285,10 @@ enum {
                           * image is zero-padded to ceil64(K), chunks of a step beyond cin are not fetched); weights as LDS
                           * tile images: [ceil32(cout)/32][ceil64(k*k*cin)/64][32 rows][8 slots][8 halfs], K order (kh, kw, cin),
                           * slot s of row r holding K chunk s ^ ((r / 2) % 8) of that row's 64-wide K step              */
+    FM_OP_STEM2 = 18,    /* the first two layers of a Darknet YOLO backbone in one launch (stem2.hip): conv 3x3 s1 (<= 4 real input
+                          * channels -> hid = 32, activation gate[0]) then conv 3x3 s2 pad 1 (32 -> cout in {64, 128}, activation act);
+                          * in[0] = the network input; w_off / b_off = the first conv as for FM_OP_STEMCONV, w2_off / b2_off = the second
+                          * in MFMA fragment order [cout/32][288/16][lane][8] (K order kh, kw, cin) + f32 bias                          */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

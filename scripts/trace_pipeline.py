@@ -18,7 +18,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench  # noqa: E402
 
-NAMES = {10: 'det: stream reaches the pass', 11: 'det: inputs ready, preprocessed', 12: 'det: network done',
+NAMES = {15: 'det: first layer (input pixels computed in it) done', 10: 'det: stream reaches the pass', 11: 'det: inputs ready, preprocessed', 12: 'det: network done',
          13: 'det: decode done', 20: 'post: begins', 21: 'post: ends', 30: 'copy(next): begins', 31: 'copy(next): ends',
          32: 'reid: begins', 33: 'reid: ends', 40: 'lk: begins', 41: 'lk: ends',
          14: 'det: preprocess begins', 22: 'post: sort done', 23: 'post: bit matrix done', 34: 'reid: crops done',
@@ -121,7 +121,7 @@ def main():
         n = min(len(ta), len(tb))
         return np.array(tb[:n]) - np.array(ta[:n])
     print('# durations (ms): median  (p10 .. p90)')
-    for a, b, nm in ((10, 11, 'det: waiting for inputs + preprocess'), (11, 12, 'det: network'), (12, 13, 'det: decode'),
+    for a, b, nm in ((10, 11, 'det: waiting for inputs + preprocess'), (11, 12, 'det: network'), (11, 15, 'det: first layer incl. resize'), (12, 13, 'det: decode'),
                      (20, 21, 'post: sort + NMS + D2H'), (30, 31, 'copy of the next frame'), (32, 33, 'reid: crop + network'),
                      (40, 41, 'lk kernel')):
         d = pairs(a, b)[5:]

@@ -271,7 +271,7 @@ def test_fused_input_stem_equals_preprocess_kernel(ctx, model):
             outs.setdefault(fused, []).append((dets, heads, stem))
     finally:
         ctx.set_option('fused_input', 1)
-    assert det.graph.layers[0]['op'] == 12                      # FM_OP_STEMCONV: the fused path really is in use
+    assert det.graph.layers[0]['op'] in (12, 18)                # FM_OP_STEMCONV / FM_OP_STEM2: the fused path really is in use
     for dets, heads, stem in outs[1][1:] + outs[0]:
         ref = outs[1][0]
         np.testing.assert_array_equal(stem, ref[2])
