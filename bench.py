@@ -545,7 +545,7 @@ def main():
     if rank == 0:
         flops, _ = mot.detector.backend.cost(1)
         n_launch = len(mot.detector.graph.layers)
-        net_avg_ms = float(np.mean(net_ms))
+        net_avg_ms = float(np.mean(net_ms)) if len(net_ms) else float('nan')
         achieved = flops / (net_avg_ms * 1e-3) / 1e12
         from fastmot_amd.utils import Profiler
         stages = {k: round(Profiler.get_avg_millis(k), 3) for k in ('preproc', 'detect', 'track', 'extract', 'assoc')}
@@ -580,8 +580,10 @@ def main():
                        'yolo_candidates_nms_out': mot.detector.last_real_count,
                        'stage_ms': stages},
             'roofline': {'bound': 'mfma', 'kernel': f'conv kernels of the detector ({cfg["yolo"]}: {n_launch} launches '
-                                                    'per frame incl. fused residual units / SPP, measured with HIP '
-                                                    'events on the detector stream inside the pipeline)',
+                                                    'per frame incl. fused residual units / SPP; the first one also resizes '
+                                                    'and normalises the frame), measured with HIP events on the detector '
+                                                    'stream inside the pipeline, on every 4th pass of the timed region (the '
+                                                    'event pair itself costs ~1 % of the frame rate)',
                          'achieved': round(achieved, 3), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_PEAK_TFLOPS, 5),
                          # HBM-side bytes per launch: NOT measured in this run (PMC counters cannot be collected from
@@ -592,7 +594,7 @@ def main():
                          # reads of the conv launches, from the same PMC passes (stand-alone replays of the network)
                          'mfma_util': traffic[3].get('mfma_util') if traffic else None,
                          'read_amplification': traffic[3].get('read_amplification') if traffic else None,
-                         'flop_per_frame': flops, 'net_ms_per_frame': round(net_avg_ms, 4),
+                         'flop_per_frame': flops, 'net_ms_per_frame': round(net_avg_ms, 4), 'net_ms_samples': len(net_ms),
                          'avg_launch_us': round(net_avg_ms * 1e3 / n_launch, 3)},
         }
         out['config']['settle_steps_untimed'] = settle_steps

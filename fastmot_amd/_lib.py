@@ -499,9 +499,11 @@ def _bind_device_io(cls):
         check(self.lib.fm_detect_async(self._ctx))
 
     def detect_net_ms(self):
+        """HIP-event time of the detector network of the pass collected last, or None when that pass was not timed
+        (option 'net_timing' = N: every N-th pass carries the event pair; 0, the default: none)."""
         ms = C.c_float(0)
         check(self.lib.fm_detect_net_ms(self._ctx, C.byref(ms)))
-        return ms.value
+        return ms.value if ms.value >= 0 else None
 
     def detect_preprocess_only(self):
         check(self.lib.fm_detect_preprocess_only(self._ctx))

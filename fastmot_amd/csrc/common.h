@@ -96,6 +96,7 @@ struct fm_ctx {
     int opt_use_graphs = 1;            // FASTMOT_GRAPHS: 0 = launch network layers one by one (no hipGraph)
     int opt_fused_input = 1;           // "fused_input" / FASTMOT_FUSED_INPUT: the networks' stem convolutions compute their input pixels from the
                                        // frame themselves (pixel_source.h); 0 = front-end kernel + input tensor (tests compare the two, A/B)
+    int opt_net_timing = 0;            // "net_timing" = N: HIP events around the detector network on every N-th pass (fm_detect_net_ms); 0 = never
     int opt_nms_general = 0;           // "nms_path" = 1: always the three-kernel sort / bit matrix / scan path (tests, A/B)
     int opt_lk_variant = 0;            // "lk_variant": diagnostic variants of the LK kernel (flow.hip lk_diag_kernel)
     void* predict_worker = nullptr;    // native KLT + Kalman worker thread of this context (flow_estimate.hip)

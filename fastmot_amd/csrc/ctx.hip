@@ -29,6 +29,7 @@ extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* key, int value) {
         ctx->opt_nms_general = value != 0;
     }
     else if (!strcmp(key, "fused_input")) ctx->opt_fused_input = value != 0;
+    else if (!strcmp(key, "net_timing")) ctx->opt_net_timing = value;
     else if (!strcmp(key, "lk_variant")) {
 #ifndef FM_DIAG
         if (value != 0) {

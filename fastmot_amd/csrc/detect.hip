@@ -51,6 +51,8 @@ struct DetState {
     hipEvent_t ev_done[NSLOT] = {nullptr, nullptr};
     hipStream_t s_fallback = nullptr;          // redo of a pass the greedy kernel declined (collect): NOT s_up, see there
     hipEvent_t ev0[NSLOT] = {nullptr, nullptr}, ev1[NSLOT] = {nullptr, nullptr};   // bracket the network launches
+    bool timed[NSLOT] = {false, false};        // ... of the passes that were timed (fm_ctx option "net_timing")
+    long n_passes = 0;
     int wr = 0, rd = 0, pending = 0, last = -1;   // slot written next / collected next / passes in flight / last collected
     uint8_t* label_mask = nullptr;
     float* rows_in = nullptr;     // test hook upload
@@ -985,7 +987,12 @@ int enqueue_post(fm_ctx* ctx, DetState* d, hipStream_t s) {
 // a pass is about to write the candidate buffers of slot d->wr on stream `s`: the post-processing of the pass that
 // used the slot before (two passes ago) must be through with them
 static int acquire_slot(DetState* d, hipStream_t s) {
-    if (d->used[d->wr]) FM_HIP(hipStreamWaitEvent(s, d->ev_done[d->wr], 0));
+    // (in steady state that post-processing ended a step ago: the host can see it, and a wait that is not enqueued is one
+    // packet fewer on the stream whose period is the step -- every packet there costs microseconds, r06_net_timing_events_ab.txt)
+    if (d->used[d->wr] && hipEventQuery(d->ev_done[d->wr]) != hipSuccess) {
+        (void)hipGetLastError();                     // (hipErrorNotReady is not an error)
+        FM_HIP(hipStreamWaitEvent(s, d->ev_done[d->wr], 0));
+    }
     return 0;
 }
 
@@ -1298,8 +1305,13 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
     // (15 us inside the pipeline, between two passes of the stream whose period is the step) and the input tensor's
     // write + read disappear.  Same functions, same values (tests/test_detect_gpu.py compares the head tensors).
     const bool fused = ctx->opt_fused_input && fm_net_stem_fusable(net, c.input_tensor);
+    // the event pair around the network is measurement, not product: two more packets on the stream whose period is the
+    // step cost 1.2 % of the frame rate (profiles/r06_net_timing_events_ab.txt) -- recorded on every N-th pass only when
+    // a caller asked for it (option "net_timing" = N; bench.py samples every 4th pass)
+    const bool timing = ctx->opt_net_timing > 0 && d->n_passes++ % ctx->opt_net_timing == 0;
+    d->timed[d->wr] = timing;
     if (fused) {
-        FM_HIP(hipEventRecord(d->ev0[d->wr], s));
+        if (timing) FM_HIP(hipEventRecord(d->ev0[d->wr], s));
         fm_trace_mark(ctx, s, 11);
         StemSrc src{};
         src.kind = 1; src.frame = frame; src.fw = ctx->frame_w; src.fh = ctx->frame_h;
@@ -1313,11 +1325,11 @@ static int detect_async_on(fm_ctx* ctx, const uint8_t* frame) {
         if (rc) return rc;
     } else {
         if ((rc = enqueue_preprocess(ctx, d, net, frame))) return rc;
-        FM_HIP(hipEventRecord(d->ev0[d->wr], s));
+        if (timing) FM_HIP(hipEventRecord(d->ev0[d->wr], s));
         fm_trace_mark(ctx, s, 11);
         if ((rc = fm_net_run_internal(ctx, FM_NET_DETECTOR, 1))) return rc;
     }
-    FM_HIP(hipEventRecord(d->ev1[d->wr], s));
+    if (timing) FM_HIP(hipEventRecord(d->ev1[d->wr], s));
     fm_trace_mark(ctx, s, 12);
     FilterArgs fa = filter_args(d, d->wr);      // (counters were zeroed by this frame's preprocess kernel)
     HeadSet hs{};
@@ -1409,6 +1421,7 @@ extern "C" int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* 
 extern "C" int fm_detect_net_ms(fm_ctx* ctx, float* ms) {
     FM_CHECK_ARG(ctx && ctx->det && ms && ctx->det->last >= 0);      // the pass collected last
     const int slot = ctx->det->last;
+    if (!ctx->det->timed[slot]) { *ms = -1.f; return 0; }       // (this pass was not timed: option "net_timing")
     FM_HIP(hipEventSynchronize(ctx->det->ev1[slot]));
     FM_HIP(hipEventElapsedTime(ms, ctx->det->ev0[slot], ctx->det->ev1[slot]));
     return 0;

@@ -55,6 +55,9 @@ int fm_ctx_bind_thread(fm_ctx* ctx);
  * the latter), "convd_cfg" (default 0 = chosen per layer; bm | bn << 8 | kg << 16 | ns << 20 | role << 24 | (spb == 2) << 25 forces
  * one tile / K-group / ring depth (0 = as deep as LDS allows, otherwise >= 2) / loader-wave / steps-per-barrier configuration
  * of FM_OP_CONVD for A/B measurements; read at every launch that is not a graph replay),
+ * "fused_input" (default 1: a network that begins with a stem convolution lets that convolution compute its input pixels from the
+ * frame -- detector resize / ReID crops -- instead of running the front-end kernel into the input tensor; 0 for A/B and tests),
+ * "net_timing" (default 0; N > 0: every N-th detector pass carries the HIP-event pair fm_detect_net_ms reads),
  * "use_graphs" (default 1;
  * 0 launches the network layers one by one instead of replaying hipGraphs), "lk_variant" (diagnostic builds only, include/fastmot_hip_diag.h;
  * 0 is the only value the shipped library accepts).  Initial values can be set with the environment
@@ -415,8 +418,8 @@ int fm_detect_last_counts(fm_ctx* ctx, int* n_candidates, int* n_detections);
 int fm_detect_preprocess_only(fm_ctx* ctx);
 int fm_filter_dets(fm_ctx* ctx, const float* rows, int n, fm_det48* out, int cap, int* n_out);
 int fm_detect_raw_candidates(fm_ctx* ctx, float* rows, int cap, int* n);
-/* HIP-event duration (ms) of the network launches of the last fm_detect_async, recorded on the
- * detector stream (the bench's live roofline measurement) */
+/* HIP-event duration (ms) of the network launches of the pass fm_detect_sync collected last, recorded on the detector
+ * stream (the bench's live roofline measurement); -1 when that pass carried no events (option "net_timing") */
 int fm_detect_net_ms(fm_ctx* ctx, float* ms);
 
 /* ---------------------------------------------------------------- feature extractor --- */

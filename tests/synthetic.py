@@ -69,6 +69,9 @@ class SyntheticVideo:
         return dets
 
 
+NET_TIMING_EVERY = 4     # bench / traces: every 4th detector pass carries the HIP-event pair (each pair costs ~1 % of the frame rate)
+
+
 class InjectedYOLODetector(YOLODetector):
     """YOLODetector whose postprocess() waits for the real GPU pipeline (network + decode + NMS
     on the seeded-random weights) and then returns the scripted detections of the synthetic video."""
@@ -80,7 +83,8 @@ class InjectedYOLODetector(YOLODetector):
             self._label = labels[0]
         self._frame_idx = 0
         self.last_real_count = self.last_candidates = 0
-        self.net_ms = []          # HIP-event time of the detector's layer sequence, one entry per postprocess()
+        self.net_ms = []          # HIP-event time of the detector's layer sequence, one entry per timed pass
+        self.ctx.set_option('net_timing', NET_TIMING_EVERY)
 
     def detect_async(self, frame):
         super().detect_async(frame)
@@ -89,7 +93,9 @@ class InjectedYOLODetector(YOLODetector):
         real = super().postprocess()
         self.last_real_count = len(real)
         self.last_candidates = self.ctx.detect_last_counts()[0]
-        self.net_ms.append(self.ctx.detect_net_ms())      # the events of THIS frame's network are complete here
+        ms = self.ctx.detect_net_ms()                      # (None: this pass carried no timing events, option 'net_timing')
+        if ms is not None:
+            self.net_ms.append(ms)                         # the events of THIS frame's network are complete here
         dets = self._video.detections(self._frame_idx, self._label, self._labels)
         self._frame_idx += 1
         return dets
