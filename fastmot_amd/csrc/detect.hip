@@ -1195,10 +1195,15 @@ extern "C" int fm_frame_promote_next(fm_ctx* ctx) {
         FM_HIP(hipStreamSynchronize(ctx->s_ext));
         FM_HIP(hipStreamSynchronize(ctx->s_flow));
         FM_HIP(hipStreamSynchronize(ctx->s_flow2));
-        FM_HIP(hipStreamWaitEvent(ctx->s_ext, ctx->ev_next_upload, 0));
-        FM_HIP(hipStreamWaitEvent(ctx->s_flow, ctx->ev_next_upload, 0));
-        FM_HIP(hipStreamWaitEvent(ctx->s_flow2, ctx->ev_next_upload, 0));
-        FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_next_upload, 0));
+        // (the copy ran a step ago: when the host already sees its event complete, four barrier packets -- one in front of
+        // the next frame's copy on the ReID stream -- need not be enqueued at all)
+        if (hipEventQuery(ctx->ev_next_upload) != hipSuccess) {
+            (void)hipGetLastError();
+            FM_HIP(hipStreamWaitEvent(ctx->s_ext, ctx->ev_next_upload, 0));
+            FM_HIP(hipStreamWaitEvent(ctx->s_flow, ctx->ev_next_upload, 0));
+            FM_HIP(hipStreamWaitEvent(ctx->s_flow2, ctx->ev_next_upload, 0));
+            FM_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_next_upload, 0));
+        }
         std::swap(ctx->frame_own, ctx->frame_own2);
         std::swap(ctx->frame_pinned, ctx->frame_pinned2);
         ctx->frame_cur = ctx->frame_own;

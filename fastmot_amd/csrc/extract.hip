@@ -99,7 +99,7 @@ static int front_end(fm_ctx* ctx, ExtState* e, NetState* ni, hipStream_t si, int
     if (ctx->opt_fused_input && fm_net_stem_fusable(ni, e->input_tensor)) {
         StemSrc src{};
         src.kind = 2; src.frame = ctx->frame_cur; src.fw = ctx->frame_w; src.fh = ctx->frame_h;
-        src.boxes = e->boxes + (size_t)off * 4;
+        src.boxes = e->boxes_host + (size_t)off * 4;
         int rc = fm_net_run_stem_from(ctx, ni, src, b);
         if (rc) return rc;
         ni->first = 1;
@@ -135,7 +135,10 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
         e->cap = cap;
     }
     // fm_feat_update (s_main, asynchronous) may still read the previous frame's embeddings
-    FM_HIP(hipStreamWaitEvent(s, ctx->ev_feat, 0));
+    if (hipEventQuery(ctx->ev_feat) != hipSuccess) {     // (long complete in a running pipeline: no barrier packet then)
+        (void)hipGetLastError();
+        FM_HIP(hipStreamWaitEvent(s, ctx->ev_feat, 0));
+    }
     if (n > ctx->emb_cap) {
         // association (s_main) may still read the previous embeddings
         FM_HIP(hipStreamSynchronize(ctx->s_main));
@@ -145,7 +148,12 @@ extern "C" int fm_extract_async(fm_ctx* ctx, int n, const double* tlbr) {
     }
     FM_HIP(hipStreamSynchronize(s));   // boxes_host reuse
     memcpy(e->boxes_host, tlbr, sizeof(double) * 4 * n);
-    FM_HIP(hipMemcpyAsync(e->boxes, e->boxes_host, sizeof(double) * 4 * n, hipMemcpyHostToDevice, s));
+    // The fused stem reads the boxes straight from this page-locked buffer (a workgroup's four doubles, one trip over PCIe,
+    // ~1.5 us): a blit copy in front of the network cost ~10 us on the chain detections -> embeddings.  The front-end
+    // kernel of the unfused path reads every box from every thread: it keeps the device copy.
+    const bool zero_copy_boxes = ctx->opt_fused_input && fm_net_stem_fusable(net, e->input_tensor);
+    if (!zero_copy_boxes)
+        FM_HIP(hipMemcpyAsync(e->boxes, e->boxes_host, sizeof(double) * 4 * n, hipMemcpyHostToDevice, s));
     fm_trace_mark(ctx, s, 32);
     const fm_tensor& t = net->tensors[e->input_tensor];
     // Several instances of the network (FM_NET_EXTRACTOR_B + i): the batch is cut into parts that run
@@ -235,7 +243,7 @@ extern "C" int fm_extract_read_input(fm_ctx* ctx, int n, float* out) {
         // boxes of the last fm_extract_async, which are still on the device
         FM_CHECK_ARG(ctx->frame_cur && n <= e->cap);
         hipLaunchKernelGGL(crop_resize_kernel, dim3((e->in_w + 127) / 128, e->in_h, n), dim3(128), 0, ctx->s_ext,
-                           ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes, n, (f16*)net->bufs[e->input_tensor],
+                           ctx->frame_cur, ctx->frame_w, ctx->frame_h, e->boxes_host, n, (f16*)net->bufs[e->input_tensor],
                            e->in_w, e->in_h, t.c);
         FM_HIP(hipGetLastError());
     }
