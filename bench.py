@@ -337,7 +337,7 @@ def pmc_traffic(n_conv_launches=None):
     hence the file; the 4th item carries the MFMA utilisation of the conv launches and their read amplification from
     the same file when it has them; `stale` is True when the file counted another number of conv launches per frame than the network
     of this run has (the kernels changed since the passes were taken); None when no file is there."""
-    for name in ('r05_pmc_conv.json', 'r04_pmc_conv.json', 'r03_pmc_conv.json', 'r02_pmc_conv.json', 'r01_pmc_conv.json'):
+    for name in ('r06_pmc_conv.json', 'r05_pmc_conv.json', 'r04_pmc_conv.json', 'r03_pmc_conv.json', 'r02_pmc_conv.json', 'r01_pmc_conv.json'):
         try:
             with open(ROOT / 'profiles' / name) as f:
                 d = json.load(f)
@@ -550,7 +550,7 @@ def main():
         from fastmot_amd.utils import Profiler
         stages = {k: round(Profiler.get_avg_millis(k), 3) for k in ('preproc', 'detect', 'track', 'extract', 'assoc')}
         from fastmot_amd.models import graph as _G
-        n_conv = sum(1 for d in mot.detector.graph.layers if d['op'] in _G.CONV_OPS + (_G.OP_RESBLOCK,))
+        n_conv = sum(1 for d in mot.detector.graph.layers if d['op'] in _G.CONV_OPS + (_G.OP_RESBLOCK, _G.OP_STEM2))
         traffic = pmc_traffic(n_conv) if args.config == 1 else None      # the PMC passes are of YOLOv4@608
         metric = ('end-to-end tracker FPS @1080p/50 dets' if args.config == 1 else
                   f'end-to-end tracker FPS @{size[0]}x{size[1]}/{cfg["n_dets"]} dets, detector_frame_skip={cfg["skip"]} '

@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>/: GPU test summary, bench lines (default command line, the driver's --steps 20 --warmup 5, configs 2
 #    and 4), rocprofv3 kernel stats of the bench command, per-layer roofline table of the detector, OSNet dispatch list,
 #    PMC traffic passes (separate rocprofv3 --pmc runs, MI355X_MICROARCH.md).  Copy what is to be judged into profiles/.
-TAG=${1:-r05}; QUICK=${2:-}
+TAG=${1:-r06}; QUICK=${2:-}
 export TMPDIR=/tmp FASTMOT_RANDOM_WEIGHTS=1
 R=$GRAFT_REPO_ROOT; [ -n "$R" ] || R=$(pwd)
 O=$R/gpurun_out/$TAG; mkdir -p $O

@@ -61,6 +61,11 @@ def layer_cost(g, d):
         rd = (x.h * x.w * d['cin'] + K * d['cout'] + (P * d['cout'] if d.get('res') is not None else 0)) * 2
         wr = P * d['cout'] * (4 if g.tensors[o.tid][3] else 2)
         return fl, rd, wr, f"{ {0: 'conv', 12: 'stem', 15: 'convS', 17: 'convD'}[op]} k{d['k']}s{d['stride']} {x.h}x{x.w}x{d['cin']}->{o.h}x{o.w}x{d['cout']}"
+    if op == 18:          # fused stem pair (stem2.hip): the two convs it replaces; reads = the input + both weight sets, the
+        m, Pm = d['hid'], x.h * x.w                      # 32-channel tensor between them no longer exists
+        fl = 2.0 * 9 * d['cin'] * m * Pm + 2.0 * 9 * m * d['cout'] * P
+        return fl, (Pm * d['cin'] + 9 * d['cin'] * m + 9 * m * d['cout']) * 2, P * d['cout'] * 2, \
+            f"stem2 k3s1+k3s2 {x.h}x{x.w}x{d['cin']}->{o.h}x{o.w}x{d['cout']}"
     if op == 14:
         w1, _, w2, _ = d['res_ref']
         m, c = w1.shape[0], w1.shape[1]
