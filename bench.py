@@ -89,7 +89,7 @@ def build_mot(cfg, video, gallery_sync=None, nms_candidates=1500):
                           yolo_detector_cfg=SimpleNamespace(model=cfg['yolo'], conf_thresh=0.25, nms_thresh=0.5,
                                                             max_area=800000, min_aspect_ratio=1.2,
                                                             max_candidates=8192, weights=weights),
-                          feature_extractor_cfgs=tuple(SimpleNamespace(model=cfg['reid'], batch_size=64)
+                          feature_extractor_cfgs=tuple(SimpleNamespace(model=cfg['reid'], batch_size=int(os.environ.get('FASTMOT_BENCH_REID_BATCH', '64')))
                                                        for _ in cfg['labels']),
                           tracker_cfg=tcfg)
     finally:
@@ -205,12 +205,13 @@ def reference_numba_constant():
 HBM_PEAK_GBS, PCIE_PEAK_GBS, FP64_PEAK_TFLOPS = 8000.0, 63.0, 78.6      # MI355X_MICROARCH.md chip table (spec)
 
 # stage boundaries the library stamps with HIP events on the stage's own stream (fm_trace_mark, csrc/*.hip)
-STAGE_TAGS = (('detector preprocess (resize + BGR->RGB + fp16 NHWC)', 14, 11), ('detector network (conv engine)', 11, 12),
+STAGE_TAGS = (('detector first launch: resize + BGR->RGB + normalise computed inside the stem pair (frame -> 1/2-resolution x 64)', 11, 15),
+              ('detector network (conv engine, first launch included)', 11, 12),
               ('head decode + threshold + compaction', 12, 13),
               ('candidate sort + greedy DIoU-NMS + box filters + write-back (whole post-processing)', 20, 21),
               ('candidate sort', 20, 22), ('DIoU-NMS bit matrix', 22, 23),
               ('NMS scan + box filters + write-back', 23, 21), ('next frame H2D copy', 30, 31),
-              ('ReID crop + resize + normalise', 32, 34), ('ReID network (OSNet) + head', 34, 35),
+              ('ReID first launch: crop + resize + normalise computed inside the 7x7 stem (boxes read from pinned memory)', 32, 34), ('ReID network (OSNet) + head', 34, 35),
               ('embedding export to pinned memory', 35, 33), ('KLT gray + pyramid + Scharr', 42, 43),
               ('KLT keypoint bookkeeping + GFTT', 44, 45), ('KLT background FAST', 46, 47), ('KLT pyramidal LK', 40, 41),
               ('Kalman warp + predict + KLT update', 50, 51), ('Kalman detection update', 52, 53),
@@ -261,14 +262,14 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
     px0 = int(W * flow) * int(H * flow)
     pyr_px = sum(px0 / 4 ** l for l in range(6))
     work = {
-        14: ('hbm', W * H * 3 + in_w * in_h * 8 * 2, 'frame u8 in + fp16 NHWC(8) out'),
+        (11, 15): ('hbm', W * H * 3 + (in_w // 2) * (in_h // 2) * 64 * 2, 'frame u8 in + the stride-2 conv\'s fp16 output (when the network begins with a stem pair)'),
         11: ('mfma', det_flops, 'conv FLOPs (2 MAC)'),
         12: ('hbm', head_bytes, 'fp32 head tensors in'),
         20: ('latency', None, f'K = {K} candidates over conf_thresh: K^2 key comparisons from LDS, then one round per NMS survivor'),
         22: ('latency', None, f'K^2/2 = {K * K // 2} pair tests (fp32 IoU pre-test, exact fp64 DIoU near the threshold)'),
         23: ('latency', None, f'greedy scan over {-(-K // 64)} chunks of 64, one workgroup'),
         30: ('pcie', W * H * 3, 'frame u8'),
-        32: ('hbm', d_chunk * eh * ew * 8 * 2, f'first chunk, {d_chunk} crops: fp16 NHWC(8) out (+ <= crop pixels in)'),
+        32: ('hbm', d_chunk * (eh // 2) * (ew // 2) * 16 * 2, f'first chunk, {d_chunk} crops: the stem\'s fp16 output (+ <= crop pixels in)'),
         34: ('hbm', ext_bytes, f'{d_call} crops (all classes): activations + weights fp16; {ext_flops / 1e9:.1f} GFLOP'),
         35: ('latency', None, f'{D} x 512 fp32'),
         42: ('hbm', W * H * 3 + W * H + px0 + pyr_px * 5.25, 'frame in, gray + half + 6-level pyramid + int16 Scharr pairs out'),
@@ -289,7 +290,7 @@ def stage_rooflines(ctx, cfg, mot, run_steps, n_steps=48):
         d = d[n // 8:]                                      # (the first steps of the window still fill the pipeline)
         us = float(np.median(d)) * 1e3
         per_step = n / n_steps
-        bound, amount, what = work[a]
+        bound, amount, what = work.get((a, b)) or work[a]
         row = {'stage': name, 'us': round(us, 2), 'per_step': round(per_step, 2), 'bound': bound, 'work': what}
         if amount and us > 0:
             if bound in ('hbm', 'pcie', 'latency'):
