@@ -551,7 +551,7 @@ def main():
         from fastmot_amd.utils import Profiler
         stages = {k: round(Profiler.get_avg_millis(k), 3) for k in ('preproc', 'detect', 'track', 'extract', 'assoc')}
         from fastmot_amd.models import graph as _G
-        n_conv = sum(1 for d in mot.detector.graph.layers if d['op'] in _G.CONV_OPS + (_G.OP_RESBLOCK, _G.OP_STEM2))
+        n_conv = sum(1 for d in mot.detector.graph.layers if d['op'] in _G.CONV_OPS + (_G.OP_RESBLOCK, _G.OP_STEM2, _G.OP_PAIR11))
         traffic = pmc_traffic(n_conv) if args.config == 1 else None      # the PMC passes are of YOLOv4@608
         metric = ('end-to-end tracker FPS @1080p/50 dets' if args.config == 1 else
                   f'end-to-end tracker FPS @{size[0]}x{size[1]}/{cfg["n_dets"]} dets, detector_frame_skip={cfg["skip"]} '

@@ -19,6 +19,10 @@ int launch_gated_sum(int nstreams, const f16* const* in, const int* in_cs, const
                      int out_cs, int out_coff, const float* const* part, int tiles, hipStream_t s);
 // one gate slot: [max_batch][GATE_SLOT_TILES][gate_c] fp32 (gate values use the first [max_batch][gate_c])
 constexpr int GATE_SLOT_TILES = 32;
+int launch_pair11(const f16* xa, int xa_cs, int xa_coff, const f16* xc, int xc_cs, int xc_coff, f16* out, int out_cs,
+                  int out_coff, const f16* w1, const float* b1, const f16* w2, const float* b2, long P, int cout, int act1,
+                  int act2, hipStream_t s);
+bool pair11_supported(int cin, int mid, int extra, int cout);
 int launch_stemconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
                     const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad, int cout,
                     int act, hipStream_t s);
@@ -247,6 +251,16 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             return launch_stemconv(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff,
                                    (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                    B, ti.h, ti.w, to.h, to.w, L.k, L.stride, L.pad, L.cout, L.act, s);
+        case FM_OP_PAIR11: {
+            FM_CHECK_ARG(L.n_in == 2 && !to.f32 && pair11_supported(L.cin, L.hid, L.cin, L.cout));
+            const fm_tensor& tc = net->tensors[L.in[1]];
+            FM_CHECK_ARG(tc.h == ti.h && tc.w == ti.w && to.h == ti.h && to.w == ti.w && L.in_coff[0] + 64 <= ti.c &&
+                         L.in_coff[1] + 64 <= tc.c && L.out_coff + L.cout <= to.c);
+            return launch_pair11(in0, ti.c, L.in_coff[0], (const f16*)net->bufs[L.in[1]], tc.c, L.in_coff[1], out, to.c, L.out_coff,
+                                 (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
+                                 (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off),
+                                 (long)B * ti.h * ti.w, L.cout, L.gate[0], L.act, s);
+        }
         case FM_OP_STEM2:
             FM_CHECK_ARG(!to.f32 && L.hid == 32 && stem2_supported(L.hid, L.cout) && L.in_coff[0] == 0 && L.out_coff + L.cout <= to.c);
             return launch_stem2(StemSrc{}, in0, ti.c, out, to.c, L.out_coff, (const f16*)(net->weights + L.w_off),
@@ -460,6 +474,10 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *flops = 2.0 * L.k * L.k * 3 * L.cout * pout;
             *bytes = pin * 8 + pout * L.cout * 2;
             break;
+        case FM_OP_PAIR11:      // the two layers it replaces (the network's algorithmic work does not change with a fusion)
+            *flops = 2.0 * L.cin * L.hid * pout + 2.0 * (L.hid + L.cin) * L.cout * pout;
+            *bytes = (pin * L.cin + pout * L.hid + (double)L.cin * L.hid) * 2 + (pout * (L.hid + L.cin) + pout * L.cout + (double)(L.hid + L.cin) * L.cout) * 2;
+            break;
         case FM_OP_STEM2:       // both convs' FLOPs; the bytes of the fused pair: input in, second conv's output out, weights
             *flops = 2.0 * 9 * 3 * L.hid * pin + 2.0 * 9 * L.hid * L.cout * pout;
             *bytes = pin * 8 + pout * L.cout * 2 + 9.0 * L.hid * L.cout * 2;
@@ -485,7 +503,7 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
     FM_CHECK_ARG(net != nullptr);
     double f = 0, b = 0;
     for (const fm_layer& L : net->layers)
-        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK) {
+        if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK || L.op == FM_OP_PAIR11) {
             double lf, lb;
             layer_cost(net, L, batch, &lf, &lb);
             f += lf;
@@ -523,7 +541,7 @@ extern "C" int fm_net_profile(fm_ctx* ctx, int which, int batch, int iters, doub
             FM_HIP(hipEventSynchronize(e1));
             float ms = 0;
             FM_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK || L.op == FM_OP_STEM2) { tc += ms; ++nc; } else { to += ms; ++no; }
+            if (L.op == FM_OP_CONV || L.op == FM_OP_CONVS || L.op == FM_OP_CONVD || L.op == FM_OP_RESBLOCK || L.op == FM_OP_STEM2 || L.op == FM_OP_PAIR11) { tc += ms; ++nc; } else { to += ms; ++no; }
         }
     FM_HIP(hipEventDestroy(e0));
     FM_HIP(hipEventDestroy(e1));

@@ -15,7 +15,7 @@ import numpy as np
 LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CONVD, OP_STEM2) = range(19)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CONVD, OP_STEM2, OP_PAIR11) = range(20)
 CONV_OPS = (OP_CONV, OP_CONVS, OP_CONVD)      # the three kernels behind Graph.conv (same fields, different weight layouts)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
@@ -139,7 +139,10 @@ class Graph:
         self.convd_level = int(os.environ.get('FASTMOT_CONVD', '1'))
         self.convd_min_cin1 = 16   # smallest cin of a 1x1 layer on it (64: profiles/r05_osnet_pointwise_on_convd_ab.txt)
         # the stem (3 -> 32, 3x3 s1) and the stride-2 3x3 conv behind it as one launch (stem2.hip, FM_OP_STEM2)
-        self.use_stem2 = os.environ.get('FASTMOT_STEM2', '1') != '0' 
+        self.use_stem2 = os.environ.get('FASTMOT_STEM2', '1') != '0'
+        # a 64 -> 64 pointwise conv into the first half of a concat + the 128 -> 64 / 128 pointwise conv over that concat as one
+        # launch (pair11.hip, FM_OP_PAIR11: the tail of the first two CSP stages)
+        self.use_pair11 = os.environ.get('FASTMOT_PAIR11', '1') != '0' 
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -183,6 +186,26 @@ class Graph:
         if not bias:
             b = np.zeros_like(b)
         w16 = w.astype(np.float16)
+        prev = self._pair11_applies(x, cout, k, stride, pad, res, f32_out, up)
+        if prev is not None:
+            # `x` is a 128-channel concat whose first 64 channels the previous layer -- a 64 -> 64 pointwise conv -- has just
+            # written: both as ONE launch (pair11.hip); that half of the concat is never stored (check_fusions: nobody else
+            # may read it afterwards).  Same K order as the unfused conv over the concat: the results are bit-identical.
+            self.layers.pop()
+            _, w1ref, b1ref = self.conv_params.pop()
+            w1p = np.zeros((64, prev['ins'][0].c, 1, 1), np.float16)
+            w1p[:] = w1ref.astype(np.float16)
+            wp = np.zeros((ceil_to(cout, 32), x.c, 1, 1), np.float16)
+            wp[:cout] = w16
+            bias2 = np.zeros(wp.shape[0], np.float32)
+            bias2[:cout] = b
+            self._pair11_dropped = getattr(self, '_pair11_dropped', []) + [(len(self.layers), x.tid, x.coff, 64)]
+            self._layer(op=OP_PAIR11, ins=[prev['ins'][0], x.slice(64, 64)], out=dst, cin=64, cout=cout, k=1, stride=1, pad=0,
+                        act=ACT[act], hid=64, gates=[prev['act']], w_off=self._push(self._pack_frag(w1p)),
+                        b_off=self._push(np.asarray(b1ref, np.float32)), w2_off=self._push(self._pack_frag(wp)),
+                        b2_off=self._push(bias2), name=name,
+                        pair_ref=(w1ref, b1ref, prev['act'], w16.astype(np.float32), b))
+            return dst
         if self._stem2_applies(x, cout, k, stride, pad, res, f32_out, up):
             # second layer of the network, a 3x3 stride-2 conv over the whole output of the stem layer: both as ONE launch
             # (stem2.hip) -- the 32-channel full-resolution tensor between them (27 MB at 608 x 608) is never stored.  The
@@ -264,9 +287,29 @@ class Graph:
                 stem['cout'] == 32 and stem['ins'][0].tid == self.input.tid and stem['out'].tid == x.tid and x.coff == 0 and
                 x.c == 32 and x.tid != self.input.tid and x.tid not in [v.tid for v in self.outputs])
 
+    def _pair11_applies(self, x, cout, k, stride, pad, res, f32_out, up):
+        """-> the previous layer's dict when it and this conv form a fusable pair, else None."""
+        if not (self.use_pair11 and self.layers and k == 1 and stride == 1 and pad == 0 and res is None and not f32_out and
+                up == 1 and cout in (64, 128) and x.c == 128 and x.cpad == 128 and x.coff % 8 == 0):
+            return None
+        prev = self.layers[-1]
+        if not (prev['op'] in CONV_OPS and prev['k'] == 1 and prev['stride'] == 1 and prev['cout'] == 64 and prev['res'] is None and
+                prev['up'] == 1 and prev['out'].tid == x.tid and prev['out'].coff == x.coff and prev['out'].c == 64 and
+                prev['ins'][0].c == 64 and prev['ins'][0].cpad % 8 == 0 and prev['ins'][0].tid != x.tid and
+                not self.tensors[x.tid][3] and self.conv_params and self.conv_params[-1][0] == len(self.layers) - 1):
+            return None
+        if x.h * x.w < 8192:        # (the small maps' pointwise layers are launch bound, not traffic bound: measured on the large ones only)
+            return None
+        return prev
+
     def check_fusions(self):
         """A fused stem pair dropped the stem's output tensor: no later layer may read it (a cfg that routes from layer 0
         has to be built with FASTMOT_STEM2=0 / use_stem2 = False)."""
+        for li, tid, coff, c in getattr(self, '_pair11_dropped', []):
+            for d in self.layers[li + 1:]:
+                for v in d['ins'] + ([d['res']] if d['res'] is not None else []):
+                    if v.tid == tid and v.coff < coff + c and coff < v.coff + v.c:
+                        raise ValueError('a fused 1x1 pair dropped a concat slice that a later layer reads: build with use_pair11 = False')
         t = getattr(self, '_stem2_dropped', None)
         if t is None:
             return
@@ -607,6 +650,9 @@ class Graph:
             elif d['op'] == OP_RESBLOCK:
                 o = d['out']
                 total += 2 * 10 * d['cin'] * d['hid'] * o.h * o.w * batch
+            elif d['op'] == OP_PAIR11:
+                o = d['out']
+                total += (2 * d['cin'] * d['hid'] + 2 * (d['hid'] + d['cin']) * d['cout']) * o.h * o.w * batch
             elif d['op'] == OP_STEM2:
                 o, i = d['out'], d['ins'][0]
                 total += (2 * 9 * i.c * d['hid'] * i.h * i.w + 2 * 9 * d['hid'] * d['cout'] * o.h * o.w) * batch

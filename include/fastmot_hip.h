@@ -292,6 +292,8 @@ enum {
                           * channels -> hid = 32, activation gate[0]) then conv 3x3 s2 pad 1 (32 -> cout in {64, 128}, activation act);
                           * in[0] = the network input; w_off / b_off = the first conv as for FM_OP_STEMCONV, w2_off / b2_off = the second
                           * in MFMA fragment order [cout/32][288/16][lane][8] (K order kh, kw, cin) + f32 bias                          */
+    FM_OP_PAIR11 = 19,   /* two 1x1 convs around a concat in one launch (pair11.hip): t = act_gate[0](W1 in[0] + b1) (64 -> hid = 64), out =
+                          * act(W2 [t | in[1]] + b2) (64 + 64 -> cout in {64, 128}); weights in MFMA fragment order (w_off / b_off, w2_off / b2_off) */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

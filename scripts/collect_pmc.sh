@@ -17,11 +17,11 @@ def load(c):
         if line.startswith('JSON '):
             return json.loads(line[5:])
 f, w = load('FETCH_SIZE'), load('WRITE_SIZE')
-conv = [k for k in f if k.startswith('conv_igemm_kernel') or 'resblock_kernel' in k or k.startswith('convs_kernel') or k.startswith('convs_halo_kernel') or k.startswith('convd_kernel') or 'stem2_kernel' in k]
+conv = [k for k in f if k.startswith('conv_igemm_kernel') or 'resblock_kernel' in k or k.startswith('convs_kernel') or k.startswith('convs_halo_kernel') or k.startswith('convd_kernel') or 'stem2_kernel' in k or 'pair11_kernel' in k]
 calls = sum(f[k]['calls'] for k in conv)
 fetch_kb = sum(f[k]['total'] for k in conv)
 write_kb = sum(w[k]['total'] for k in conv if k in w)
-out = dict(kernel='conv_igemm_kernel + convd_kernel + convs_kernel + convs_halo_kernel + resblock_kernel + stem2_kernel (all template instances)', launches=calls, replays=6,
+out = dict(kernel='conv_igemm_kernel + convd_kernel + convs_kernel + convs_halo_kernel + resblock_kernel + stem2_kernel + pair11_kernel (all template instances)', launches=calls, replays=6,
            fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb,
            correction='FETCH_SIZE x2 (gfx950: 128 B requests tallied at 64 B for 16 B/lane loads); WRITE_SIZE raw (uncalibrated)',
            traffic_bytes_per_launch=round((2 * fetch_kb + write_kb) * 1024 / calls),

@@ -61,6 +61,10 @@ def layer_cost(g, d):
         rd = (x.h * x.w * d['cin'] + K * d['cout'] + (P * d['cout'] if d.get('res') is not None else 0)) * 2
         wr = P * d['cout'] * (4 if g.tensors[o.tid][3] else 2)
         return fl, rd, wr, f"{ {0: 'conv', 12: 'stem', 15: 'convS', 17: 'convD'}[op]} k{d['k']}s{d['stride']} {x.h}x{x.w}x{d['cin']}->{o.h}x{o.w}x{d['cout']}"
+    if op == 19:          # fused pointwise pair (pair11.hip): reads = both inputs + both weight sets
+        m, c2 = d['hid'], d['cin']
+        return 2.0 * P * (d['cin'] * m + (m + c2) * d['cout']), (P * (d['cin'] + c2) + d['cin'] * m + (m + c2) * d['cout']) * 2, P * d['cout'] * 2, \
+            f"pair11 k1+k1 {o.h}x{o.w}x{d['cin']}(+{c2})->{d['cout']}"
     if op == 18:          # fused stem pair (stem2.hip): the two convs it replaces; reads = the input + both weight sets, the
         m, Pm = d['hid'], x.h * x.w                      # 32-channel tensor between them no longer exists
         fl = 2.0 * 9 * d['cin'] * m * Pm + 2.0 * 9 * m * d['cout'] * P

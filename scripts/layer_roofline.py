@@ -59,6 +59,12 @@ for i, (d, (s, e, name)) in enumerate(zip(g.layers, rows)):
         by = (x.h * x.w * d['cin'] + P * d['cout'] * (2 if g.tensors[o.tid][3] else 1) + K * d['cout']) * 2
         shape = f"k{d['k']}s{d['stride']} {x.h}x{x.w}x{d['cin']} -> {o.h}x{o.w}x{d['cout']}"
         kind = {0: 'conv', 12: 'stemconv', 15: 'convS', 17: 'convD'}[op]
+    elif op == 19:                             # fused pointwise pair: counted as the two layers it replaces
+        m, c2 = d['hid'], d['cin']
+        fl = 2.0 * P * (d['cin'] * m + (m + c2) * d['cout'])
+        by = (P * d['cin'] + P * m + d['cin'] * m) * 2 + (P * (m + c2) + P * d['cout'] + (m + c2) * d['cout']) * 2
+        shape = f"k1+k1 {o.h}x{o.w}x{d['cin']}(+{c2}) -> {d['cout']}"
+        kind = 'pair11'
     elif op == 18:                             # fused stem pair: conv 3x3 s1 (cin -> 32) + conv 3x3 s2 (32 -> cout), counted as the
         m, Pm = d['hid'], x.h * x.w            # two layers it replaces (the table's roofline is the network's, not the fusion's)
         fl = 2.0 * 9 * d['cin'] * m * Pm + 2.0 * 9 * m * d['cout'] * P

@@ -587,3 +587,33 @@ def test_stem_pair_fused(ctx, cout, act1, act2, h, w, n):
             bufs, _ = torch_ref.run_graph(g, nchw(x[..., :3].astype(np.float32)))
             close(outs[0], nhwc(bufs[y.tid][:, :cout]), what='fused stem pair vs torch')
     close(outs[0], outs[1], rel=4e-3, abs_=1e-3, what='fused stem pair vs the two layers')
+
+
+@pytest.mark.parametrize('cout,act1,act2,h,w,n', [(64, 'mish', 'mish', 96, 96, 1), (128, 'mish', 'leaky', 91, 101, 2),
+                                                 (64, 'leaky', 'mish', 304, 304, 1), (128, 'mish', 'mish', 200, 200, 1)])
+def test_pointwise_pair_fused(ctx, cout, act1, act2, h, w, n):
+    """FM_OP_PAIR11 (pair11.hip): a 64 -> 64 pointwise conv into the first half of a concat + the pointwise conv over the
+    concat in one launch == the two layers (bit for bit: same K order, same MFMA sequence per output element) == torch;
+    pixel counts that are not a multiple of the 128-pixel tile, batch 2, the 304 x 304 map of YOLOv4's first stage."""
+    rng = np.random.default_rng(cout + h)
+    x = rng.normal(0, 1, (n, h, w, 64)).astype(np.float16)
+    outs = []
+    for fuse in (True, False):
+        g = Graph(RandomWeights(seed=13), (h, w), 64)
+        g.use_pair11 = fuse
+        cat = g.new(h, w, 128)
+        g.conv('A', g.input, 64, 1, 1, 'mish', dst=cat.slice(64, 64))
+        b = g.conv('B', g.input, 64, 1, 1, 'mish')
+        g.conv('t', b, 64, 1, 1, act1, dst=cat.slice(0, 64))
+        y = g.conv('y', cat, cout, 1, 1, act2)
+        g.outputs.append(y)
+        assert (g.layers[-1]['op'] == 19) == fuse and len(g.layers) == (3 if fuse else 4)
+        net = HipNet(ctx, NET_DETECTOR, g, n)
+        net.write(g.input, x)
+        net.run(n)
+        outs.append(net.read(y, n))
+        net.close()
+        if fuse:
+            bufs, _ = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+            close(outs[0], nhwc(bufs[y.tid][:, :cout]), what='fused pointwise pair vs torch')
+    np.testing.assert_array_equal(outs[0], outs[1])

@@ -66,6 +66,14 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             if emulate_fp16_storage:
                 y = y.half().float()
             wr(d['out'], act_fn(F.conv2d(y, w2, b2, padding=1), d['act']) + xin)
+        elif op == G.OP_PAIR11:
+            w1, b1, act1, w2, b2 = d['pair_ref']
+            t = act_fn(F.conv2d(xin, torch.from_numpy(np.asarray(w1, np.float32)), torch.from_numpy(np.asarray(b1, np.float32))), act1)
+            if emulate_fp16_storage:
+                t = t.half().float()
+            cat = torch.cat([t, rd(d['ins'][1])], dim=1)
+            wr(d['out'], act_fn(F.conv2d(cat, torch.from_numpy(np.asarray(w2, np.float32)), torch.from_numpy(np.asarray(b2, np.float32))),
+                                d['act']))
         elif op == G.OP_STEM2:
             w1, b1, act1, w2, b2 = d['stem2_ref']
             y = act_fn(F.conv2d(xin, torch.from_numpy(np.asarray(w1, np.float32)), torch.from_numpy(np.asarray(b1, np.float32)),
