@@ -262,10 +262,7 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                                  (long)B * ti.h * ti.w, L.cout, L.gate[0], L.act, s);
         }
         case FM_OP_STEM2:
-            FM_CHECK_ARG(!to.f32 && L.hid == 32 && stem2_supported(L.hid, L.cout) && L.in_coff[0] == 0 && L.out_coff + L.cout <= to.c);
-            return launch_stem2(StemSrc{}, in0, ti.c, out, to.c, L.out_coff, (const f16*)(net->weights + L.w_off),
-                                (const float*)(net->weights + L.b_off), (const f16*)(net->weights + L.w2_off),
-                                (const float*)(net->weights + L.b2_off), B, ti.h, ti.w, to.h, to.w, L.cout, L.gate[0], L.act, s);
+            return launch_stem2_layer(L, StemSrc{}, net, B, s);
         case FM_OP_SPP:
             FM_CHECK_ARG(to.h == ti.h && to.w == ti.w && L.out_coff + 3 * L.cin <= to.c);
             return launch_spp(in0, ti.c, L.in_coff[0], out, to.c, L.out_coff, B, ti.h, ti.w, L.cin, s);
@@ -348,6 +345,22 @@ bool fm_net_stem_fusable(const NetState* net, int input_tensor) {
     return true;
 }
 
+int launch_stem2_layer(const fm_layer& L, const StemSrc& src, const NetState* net, int batch, hipStream_t s) {
+    const fm_tensor& ti = net->tensors[L.in[0]];
+    const fm_tensor& to = net->tensors[L.out];
+    const bool three = L.gate[1] > 0;
+    const int cout2 = three ? L.gate[1] : L.cout, act2 = three ? L.gate[2] : L.act;
+    FM_CHECK_ARG(!to.f32 && L.hid == 32 && stem2_supported(L.hid, cout2) && L.in_coff[0] == 0 && L.out_coff + L.cout <= to.c);
+    FM_CHECK_ARG(!three || stem3_supported(cout2, L.cout));
+    const char* w2 = net->weights + L.w2_off;
+    const char* b2 = net->weights + L.b2_off;
+    return launch_stem2(src, (const f16*)net->bufs[L.in[0]], ti.c, (f16*)net->bufs[L.out], to.c, L.out_coff,
+                        (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off), (const f16*)w2,
+                        (const float*)b2, batch, ti.h, ti.w, to.h / 1, to.w / 1, cout2, L.gate[0], act2, s, three ? L.cout : 0,
+                        three ? (const f16*)(w2 + (size_t)cout2 * 288 * 2) : nullptr,
+                        three ? (const float*)(b2 + (size_t)cout2 * 4) : nullptr, L.act);
+}
+
 // Layer 0 of `net` on `src` instead of the input tensor, launched eagerly on the network's stream (its arguments -- the
 // frame, the boxes -- change from call to call: not part of the captured graph); fm_net_run then starts at layer 1
 // (net->first, which the caller sets around its fm_net_run call).
@@ -358,14 +371,9 @@ int fm_net_run_stem_from(fm_ctx* ctx, NetState* net, const StemSrc& src, int bat
     const fm_tensor& ti = net->tensors[L.in[0]];
     const fm_tensor& to = net->tensors[L.out];
     if (L.op == FM_OP_STEM2) {
-        FM_CHECK_ARG(src.kind != 2 && !to.f32 && L.hid == 32 && stem2_supported(L.hid, L.cout) && L.out_coff + L.cout <= to.c);
-        return launch_stem2(src, (const f16*)net->bufs[L.in[0]], ti.c, (f16*)net->bufs[L.out], to.c, L.out_coff,
-                            (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
-                            (const f16*)(net->weights + L.w2_off), (const float*)(net->weights + L.b2_off), batch, ti.h, ti.w,
-                            to.h, to.w, L.cout, L.gate[0], L.act, net->stream);
+        FM_CHECK_ARG(src.kind != 2);
+        return launch_stem2_layer(L, src, net, batch, net->stream);
     }
-    FM_CHECK_ARG(!to.f32 && (ti.h + 2 * L.pad - L.k) / L.stride + 1 == to.h &&
-                 (ti.w + 2 * L.pad - L.k) / L.stride + 1 == to.w && L.out_coff + ((L.cout + 7) & ~7) <= to.c);
     return launch_stemconv_src(src, (const f16*)net->bufs[L.in[0]], ti.c, 0, (f16*)net->bufs[L.out], to.c, L.out_coff,
                                (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off), batch, ti.h,
                                ti.w, to.h, to.w, L.k, L.stride, L.pad, L.cout, L.act, net->stream);
@@ -479,8 +487,9 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
             *bytes = (pin * L.cin + pout * L.hid + (double)L.cin * L.hid) * 2 + (pout * (L.hid + L.cin) + pout * L.cout + (double)(L.hid + L.cin) * L.cout) * 2;
             break;
         case FM_OP_STEM2:       // both convs' FLOPs; the bytes of the fused pair: input in, second conv's output out, weights
-            *flops = 2.0 * 9 * 3 * L.hid * pin + 2.0 * 9 * L.hid * L.cout * pout;
-            *bytes = pin * 8 + pout * L.cout * 2 + 9.0 * L.hid * L.cout * 2;
+            *flops = 2.0 * 9 * 3 * L.hid * pin + 2.0 * 9 * L.hid * (L.gate[1] > 0 ? L.gate[1] : L.cout) * pout +
+                     (L.gate[1] > 0 ? 2.0 * L.gate[1] * L.cout * pout : 0.);
+            *bytes = pin * 8 + pout * L.cout * 2 + 9.0 * L.hid * (L.gate[1] > 0 ? L.gate[1] : L.cout) * 2;
             break;
         case FM_OP_RESBLOCK:
             *flops = 2.0 * 10 * L.cin * L.hid * pout;
@@ -514,8 +523,13 @@ extern "C" int fm_net_cost(fm_ctx* ctx, int which, int batch, double* flops, dou
             const fm_tensor& ti = net->tensors[L.in[0]];
             const fm_tensor& to = net->tensors[L.out];
             const double pmid = (double)batch * ti.h * ti.w, pout = (double)batch * to.h * to.w;
-            f += 2.0 * 9 * L.hid * L.cout * pout;
-            b += pmid * L.hid * 2 + pout * L.cout * 2 + 9.0 * L.hid * L.cout * 2;
+            const int c2 = L.gate[1] > 0 ? L.gate[1] : L.cout;
+            f += 2.0 * 9 * L.hid * c2 * pout;
+            b += pmid * L.hid * 2 + pout * c2 * 2 + 9.0 * L.hid * c2 * 2;
+            if (L.gate[1] > 0) {        // ... and the pointwise conv behind it
+                f += 2.0 * c2 * L.cout * pout;
+                b += pout * c2 * 2 + pout * L.cout * 2 + (double)c2 * L.cout * 2;
+            }
         }
     *flops = f;
     *bytes = b;

@@ -120,8 +120,12 @@ int launch_stemconv_src(const StemSrc& src, const f16* in, int in_cs, int in_cof
                         int cout, int act, hipStream_t s);
 int launch_stem2(const StemSrc& src, const f16* in, int in_cs, f16* out, int out_cs, int out_coff, const f16* w1,
                  const float* b1, const f16* w2, const float* b2, int N, int H, int W, int Ho, int Wo, int cout, int act1,
-                 int act2, hipStream_t s);
+                 int act2, hipStream_t s, int cout3 = 0, const f16* w3 = nullptr, const float* b3 = nullptr, int act3 = 0);
 bool stem2_supported(int mid, int cout);
+bool stem3_supported(int cout2, int cout3);
+// FM_OP_STEM2 of a layer table: two stages (gate[1] < 0: cout / act are the second conv's) or three (gate[1] = the second
+// conv's channels, gate[2] its activation, cout / act the pointwise conv's; its weights / bias lie behind the second conv's)
+int launch_stem2_layer(const fm_layer& L, const StemSrc& src, const NetState* net, int batch, hipStream_t s);
 // runs layer 0 of `net` -- a stem convolution over the network's input tensor -- on `src` instead of that tensor
 bool fm_net_stem_fusable(const NetState* net, int input_tensor);
 int fm_net_run_stem_from(fm_ctx* ctx, NetState* net, const StemSrc& src, int batch);

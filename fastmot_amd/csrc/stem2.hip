@@ -17,12 +17,15 @@
 
 namespace {
 
-template <int COUT, int SRC>
+// C3 > 0: a pointwise conv COUT -> C3 (+ bias + act3) over the tile follows in the same launch (the first CSP stage's merged
+// 1x1 conv: the stride-2 conv's output is then never stored either).  w3 in fragment order [C3 / 32][COUT / 16][lane][8].
+template <int COUT, int SRC, int C3>
 __global__ __launch_bounds__(256) void stem2_kernel(const StemSrc src, const f16* __restrict__ in, int in_cs,
                                                     f16* __restrict__ out, int out_cs, int out_coff,
                                                     const f16* __restrict__ w1, const float* __restrict__ b1,
                                                     const f16* __restrict__ w2, const float* __restrict__ b2,
-                                                    int H, int W, int Ho, int Wo, int act1, int act2) {
+                                                    const f16* __restrict__ w3, const float* __restrict__ b3,
+                                                    int H, int W, int Ho, int Wo, int act1, int act2, int act3) {
     constexpr int TO = 8, MW = 2 * TO + 1, NPOS = MW * MW, PW = MW + 2, M = 32, S = M + 8;
     constexpr int KP1 = 48, NKS1 = 3, TAPS = 9;
     constexpr int NCT = COUT / 32, NPT = TO * TO / 32, NT2 = NCT * NPT / 4;      // phase-2 tiles per wave
@@ -30,6 +33,8 @@ __global__ __launch_bounds__(256) void stem2_kernel(const StemSrc src, const f16
     static_assert(NCT * NPT % 4 == 0, "tile / wave split");
     __shared__ __attribute__((aligned(16))) uint2 patch[PW * PW];
     __shared__ __attribute__((aligned(16))) f16 mid[NPOS * S];
+    constexpr int SD = COUT + 8;                                  // row stride of the phase-3 tile (conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) f16 dtile[C3 > 0 ? TO * TO * SD : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fh = lane >> 5;
     const int ox0 = blockIdx.x * TO, oy0 = blockIdx.y * TO;
@@ -134,34 +139,89 @@ __global__ __launch_bounds__(256) void stem2_kernel(const StemSrc src, const f16
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa2[t][2 * tap + 1], fb1, acc, 0, 0, 0);
         }
         const int oy = oy0 + py, ox = ox0 + px;
-        if (oy < Ho && ox < Wo) {
-            f16* dst = out + ((n * Ho + oy) * (long)Wo + ox) * out_cs + out_coff + ct * 32;
+        if constexpr (C3 == 0) {
+            if (oy < Ho && ox < Wo) {
+                f16* dst = out + ((n * Ho + oy) * (long)Wo + ox) * out_cs + out_coff + ct * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 8 * g + 4 * fh;
+                    const float4 bv = *reinterpret_cast<const float4*>(b2 + ct * 32 + co);
+                    float a4[4] = {acc[4 * g + 0] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+                    apply_act_n<4>(a4, act2);
+                    f16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (f16)a4[e];
+                    *reinterpret_cast<f16x4*>(dst + co) = o;
+                }
+            }
+        } else {
+            // the tile's fp16 values -- what the layer would have stored -- go to an LDS tile of their own for the pointwise
+            // conv (`mid` is still being read by the other waves' phase 2)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = 8 * g + 4 * fh;
                 const float4 bv = *reinterpret_cast<const float4*>(b2 + ct * 32 + co);
                 float a4[4] = {acc[4 * g + 0] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
                 apply_act_n<4>(a4, act2);
-                f16x4 o;
+                union { f16 h[4]; uint2 u; } pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (f16)a4[e];
-                *reinterpret_cast<f16x4*>(dst + co) = o;
+                for (int e = 0; e < 4; ++e) pk.h[e] = (f16)a4[e];
+                *reinterpret_cast<uint2*>(&dtile[pix * SD + ct * 32 + co]) = pk.u;
+            }
+        }
+    }
+    if constexpr (C3 > 0) {
+        // ---- phase 3: pointwise conv over the 64-pixel tile: (C3 / 32) cout tiles x 2 pixel tiles over the 4 waves
+        constexpr int NC3 = C3 / 32, NT3 = NC3 * NPT / 4, KS3 = COUT / 16;
+        f16x8 fa3[NT3][KS3];
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+            const int ct = (wave * NT3 + t) % NC3;
+#pragma unroll
+            for (int q = 0; q < KS3; ++q) fa3[t][q] = *reinterpret_cast<const f16x8*>(w3 + (((long)ct * KS3 + q) * 64 + lane) * 8);
+        }
+        __syncthreads();                                        // dtile complete
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+            const int tile = wave * NT3 + t, ct = tile % NC3, ptile = tile / NC3;
+            const int pix = ptile * 32 + frow, py = pix / TO, px = pix % TO;
+            const f16* bsrc = dtile + pix * SD + fh * 8;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < KS3; ++q)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa3[t][q], *reinterpret_cast<const f16x8*>(bsrc + q * 16), acc, 0, 0, 0);
+            const int oy = oy0 + py, ox = ox0 + px;
+            if (oy < Ho && ox < Wo) {
+                f16* dst = out + ((n * Ho + oy) * (long)Wo + ox) * out_cs + out_coff + ct * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 8 * g + 4 * fh;
+                    const float4 bv = *reinterpret_cast<const float4*>(b3 + ct * 32 + co);
+                    float a4[4] = {acc[4 * g + 0] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+                    apply_act_n<4>(a4, act3);
+                    f16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (f16)a4[e];
+                    *reinterpret_cast<f16x4*>(dst + co) = o;
+                }
             }
         }
     }
 }
 
-template <int COUT>
+template <int COUT, int C3>
 int launch_cout(const StemSrc& src, const f16* in, int in_cs, f16* out, int out_cs, int out_coff, const f16* w1,
-                const float* b1, const f16* w2, const float* b2, int N, int H, int W, int Ho, int Wo, int act1, int act2,
-                hipStream_t s) {
+                const float* b1, const f16* w2, const float* b2, const f16* w3, const float* b3, int N, int H, int W, int Ho,
+                int Wo, int act1, int act2, int act3, hipStream_t s) {
     const dim3 grid((Wo + 7) / 8, (Ho + 7) / 8, N), block(256);
     if (src.kind == 1)
-        hipLaunchKernelGGL((stem2_kernel<COUT, 1>), grid, block, 0, s, src, in, in_cs, out, out_cs, out_coff, w1, b1, w2, b2, H,
-                           W, Ho, Wo, act1, act2);
+        hipLaunchKernelGGL((stem2_kernel<COUT, 1, C3>), grid, block, 0, s, src, in, in_cs, out, out_cs, out_coff, w1, b1, w2, b2,
+                           w3, b3, H, W, Ho, Wo, act1, act2, act3);
     else
-        hipLaunchKernelGGL((stem2_kernel<COUT, 0>), grid, block, 0, s, src, in, in_cs, out, out_cs, out_coff, w1, b1, w2, b2, H,
-                           W, Ho, Wo, act1, act2);
+        hipLaunchKernelGGL((stem2_kernel<COUT, 0, C3>), grid, block, 0, s, src, in, in_cs, out, out_cs, out_coff, w1, b1, w2, b2,
+                           w3, b3, H, W, Ho, Wo, act1, act2, act3);
     FM_HIP(hipGetLastError());
     return 0;
 }
@@ -169,15 +229,22 @@ int launch_cout(const StemSrc& src, const f16* in, int in_cs, f16* out, int out_
 }  // namespace
 
 bool stem2_supported(int mid, int cout) { return mid == 32 && (cout == 64 || cout == 128); }
+bool stem3_supported(int cout2, int cout3) { return cout2 == 64 && (cout3 == 64 || cout3 == 128); }
 
 // w1: the stem's weights as for FM_OP_STEMCONV ([32][48] fp16, K order (kh, kw, c4)), b1 f32[32]; w2: the second conv's in
-// MFMA A-fragment order [cout / 32][288 / 16][lane][8] (K order (kh, kw, cin); Graph._pack_frag), b2 f32[cout]
+// MFMA A-fragment order [cout / 32][288 / 16][lane][8] (K order (kh, kw, cin); Graph._pack_frag), b2 f32[cout]; cout3 > 0: a
+// pointwise conv cout -> cout3 follows (w3 fragment order [cout3 / 32][cout / 16][lane][8], b3 f32[cout3]) and `out` has cout3 channels
 int launch_stem2(const StemSrc& src, const f16* in, int in_cs, f16* out, int out_cs, int out_coff, const f16* w1,
                  const float* b1, const f16* w2, const float* b2, int N, int H, int W, int Ho, int Wo, int cout, int act1,
-                 int act2, hipStream_t s) {
+                 int act2, hipStream_t s, int cout3, const f16* w3, const float* b3, int act3) {
     FM_CHECK_ARG(stem2_supported(32, cout) && in_cs % 4 == 0 && out_cs % 4 == 0 && out_coff % 4 == 0);
     FM_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
     FM_CHECK_ARG(src.kind == 0 || (src.kind == 1 && src.frame && src.fw > 0 && src.fh > 0));
-    if (cout == 64) return launch_cout<64>(src, in, in_cs, out, out_cs, out_coff, w1, b1, w2, b2, N, H, W, Ho, Wo, act1, act2, s);
-    return launch_cout<128>(src, in, in_cs, out, out_cs, out_coff, w1, b1, w2, b2, N, H, W, Ho, Wo, act1, act2, s);
+    FM_CHECK_ARG(cout3 == 0 || (stem3_supported(cout, cout3) && w3 && b3));
+#define STEM2_ARGS src, in, in_cs, out, out_cs, out_coff, w1, b1, w2, b2, w3, b3, N, H, W, Ho, Wo, act1, act2, act3, s
+    if (cout3 == 64) return launch_cout<64, 64>(STEM2_ARGS);
+    if (cout3 == 128) return launch_cout<64, 128>(STEM2_ARGS);
+    if (cout == 64) return launch_cout<64, 0>(STEM2_ARGS);
+    return launch_cout<128, 0>(STEM2_ARGS);
+#undef STEM2_ARGS
 }

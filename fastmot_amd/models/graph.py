@@ -139,7 +139,8 @@ class Graph:
         self.convd_level = int(os.environ.get('FASTMOT_CONVD', '1'))
         self.convd_min_cin1 = 16   # smallest cin of a 1x1 layer on it (64: profiles/r05_osnet_pointwise_on_convd_ab.txt)
         # the stem (3 -> 32, 3x3 s1) and the stride-2 3x3 conv behind it as one launch (stem2.hip, FM_OP_STEM2)
-        self.use_stem2 = os.environ.get('FASTMOT_STEM2', '1') != '0'
+        self.use_stem2 = os.environ.get('FASTMOT_STEM2', '2') != '0'
+        self.use_stem3 = os.environ.get('FASTMOT_STEM2', '2') == '2'     # ... and the pointwise conv behind the pair as its third stage
         # a 64 -> 64 pointwise conv into the first half of a concat + the 128 -> 64 / 128 pointwise conv over that concat as one
         # launch (pair11.hip, FM_OP_PAIR11: the tail of the first two CSP stages)
         self.use_pair11 = os.environ.get('FASTMOT_PAIR11', '1') != '0' 
@@ -205,6 +206,25 @@ class Graph:
                         b_off=self._push(np.asarray(b1ref, np.float32)), w2_off=self._push(self._pack_frag(wp)),
                         b2_off=self._push(bias2), name=name,
                         pair_ref=(w1ref, b1ref, prev['act'], w16.astype(np.float32), b))
+            return dst
+        if self._stem3_applies(x, cout, k, stride, pad, res, f32_out, up):
+            # a pointwise conv over the whole output of the stem pair (the first CSP stage's merged 1x1 conv): third stage of the
+            # same launch (stem2.hip, C3) -- the stride-2 conv's output is never stored either
+            pair = self.layers.pop()
+            w1ref, b1ref, a1, w2ref, b2ref = pair['stem2_ref']
+            w2p = np.zeros((64, 32, 3, 3), np.float16)
+            w2p[:] = np.asarray(w2ref, np.float16)
+            w3p = np.zeros((ceil_to(cout, 32), 64, 1, 1), np.float16)
+            w3p[:cout] = w16
+            b23 = np.zeros(64 + w3p.shape[0], np.float32)
+            b23[:64] = b2ref
+            b23[64:64 + cout] = b
+            blob2 = np.concatenate([self._pack_frag(w2p).reshape(-1), self._pack_frag(w3p).reshape(-1)])
+            self._stem2_dropped = [self._stem2_dropped, x.tid] if not isinstance(self._stem2_dropped, list) else self._stem2_dropped + [x.tid]
+            self._layer(op=OP_STEM2, ins=pair['ins'], out=dst, cin=pair['cin'], cout=cout, k=3, stride=2, pad=1, act=ACT[act],
+                        hid=32, gates=[a1, 64, pair['act']], w_off=pair['w_off'], b_off=pair['b_off'],
+                        w2_off=self._push(blob2), b2_off=self._push(b23), name=name,
+                        stem2_ref=(w1ref, b1ref, a1, w2ref, b2ref), stem3_ref=(pair['act'], w16.astype(np.float32), b))
             return dst
         if self._stem2_applies(x, cout, k, stride, pad, res, f32_out, up):
             # second layer of the network, a 3x3 stride-2 conv over the whole output of the stem layer: both as ONE launch
@@ -302,6 +322,14 @@ class Graph:
             return None
         return prev
 
+    def _stem3_applies(self, x, cout, k, stride, pad, res, f32_out, up):
+        if not (self.use_stem2 and self.use_stem3 and len(self.layers) == 1 and k == 1 and stride == 1 and pad == 0 and res is None and
+                not f32_out and up == 1 and cout in (64, 128)):
+            return False
+        pair = self.layers[0]
+        return (pair['op'] == OP_STEM2 and len(pair['gates']) == 1 and pair['cout'] == 64 and pair['out'].tid == x.tid and
+                x.coff == 0 and x.c == 64 and pair['out'].coff == 0 and x.tid not in [v.tid for v in self.outputs])
+
     def check_fusions(self):
         """A fused stem pair dropped the stem's output tensor: no later layer may read it (a cfg that routes from layer 0
         has to be built with FASTMOT_STEM2=0 / use_stem2 = False)."""
@@ -313,9 +341,10 @@ class Graph:
         t = getattr(self, '_stem2_dropped', None)
         if t is None:
             return
+        dropped = t if isinstance(t, list) else [t]
         for d in self.layers:
             used = [v.tid for v in d['ins']] + ([d['res'].tid] if d['res'] is not None else [])
-            if t in used or t in [v.tid for v in self.outputs]:
+            if any(t in used or t in [v.tid for v in self.outputs] for t in dropped):
                 raise ValueError('the stem\'s output is read by another layer: build this network with use_stem2 = False')
 
     @staticmethod
@@ -655,5 +684,8 @@ class Graph:
                 total += (2 * d['cin'] * d['hid'] + 2 * (d['hid'] + d['cin']) * d['cout']) * o.h * o.w * batch
             elif d['op'] == OP_STEM2:
                 o, i = d['out'], d['ins'][0]
-                total += (2 * 9 * i.c * d['hid'] * i.h * i.w + 2 * 9 * d['hid'] * d['cout'] * o.h * o.w) * batch
+                c2 = d['gates'][1] if len(d['gates']) > 1 else d['cout']
+                total += (2 * 9 * i.c * d['hid'] * i.h * i.w + 2 * 9 * d['hid'] * c2 * o.h * o.w) * batch
+                if len(d['gates']) > 1:
+                    total += 2 * c2 * d['cout'] * o.h * o.w * batch
         return total

@@ -67,9 +67,10 @@ def layer_cost(g, d):
             f"pair11 k1+k1 {o.h}x{o.w}x{d['cin']}(+{c2})->{d['cout']}"
     if op == 18:          # fused stem pair (stem2.hip): the two convs it replaces; reads = the input + both weight sets, the
         m, Pm = d['hid'], x.h * x.w                      # 32-channel tensor between them no longer exists
-        fl = 2.0 * 9 * d['cin'] * m * Pm + 2.0 * 9 * m * d['cout'] * P
-        return fl, (Pm * d['cin'] + 9 * d['cin'] * m + 9 * m * d['cout']) * 2, P * d['cout'] * 2, \
-            f"stem2 k3s1+k3s2 {x.h}x{x.w}x{d['cin']}->{o.h}x{o.w}x{d['cout']}"
+        c2 = d['gates'][1] if len(d['gates']) > 1 else d['cout']
+        fl = 2.0 * 9 * d['cin'] * m * Pm + 2.0 * 9 * m * c2 * P + (2.0 * c2 * d['cout'] * P if len(d['gates']) > 1 else 0.)
+        return fl, (Pm * d['cin'] + 9 * d['cin'] * m + 9 * m * c2 + (c2 * d['cout'] if len(d['gates']) > 1 else 0)) * 2, P * d['cout'] * 2, \
+            f"stem2 k3s1+k3s2{'+k1' if len(d['gates']) > 1 else ''} {x.h}x{x.w}x{d['cin']}->{o.h}x{o.w}x{d['cout']}"
     if op == 14:
         w1, _, w2, _ = d['res_ref']
         m, c = w1.shape[0], w1.shape[1]

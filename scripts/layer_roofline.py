@@ -67,9 +67,14 @@ for i, (d, (s, e, name)) in enumerate(zip(g.layers, rows)):
         kind = 'pair11'
     elif op == 18:                             # fused stem pair: conv 3x3 s1 (cin -> 32) + conv 3x3 s2 (32 -> cout), counted as the
         m, Pm = d['hid'], x.h * x.w            # two layers it replaces (the table's roofline is the network's, not the fusion's)
-        fl = 2.0 * 9 * d['cin'] * m * Pm + 2.0 * 9 * m * d['cout'] * P
-        by = (Pm * d['cin'] + Pm * m + 9 * d['cin'] * m) * 2 + (Pm * m + P * d['cout'] + 9 * m * d['cout']) * 2
-        shape = f"k3s1+k3s2 {x.h}x{x.w}x{d['cin']} -> {o.h}x{o.w}x{d['cout']}"
+        c2 = d['gates'][1] if len(d['gates']) > 1 else d['cout']
+        fl = 2.0 * 9 * d['cin'] * m * Pm + 2.0 * 9 * m * c2 * P
+        by = (Pm * d['cin'] + Pm * m + 9 * d['cin'] * m) * 2 + (Pm * m + P * c2 + 9 * m * c2) * 2
+        shape = f"k3s1+k3s2 {x.h}x{x.w}x{d['cin']} -> {o.h}x{o.w}x{c2}"
+        if len(d['gates']) > 1:                # ... + the pointwise conv behind them
+            fl += 2.0 * c2 * d['cout'] * P
+            by += (P * c2 + P * d['cout'] + c2 * d['cout']) * 2
+            shape = f"k3s1+k3s2+k1 {x.h}x{x.w}x{d['cin']} -> {o.h}x{o.w}x{d['cout']}"
         kind = 'stem2'
     elif op == 14:                             # fused residual unit: 1x1 (c -> m) + 3x3 (m -> c) + shortcut
         w1, _, w2, _ = d['res_ref']

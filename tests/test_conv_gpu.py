@@ -473,9 +473,12 @@ def test_yolov4_small_input(ctx, monkeypatch, resblock):
     n_res = sum(d['op'] == 14 for d in g.layers)
     assert n_res == (19 if resblock == '1' else 0)
     # 110 conv layers of yolov4.cfg; the two sibling 1x1 convs of each of the 5 CSP stages run as one
-    # ... and the stem with the stride-2 conv behind it (FM_OP_STEM2 = 18: two convs in one entry)
-    assert sum(d['op'] in (0, 12, 15, 17) for d in g.layers) + 2 * n_res + 2 * (g.layers[0]['op'] == 18) == 110 - 5
-    assert g.layers[0]['op'] == 18
+    # ... and the stem with the stride-2 conv and the first stage's merged 1x1 conv behind it (FM_OP_STEM2 = 18: three convs
+    # in one entry), two pointwise convs around a concat (FM_OP_PAIR11 = 19: two; only on maps of >= 8192 pixels)
+    convs = {0: 1, 12: 1, 15: 1, 17: 1, 14: 2, 19: 2}
+    n_convs = sum(convs.get(d['op'], 0) for d in g.layers) + sum(len(d['gates']) for d in g.layers if d['op'] == 18)
+    assert n_convs == 110 - 5
+    assert g.layers[0]['op'] == 18 and len(g.layers[0]['gates']) == 3
     net = HipNet(ctx, NET_DETECTOR, g, 1)
     rng = np.random.default_rng(22)
     x = rng.uniform(0, 1, (1, 96, 96, 3)).astype(np.float16)
@@ -561,12 +564,15 @@ def test_convd_conv(ctx, cin, cout, k, stride, act, h, w, n, extra, cfg):
     close(outs[0], outs[1], rel=1e-2, abs_=2e-3, what='convd vs tiled')
 
 
-@pytest.mark.parametrize('cout,act1,act2,h,w,n', [(64, 'mish', 'mish', 64, 96, 1), (64, 'leaky', 'mish', 37, 51, 2),
-                                                 (128, 'mish', 'leaky', 24, 40, 1), (64, 'mish', 'mish', 608, 608, 1)])
-def test_stem_pair_fused(ctx, cout, act1, act2, h, w, n):
-    """FM_OP_STEM2 (stem2.hip): the stem conv (3 -> 32, 3x3 s1) and the 3x3 stride-2 conv behind it in one launch ==
-    the two layers of the unfused table (same parameters: the stem's fp16 values are the same by construction, the
-    second conv accumulates in another order) == the torch reference; odd map sizes, batch 2, YOLOv4's own 608 x 608."""
+@pytest.mark.parametrize('cout,act1,act2,h,w,n,c3', [(64, 'mish', 'mish', 64, 96, 1, 0), (64, 'leaky', 'mish', 37, 51, 2, 0),
+                                                    (128, 'mish', 'leaky', 24, 40, 1, 0), (64, 'mish', 'mish', 608, 608, 1, 0),
+                                                    (64, 'mish', 'mish', 37, 51, 2, 128), (64, 'mish', 'leaky', 64, 96, 1, 64),
+                                                    (64, 'mish', 'mish', 608, 608, 1, 128)])
+def test_stem_pair_fused(ctx, cout, act1, act2, h, w, n, c3):
+    """FM_OP_STEM2 (stem2.hip): the stem conv (3 -> 32, 3x3 s1) and the 3x3 stride-2 conv behind it in one launch -- and,
+    c3 > 0, the pointwise conv behind that as a third stage -- == the layers of the unfused table (same parameters: the
+    stem's fp16 values are the same by construction, the second conv accumulates in another order) == the torch reference;
+    odd map sizes, batch 2, YOLOv4's own 608 x 608."""
     rng = np.random.default_rng(cout + h)
     x = np.zeros((n, h, w, 8), np.float16)
     x[..., :3] = rng.uniform(0, 1, (n, h, w, 3))
@@ -576,8 +582,11 @@ def test_stem_pair_fused(ctx, cout, act1, act2, h, w, n):
         g.use_stem2 = fuse
         y = g.conv('s', g.input, 32, 3, 1, act1)
         y = g.conv('d', y, cout, 3, 2, act2)
+        if c3:
+            y = g.conv('p', y, c3, 1, 1, 'mish')
         g.outputs.append(y)
-        assert [d['op'] for d in g.layers] == ([18] if fuse else [12, g.layers[1]['op']])
+        assert ([d['op'] for d in g.layers] == [18]) == fuse and len(g.layers) == (1 if fuse else 2 + (c3 > 0))
+        assert not fuse or len(g.layers[0]['gates']) == (3 if c3 else 1)
         net = HipNet(ctx, NET_DETECTOR, g, n)
         net.write(g.input, x)
         net.run(n)
@@ -585,8 +594,8 @@ def test_stem_pair_fused(ctx, cout, act1, act2, h, w, n):
         net.close()
         if fuse:
             bufs, _ = torch_ref.run_graph(g, nchw(x[..., :3].astype(np.float32)))
-            close(outs[0], nhwc(bufs[y.tid][:, :cout]), what='fused stem pair vs torch')
-    close(outs[0], outs[1], rel=4e-3, abs_=1e-3, what='fused stem pair vs the two layers')
+            close(outs[0], nhwc(bufs[y.tid][:, :y.c]), what='fused stem pair vs torch')
+    close(outs[0], outs[1], rel=4e-3, abs_=1e-3, what='fused stem pair vs the separate layers')
 
 
 @pytest.mark.parametrize('cout,act1,act2,h,w,n', [(64, 'mish', 'mish', 96, 96, 1), (128, 'mish', 'leaky', 91, 101, 2),

@@ -76,12 +76,19 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
                                 d['act']))
         elif op == G.OP_STEM2:
             w1, b1, act1, w2, b2 = d['stem2_ref']
+            three = 'stem3_ref' in d
             y = act_fn(F.conv2d(xin, torch.from_numpy(np.asarray(w1, np.float32)), torch.from_numpy(np.asarray(b1, np.float32)),
                                 padding=1), act1)
             if emulate_fp16_storage:
                 y = y.half().float()
-            wr(d['out'], act_fn(F.conv2d(y, torch.from_numpy(np.asarray(w2, np.float32)), torch.from_numpy(np.asarray(b2, np.float32)),
-                                         stride=2, padding=1), d['act']))
+            y = act_fn(F.conv2d(y, torch.from_numpy(np.asarray(w2, np.float32)), torch.from_numpy(np.asarray(b2, np.float32)),
+                                stride=2, padding=1), d['stem3_ref'][0] if three else d['act'])
+            if three:
+                if emulate_fp16_storage:
+                    y = y.half().float()
+                _, w3, b3 = d['stem3_ref']
+                y = act_fn(F.conv2d(y, torch.from_numpy(np.asarray(w3, np.float32)), torch.from_numpy(np.asarray(b3, np.float32))), d['act'])
+            wr(d['out'], y)
         elif op == G.OP_DWCONV3:
             w, b = params[idx]
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), padding=1, groups=xin.shape[1])
