@@ -710,6 +710,209 @@ __global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_kernel(LKArgs a, int 
     }
 }
 
+// ---- round 6: the same two-points-per-wavefront kernel with everything that does NOT depend on the tracked position taken
+// out of the level loop.  In calcOpticalFlowPyrLK a level's template terms -- the window's samples of the previous frame
+// I, its Scharr derivatives, the matrix sums A11 / A12 / A22 -- are functions of the ORIGINAL point and the level alone;
+// only the iterations follow the position found on the coarser level.  lk_pair_kernel fetched and summed them level by
+// level: per level two dependent trips to memory (~500-700 cycles each beside the networks) and three 24-step serial
+// scans in front of the first iteration, six times in a row.  Here all levels' loads are requested at once and the 3 x
+// levels scans run interleaved (18 independent chains: the DPP adds issue back to back instead of waiting for each other);
+// the level loop keeps the patch fill and the iterations.  Every value is computed by the same operations in the same
+// order as before: bit-identical (tests/test_flow_gpu.py, the e2e parity tests).  Up to LK_PRE levels (the reference's
+// maxLevel = 5 gives 6); deeper pyramids take lk_pair_kernel.
+constexpr int LK_PRE = 6;
+
+template <int WINC>
+__global__ __launch_bounds__(256) FM_SGPR_CAP void lk_pair_pre_kernel(LKArgs a, int n, const float* __restrict__ prev_pts,
+                                                                      float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                                      float* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t patch_all[8 * LK_PW * LK_PW];
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = gidx & 63, g = l & 31, hb = l & 32;
+    const int pt = (gidx >> 6) * 2 + (l >> 5);
+    constexpr int win = WINC, NW = WINC * WINC;
+    if (pt >= n || g >= NW) return;
+    uint8_t* const patch = patch_all + ((threadIdx.x >> 5) & 7) * (LK_PW * LK_PW);
+    int sx0 = 0, sy0 = 0;
+    bool have_patch = false;
+    const int wy = g / win, wx = g % win;
+    const float half = (win - 1) * 0.5f;
+    const float px0 = prev_pts[2 * pt], py0 = prev_pts[2 * pt + 1];
+    float nx = 0.f, ny = 0.f;
+    bool st = true;
+    float er = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    auto weights = [](float fa, float fb, int& iw00, int& iw01, int& iw10, int& iw11) {
+        iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << 14));
+        iw01 = __float2int_rn(fa * (1.f - fb) * (1 << 14));
+        iw10 = __float2int_rn((1.f - fa) * fb * (1 << 14));
+        iw11 = (1 << 14) - iw00 - iw01 - iw10;
+    };
+    auto sample = [&](const uint8_t* img, int w, int h, int bx, int by, int iw00, int iw01, int iw10, int iw11) -> int {
+        const uint8_t* r0 = img + (size_t)reflect101(by + wy, h) * w;
+        const uint8_t* r1 = img + (size_t)reflect101(by + wy + 1, h) * w;
+        const int c0 = reflect101(bx + wx, w), c1 = reflect101(bx + wx + 1, w);
+        return LK_DESCALE(lk_px(r0, c0) * iw00 + lk_px(r0, c1) * iw01 + lk_px(r1, c0) * iw10 + lk_px(r1, c1) * iw11, 14 - 5);
+    };
+    auto sample_j = [&](const uint8_t* img, int w, int h, int bx, int by, int iw00, int iw01, int iw10, int iw11) -> int {
+        if (have_patch && bx >= sx0 && by >= sy0 && bx + win + 1 <= sx0 + LK_PW && by + win + 1 <= sy0 + LK_PW) {
+            const uint8_t* q = patch + (by - sy0 + wy) * LK_PW + (bx - sx0 + wx);
+            return LK_DESCALE((int)q[0] * iw00 + (int)q[1] * iw01 + (int)q[LK_PW] * iw10 + (int)q[LK_PW + 1] * iw11, 14 - 5);
+        }
+        return sample(img, w, h, bx, by, iw00, iw01, iw10, iw11);
+    };
+    auto fill_patch = [&](const uint8_t* img, int w, int h, int x0, int y0) {
+        sx0 = x0; sy0 = y0;
+        const bool inside = x0 >= 0 && x0 + LK_PW + 4 <= w;
+        for (int item = g; item < LK_PW * LK_PW / 4; item += NW) {
+            const int r = item >> 2, c = (item & 3) * 4;
+            const uint8_t* row = img + (size_t)reflect101(y0 + r, h) * w;
+            uint32_t v;
+            if (inside) {
+                const uintptr_t ad = reinterpret_cast<uintptr_t>(row) + (uintptr_t)(x0 + c);
+                const uint32_t* al = reinterpret_cast<const uint32_t*>(ad & ~uintptr_t(3));
+                v = __builtin_amdgcn_alignbyte(al[1], al[0], (uint32_t)(ad & 3));
+            } else {
+                v = (uint32_t)row[reflect101(x0 + c, w)] | (uint32_t)row[reflect101(x0 + c + 1, w)] << 8 |
+                    (uint32_t)row[reflect101(x0 + c + 2, w)] << 16 | (uint32_t)row[reflect101(x0 + c + 3, w)] << 24;
+            }
+            *reinterpret_cast<uint32_t*>(patch + r * LK_PW + c) = v;
+        }
+        have_patch = true;
+    };
+
+    // ---- the template terms of every level
+    int ivalL[LK_PRE], ixL[LK_PRE], iyL[LK_PRE];
+    bool posok[LK_PRE];
+#pragma unroll
+    for (int lv = 0; lv < LK_PRE; ++lv) {
+        ivalL[lv] = ixL[lv] = iyL[lv] = 0;
+        posok[lv] = false;
+        if (lv < a.levels) {
+            const int w = a.w[lv], h = a.h[lv];
+            const float sc = 1.f / (float)(1 << lv);
+            const float ppx = px0 * sc - half, ppy = py0 * sc - half;
+            const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+            posok[lv] = !(ipx < -win || ipx >= w || ipy < -win || ipy >= h);
+            // (a position outside the level is never used: its loads go to a clamped one)
+            const int cx = min(max(ipx, -win), w - 1), cy = min(max(ipy, -win), h - 1);
+            int iw00, iw01, iw10, iw11;
+            weights(ppx - ipx, ppy - ipy, iw00, iw01, iw10, iw11);
+            ivalL[lv] = sample(a.I[lv], w, h, cx, cy, iw00, iw01, iw10, iw11);
+            const int16_t* D = a.D[lv];
+            const int xx0 = cx + wx, xx1 = xx0 + 1, yy0 = cy + wy, yy1 = yy0 + 1;
+            auto dv = [&](int xx, int yy) -> int2 {      // derivative image is zero outside (BORDER_CONSTANT), lkpyramid.cpp
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h) return make_int2(0, 0);
+                const int v = *reinterpret_cast<const int*>(D + ((size_t)yy * w + xx) * 2);
+                return make_int2((int)(short)(v & 0xffff), (int)(short)(v >> 16));
+            };
+            const int2 d00 = dv(xx0, yy0), d01 = dv(xx1, yy0), d10 = dv(xx0, yy1), d11 = dv(xx1, yy1);
+            ixL[lv] = LK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
+            iyL[lv] = LK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
+        }
+    }
+    float A11L[LK_PRE], A12L[LK_PRE], A22L[LK_PRE];
+    {
+        float v0[LK_PRE], v1[LK_PRE], v2[LK_PRE], s0[LK_PRE], s1[LK_PRE], s2[LK_PRE];
+#pragma unroll
+        for (int lv = 0; lv < LK_PRE; ++lv) {
+            s0[lv] = v0[lv] = (float)(ixL[lv] * ixL[lv]);
+            s1[lv] = v1[lv] = (float)(ixL[lv] * iyL[lv]);
+            s2[lv] = v2[lv] = (float)(iyL[lv] * iyL[lv]);
+        }
+#pragma unroll
+        for (int k = 1; k < NW; ++k)
+#pragma unroll
+            for (int lv = 0; lv < LK_PRE; ++lv) {
+                s0[lv] = seq_step(s0[lv], v0[lv]); s1[lv] = seq_step(s1[lv], v1[lv]); s2[lv] = seq_step(s2[lv], v2[lv]);
+            }
+#pragma unroll
+        for (int lv = 0; lv < LK_PRE; ++lv) {
+            A11L[lv] = half_value(s0[lv], NW - 1, hb); A12L[lv] = half_value(s1[lv], NW - 1, hb); A22L[lv] = half_value(s2[lv], NW - 1, hb);
+        }
+    }
+
+    // ---- coarse to fine: what follows the position
+#pragma unroll
+    for (int lv = LK_PRE - 1; lv >= 0; --lv) {
+        if (lv >= a.levels) continue;
+        const int level = lv;
+        const int w = a.w[lv], h = a.h[lv];
+        const uint8_t* J = a.J[lv];
+        have_patch = false;
+        const float sc = 1.f / (float)(1 << level);
+        if (level == a.levels - 1) { nx = px0 * sc; ny = py0 * sc; }
+        else { nx *= 2.f; ny *= 2.f; }
+        if (!posok[lv]) {
+            if (level == 0) { st = false; er = 0.f; }
+            continue;
+        }
+        const int ival = ivalL[lv], ixval = ixL[lv], iyval = iyL[lv];
+        float A11 = A11L[lv] * FLT_SCALE, A12 = A12L[lv] * FLT_SCALE, A22 = A22L[lv] * FLT_SCALE;
+        float Dt = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
+        if (minEig < a.min_eig_thresh || Dt < 1.1920929e-07f) {
+            if (level == 0) st = false;
+            continue;
+        }
+        Dt = 1.f / Dt;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        float outx = nx + half, outy = ny + half;
+        {
+            const int fx = (int)floorf(nx), fy = (int)floorf(ny);
+            if (fx >= -win && fx < w && fy >= -win && fy < h) fill_patch(J, w, h, fx - LK_PR, fy - LK_PR);
+        }
+        int iw00, iw01, iw10, iw11;
+        for (int j = 0; j < a.max_count; ++j) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -win || inx >= w || iny < -win || iny >= h) {
+                if (level == 0) st = false;
+                break;
+            }
+            weights(nx - inx, ny - iny, iw00, iw01, iw10, iw11);
+            const int diff = sample_j(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            float b1, b2;
+            {
+                const float v0 = (float)(diff * ixval), v1 = (float)(diff * iyval);
+                float a0 = v0, a1 = v1;
+#pragma unroll
+                for (int k = 1; k < NW; ++k) { a0 = seq_step(a0, v0); a1 = seq_step(a1, v1); }
+                b1 = half_value(a0, NW - 1, hb); b2 = half_value(a1, NW - 1, hb);
+            }
+            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+            nx += dx; ny += dy;
+            outx = nx + half; outy = ny + half;
+            if (dx * dx + dy * dy <= a.eps2) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        nx = outx; ny = outy;
+        if (st && level == 0) {
+            const float ex = nx - half, ey = ny - half;
+            const int inx = (int)floorf(ex), iny = (int)floorf(ey);
+            if (inx < -win || inx >= w || iny < -win || iny >= h) { st = false; continue; }
+            weights(ex - inx, ey - iny, iw00, iw01, iw10, iw11);
+            const int diff = sample_j(J, w, h, inx, iny, iw00, iw01, iw10, iw11) - ival;
+            const float v0 = fabsf((float)diff);
+            float a0 = v0;
+#pragma unroll
+            for (int k = 1; k < NW; ++k) a0 = seq_step(a0, v0);
+            er = half_value(a0, NW - 1, hb) * 1.f / (32 * win * win);
+        }
+    }
+    if (g == 0) {
+        next_pts[2 * pt] = nx;
+        next_pts[2 * pt + 1] = ny;
+        status[pt] = st ? 1 : 0;
+        err[pt] = er;
+    }
+}
+
 #ifdef FM_DIAG      // diagnostic builds only (FASTMOT_EXTRA_HIPCC_FLAGS=-DFM_DIAG, include/fastmot_hip_diag.h)
 // ---- diagnostic variants of the LK kernel (round 3: bisect of the results that differ under load).
 // MODE 0: window sums as DPP scans (the production arithmetic), 1: through LDS (no cross-lane VALU operation),
@@ -2072,7 +2275,14 @@ extern "C" int fm_flow_lk(fm_ctx* ctx, int n, const float* prev_pts, float* next
                 fm_trace_mark(ctx, s, 40);
                 // (PATCH = false, the global-load sampling of rounds 3-4, measured equal within the spread:
                 // profiles/r05_lk_patch_and_ring_depth_ab.txt)
-                if (a.win == 5)
+                // (lk_pair_pre_kernel against lk_pair_kernel: 77 vs 90 us inside the pipeline at 1080p, config[4] 185 vs 176
+                // frames/s, profiles/r06_lk_template_terms_ab.txt)
+                if (a.levels <= LK_PRE) {      // template terms of all levels up front (bit-identical; see the kernel)
+                    if (a.win == 5)
+                        hipLaunchKernelGGL((lk_pair_pre_kernel<5>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                    else
+                        hipLaunchKernelGGL((lk_pair_pre_kernel<3>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
+                } else if (a.win == 5)
                     hipLaunchKernelGGL((lk_pair_kernel<5, true>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
                 else
                     hipLaunchKernelGGL((lk_pair_kernel<3, true>), grid2, dim3(threads), 0, s, a, n, in_pts, o_pts, o_stat, o_errp);
