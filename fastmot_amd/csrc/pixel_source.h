@@ -66,41 +66,54 @@ __device__ __forceinline__ ResizeCoef lin_coef(int d, double scale, int ssize) {
 // pixel (x, y) of the ow x oh network input of the crop `bx` (tlbr, doubles): crop (astype(int) truncation,
 // maximum(., 0), inclusive bottom-right, numpy slice clamp) -> cv2.resize INTER_LINEAR (an exact 2x decimation in both
 // axes goes to INTER_AREA: rounded 2x2 mean) -> BGR -> RGB -> (v / 255 - mean) / std.  o: 8 halfs, channels 3..7 zero.
-__device__ __forceinline__ void crop_input_pixel(const uint8_t* __restrict__ frame, int fw, int fh,
-                                                 const double* __restrict__ bx, int x, int y, int ow, int oh, f16x8& o) {
+// the resized crop's pixel as uint8 BGR (bgr[c]); false when the crop is empty (the network input is zero then)
+__device__ __forceinline__ bool crop_u8_pixel(const uint8_t* __restrict__ frame, int fw, int fh,
+                                              const double* __restrict__ bx, int x, int y, int ow, int oh, int bgr[3]) {
     int x1 = max((int)bx[0], 0), y1 = max((int)bx[1], 0);
     int x2 = max((int)bx[2], 0), y2 = max((int)bx[3], 0);
     x2 = min(x2 + 1, fw); y2 = min(y2 + 1, fh);
     const int cw = x2 - x1, ch = y2 - y1;
+    if (!(cw > 0 && ch > 0)) return false;
+    const ResizeCoef cx = lin_coef(x, (double)cw / ow, cw);
+    const ResizeCoef cy = lin_coef(y, (double)ch / oh, ch);
+    const int sx1 = min(cx.s + 1, cw - 1), sy1 = min(cy.s + 1, ch - 1);
+    const bool area2 = cw == 2 * ow && ch == 2 * oh;
+    // both branches read two neighbouring pixels of two rows: one 8-byte load per row (load_px2)
+    const int ax = area2 ? 2 * x : cx.s, ay0 = area2 ? 2 * y : cy.s, ay1 = area2 ? 2 * y + 1 : sy1;
+    const uint64_t q0 = load_px2(frame + ((size_t)(y1 + ay0) * fw + x1 + ax) * 3);
+    const uint64_t q1 = load_px2(frame + ((size_t)(y1 + ay1) * fw + x1 + ax) * 3);
+    const int sh = (area2 || sx1 != cx.s) ? 24 : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int a0 = (int)((q0 >> (8 * c)) & 255), a1 = (int)((q0 >> (sh + 8 * c)) & 255);
+        const int b0 = (int)((q1 >> (8 * c)) & 255), b1 = (int)((q1 >> (sh + 8 * c)) & 255);
+        if (area2) {
+            bgr[c] = (a0 + a1 + b0 + b1 + 2) >> 2;
+        } else {
+            const int S0 = a0 * cx.a0 + a1 * cx.a1;
+            const int S1 = b0 * cx.a0 + b1 * cx.a1;
+            const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            bgr[c] = min(max(v, 0), 255);
+        }
+    }
+    return true;
+}
+
+// (v / 255 - mean) / std of RGB channel rc for a uint8 value (feature_extractor.py:88-98), rounded to fp16 through float.
+// Two float64 divisions: the fused stem tabulates the 3 x 256 values once per workgroup instead of dividing per pixel.
+__device__ __forceinline__ f16 crop_normalise(int u8, int rc) {
+    const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+    return (f16)(float)(((double)u8 / 255. - mean[rc]) / stdv[rc]);
+}
+
+__device__ __forceinline__ void crop_input_pixel(const uint8_t* __restrict__ frame, int fw, int fh,
+                                                 const double* __restrict__ bx, int x, int y, int ow, int oh, f16x8& o) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (f16)0.f;
-    if (cw > 0 && ch > 0) {
-        const ResizeCoef cx = lin_coef(x, (double)cw / ow, cw);
-        const ResizeCoef cy = lin_coef(y, (double)ch / oh, ch);
-        const int sx1 = min(cx.s + 1, cw - 1), sy1 = min(cy.s + 1, ch - 1);
-        const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
-        const bool area2 = cw == 2 * ow && ch == 2 * oh;
-        // both branches read two neighbouring pixels of two rows: one 8-byte load per row (load_px2)
-        const int ax = area2 ? 2 * x : cx.s, ay0 = area2 ? 2 * y : cy.s, ay1 = area2 ? 2 * y + 1 : sy1;
-        const uint64_t q0 = load_px2(frame + ((size_t)(y1 + ay0) * fw + x1 + ax) * 3);
-        const uint64_t q1 = load_px2(frame + ((size_t)(y1 + ay1) * fw + x1 + ax) * 3);
-        const int sh = (area2 || sx1 != cx.s) ? 24 : 0;
+    int bgr[3];
+    if (crop_u8_pixel(frame, fw, fh, bx, x, y, ow, oh, bgr)) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int a0 = (int)((q0 >> (8 * c)) & 255), a1 = (int)((q0 >> (sh + 8 * c)) & 255);
-            const int b0 = (int)((q1 >> (8 * c)) & 255), b1 = (int)((q1 >> (sh + 8 * c)) & 255);
-            int u8;
-            if (area2) {
-                u8 = (a0 + a1 + b0 + b1 + 2) >> 2;
-            } else {
-                const int S0 = a0 * cx.a0 + a1 * cx.a1;
-                const int S1 = b0 * cx.a0 + b1 * cx.a1;
-                const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
-                u8 = min(max(v, 0), 255);
-            }
-            const int rc = 2 - c;    // BGR -> RGB
-            o[rc] = (f16)(float)(((double)u8 / 255. - mean[rc]) / stdv[rc]);
-        }
+        for (int c = 0; c < 3; ++c) o[2 - c] = crop_normalise(bgr[c], 2 - c);      // BGR -> RGB
     }
 }
 

@@ -36,6 +36,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemSrc src, const
     const long n = blockIdx.z;
     const f16* img = in + n * (long)H * W * in_cs + in_coff;
     if (SRC != 0 && src.zero4 && tid < 4 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) src.zero4[tid] = 0;
+    // crops: the normalisation (v / 255 - mean) / std costs two float64 divisions per channel; it is a function of the uint8
+    // value alone, so the workgroup tabulates its 3 x 256 results once (crop_normalise: the values of the front-end kernel)
+    __shared__ f16 norm_lut[SRC == 2 ? 3 * 256 : 2];
+    if constexpr (SRC == 2) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) norm_lut[i * 256 + tid] = crop_normalise(tid, i);
+        __syncthreads();
+    }
     // (unrolled, loads unconditional on clamped coordinates, zeroing afterwards: all trips to memory of a thread's patch
     // positions are in flight together -- a load inside a divergent branch waits on the spot)
     constexpr int NIT = (PH * PW + 255) / 256;
@@ -55,10 +63,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemSrc src, const
             pk.h[0] = (f16)rgb[0]; pk.h[1] = (f16)rgb[1]; pk.h[2] = (f16)rgb[2]; pk.h[3] = (f16)0.f;
             v = pk.u;
         } else {
-            f16x8 o;
-            crop_input_pixel(src.frame, src.fw, src.fh, src.boxes + n * 4, cx, cy, W, H, o);
+            int bgr[3];
             union { f16 h[4]; uint2 u; } pk;
-            pk.h[0] = o[0]; pk.h[1] = o[1]; pk.h[2] = o[2]; pk.h[3] = o[3];
+            pk.u = make_uint2(0u, 0u);
+            if (crop_u8_pixel(src.frame, src.fw, src.fh, src.boxes + n * 4, cx, cy, W, H, bgr)) {
+                pk.h[0] = norm_lut[0 * 256 + bgr[2]]; pk.h[1] = norm_lut[1 * 256 + bgr[1]]; pk.h[2] = norm_lut[2 * 256 + bgr[0]];
+            }
             v = pk.u;
         }
         if (!inside) v = make_uint2(0u, 0u);
