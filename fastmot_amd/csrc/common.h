@@ -135,6 +135,7 @@ struct fm_ctx {
 
     // ---- per-frame embeddings on the device [n][dim] f32
     float* emb = nullptr;
+    float* emb_host = nullptr;   // page-locked mirror [emb_cap][dim]: the ReID head writes a row to both (no export launch, round 6)
     int emb_cap = 0;
     int emb_n = 0;
 

@@ -177,6 +177,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx) {
     for (void* p : {(void*)ctx->mean, (void*)ctx->cov, (void*)ctx->feat_sum, (void*)ctx->feat_avg,
                     (void*)ctx->feat_cnt, (void*)ctx->emb})
         if (p) (void)hipFree(p);
+    if (ctx->emb_host) (void)hipHostFree(ctx->emb_host);
     for (DevBuf* b : {&ctx->as_in, &ctx->as_pair, &ctx->as_stage_in, &ctx->as_cost, &ctx->as_work,
                       &ctx->as_out, &ctx->io0, &ctx->io1, &ctx->feat_in, &ctx->occ_in, &ctx->occ_out})
         b->release();
@@ -324,6 +325,8 @@ extern "C" int fm_trk_copy_state(fm_ctx* ctx, int dst, int src) {
 }
 
 // ------------------------------------------------------------------ ReID feature table
+void fm_net_drop_graphs(NetState* net);
+
 extern "C" int fm_feat_configure(fm_ctx* ctx, int dim) {
     FM_CHECK_ARG(ctx && dim > 0 && dim % 4 == 0);
     if (dim == ctx->feat_dim) return 0;
@@ -338,19 +341,32 @@ extern "C" int fm_feat_configure(fm_ctx* ctx, int dim) {
     FM_HIP(hipMemset(ctx->feat_sum, 0, n * sizeof(float)));
     FM_HIP(hipMemset(ctx->feat_avg, 0, n * sizeof(float)));
     FM_HIP(hipMemset(ctx->feat_cnt, 0, (size_t)ctx->slot_cap * sizeof(int32_t)));
+    fm_net_drop_graphs(ctx->ext_net);                 // (they hold the embedding buffers' pointers)
+    for (NetState* x : ctx->ext_net_x) fm_net_drop_graphs(x);
     if (ctx->emb) FM_HIP(hipFree(ctx->emb));
-    ctx->emb = nullptr;
+    if (ctx->emb_host) FM_HIP(hipHostFree(ctx->emb_host));
+    ctx->emb = ctx->emb_host = nullptr;
     ctx->emb_cap = ctx->emb_n = 0;
     return 0;
 }
+
+void fm_net_drop_graphs(NetState* net);
 
 int fm_emb_reserve(fm_ctx* ctx, int n) {
     if (n <= ctx->emb_cap) return 0;
     int ncap = ctx->emb_cap ? ctx->emb_cap : 64;
     while (ncap < n) ncap *= 2;
+    // captured graphs of the ReID networks hold these pointers (the head layer writes the embedding rows): they go with the
+    // buffers.  (Until round 6 a batch that outgrew the buffer after smaller batches had been captured replayed graphs that
+    // wrote through the freed pointer.)
+    fm_net_drop_graphs(ctx->ext_net);
+    for (NetState* x : ctx->ext_net_x) fm_net_drop_graphs(x);
     if (ctx->emb) FM_HIP(hipFree(ctx->emb));
-    ctx->emb = nullptr;
+    if (ctx->emb_host) FM_HIP(hipHostFree(ctx->emb_host));
+    ctx->emb = ctx->emb_host = nullptr;
+    ctx->emb_cap = 0;
     FM_HIP(hipMalloc(&ctx->emb, (size_t)ncap * ctx->feat_dim * sizeof(float)));
+    FM_HIP(hipHostMalloc(&ctx->emb_host, (size_t)ncap * ctx->feat_dim * sizeof(float), hipHostMallocDefault));
     ctx->emb_cap = ncap;
     return 0;
 }

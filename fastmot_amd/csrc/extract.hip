@@ -21,7 +21,8 @@ struct ExtState {
     double* boxes_host = nullptr;  // pinned
     int cap = 0;
     DevBuf emb_out;                // pinned read-back buffer of fm_extract_sync
-    int exported_n = -1;           // rows of ctx->emb that export_kernel wrote to emb_out.h behind the last network pass
+    int exported_n = -1;           // rows of ctx->emb that reached page-locked memory behind the last network pass
+    bool mirror_export = false;    // ... in ctx->emb_host (written by the head layer itself) instead of emb_out.h (export_kernel)
 };
 
 // ctx->emb was written by something other than the extractor (fm_emb_upload): the exported copy is stale
@@ -75,6 +76,14 @@ int fm_emb_reserve(fm_ctx* ctx, int n);
 static int export_embeddings(fm_ctx* ctx, ExtState* e, int n, hipStream_t s) {
     const size_t bytes = sizeof(float) * (size_t)n * ctx->feat_dim;
     e->exported_n = -1;
+    if (ctx->emb_host) {
+        // round 6: the head layer wrote every row to ctx->emb_host as well (ops.hip head_kernel): nothing to launch
+        e->exported_n = n;
+        e->mirror_export = true;
+        FM_HIP(hipEventRecord(ctx->ev_ext_done, s));
+        return 0;
+    }
+    e->mirror_export = false;
     if (bytes > e->emb_out.cap) {             // (growing frees the old buffers: nothing may be in flight on them)
         FM_HIP(hipStreamSynchronize(s));
         int rc = e->emb_out.reserve(bytes);
@@ -227,7 +236,11 @@ extern "C" int fm_extract_sync(fm_ctx* ctx, int n, float* emb) {
         FM_HIP(hipMemcpyAsync(ctx->ext->emb_out.h, ctx->emb, bytes, hipMemcpyDeviceToHost, ctx->s_ext));
         FM_HIP(hipStreamSynchronize(ctx->s_ext));
     } else {
-        FM_HIP(hipEventSynchronize(ctx->ev_ext_done));   // the export kernel's rows are in page-locked memory
+        FM_HIP(hipEventSynchronize(ctx->ev_ext_done));   // the rows are in page-locked memory
+        if (ctx->ext->mirror_export) {
+            memcpy(emb, ctx->emb_host, bytes);
+            return 0;
+        }
     }
     memcpy(emb, ctx->ext->emb_out.h, bytes);
     return 0;

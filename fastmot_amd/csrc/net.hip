@@ -48,7 +48,7 @@ int launch_gate_sum(int nstreams, const f16* const* in, const int* in_cs, const 
                     const float* const* gate, f16* out, int out_cs, int out_coff, int N, int HW, int C,
                     hipStream_t s);
 int launch_head(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int D, const f16* w,
-                const float* b, float* out, float* raw_out, hipStream_t s);
+                const float* b, float* out, float* raw_out, hipStream_t s, float* mirror = nullptr);
 int fm_emb_reserve(fm_ctx* ctx, int n);
 
 
@@ -70,6 +70,14 @@ static NetState*& net_slot(fm_ctx* ctx, int which) {
 }
 NetState* fm_net_get(fm_ctx* ctx, int which) { return net_slot(ctx, which); }
 int fm_net_run_internal(fm_ctx* ctx, int which, int batch) { return fm_net_run(ctx, which, batch); }
+
+// captured graphs bake the pointers their layers were launched with: whoever re-allocates one of those drops the graphs
+void fm_net_drop_graphs(NetState* net) {
+    if (!net) return;
+    (void)hipStreamSynchronize(net->stream);
+    for (auto& g : net->graphs) (void)hipGraphExecDestroy(g.second);
+    net->graphs.clear();
+}
 
 static size_t elem_size(const fm_tensor& t) { return t.f32 ? 4 : 2; }
 
@@ -312,7 +320,8 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
             FM_CHECK_ARG(L.cout == ctx->feat_dim && net->emb_offset + B <= ctx->emb_cap);
             return launch_head(in0, ti.c, L.in_coff[0], B, ti.h * ti.w, L.cin, L.cout,
                                (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
-                               ctx->emb + (size_t)net->emb_offset * ctx->feat_dim, nullptr, s);
+                               ctx->emb + (size_t)net->emb_offset * ctx->feat_dim, nullptr, s,
+                               ctx->emb_host ? ctx->emb_host + (size_t)net->emb_offset * ctx->feat_dim : nullptr);
         default:
             fm_set_error("unknown layer op %d", L.op);
             return FM_ERR_ARG;

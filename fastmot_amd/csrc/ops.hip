@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void gated_sum_part_kernel(GatedSumPartArgs a,
 __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ in, int in_cs, int in_coff,
                                                    int HW, int C, int D, const f16* __restrict__ w,
                                                    const float* __restrict__ b, float* __restrict__ out,
-                                                   float* __restrict__ raw_out) {
+                                                   float* __restrict__ raw_out, float* __restrict__ mirror) {
     extern __shared__ float sm[];   // [groups][C] | gap[C] | feat[D] | red[256]
     const int n = blockIdx.x, tid = threadIdx.x;
     const int c8n = C / 8;
@@ -490,7 +490,9 @@ __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ in, i
     const float inv = 1.f / sqrtf(red[0]);
     for (int d = tid; d < D; d += 256) {
         if (raw_out) raw_out[(size_t)n * D + d] = feat[d];
-        out[(size_t)n * D + d] = feat[d] * inv;
+        const float v = feat[d] * inv;
+        out[(size_t)n * D + d] = v;
+        if (mirror) mirror[(size_t)n * D + d] = v;      // the same row in page-locked host memory (no export launch behind the network)
     }
 }
 
@@ -636,12 +638,12 @@ int launch_gate_sum(int nstreams, const f16* const* in, const int* in_cs, const 
 }
 
 int launch_head(const f16* in, int in_cs, int in_coff, int N, int HW, int C, int D, const f16* w,
-                const float* b, float* out, float* raw_out, hipStream_t s) {
+                const float* b, float* out, float* raw_out, hipStream_t s, float* mirror) {
     FM_CHECK_ARG(C % 8 == 0 && C / 8 <= 256 && in_cs % 8 == 0 && in_coff % 8 == 0);
     const int groups = 256 / (C / 8);
     const size_t shmem = sizeof(float) * ((size_t)groups * C + C + D + 256);
     hipLaunchKernelGGL(head_kernel, dim3(N), dim3(256), shmem, s, in, in_cs, in_coff, HW, C, D, w, b, out,
-                       raw_out);
+                       raw_out, mirror);
     FM_HIP(hipGetLastError());
     return 0;
 }

@@ -306,3 +306,26 @@ def test_fused_input_stem_equals_crop_kernel(ctx, model, n):
         inp = ctx.extract_read_input(n, 128, 256)            # (refilled by the front-end kernel on the fused path)
         exp = cv_oracle.reid_preprocess(frame, boxes).transpose(0, 2, 3, 1)
         np.testing.assert_allclose(inp, exp, rtol=0, atol=2.5e-3)
+
+
+def test_embedding_buffer_growth_keeps_captured_graphs_valid(ctx):
+    """The ReID head layer writes its rows through pointers baked into captured graphs.  A batch larger than the
+    embedding buffer re-allocates it (device rows + their page-locked mirror): the graphs captured for earlier, smaller
+    batches must not survive that (until round 6 they did, and replayed into the freed buffer)."""
+    size = (640, 360)
+    frame = synthetic_frame(*size, seed=8)
+    ext = FeatureExtractor('OSNet025', batch_size=8, weights=RandomWeights(seed=3), size=size)
+    rng = np.random.default_rng(1)
+
+    def boxes(n):
+        tl = rng.uniform([0, 0], [500, 200], (n, 2))
+        return np.concatenate([tl, tl + rng.uniform([10, 20], [120, 150], (n, 2))], axis=1)
+    small = boxes(5)
+    first = [ext(frame, small).copy() for _ in range(3)]            # eager validation, capture, replay
+    many = boxes(150)                                               # > 64 rows (and > 128): the buffers grow
+    big = ext(frame, many).copy()
+    again = ext(frame, small).copy()
+    np.testing.assert_array_equal(first[0], first[2])
+    np.testing.assert_array_equal(again, first[0])
+    np.testing.assert_array_equal(ext(frame, many), big)
+    np.testing.assert_allclose(np.linalg.norm(big, axis=1), 1, atol=1e-5)
