@@ -23,6 +23,9 @@ int launch_pair11(const f16* xa, int xa_cs, int xa_coff, const f16* xc, int xc_c
                   int out_coff, const f16* w1, const float* b1, const f16* w2, const float* b2, long P, int cout, int act1,
                   int act2, hipStream_t s);
 bool pair11_supported(int cin, int mid, int extra, int cout);
+int launch_ostail(const f16* in, int in_cs, int in_coff, const f16* ph, const float* pf, int N, float* out, float* raw_out,
+                  float* mirror, hipStream_t s);
+bool ostail_supported(int in_h, int in_w, int cin, int mid, int cout, int feat, int n_halfs, int n_floats);
 int launch_stemconv(const f16* in, int in_cs, int in_coff, f16* out, int out_cs, int out_coff, const f16* w,
                     const float* bias, int N, int H, int W, int Ho, int Wo, int k, int stride, int pad, int cout,
                     int act, hipStream_t s);
@@ -128,6 +131,9 @@ extern "C" int fm_net_create(fm_ctx* ctx, int which, int max_batch, int n_tensor
         for (int i = 0; i < L.n_in; ++i) FM_CHECK_ARG(L.in[i] >= 0 && L.in[i] < n_tensors);
         FM_CHECK_ARG(L.res_mode == FM_RES_NONE || (L.res >= 0 && L.res < n_tensors));
         FM_CHECK_ARG(L.w_off >= 0 && (size_t)L.w_off <= weight_bytes && L.w_off % 16 == 0 && L.b_off % 16 == 0);
+        if (L.op == FM_OP_OSTAIL)       // its two parameter blobs carry their sizes
+            FM_CHECK_ARG(L.stride > 0 && L.pad > 0 && L.b_off >= 0 && (size_t)L.w_off + (size_t)L.stride * 2 <= weight_bytes &&
+                         (size_t)L.b_off + (size_t)L.pad * 4 <= weight_bytes);
     }
     FM_HIP(hipMalloc(&net->weights, weight_bytes));
     FM_HIP(hipMemcpy(net->weights, weights, weight_bytes, hipMemcpyHostToDevice));
@@ -322,6 +328,12 @@ static int run_layer(fm_ctx* ctx, NetState* net, const fm_layer& L, int B) {
                                (const f16*)(net->weights + L.w_off), (const float*)(net->weights + L.b_off),
                                ctx->emb + (size_t)net->emb_offset * ctx->feat_dim, nullptr, s,
                                ctx->emb_host ? ctx->emb_host + (size_t)net->emb_offset * ctx->feat_dim : nullptr);
+        case FM_OP_OSTAIL:
+            FM_CHECK_ARG(L.cout == ctx->feat_dim && net->emb_offset + B <= ctx->emb_cap && L.in_coff[0] + L.cin <= ti.c &&
+                         ostail_supported(ti.h, ti.w, L.cin, L.hid, L.k, L.cout, L.stride, L.pad));
+            return launch_ostail(in0, ti.c, L.in_coff[0], (const f16*)(net->weights + L.w_off),
+                                 (const float*)(net->weights + L.b_off), B, ctx->emb + (size_t)net->emb_offset * ctx->feat_dim,
+                                 nullptr, ctx->emb_host ? ctx->emb_host + (size_t)net->emb_offset * ctx->feat_dim : nullptr, s);
         default:
             fm_set_error("unknown layer op %d", L.op);
             return FM_ERR_ARG;
@@ -507,6 +519,12 @@ static void layer_cost(const NetState* net, const fm_layer& L, int B, double* fl
         case FM_OP_SPP: *bytes = (pin + 3 * pout) * L.cin * 2; break;
         case FM_OP_GATE: *bytes = pin * L.cin * 2; break;
         case FM_OP_GATE_SUM: *bytes = (pin * L.n_in + pout) * L.cin * 2; break;
+        case FM_OP_OSTAIL: {    // the eleven layers it replaces: 128 pixels per sample, cin -> (hid | k) -> k -> k, head k -> cout
+            const double px = 128.0 * B, m = L.hid, c = L.k, lite = 10.0 * (m + 9) * m;
+            *flops = 2.0 * px * (L.cin * m + lite + (m + L.cin) * c + c * m + lite + m * c + c * c) + 2.0 * c * L.cout * B;
+            *bytes = pin * L.cin * 2 + ((double)L.stride) * 2 + (double)B * L.cout * 4;
+            break;
+        }
         case FM_OP_HEAD:
             *flops = 2.0 * L.cin * L.cout * B;
             *bytes = pin * L.cin * 2 + (double)L.cin * L.cout * 2;

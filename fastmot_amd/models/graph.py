@@ -15,7 +15,8 @@ import numpy as np
 LOGGER = logging.getLogger(__name__)
 
 (OP_CONV, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_UPSAMPLE2, OP_COPY, OP_GATE, OP_GATE_SUM, OP_HEAD,
- OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CONVD, OP_STEM2, OP_PAIR11) = range(20)
+ OP_LITECONV, OP_SPP, OP_GATED_SUM, OP_STEMCONV, OP_ADD, OP_RESBLOCK, OP_CONVS, OP_LITECHAIN, OP_CONVD, OP_STEM2, OP_PAIR11,
+ OP_OSTAIL) = range(21)
 CONV_OPS = (OP_CONV, OP_CONVS, OP_CONVD)      # the three kernels behind Graph.conv (same fields, different weight layouts)
 SPP_MAX_HW = 2048
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2, 'relu': 3, 'logistic': 4, 'swish': 5}
@@ -143,7 +144,9 @@ class Graph:
         self.use_stem3 = os.environ.get('FASTMOT_STEM2', '2') == '2'     # ... and the pointwise conv behind the pair as its third stage
         # a 64 -> 64 pointwise conv into the first half of a concat + the 128 -> 64 / 128 pointwise conv over that concat as one
         # launch (pair11.hip, FM_OP_PAIR11: the tail of the first two CSP stages)
-        self.use_pair11 = os.environ.get('FASTMOT_PAIR11', '1') != '0' 
+        self.use_pair11 = os.environ.get('FASTMOT_PAIR11', '1') != '0'
+        # OSNet x0.25's 16 x 8 stage + conv5 + head as one launch, one workgroup per sample (ostail.hip, FM_OP_OSTAIL)
+        self.use_ostail = os.environ.get('FASTMOT_OSTAIL', '1') != '0'
         self.conv_params = []  # (layer index, folded fp16-rounded weight fp32, bias) for the test oracle
         h, w = in_hw
         self.input = self.new(h, w, in_c)
@@ -346,6 +349,69 @@ class Graph:
             used = [v.tid for v in d['ins']] + ([d['res'].tid] if d['res'] is not None else [])
             if any(t in used or t in [v.tid for v in self.outputs] for t in dropped):
                 raise ValueError('the stem\'s output is read by another layer: build this network with use_stem2 = False')
+
+    def fuse_ostail(self, first):
+        """Collapses layers[first:] -- built by models/reid.py osnet_graph as: transition AvgPool2d(2, 2) over a 32 x 16 x 96 map,
+        OSBlock 96 -> 128 (conv1, four-stream chain, gate, conv3 + downsample over the concat [x2 | x]), OSBlock 128 -> 128
+        (conv1, chain, gate, conv3 + identity), conv5, head 128 -> 512 -- into ONE FM_OP_OSTAIL layer (ostail.hip: one
+        workgroup per sample keeps the 128-pixel maps in LDS from the pool to the embedding).  Returns False, leaving the
+        table as it is, when the layers are not that sequence (other widths, per-depth LightConv launches)."""
+        sub = self.layers[first:]
+        if not self.use_ostail or len(sub) != 11:
+            return False
+        pool, c1a, cha, ga, c3a, c1b, chb, gb, c3b, c5, head = sub
+        relu = ACT['relu']
+
+        def conv(d, cin, cout, res=False):
+            return (d['op'] in CONV_OPS and d['k'] == 1 and d['stride'] == 1 and d['ins'][0].c == cin and d['cout'] == cout and
+                    d['act'] == relu and (d['res'] is not None) == res and d['up'] == 1)
+
+        def streams(ch, g, x1):
+            return (ch['op'] == OP_LITECHAIN and ch['cout'] == 32 and ch['act'] == relu and ch['ins'][0].tid == x1['out'].tid and
+                    g['op'] == OP_GATED_SUM and g['hid'] == 2 and len(g['ins']) == 4 and all(v.tid == ch['out'].tid for v in g['ins']))
+        x = pool['ins'][0]
+        ok = (pool['op'] == OP_AVGPOOL and (pool['k'], pool['stride'], pool['pad']) == (2, 2, 0) and (x.h, x.w, x.c) == (32, 16, 96) and
+              x.coff % 8 == 0 and conv(c1a, 96, 32) and c1a['ins'][0].tid == pool['out'].tid and streams(cha, ga, c1a) and
+              conv(c3a, 128, 128) and c3a['ins'][0].tid == pool['out'].tid == ga['out'].tid and
+              (ga['out'].coff, pool['out'].coff) == (c3a['ins'][0].coff, c3a['ins'][0].coff + 32) and
+              conv(c1b, 128, 32) and c1b['ins'][0].tid == c3a['out'].tid and streams(chb, gb, c1b) and
+              conv(c3b, 32, 128, res=True) and c3b['res_mode'] == RES_BEFORE_ACT and c3b['res'].tid == c3a['out'].tid and
+              c3b['ins'][0].tid == gb['out'].tid and conv(c5, 128, 128) and c5['ins'][0].tid == c3b['out'].tid and
+              head['op'] == OP_HEAD and head['cout'] == 512 and head['ins'][0].tid == c5['out'].tid and
+              (head['ins'][0].h, head['ins'][0].w) == (16, 8))
+        if not ok:
+            return False
+        cp = {i: (w, b) for i, w, b in self.conv_params}
+
+        def frag(w):
+            w = np.asarray(w, np.float32)
+            return self._pack_frag(w.reshape(w.shape[0], -1, 1, 1).astype(np.float16)).reshape(-1)
+
+        def chain(ch):
+            refs = ch['lite_ref']
+            return (np.concatenate([frag(pw) for pw, _, _ in refs]),
+                    np.concatenate([np.asarray(wd, np.float16).reshape(32, 9).T.reshape(-1) for _, wd, _ in refs]),
+                    np.concatenate([np.asarray(bd, np.float32) for _, _, bd in refs]))
+
+        def gate(g):
+            w1, b1, w2, b2 = (np.asarray(a, np.float32) for a in g['gate_ref'])
+            return np.concatenate([w1.reshape(-1), b1, np.zeros(2, np.float32), w2.reshape(-1), b2])
+        (w1a, b1a), (w3a, b3a), (w1b, b1b), (w3b, b3b), (w5, b5) = (cp[first + i] for i in (1, 4, 5, 8, 9))
+        pwa, dwa, bca = chain(cha)
+        pwb, dwb, bcb = chain(chb)
+        wfc, bfc = head['head_ref']
+        halfs = np.concatenate([frag(w1a), pwa, dwa, frag(w3a), frag(w1b), pwb, dwb, frag(w3b), frag(w5),
+                                np.asarray(wfc, np.float16).reshape(-1)])
+        floats = np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in
+                                 (b1a, bca, gate(ga), b3a, b1b, bcb, gate(gb), b3b, b5, bfc)])
+        assert halfs.dtype == np.float16 and floats.dtype == np.float32 and (len(halfs), len(floats)) == (135808, 1928)
+        del self.layers[first:]
+        self.conv_params = [(i, w, b) for i, w, b in self.conv_params if i < first]
+        # (out: as FM_OP_HEAD, a view of the input -- the result goes to the context's embedding buffer)
+        self._layer(op=OP_OSTAIL, ins=[x], out=View(x.tid, x.coff, x.c, x.h, x.w), cin=96, hid=32, k=128, cout=512, stride=len(halfs), pad=len(floats),
+                    w_off=self._push(halfs), b_off=self._push(floats), name='ostail',
+                    sub=[(d, cp.get(first + i)) for i, d in enumerate(sub)])
+        return True
 
     @staticmethod
     def resblock_supported(c, mid):

@@ -136,11 +136,13 @@ def osnet_graph(model, weights, fuse_lightconv=True):
     x = down_block('conv3.0', lambda dst: g.pool(t2, 2, 2, 0, avg=True, dst=dst), c1, c2, H // 8, W // 8)
     x = osblock('conv3.1', x, c2)
     t3 = g.conv('conv3.t', x, c2, 1, 1, 'relu')
+    tail = len(g.layers)
     x = down_block('conv4.0', lambda dst: g.pool(t3, 2, 2, 0, avg=True, dst=dst), c2, c3, H // 16, W // 16)
     x = osblock('conv4.1', x, c3)
     x = g.conv('conv5', x, c3, 1, 1, 'relu')
     g.head('fc', x, model.OUTPUT_LAYOUT)
     g.outputs = [x]
+    g.fuse_ostail(tail)       # x0.25 widths: everything after the last transition conv as one launch (ostail.hip)
     return g, x
 
 

@@ -294,6 +294,11 @@ enum {
                           * in MFMA fragment order [cout/32][288/16][lane][8] (K order kh, kw, cin) + f32 bias                          */
     FM_OP_PAIR11 = 19,   /* two 1x1 convs around a concat in one launch (pair11.hip): t = act_gate[0](W1 in[0] + b1) (64 -> hid = 64), out =
                           * act(W2 [t | in[1]] + b2) (64 + 64 -> cout in {64, 128}); weights in MFMA fragment order (w_off / b_off, w2_off / b2_off) */
+    FM_OP_OSTAIL = 20,   /* OSNet x0.25's last stage and head in one launch, one workgroup per sample (ostail.hip): AvgPool2d(2, 2) of
+                          * in[0] (32 x 16 x cin = 96) -> OSBlock (96 -> k = 128, hid = 32 mid channels, with downsample) -> OSBlock
+                          * (128 -> 128) -> conv5 -> GAP -> fc (cout = 512, BN folded) -> ReLU -> L2 normalise -> ctx embeddings (as
+                          * FM_OP_HEAD).  w_off: the fp16 parameters (`stride` halfs), b_off: the fp32 ones (`pad` floats) in the
+                          * order ostail.hip documents (pointwise weights in MFMA fragment order)                                      */
     FM_OP_GATED_SUM = 11 /* OSNet unified aggregation gate in one launch: out = sum_i in[i] *
                           * sigmoid(fc2(relu(fc1(GAP(in[i]))))) with shared fc weights
                           * (w_off, b_off, w2_off, b2_off, hid) -- FM_OP_GATE x n_in + FM_OP_GATE_SUM */

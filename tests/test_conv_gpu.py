@@ -461,6 +461,33 @@ def test_osnet_embeddings(ctx, model, size, batch):
     net.close()
 
 
+@pytest.mark.parametrize('batch', [1, 3])
+def test_osnet_tail_fused(ctx, monkeypatch, batch):
+    """FM_OP_OSTAIL (ostail.hip: OSNet x0.25's 16 x 8 stage, conv5 and head as one launch, one workgroup per sample) against
+    the eleven launches it replaces and against PyTorch.  Every stored tensor of the unfused path is rounded to fp16 at the
+    same point and the MFMA K order is the same; the two average pools (gate, head) add their fp32 terms in another order."""
+    cls = ReID.get_model('OSNet025')
+    rng = np.random.default_rng(21 + batch)
+    x = rng.normal(0, 1, (batch, 256, 128, 3)).astype(np.float16)
+    ctx.feat_configure(512)
+    embs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('FASTMOT_OSTAIL', fused)
+        g, _ = cls.build_graph(RandomWeights(seed=17))
+        assert (g.layers[-1]['op'] == 20) == (fused == '1') and len(g.layers) == (22 if fused == '1' else 32)
+        net = HipNet(ctx, NET_EXTRACTOR, g, batch)
+        for _ in range(2):                       # the second run starts from a used LDS / arena
+            net.write(g.input, x)
+            net.run(batch)
+        embs.append(net.read_embeddings(batch))
+        net.close()
+        _, ref = torch_ref.run_graph(g, nchw(x.astype(np.float32)))
+        assert np.abs(embs[-1] - ref.numpy()).max() < 4e-3, (fused, np.abs(embs[-1] - ref.numpy()).max())
+    np.testing.assert_allclose(np.linalg.norm(embs[0], axis=1), 1.0, atol=1e-5)
+    assert np.abs(embs[0] - embs[1]).max() < 2e-4, np.abs(embs[0] - embs[1]).max()
+    assert (np.sum(embs[0] * embs[1], axis=1) > 0.999999).all()
+
+
 @pytest.mark.parametrize('resblock', ['1', '0'])
 def test_yolov4_small_input(ctx, monkeypatch, resblock):
     """Whole YOLOv4 topology (110 convs, SPP, PAN) at 96x96 so the CPU reference finishes in seconds;

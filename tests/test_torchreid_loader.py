@@ -39,6 +39,37 @@ def test_checkpoint_loader_cpu(model_name, fuse, tmp_path):
     assert (np.sum(emb * expect, axis=1) > 0.9999).all()
 
 
+def test_fused_tail_table_is_the_eleven_layers_it_replaces(monkeypatch):
+    """At the real 256 x 128 input OSNet x0.25's table ends in ONE FM_OP_OSTAIL layer (Graph.fuse_ostail): its parameter
+    blobs have the sizes csrc/ostail.hip indexes, the layers it stands for stay attached for the PyTorch interpreter, and
+    that interpreter gives the torchreid module's embeddings for both tables.  x1.0's widths keep their layers."""
+    Full, ref, x, expect = setup('OSNet025', (256, 128), n=2)
+    sd = {k: v.numpy() for k, v in ref.state_dict().items()}
+    embs = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('FASTMOT_OSTAIL', fused)
+        w = TorchreidWeights(sd)
+        g, _ = Full.build_graph(w)
+        assert w.unused() == []
+        tail = g.layers[-1]
+        if fused == '1':
+            assert len(g.layers) == 22 and tail['op'] == 20 and len(tail['sub']) == 11
+            assert (tail['cin'], tail['hid'], tail['k'], tail['cout'], tail['stride'], tail['pad']) == (96, 32, 128, 512, 135808, 1928)
+            assert tail['w_off'] % 16 == 0 and tail['b_off'] % 16 == 0 and tail['b_off'] + 4 * 1928 <= len(g.blob)
+            assert all(i < len(g.layers) - 1 for i, _, _ in g.conv_params)
+            g.tables(max_batch=2, reuse=True)
+        else:
+            assert len(g.layers) == 32 and tail['op'] == 8
+        _, emb = torch_ref.run_graph(g, x, emulate_fp16_storage=False)
+        embs[fused] = emb.numpy()
+        assert np.abs(embs[fused] - expect).max() < 5e-3
+    np.testing.assert_array_equal(embs['1'], embs['0'])
+    monkeypatch.setenv('FASTMOT_OSTAIL', '1')
+    g10, _ = ReID.get_model('OSNet10').build_graph(TorchreidWeights({k: v.numpy() for k, v in
+                                                                      tr.random_osnet(ReID.get_model('OSNet10').CHANNELS).state_dict().items()}))
+    assert g10.layers[-1]['op'] == 8
+
+
 def test_checkpoint_mismatch_is_an_error():
     Small, ref, _, _ = setup('OSNet025', (64, 32))
     sd = {k: v.numpy() for k, v in ref.state_dict().items()}

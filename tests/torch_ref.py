@@ -46,11 +46,15 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             val = val.half().float()
         bufs[v.tid][:, v.coff:v.coff + v.c] = val
 
-    for idx, d in enumerate(graph.layers):
+    def step(d, wb):
+        nonlocal emb
         op = d['op']
         xin = rd(d['ins'][0])
-        if op in G.CONV_OPS + (G.OP_STEMCONV,):
-            w, b = params[idx]
+        if op == G.OP_OSTAIL:            # the layers the fused launch replaces, with their own references
+            for sd, swb in d['sub']:
+                step(sd, swb)
+        elif op in G.CONV_OPS + (G.OP_STEMCONV,):
+            w, b = wb
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), stride=d['stride'], padding=d['pad'])
             if d['res_mode'] == G.RES_BEFORE_ACT:
                 y = y + rd(d['res'])
@@ -90,7 +94,7 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
                 y = act_fn(F.conv2d(y, torch.from_numpy(np.asarray(w3, np.float32)), torch.from_numpy(np.asarray(b3, np.float32))), d['act'])
             wr(d['out'], y)
         elif op == G.OP_DWCONV3:
-            w, b = params[idx]
+            w, b = wb
             y = F.conv2d(xin, torch.from_numpy(w), torch.from_numpy(b), padding=1, groups=xin.shape[1])
             wr(d['out'], act_fn(y, d['act']))
         elif op == G.OP_LITECONV:
@@ -156,4 +160,7 @@ def run_graph(graph, x_nchw, emulate_fp16_storage=True):
             emb = feat / feat.norm(dim=1, keepdim=True)
         else:
             raise ValueError(op)
+
+    for idx, d in enumerate(graph.layers):
+        step(d, params.get(idx))
     return bufs, emb
