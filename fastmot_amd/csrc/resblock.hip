@@ -14,6 +14,7 @@
 // The halo makes phase 1 do (th+2)(tw+2)/(th tw) = 1.56x (8x8) / 1.88x (4x8) of the 1x1 work; it is
 // 1/9 of the total.
 #include "net.h"
+#include <cstdlib>
 
 namespace {
 
@@ -249,6 +250,12 @@ int launch_resblock(const f16* x, int x_cs, int x_coff, f16* out, int out_cs, in
     if (C == C_ && M == M_)                                                                                    \
         return resblock_launch<C_, M_, TH_, NW_, CS_, KS_>(x, x_cs, x_coff, out, out_cs, out_coff, w1, b1, w2, \
                                                            b2, N, H, W, act1, act2, s)
+    // The 152^2 / 76^2 units split the taps of an accumulator tile over two waves (8 waves per workgroup; round 6,
+    // scripts/resblock_sweep.py, HIP events around eager launches: 12.1 -> 11.75 us and 11.9 -> 11.35 us; an 8 x 8 pixel tile with
+    // 8 waves 14.9, with 16 waves and the split 24.8 -- it spills).  FASTMOT_RB_VARIANT=0: one wave per tile, as before.
+    static const int variant = getenv("FASTMOT_RB_VARIANT") ? atoi(getenv("FASTMOT_RB_VARIANT")) : 1;
+    if (variant == 1) { RB(64, 64, 8, 8, 1, 2); RB(128, 128, 4, 8, 1, 2); }
+    if (variant == 2) { RB(128, 128, 8, 8, 1, 1); }
     // measured per stage of YOLOv4-608 (rocprofv3, graph replay; unfused 1x1 + split-K 3x3 + reduce in brackets):
     RB(64, 32, 8, 4, 1, 1);       // 304^2: 8 x 8 pixels, 2 cout x 2 pixel tiles       20.9 us (29)
     RB(64, 64, 8, 4, 1, 1);       // 152^2                                             14 us (20)
