@@ -42,7 +42,9 @@ for m in YOLOv4_608 YOLOv4P6_1280 YOLOv4CSP_640; do
   cd $R && FASTMOT_CONVD=0 python scripts/layer_roofline.py /tmp/tr0_${TAG}_$m $m > $O/layers_${m}_convd0.txt 2>&1; echo "$m without convd: $(tail -2 $O/layers_${m}_convd0.txt | head -1)"
 done
 cd /tmp && rm -rf /tmp/tro_$TAG && rocprofv3 --kernel-trace -d /tmp/tro_$TAG -o t -- python $R/scripts/trace_net.py 1 50 > /dev/null 2>&1
-cd $R && python scripts/rocpd_dispatches.py "$(find /tmp/tro_$TAG -name '*.db' | head -1)" 40 > $O/osnet_b50_dispatches.txt 2>&1; tail -3 $O/osnet_b50_dispatches.txt
+cd $R && python scripts/rocpd_dispatches.py "$(find /tmp/tro_$TAG -name '*.db' | head -1)" 44 > $O/osnet_b50_dispatches.txt 2>&1; tail -3 $O/osnet_b50_dispatches.txt
+# phases of the fused OSNet tail (profiling build of ostail.hip: bash scripts/build_timing_lib.sh ostail.hip -DFM_OST_TIMING before the call)
+[ -f fastmot_amd/libfastmot_hip_timing.so ] && FASTMOT_LIB_PATH=$R/fastmot_amd/libfastmot_hip_timing.so timeout 200 python scripts/ost_timing.py 50 2>&1 | grep -v SEEDED > $O/osnet_tail_phases.txt
 fi
 if [ -z "$QUICK" ]; then
     bash scripts/collect_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_conv.json gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt gpurun_out/pmc_sq_yolo.txt gpurun_out/pmc_layers.txt $O/ 2>/dev/null; tail -3 $O/pmc.log | cut -c1-400
